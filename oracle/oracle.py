@@ -1,0 +1,243 @@
+"""numpy/ctypes front-end of the CPU oracle (test infrastructure only).
+
+Restates, on numpy arrays, the reference operators of the hot path
+(/root/reference paths in every docstring).  Heavy loops live in
+hsg_oracle.c (canonical summation order, see its header); the integer /
+bookkeeping parts are plain numpy.
+
+Parity status: PINNED by tests/golden/*.npz (generated from the reference by
+tools/gen_golden.py, checked by tests/test_oracle_golden.py).
+
+Nothing under hsg_amd/ imports this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, 'libhsg_oracle.so')
+
+CHUNK = 2048      # canonical chunk length of order C2
+EPS = np.float32(1e-12)
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_f64p = ctypes.POINTER(ctypes.c_double)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_lib = None
+
+
+def build():
+  subprocess.check_call(['make', '-s', '-C', _HERE])
+
+
+def lib():
+  global _lib
+  if _lib is None:
+    if not os.path.exists(_SO):
+      build()
+    L = ctypes.CDLL(_SO)
+    L.orc_prep.restype = ctypes.c_int64
+    _lib = L
+  return _lib
+
+
+def _p(a, t):
+  return a.ctypes.data_as(t) if a is not None else None
+
+
+def _f32(a):
+  return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i64(a):
+  return np.ascontiguousarray(a, dtype=np.int64)
+
+
+# --------------------------------------------------------------------------
+def normalize_embedding(x, eps=EPS):
+  """hsg/utils/general/common.py:101-120."""
+  x = _f32(x)
+  out = np.empty_like(x)
+  d = x.shape[-1]
+  lib().orc_normalize_rows(_p(x, _f32p), ctypes.c_int64(x.size // d), d,
+                           ctypes.c_float(eps), _p(out, _f32p))
+  return out
+
+
+def grid_seed_axis(k, n):
+  """round_half_even(linspace(0, k-1, n)) as exact integer arithmetic.
+
+  hsg/utils/segsort/common.py:145-148.  value_i = i*(k-1)/(n-1).
+  """
+  if n == 1:
+    return np.zeros(1, np.int64)
+  i = np.arange(n, dtype=np.int64)
+  num = i * (k - 1)
+  den = n - 1
+  q, r = np.divmod(num, den)
+  up = (2 * r > den) | ((2 * r == den) & (q % 2 == 1))
+  return q + up.astype(np.int64)
+
+
+def initialize_cluster_labels(num_clusters, img_dimensions):
+  """hsg/utils/segsort/common.py:129-153: y + (y.max()+1) * x."""
+  y = grid_seed_axis(num_clusters[0], img_dimensions[0])
+  x = grid_seed_axis(num_clusters[1], img_dimensions[1])
+  return y[:, None] + (y.max() + 1) * x[None, :]
+
+
+def dense_relabel(v):
+  """torch.unique(v, return_inverse=True)[1]: rank among sorted unique."""
+  return np.unique(v, return_inverse=True)[1].astype(np.int64).reshape(v.shape)
+
+
+def prepare_prototype_labels(semantic_labels, instance_labels, offset=256):
+  """hsg/utils/segsort/common.py:192-218."""
+  pan = _i64(semantic_labels) + _i64(instance_labels) * int(offset)
+  uniq, inv = np.unique(pan, return_inverse=True)
+  return uniq % int(offset), inv.astype(np.int64)
+
+
+def calculate_prototypes_from_labels(embeddings, labels, max_label=None,
+                                     chunk=CHUNK):
+  """hsg/utils/segsort/common.py:11-41 with summation order C2."""
+  x = _f32(embeddings).reshape(-1, embeddings.shape[-1])
+  lab = _i64(labels).reshape(-1)
+  P = int(lab.max()) + 1 if max_label is None else int(max_label)
+  out = np.empty((P, x.shape[1]), np.float32)
+  lib().orc_prototypes(_p(x, _f32p), ctypes.c_int64(x.shape[0]), x.shape[1],
+                       _p(lab, _i64p), ctypes.c_int64(P), chunk,
+                       ctypes.c_float(EPS), _p(out, _f32p))
+  return out
+
+
+def segment_mean(x, index, chunk=CHUNK):
+  """hsg/utils/general/common.py:123-147."""
+  x = _f32(x).reshape(-1, x.shape[-1])
+  idx = _i64(index).reshape(-1)
+  P = int(idx.max()) + 1
+  out = np.empty((P, x.shape[1]), np.float32)
+  lib().orc_segment_mean(_p(x, _f32p), ctypes.c_int64(x.shape[0]), x.shape[1],
+                         _p(idx, _i64p), ctypes.c_int64(P), chunk,
+                         _p(out, _f32p))
+  return out
+
+
+def find_nearest_prototypes(embeddings, prototypes, return_best=False):
+  """hsg/utils/segsort/common.py:44-64."""
+  c = _f32(prototypes)
+  x = _f32(embeddings).reshape(-1, c.shape[-1])
+  out = np.empty(x.shape[0], np.int32)
+  best = np.empty(x.shape[0], np.float32) if return_best else None
+  lib().orc_assign(_p(x, _f32p), ctypes.c_int64(x.shape[0]), x.shape[1],
+                   _p(c, _f32p), c.shape[0], _p(out, _i32p), _p(best, _f32p))
+  return (out.astype(np.int64), best) if return_best else out.astype(np.int64)
+
+
+def kmeans_with_initial_labels(embeddings, initial_labels, max_label=None,
+                               iterations=10, chunk=CHUNK, return_centroids=False):
+  """hsg/utils/segsort/common.py:67-97."""
+  x = _f32(embeddings)
+  init = np.ascontiguousarray(initial_labels, dtype=np.int32)
+  K = int(init.max()) + 1 if max_label is None else int(max_label)
+  out = np.empty(x.shape[0], np.int32)
+  cent = np.empty((K, x.shape[1]), np.float32)
+  lib().orc_kmeans(_p(x, _f32p), ctypes.c_int64(x.shape[0]), x.shape[1],
+                   _p(init, _i32p), K, int(iterations), chunk,
+                   ctypes.c_float(EPS), _p(out, _i32p), _p(cent, _f32p))
+  out = out.astype(np.int64)
+  return (out, cent) if return_centroids else out
+
+
+def segment_by_kmeans(embeddings, labels=None, num_clusters=(5, 5),
+                      local_features=None, ignore_index=None, iterations=10,
+                      gpu_id=0, chunk=CHUNK):
+  """hsg/utils/segsort/common.py:270-408 (cluster_indices= kwarg never used).
+
+  embeddings [B,C,H,W] f32; labels [B,H,W] i64 or None; local_features
+  [H,W,2] or [B,H,W,2] f32 (REQUIRED here: the float32 bit patterns of
+  torch.linspace are input data).  Returns the reference's
+  5-tuple as numpy arrays.
+  """
+  x = _f32(embeddings)
+  B, C, H, W = x.shape
+  D = C + 2
+  loc = _f32(local_features)
+  loc_sb = 0 if loc.ndim == 3 else H * W * 2
+  if labels is None and ignore_index is not None:
+    labels = np.zeros((B, H, W), np.int64)                 # common.py:326-329
+  lab = _i64(labels) if labels is not None else None
+  n_max = B * H * W
+  emb = np.empty((n_max, C), np.float32)
+  emb_loc = np.empty((n_max, D), np.float32)
+  lab_out = np.empty(n_max, np.int64)
+  counts = np.empty(B, np.int64)
+  n = lib().orc_prep(_p(x, _f32p), B, C, H, W, _p(loc, _f32p),
+                     ctypes.c_int64(loc_sb), _p(lab, _i64p),
+                     int(ignore_index is not None),
+                     ctypes.c_int64(0 if ignore_index is None else int(ignore_index)),
+                     ctypes.c_float(EPS), _p(emb, _f32p), _p(emb_loc, _f32p),
+                     _p(lab_out, _i64p), _p(counts, _i64p))
+  emb, emb_loc, lab_out = emb[:n], emb_loc[:n], lab_out[:n]
+
+  # common.py:320-323, 341-345: grid seeds, densely relabelled per image
+  seeds = dense_relabel(initialize_cluster_labels(num_clusters, (H, W)).reshape(-1))
+  K = int(seeds.max()) + 1
+  cluster = np.empty(n, np.int64)
+  batch = np.empty(n, np.int64)
+  off = 0
+  for b in range(B):
+    cnt = int(counts[b])
+    if lab is not None and ignore_index is not None:
+      keep = lab[b].reshape(-1) != int(ignore_index)
+      init = seeds[keep]
+    else:
+      init = seeds
+    if cnt > 0:                                             # common.py:368
+      cluster[off:off + cnt] = kmeans_with_initial_labels(
+          emb_loc[off:off + cnt], init, K, iterations, chunk)
+    batch[off:off + cnt] = b + B * gpu_id                  # common.py:375-381
+    off += cnt
+
+  # common.py:398-405
+  if n > 0:
+    lab_div = int(cluster.max()) + 1
+    cluster = dense_relabel(batch * lab_div + cluster)
+    _, cluster = prepare_prototype_labels(lab_out, cluster, int(lab_out.max()) + 1)
+  return emb, emb_loc, lab_out, cluster, batch
+
+
+def segsort_nll(embeddings, semantic_labels, instance_labels, prototypes,
+                prototype_semantic_labels, concentration, group_mode='segsort+',
+                want_grads=False, gscale=None):
+  """hsg/utils/segsort/loss.py:15-82 per-pixel negative log-likelihood (f64)."""
+  e = _f32(embeddings).reshape(-1, embeddings.shape[-1])
+  p = _f32(prototypes).reshape(-1, prototypes.shape[-1])
+  sem = _i64(semantic_labels).reshape(-1)
+  inst = _i64(instance_labels).reshape(-1)
+  psem = _i64(prototype_semantic_labels).reshape(-1)
+  n, c = e.shape
+  nll = np.empty(n, np.float64)
+  ge = np.zeros((n, c), np.float64) if want_grads else None
+  gp = np.zeros((p.shape[0], c), np.float64) if want_grads else None
+  if gscale is None:
+    gscale = 1.0 / max(n, 1)
+  lib().orc_segsort_nll(_p(e, _f32p), ctypes.c_int64(n), c, _p(sem, _i64p),
+                        _p(inst, _i64p), _p(p, _f32p), ctypes.c_int64(p.shape[0]),
+                        _p(psem, _i64p), ctypes.c_float(concentration),
+                        int(group_mode == 'segsort+'), _p(nll, _f64p),
+                        ctypes.c_double(gscale), _p(ge, _f64p), _p(gp, _f64p))
+  return (nll, ge, gp) if want_grads else nll
+
+
+def segsort_loss(*args, reduction='mean', **kw):
+  """hsg/utils/segsort/loss.py:149-190 SegSortLoss.forward."""
+  nll = segsort_nll(*args, **kw)
+  if reduction == 'mean':
+    return float(nll.mean())
+  if reduction == 'sum':
+    return float(nll.sum())
+  return nll

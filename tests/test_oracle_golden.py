@@ -1,0 +1,99 @@
+"""Pins the CPU oracle to the reference's own outputs (tests/golden, produced
+by tools/gen_golden.py from /root/reference).  CPU only."""
+import numpy as np
+import pytest
+
+from tests import util
+from hsg_amd.utils import synth
+
+FTOL = 2e-6       # float outputs: |oracle - reference| (unit-norm rows)
+
+
+def test_f1_normalize(oracle):
+  g = util.load('f1_normalize')
+  n, d = (int(v) for v in g['shape'])
+  x = synth.gaussish(int(g['seed']), n * d).reshape(n, d).copy()
+  x[3] = 0.0
+  x[7] *= np.float32(1e-20)
+  x[11] *= np.float32(1e-9)
+  y = oracle.normalize_embedding(x)
+  assert np.abs(y - g['y']).max() <= FTOL
+  assert np.all(y[3] == 0.0)
+
+
+def test_f2_grid_seeds(oracle):
+  g = util.load('f2_grid_seeds')
+  for key in g.files:
+    n, k = (int(t[1:]) for t in key.split('_'))
+    assert np.array_equal(oracle.grid_seed_axis(k, n), g[key].astype(np.int64)), key
+
+
+@pytest.mark.parametrize('case', util.F3_CASES)
+def test_f3_kmeans(oracle, case):
+  g = util.load('f3_kmeans_' + case)
+  shape = tuple(int(v) for v in g['shape'])
+  grid = tuple(int(v) for v in g['grid'])
+  x = synth.embeddings_nchw(int(g['seed']), shape, str(g['flavour']))
+  B, C, H, W = shape
+  loc = util.loc_from_lin(g['ylin'], g['xlin'])
+  emb, emb_loc, _, _, _ = oracle.segment_by_kmeans(x, None, grid, loc, None, 0)
+  seeds = oracle.dense_relabel(oracle.initialize_cluster_labels(grid, (H, W)).reshape(-1))
+  K = int(g['K'])
+  assert int(seeds.max()) + 1 == K
+  for b in range(B):
+    rows = emb_loc[b * H * W:(b + 1) * H * W]
+    for it in (1, 2, 10, 15):
+      lab = oracle.kmeans_with_initial_labels(rows, seeds, K, it)
+      ref = g['b%d_it%d' % (b, it)].astype(np.int64)
+      bad = np.nonzero(lab != ref)[0]
+      assert bad.size == 0, '%s b%d it%d: %d label mismatches' % (case, b, it, bad.size)
+    _, cen = oracle.kmeans_with_initial_labels(rows, seeds, K, 10, return_centroids=True)
+    assert np.abs(cen - g['b%d_cent10' % b]).max() <= FTOL
+
+
+@pytest.mark.parametrize('case', util.F4_CASES)
+def test_f4_segment_by_kmeans(oracle, case):
+  g = util.load('f4_segkm_' + case)
+  x, lab, grid, ign, iters, loc = util.f4_inputs(g)
+  emb, emb_loc, labels, cluster, batch = oracle.segment_by_kmeans(
+      x, lab, grid, loc, ign, iters)
+  assert np.array_equal(labels, g['labels'].astype(np.int64))
+  assert np.array_equal(batch, g['batch'].astype(np.int64))
+  assert np.array_equal(cluster, g['cluster'].astype(np.int64))
+  assert np.abs(emb[::util.ROW_STRIDE] - g['emb_rows']).max() <= FTOL
+  assert np.abs(emb_loc[::util.ROW_STRIDE] - g['emb_loc_rows']).max() <= FTOL
+  n = max(1, emb.shape[0])
+  assert np.abs(emb.astype(np.float64).sum(0) - g['emb_colsum']).max() <= 2e-7 * n
+  assert np.abs(emb_loc.astype(np.float64).sum(0) - g['emb_loc_colsum']).max() <= 2e-7 * n
+
+
+def test_f5_prototypes(oracle):
+  g = util.load('f5_prototypes')
+  n, d = int(g['n']), int(g['d'])
+  x = oracle.normalize_embedding(synth.gaussish(int(g['seed']), n * d).reshape(n, d))
+  lab = g['labels'].astype(np.int64)
+  assert np.abs(oracle.calculate_prototypes_from_labels(x, lab) - g['p_auto']).max() <= FTOL
+  pad = oracle.calculate_prototypes_from_labels(x, lab, 64)
+  assert np.abs(pad - g['p_pad']).max() <= FTOL
+  assert np.all(pad[5] == 0) and np.all(pad[37:] == 0)      # empty -> exact zero rows
+  assert np.abs(oracle.segment_mean(x, lab) - g['seg_mean']).max() <= FTOL
+
+
+def test_f6_segsort_loss(oracle):
+  g = util.load('f6_segsort_loss')
+  n, c, P = int(g['n']), int(g['c']), int(g['P'])
+  e = oracle.normalize_embedding(synth.gaussish(int(g['seed']), n * c).reshape(n, c))
+  inst = g['inst'].astype(np.int64)
+  psem = g['psem'].astype(np.int64)
+  sem = psem[inst]
+  proto = oracle.calculate_prototypes_from_labels(e, inst, P)
+  assert np.abs(proto - g['proto']).max() <= FTOL
+  for kappa in (10, 16):
+    for mode, tag in (('segsort+', 'plus'), ('segsort', 'plain')):
+      key = 'k%d_%s' % (kappa, tag)
+      nll, ge, gp = oracle.segsort_nll(e, sem, inst, proto, psem, float(kappa), mode,
+                                       want_grads=True)
+      assert abs(nll.mean() - float(g[key + '_loss'])) <= 1e-4        # north_star tolerance
+      assert np.abs(nll - g[key + '_nll']).max() <= 1e-4
+      assert np.abs(ge[::7] - g[key + '_gemb']).max() <= 1e-6
+      assert np.abs(gp - g[key + '_gproto']).max() <= 1e-5

@@ -1,0 +1,46 @@
+"""Shared helpers: rebuild fixture inputs from the portable generator."""
+import os
+
+import numpy as np
+
+from hsg_amd.utils import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+ROW_STRIDE = 29        # tools/gen_golden.py
+
+
+def load(name):
+  return np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+
+
+def loc_from_lin(ylin, xlin):
+  """[H,W,2] float32: (linspace01 - 0.5) on a 'ij' meshgrid (common.py:313-316)."""
+  y = (ylin.astype(np.float32) - np.float32(0.5))
+  x = (xlin.astype(np.float32) - np.float32(0.5))
+  loc = np.empty((y.size, x.size, 2), np.float32)
+  loc[..., 0] = y[:, None]
+  loc[..., 1] = x[None, :]
+  return loc
+
+
+def f4_inputs(g):
+  """(embeddings NCHW, labels or None, grid, ignore or None, iters, loc)."""
+  shape = tuple(int(v) for v in g['shape'])
+  x = synth.embeddings_nchw(int(g['seed']), shape, str(g['flavour']))
+  ign = int(g['ignore'])
+  ign = None if ign < 0 else ign
+  lab = None
+  if bool(g['has_labels']):
+    B, _, H, W = shape
+    lab = synth.overseg_labels(int(g['label_seed']), B, H, W, regions=48,
+                               ignore_rows=4 if ign is not None else 0,
+                               ignore_index=255)
+    for b in g['fully_ignored']:
+      lab[int(b)] = 255
+  return x, lab, tuple(int(v) for v in g['grid']), ign, int(g['iters']), \
+      loc_from_lin(g['ylin'], g['xlin'])
+
+
+F4_CASES = ['cfg1_nolabel', 'cfg1_overseg', 'k1_it1', 'mix_overseg', 'c256k64',
+            'ragged', 'noignore_labels']
+F3_CASES = ['cfg1', 'c256k64', 'c384k128', 'mix']

@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REAL reference (runs only in the build
+container, where /root/reference exists; never on the GPU box).
+
+    python tools/gen_golden.py            # rewrites tests/golden/*.npz
+
+Inputs come from hsg_amd.utils.synth (portable integer-hash generator), so the
+fixtures store only (a) the float32 linspace tables that the reference obtains
+from torch.linspace (treated as data) and (b) the reference's outputs: integer
+outputs in full, float outputs on a strided subset of rows plus a float64
+checksum per column.
+
+Harness shims (not part of any shipped code):
+  * hsg/utils/segsort/common.py:376-377 multiplies by `device.index`, which is
+    None on CPU; the function source is re-executed with `(… or 0)`.
+"""
+import inspect
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, '/root/reference')
+
+import hsg.utils.general.common as ref_general        # noqa: E402
+import hsg.utils.segsort.common as ref_common         # noqa: E402
+import hsg.utils.segsort.loss as ref_loss             # noqa: E402
+from hsg_amd.utils import synth                       # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+ROW_STRIDE = 29
+
+torch.set_num_threads(8)
+torch.manual_seed(0)
+
+# ---- shim: CPU-safe segment_by_kmeans ------------------------------------
+_src = inspect.getsource(ref_common.segment_by_kmeans)
+_src = _src.replace('cur_cluster_indices.device.index',
+                    '(cur_cluster_indices.device.index or 0)')
+_ns = dict(ref_common.__dict__)
+exec(_src, _ns)
+ref_segment_by_kmeans = _ns['segment_by_kmeans']
+
+
+def sub_rows(a):
+  a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+  return a[::ROW_STRIDE].copy(), a.astype(np.float64).sum(0)
+
+
+def save(name, **kw):
+  path = os.path.join(OUT, name + '.npz')
+  np.savez_compressed(path, **kw)
+  print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024))
+
+
+def lin01(n):
+  return torch.linspace(0, 1, n).numpy().copy()
+
+
+# ---- F1 normalize_embedding ----------------------------------------------
+def f1():
+  x = synth.gaussish(synth.SEED_BASE + 101, 257 * 96).reshape(257, 96).copy()
+  x[3] = 0.0                      # zero row -> eps path
+  x[7] *= np.float32(1e-20)       # tiny row, norm < eps
+  x[11] *= np.float32(1e-9)
+  y = ref_general.normalize_embedding(torch.from_numpy(x)).numpy()
+  save('f1_normalize', seed=synth.SEED_BASE + 101, shape=np.array(x.shape), y=y)
+
+
+# ---- F2 grid seeds ---------------------------------------------------------
+def f2():
+  rec = {}
+  for n in (1, 2, 3, 7, 14, 16, 28, 32, 33, 48, 56, 64, 96, 100, 112, 224, 225,
+            256, 448, 449, 512, 513, 768, 1024, 2048):
+    for k in (1, 2, 3, 4, 5, 6, 8, 12, 16, 24):
+      v = torch.linspace(0, k - 1, n).round_().long().numpy()
+      rec['n%d_k%d' % (n, k)] = v.astype(np.int16)
+  save('f2_grid_seeds', **rec)
+  rec = {}
+  for n in (14, 28, 32, 56, 64, 224, 448, 449, 512, 768, 1024, 2048):
+    rec['n%d' % n] = lin01(n)
+  save('f2_linspace01', **rec)
+
+
+# ---- F3 kmeans_with_initial_labels ----------------------------------------
+def _prep(x_nchw):
+  """Reference's own prologue (common.py:306-352) to get emb_loc rows."""
+  e = torch.from_numpy(x_nchw).permute(0, 2, 3, 1).contiguous()
+  B, H, W, C = e.shape
+  e = ref_general.normalize_embedding(e)
+  loc = ref_common.generate_location_features((H, W), 'cpu', 'float') - 0.5
+  out = []
+  for b in range(B):
+    el = torch.cat([e[b].view(-1, C), loc.view(-1, 2)], -1)
+    out.append(ref_general.normalize_embedding(el))
+  return out
+
+
+def f3():
+  cases = [
+      ('cfg1', synth.SEED_BASE + 1, (2, 32, 64, 64), (2, 4), 'iid'),
+      ('c256k64', synth.SEED_BASE + 2, (1, 256, 64, 64), (8, 8), 'iid'),
+      ('c384k128', synth.SEED_BASE + 5, (1, 384, 48, 64), (8, 16), 'iid'),
+      ('mix', synth.SEED_BASE + 12, (1, 64, 96, 96), (6, 6), 'mixture'),
+  ]
+  for name, seed, shape, grid, flav in cases:
+    x = synth.embeddings_nchw(seed, shape, flav)
+    rows = _prep(x)
+    H, W = shape[2], shape[3]
+    init = ref_common.initialize_cluster_labels(grid, (H, W), 'cpu').view(-1)
+    _, init = torch.unique(init, return_inverse=True)
+    K = int(init.max()) + 1
+    rec = dict(seed=seed, shape=np.array(shape), grid=np.array(grid), flavour=flav,
+               ylin=lin01(H), xlin=lin01(W), K=K)
+    for b, el in enumerate(rows):
+      for it in (1, 2, 10, 15):
+        lab = ref_common.kmeans_with_initial_labels(el, init, K, it)
+        rec['b%d_it%d' % (b, it)] = lab.numpy().astype(np.int16)
+      # centroids + top-2 margin after the 10-iteration run's last M-step
+      lab9 = ref_common.kmeans_with_initial_labels(el, init, K, 9)
+      cen = ref_common.calculate_prototypes_from_labels(el, lab9, K)
+      sims = el @ cen.t()
+      top2 = sims.topk(min(2, K), 1).values
+      rec['b%d_cent10' % b] = cen.numpy()
+      if K > 1:
+        rec['b%d_margin10' % b] = (top2[:, 0] - top2[:, 1]).numpy()
+    save('f3_kmeans_' + name, **rec)
+
+
+# ---- F4 segment_by_kmeans ---------------------------------------------------
+def f4():
+  cases = [
+      # name, seed, shape, grid, flavour, labels?, ignore, iters
+      ('cfg1_nolabel', synth.SEED_BASE + 1, (4, 32, 64, 64), (2, 4), 'iid', False, None, 10),
+      ('cfg1_overseg', synth.SEED_BASE + 1, (4, 32, 64, 64), (2, 4), 'iid', True, 255, 10),
+      ('k1_it1', synth.SEED_BASE + 21, (3, 16, 14, 14), (1, 1), 'iid', True, 255, 1),
+      ('mix_overseg', synth.SEED_BASE + 22, (2, 64, 56, 72), (4, 4), 'mixture', True, 255, 15),
+      ('c256k64', synth.SEED_BASE + 2, (2, 256, 48, 48), (8, 8), 'iid', False, None, 10),
+      ('ragged', synth.SEED_BASE + 23, (2, 24, 37, 53), (3, 5), 'iid', True, 255, 10),
+      ('noignore_labels', synth.SEED_BASE + 24, (2, 32, 32, 32), (4, 4), 'mixture', True, None, 10),
+  ]
+  for name, seed, shape, grid, flav, has_lab, ign, iters in cases:
+    B, C, H, W = shape
+    x = synth.embeddings_nchw(seed, shape, flav)
+    lab = None
+    if has_lab:
+      lab = synth.overseg_labels(seed + 7, B, H, W, regions=48,
+                                 ignore_rows=4 if ign is not None else 0,
+                                 ignore_index=255)
+      if name == 'k1_it1':
+        lab[1] = 255                       # one image fully ignored
+    out = ref_segment_by_kmeans(
+        torch.from_numpy(x), None if lab is None else torch.from_numpy(lab),
+        list(grid), ignore_index=ign, iterations=iters)
+    emb, emb_loc, labels, cidx, bidx = out
+    es, ec = sub_rows(emb)
+    ls, lc = sub_rows(emb_loc)
+    save('f4_segkm_' + name, seed=seed, shape=np.array(shape), grid=np.array(grid),
+         flavour=flav, has_labels=has_lab, ignore=-1 if ign is None else ign,
+         iters=iters, label_seed=seed + 7, ylin=lin01(H), xlin=lin01(W),
+         emb_rows=es, emb_colsum=ec, emb_loc_rows=ls, emb_loc_colsum=lc,
+         labels=labels.numpy().astype(np.int32), cluster=cidx.numpy().astype(np.int32),
+         batch=bidx.numpy().astype(np.int32),
+         fully_ignored=np.array([1] if name == 'k1_it1' else [], np.int64))
+
+
+# ---- F5 calculate_prototypes_from_labels / segment_mean ---------------------
+def f5():
+  seed = synth.SEED_BASE + 31
+  n, d = 5000, 66
+  x = ref_general.normalize_embedding(
+      torch.from_numpy(synth.gaussish(seed, n * d).reshape(n, d).copy()))
+  lab = torch.from_numpy((synth.hash_u64(seed + 1, n) % np.uint64(37)).astype(np.int64))
+  lab[lab == 5] = 6                       # label 5 empty
+  p_auto = ref_common.calculate_prototypes_from_labels(x, lab)
+  p_pad = ref_common.calculate_prototypes_from_labels(x, lab, 64)
+  sm = ref_general.segment_mean(x, lab)
+  save('f5_prototypes', seed=seed, n=n, d=d, labels=lab.numpy().astype(np.int16),
+       p_auto=p_auto.numpy(), p_pad=p_pad.numpy(), seg_mean=sm.numpy())
+
+
+# ---- F6 SegSortLoss ---------------------------------------------------------
+def f6():
+  seed = synth.SEED_BASE + 41
+  n, c, P = 3000, 48, 97
+  e = ref_general.normalize_embedding(
+      torch.from_numpy(synth.gaussish(seed, n * c).reshape(n, c).copy()))
+  inst = torch.from_numpy((synth.hash_u64(seed + 1, n) % np.uint64(P)).astype(np.int64))
+  psem = torch.from_numpy((synth.hash_u64(seed + 2, P) % np.uint64(9)).astype(np.int64))
+  psem[-1] = 1000                          # a class with a single prototype
+  sem = psem[inst]
+  rec = dict(seed=seed, n=n, c=c, P=P, inst=inst.numpy().astype(np.int16),
+             psem=psem.numpy().astype(np.int16))
+  for kappa in (10.0, 16.0):
+    for mode in ('segsort+', 'segsort'):
+      ee = e.clone().requires_grad_(True)
+      proto = ref_common.calculate_prototypes_from_labels(ee, inst, P)
+      pp = proto.detach().clone().requires_grad_(True)
+      loss = ref_loss.SegSortLoss(kappa, mode)(ee, sem, inst, pp, psem)
+      loss.backward()
+      nll = ref_loss.SegSortLoss(kappa, mode, reduction='none')(
+          e, sem, inst, proto.detach(), psem).view(-1)
+      tag = 'k%d_%s' % (int(kappa), 'plus' if mode == 'segsort+' else 'plain')
+      rec[tag + '_loss'] = np.float64(loss.item())
+      rec[tag + '_nll'] = nll.numpy()
+      rec[tag + '_gemb'] = ee.grad.numpy()[::7].copy()
+      rec[tag + '_gproto'] = pp.grad.numpy()
+      rec['proto'] = proto.detach().numpy()
+  save('f6_segsort_loss', **rec)
+
+
+if __name__ == '__main__':
+  os.makedirs(OUT, exist_ok=True)
+  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6']
+  for w in which:
+    globals()[w]()
