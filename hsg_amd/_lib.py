@@ -1,0 +1,88 @@
+"""ctypes binding of libhsgk.so (include/hsgk.h).
+
+The library is the product: if it is missing or fails to load, importing the
+operators fails loudly -- there is no CPU / eager fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, 'csrc', 'libhsgk.so')
+
+CHUNK = 2048
+EPS = 1e-12
+
+
+class HsgkError(RuntimeError):
+  pass
+
+
+class SegkmMeta(ctypes.Structure):
+  _fields_ = [(n, ctypes.c_int64) for n in (
+      'n_rows', 'n_segments', 'label_min', 'label_max', 'n_chunks', 'error',
+      'relabel_mode', 'relabel_L')]
+
+
+class SegkmArgs(ctypes.Structure):
+  _fields_ = [
+      ('embeddings', ctypes.c_void_p), ('labels', ctypes.c_void_p),
+      ('loc', ctypes.c_void_p), ('loc_batch_stride', ctypes.c_int64),
+      ('seed_map', ctypes.c_void_p),
+      ('B', ctypes.c_int32), ('C', ctypes.c_int32), ('H', ctypes.c_int32),
+      ('W', ctypes.c_int32), ('K', ctypes.c_int32), ('iterations', ctypes.c_int32),
+      ('has_ignore', ctypes.c_int32),
+      ('ignore_index', ctypes.c_int64), ('batch_offset', ctypes.c_int64),
+      ('table_cap', ctypes.c_int64),
+      ('out_embeddings', ctypes.c_void_p), ('out_embeddings_loc', ctypes.c_void_p),
+      ('out_labels', ctypes.c_void_p), ('out_cluster', ctypes.c_void_p),
+      ('out_batch', ctypes.c_void_p), ('meta', ctypes.c_void_p),
+      ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t)]
+
+
+_lib = None
+
+_vp, _i64, _i32, _f32, _sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                              ctypes.c_float, ctypes.c_size_t)
+
+# name -> (restype, argtypes); must list every symbol include/hsgk.h declares
+SIGNATURES = {
+    'hsgk_version': (_i32, []),
+    'hsgk_last_error': (ctypes.c_char_p, []),
+    'hsgk_normalize_rows': (_i32, [_vp, _i64, _i32, _f32, _vp, _vp]),
+    'hsgk_segment_by_kmeans_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32, _i32, _i64]),
+    'hsgk_segment_by_kmeans': (_i32, [ctypes.POINTER(SegkmArgs), _vp]),
+    'hsgk_kmeans_workspace_bytes': (_sz, [_i64, _i32, _i32]),
+    'hsgk_kmeans_with_initial_labels': (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _sz, _vp]),
+    'hsgk_assign_workspace_bytes': (_sz, [_i64, _i32, _i32]),
+    'hsgk_find_nearest_prototypes': (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
+}
+
+
+def lib():
+  """Loads libhsgk.so once; raises HsgkError if it is not built."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(SO_PATH):
+      raise HsgkError(
+          'libhsgk.so is not built (%s). Run `python -c "import __graft_entry__ as g; '
+          'g.build()"` or `make -C hsg_amd/csrc`. There is no fallback path.' % SO_PATH)
+    try:
+      L = ctypes.CDLL(SO_PATH)
+    except OSError as e:
+      raise HsgkError('cannot load %s: %s' % (SO_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+      fn = getattr(L, name)
+      fn.restype = res
+      fn.argtypes = args
+    _lib = L
+  return _lib
+
+
+def check(rc):
+  if rc != 0:
+    raise HsgkError('libhsgk error %d: %s' % (rc, lib().hsgk_last_error().decode()))
+
+
+def stream_ptr():
+  import torch
+  return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,171 @@
+// api.hip -- extern "C" surface of libhsgk.so (include/hsgk.h) and the host
+// orchestration of segment_by_kmeans.  Host code only enqueues kernels on the
+// caller's stream; it never allocates or synchronises.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace hsgk {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+struct KmeansScratch {
+  ChunkTable t;
+  int32_t *klab;
+  float *best;
+  float *partial;
+  float *cent;
+  int max_chunks;
+};
+
+static int max_chunks_for(int B, int64_t rows_per_img) {
+  return (int)(B * ((rows_per_img + HSGK_CHUNK - 1) / HSGK_CHUNK));
+}
+
+static void carve_kmeans(Carver &cv, int B, int64_t rows_per_img, int d, int K,
+                         KmeansScratch *k) {
+  const int mc = max_chunks_for(B, rows_per_img);
+  const size_t mcs = mc > 0 ? mc : 1;
+  k->max_chunks = mc;
+  k->t.img_row0 = cv.take<int64_t>(B + 1);
+  k->t.img_chunk0 = cv.take<int32_t>(B + 1);
+  k->t.chunk_row0 = cv.take<int64_t>(mcs);
+  k->t.chunk_rows = cv.take<int32_t>(mcs);
+  k->t.chunk_img = cv.take<int32_t>(mcs);
+  k->klab = cv.take<int32_t>((size_t)B * rows_per_img + 1);
+  k->best = cv.take<float>((size_t)B * rows_per_img + 1);
+  k->partial = cv.take<float>(mcs * K * d);
+  k->cent = cv.take<float>((size_t)B * K * d + 1);
+}
+
+static int lloyd(const float *x, int d, int K, int B, int iterations,
+                 const KmeansScratch &k, const hsgk_segkm_meta *meta, hipStream_t s) {
+  for (int it = 0; it < iterations; ++it) {
+    if (int rc = launch_accumulate(x, d, k.klab, k.t, k.max_chunks, K, k.partial, meta, s)) return rc;
+    if (int rc = launch_finalize(k.partial, d, K, B, k.t, HSGK_EPS, k.cent, s)) return rc;
+    if (int rc = launch_assign(x, d, k.cent, K, k.t, k.max_chunks, k.klab, k.best, meta, s)) return rc;
+  }
+  return 0;
+}
+
+}  // namespace hsgk
+
+using namespace hsgk;
+
+extern "C" {
+
+int hsgk_version(void) { return HSGK_VERSION; }
+const char *hsgk_last_error(void) { return g_err; }
+
+int hsgk_normalize_rows(const float *x, int64_t n, int d, float eps, float *out,
+                        hsgk_stream_t stream) {
+  HSGK_REQUIRE(n >= 0 && d >= 1, "bad shape");
+  return launch_normalize_rows(x, n, d, eps, out, static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------
+size_t hsgk_segment_by_kmeans_workspace_bytes(int B, int C, int H, int W, int K,
+                                              int64_t table_cap) {
+  const int64_t HW = (int64_t)H * W;
+  const int ntiles = (int)((HW + kTilePix - 1) / kTilePix);
+  Carver cv(nullptr);
+  cv.take<int32_t>((size_t)B * ntiles);                                  // tile_cnt
+  cv.take<char>(align_up((size_t)B * ntiles, 64) * 4 + (size_t)B * 8);   // tile_off + img_cnt
+  KmeansScratch k;
+  carve_kmeans(cv, B, HW, C + 2, K, &k);
+  cv.take<int32_t>((size_t)table_cap * 2);
+  cv.take<int32_t>((size_t)table_cap / 2048 + 2);
+  return cv.off + 256;
+}
+
+int hsgk_segment_by_kmeans(const hsgk_segkm_args *a, hsgk_stream_t stream) {
+  HSGK_REQUIRE(a != nullptr, "null args");
+  HSGK_REQUIRE(a->B >= 1 && a->C >= 1 && a->H >= 1 && a->W >= 1, "bad shape");
+  HSGK_REQUIRE(a->K >= 1 && a->iterations >= 0, "bad K / iterations");
+  HSGK_REQUIRE(a->embeddings && a->loc && a->seed_map && a->meta, "null input");
+  HSGK_REQUIRE(a->out_embeddings && a->out_embeddings_loc && a->out_labels &&
+                   a->out_cluster && a->out_batch, "null output");
+  HSGK_REQUIRE(a->workspace_bytes >=
+                   hsgk_segment_by_kmeans_workspace_bytes(a->B, a->C, a->H, a->W, a->K,
+                                                          a->table_cap),
+               "workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t HW = (int64_t)a->H * a->W;
+  const int ntiles = (int)((HW + kTilePix - 1) / kTilePix);
+  const int D = a->C + 2;
+
+  Carver cv(a->workspace);
+  int32_t *tile_cnt = cv.take<int32_t>((size_t)a->B * ntiles);
+  int32_t *tile_off = reinterpret_cast<int32_t *>(
+      cv.take<char>(align_up((size_t)a->B * ntiles, 64) * 4 + (size_t)a->B * 8));
+  KmeansScratch k;
+  carve_kmeans(cv, a->B, HW, D, a->K, &k);
+  int32_t *table = cv.take<int32_t>((size_t)a->table_cap * 2);
+  int32_t *scan_tmp = cv.take<int32_t>((size_t)a->table_cap / 2048 + 2);
+
+  const bool compact = a->labels != nullptr && a->has_ignore;
+  if (int rc = launch_count_valid(a->labels, a->B, HW, a->has_ignore, a->ignore_index,
+                                  tile_cnt, a->meta, s)) return rc;
+  if (int rc = launch_build_tables(compact ? tile_cnt : nullptr, a->B, HW, ntiles, tile_off,
+                                   k.t, k.max_chunks, a->meta, s)) return rc;
+  if (int rc = launch_prep(*a, compact ? tile_off : nullptr, k.t, k.klab, s)) return rc;
+  if (int rc = lloyd(a->out_embeddings_loc, D, a->K, a->B, a->iterations, k, a->meta, s)) return rc;
+  if (int rc = launch_relabel(*a, k.t, k.max_chunks, k.klab, table, scan_tmp, s)) return rc;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+size_t hsgk_kmeans_workspace_bytes(int64_t n, int d, int K) {
+  Carver cv(nullptr);
+  cv.take<hsgk_segkm_meta>(1);
+  KmeansScratch k;
+  carve_kmeans(cv, 1, n, d, K, &k);
+  return cv.off + 256;
+}
+
+int hsgk_kmeans_with_initial_labels(const float *x, int64_t n, int d, int64_t *labels_io,
+                                    int K, int iterations, void *workspace,
+                                    size_t workspace_bytes, hsgk_stream_t stream) {
+  HSGK_REQUIRE(n >= 0 && d >= 1 && K >= 1 && iterations >= 0, "bad shape");
+  HSGK_REQUIRE(workspace_bytes >= hsgk_kmeans_workspace_bytes(n, d, K), "workspace too small");
+  if (n == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Carver cv(workspace);
+  hsgk_segkm_meta *meta = cv.take<hsgk_segkm_meta>(1);
+  KmeansScratch k;
+  carve_kmeans(cv, 1, n, d, K, &k);
+  if (int rc = launch_flat_table(n, k.t, k.max_chunks, meta, s)) return rc;
+  if (int rc = launch_i64_to_i32(labels_io, n, k.klab, s)) return rc;
+  if (int rc = lloyd(x, d, K, 1, iterations, k, meta, s)) return rc;
+  return launch_i32_to_i64(k.klab, n, labels_io, s);
+}
+
+size_t hsgk_assign_workspace_bytes(int64_t n, int d, int K) {
+  return hsgk_kmeans_workspace_bytes(n, d, 1) + 0 * K;
+}
+
+int hsgk_find_nearest_prototypes(const float *x, int64_t n, int d, const float *prototypes,
+                                 int K, int64_t *labels_out, void *workspace,
+                                 size_t workspace_bytes, hsgk_stream_t stream) {
+  HSGK_REQUIRE(n >= 0 && d >= 1 && K >= 1, "bad shape");
+  HSGK_REQUIRE(workspace_bytes >= hsgk_assign_workspace_bytes(n, d, K), "workspace too small");
+  if (n == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Carver cv(workspace);
+  hsgk_segkm_meta *meta = cv.take<hsgk_segkm_meta>(1);
+  KmeansScratch k;
+  carve_kmeans(cv, 1, n, d, 1, &k);
+  if (int rc = launch_flat_table(n, k.t, k.max_chunks, meta, s)) return rc;
+  if (int rc = launch_assign(x, d, prototypes, K, k.t, k.max_chunks, k.klab, k.best, meta, s)) return rc;
+  return launch_i32_to_i64(k.klab, n, labels_out, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,98 @@
+// Internal helpers shared by the libhsgk translation units (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/hsgk.h"
+
+namespace hsgk {
+
+void set_error(const char *fmt, ...);
+
+#define HSGK_CHECK_HIP(expr)                                                   \
+  do {                                                                         \
+    hipError_t e__ = (expr);                                                   \
+    if (e__ != hipSuccess) {                                                   \
+      hsgk::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr,            \
+                      hipGetErrorString(e__));                                 \
+      return -2;                                                               \
+    }                                                                          \
+  } while (0)
+
+#define HSGK_REQUIRE(cond, msg)                                                \
+  do {                                                                         \
+    if (!(cond)) {                                                             \
+      hsgk::set_error("%s:%d requirement failed: %s (%s)", __FILE__, __LINE__, \
+                      #cond, msg);                                             \
+      return -1;                                                               \
+    }                                                                          \
+  } while (0)
+
+#define HSGK_LAUNCH_CHECK()                                                    \
+  do {                                                                         \
+    hipError_t e__ = hipGetLastError();                                        \
+    if (e__ != hipSuccess) {                                                   \
+      hsgk::set_error("%s:%d kernel launch -> %s", __FILE__, __LINE__,        \
+                      hipGetErrorString(e__));                                 \
+      return -3;                                                               \
+    }                                                                          \
+  } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Carves consecutive 256-byte aligned regions out of one workspace buffer.
+struct Carver {
+  char *base;
+  size_t off = 0;
+  explicit Carver(void *p) : base(static_cast<char *>(p)) {}
+  template <typename T> T *take(size_t count) {
+    T *p = reinterpret_cast<T *>(base + off);
+    off += align_up(count * sizeof(T), 256);
+    return p;
+  }
+};
+
+// Chunk table of one batch (device resident, built by build_tables_kernel).
+// A chunk is <= HSGK_CHUNK consecutive rows of ONE image.
+struct ChunkTable {
+  int64_t *img_row0;   // [B+1] first output row of each image
+  int32_t *img_chunk0; // [B+1] first chunk of each image
+  int64_t *chunk_row0; // [max_chunks]
+  int32_t *chunk_rows; // [max_chunks]
+  int32_t *chunk_img;  // [max_chunks]
+};
+
+constexpr int kTilePix = 64;      // prep kernel tile (pixels)
+constexpr int kAssignTile = 256;  // assign kernel tile (rows)
+
+// ---- kernels implemented across the .hip files (host launchers) -----------
+int launch_count_valid(const int64_t *labels, int B, int64_t HW, int has_ignore,
+                       int64_t ignore, int32_t *tile_cnt, hsgk_segkm_meta *meta,
+                       hipStream_t s);
+int launch_build_tables(const int32_t *tile_cnt, int B, int64_t HW, int ntiles,
+                        int32_t *tile_off, ChunkTable t, int max_chunks,
+                        hsgk_segkm_meta *meta, hipStream_t s);
+int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off,
+                const ChunkTable &t, int32_t *klab, hipStream_t s);
+int launch_normalize_rows(const float *x, int64_t n, int d, float eps, float *out,
+                          hipStream_t s);
+
+int launch_accumulate(const float *x, int d, const int32_t *klab,
+                      const ChunkTable &t, int max_chunks, int K, float *partial,
+                      const hsgk_segkm_meta *meta, hipStream_t s);
+int launch_finalize(const float *partial, int d, int K, int B, const ChunkTable &t,
+                    float eps, float *cent, hipStream_t s);
+int launch_assign(const float *x, int d, const float *cent, int K,
+                  const ChunkTable &t, int max_chunks, int32_t *klab, float *best,
+                  const hsgk_segkm_meta *meta, hipStream_t s);
+
+int launch_relabel(const hsgk_segkm_args &a, const ChunkTable &t, int max_chunks,
+                   const int32_t *klab, int32_t *table, int32_t *scan_tmp,
+                   hipStream_t s);
+int launch_i64_to_i32(const int64_t *in, int64_t n, int32_t *out, hipStream_t s);
+int launch_i32_to_i64(const int32_t *in, int64_t n, int64_t *out, hipStream_t s);
+int launch_flat_table(int64_t n, ChunkTable t, int max_chunks, hsgk_segkm_meta *meta,
+                      hipStream_t s);
+
+}  // namespace hsgk

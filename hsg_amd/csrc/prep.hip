@@ -1,0 +1,360 @@
+// prep.hip -- front half of segment_by_kmeans (reference
+// hsg/utils/segsort/common.py:306-365): NCHW -> normalised NHWC rows, append
+// the two location channels and re-normalise, drop ignore-labelled pixels
+// (stable compaction), and emit the grid-seed label of every kept pixel.
+//
+// Canonical arithmetic: every sum of squares is one fmaf
+// chain in ascending channel order starting from +0.0f; sqrtf and '/' are the
+// correctly rounded IEEE operations (hipcc default, no fast-math).
+#include "common.h"
+
+namespace hsgk {
+
+// --------------------------------------------------------------------------
+// Row L2 normalisation of an [n,d] matrix (normalize_embedding,
+// general/common.py:101-120).  One wave per row is pointless for a serial
+// chain, so one THREAD owns one row and waves stream 64 rows at a time; this
+// entry point serves small tables (prototypes, tests), not the pixel stream.
+__global__ void normalize_rows_kernel(const float *__restrict__ x, int64_t n, int d,
+                                      float eps, float *__restrict__ out) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const float *xr = x + r * d;
+  float ss = 0.0f;
+  for (int i = 0; i < d; ++i) ss = fmaf(xr[i], xr[i], ss);
+  float nrm = sqrtf(ss);
+  if (!(nrm >= eps)) nrm = eps;
+  float *yr = out + r * d;
+  for (int i = 0; i < d; ++i) yr[i] = xr[i] / nrm;
+}
+
+int launch_normalize_rows(const float *x, int64_t n, int d, float eps, float *out,
+                          hipStream_t s) {
+  if (n <= 0) return 0;
+  int64_t blocks = (n + 63) / 64;
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)blocks), dim3(64), 0, s, x,
+                     n, d, eps, out);
+  HSGK_LAUNCH_CHECK();
+  return 0;
+}
+
+// --------------------------------------------------------------------------
+// Per 64-pixel tile: number of kept pixels (+ min/max of kept labels).
+__global__ void count_valid_kernel(const int64_t *__restrict__ labels, int64_t HW,
+                                   int ntiles, int has_ignore, int64_t ignore,
+                                   int32_t *__restrict__ tile_cnt,
+                                   hsgk_segkm_meta *meta) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  if (t >= ntiles) return;
+  const int64_t pix = (int64_t)t * kTilePix + lane;
+  bool keep = false;
+  int64_t lab = 0;
+  if (pix < HW) {
+    lab = labels[(int64_t)b * HW + pix];
+    keep = !(has_ignore && lab == ignore);
+  }
+  unsigned long long m = __ballot(keep);
+  int64_t lo = keep ? lab : INT64_MAX;
+  int64_t hi = keep ? lab : INT64_MIN;
+  for (int off = 32; off > 0; off >>= 1) {
+    int64_t olo = __shfl_xor(lo, off);
+    int64_t ohi = __shfl_xor(hi, off);
+    lo = olo < lo ? olo : lo;
+    hi = ohi > hi ? ohi : hi;
+  }
+  if (lane == 0) {
+    tile_cnt[(int64_t)b * ntiles + t] = __popcll(m);
+    if (m) {
+      atomicMin(reinterpret_cast<long long *>(&meta->label_min), (long long)lo);
+      atomicMax(reinterpret_cast<long long *>(&meta->label_max), (long long)hi);
+    }
+  }
+}
+
+__global__ void init_meta_kernel(hsgk_segkm_meta *meta, int has_labels) {
+  meta->n_rows = 0;
+  meta->n_segments = 0;
+  meta->label_min = has_labels ? INT64_MAX : 0;
+  meta->label_max = has_labels ? INT64_MIN : 0;
+  meta->n_chunks = 0;
+  meta->error = 0;
+  meta->relabel_mode = 0;
+  meta->relabel_L = 1;
+}
+
+int launch_count_valid(const int64_t *labels, int B, int64_t HW, int has_ignore,
+                       int64_t ignore, int32_t *tile_cnt, hsgk_segkm_meta *meta,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(init_meta_kernel, dim3(1), dim3(1), 0, s, meta, labels != nullptr);
+  HSGK_LAUNCH_CHECK();
+  if (!labels) return 0;
+  int ntiles = (int)((HW + kTilePix - 1) / kTilePix);
+  dim3 grid((ntiles + 3) / 4, B);
+  hipLaunchKernelGGL(count_valid_kernel, grid, dim3(256), 0, s, labels, HW, ntiles,
+                     has_ignore, ignore, tile_cnt, meta);
+  HSGK_LAUNCH_CHECK();
+  return 0;
+}
+
+// --------------------------------------------------------------------------
+// Exclusive prefix of the tile counts inside each image (one WG per image).
+__global__ void scan_tiles_kernel(const int32_t *__restrict__ tile_cnt, int ntiles,
+                                  int32_t *__restrict__ tile_off,
+                                  int64_t *__restrict__ img_cnt) {
+  __shared__ int32_t wsum[4];
+  __shared__ int32_t carry;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < ntiles; t0 += 256) {
+    int t = t0 + tid;
+    int v = t < ntiles ? tile_cnt[(int64_t)b * ntiles + t] : 0;
+    int incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      int o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int base = carry;
+    for (int i = 0; i < w; ++i) base += wsum[i];
+    if (t < ntiles) tile_off[(int64_t)b * ntiles + t] = base + incl - v;
+    __syncthreads();
+    if (tid == 255) carry = base + incl;
+    __syncthreads();
+  }
+  if (tid == 0) img_cnt[b] = carry;
+}
+
+// Image row offsets + chunk table.  img_cnt == nullptr -> every image keeps HW.
+__global__ void build_tables_kernel(const int64_t *__restrict__ img_cnt, int64_t HW,
+                                    int B, ChunkTable t, int max_chunks,
+                                    hsgk_segkm_meta *meta) {
+  if (threadIdx.x == 0) {
+    int64_t row = 0;
+    int32_t ch = 0;
+    for (int b = 0; b < B; ++b) {
+      int64_t c = img_cnt ? img_cnt[b] : HW;
+      t.img_row0[b] = row;
+      t.img_chunk0[b] = ch;
+      row += c;
+      ch += (int32_t)((c + HSGK_CHUNK - 1) / HSGK_CHUNK);
+    }
+    t.img_row0[B] = row;
+    t.img_chunk0[B] = ch;
+    meta->n_rows = row;
+    meta->n_chunks = ch;
+    if (row == 0) { meta->label_min = 0; meta->label_max = 0; }
+    if (meta->label_min < 0) meta->error = 1;
+  }
+  __syncthreads();
+  for (int b = 0; b < B; ++b) {
+    const int64_t r0 = t.img_row0[b];
+    const int64_t cnt = t.img_row0[b + 1] - r0;
+    const int32_t c0 = t.img_chunk0[b];
+    const int32_t nc = t.img_chunk0[b + 1] - c0;
+    for (int c = threadIdx.x; c < nc; c += blockDim.x) {
+      if (c0 + c >= max_chunks) continue;
+      int64_t off = (int64_t)c * HSGK_CHUNK;
+      int64_t left = cnt - off;
+      t.chunk_row0[c0 + c] = r0 + off;
+      t.chunk_rows[c0 + c] = (int32_t)(left < HSGK_CHUNK ? left : HSGK_CHUNK);
+      t.chunk_img[c0 + c] = b;
+    }
+  }
+}
+
+int launch_build_tables(const int32_t *tile_cnt, int B, int64_t HW, int ntiles,
+                        int32_t *tile_off, ChunkTable t, int max_chunks,
+                        hsgk_segkm_meta *meta, hipStream_t s) {
+  // img counts are parked in chunk_row0's tail?  No: reuse img_row0 memory is
+  // unsafe (read-after-write in the same kernel), so the counts live in the
+  // first B entries of chunk_row0 ONLY until build_tables_kernel has read
+  // them into registers -- instead we keep them separate: tile_off has
+  // B*ntiles int32 entries followed by B int64 counts (see workspace carve).
+  int64_t *img_cnt = nullptr;
+  if (tile_cnt) {
+    img_cnt = reinterpret_cast<int64_t *>(tile_off + align_up((size_t)B * ntiles, 64));
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(B), dim3(256), 0, s, tile_cnt, ntiles,
+                       tile_off, img_cnt);
+    HSGK_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(build_tables_kernel, dim3(1), dim3(256), 0, s, img_cnt, HW, B, t,
+                     max_chunks, meta);
+  HSGK_LAUNCH_CHECK();
+  return 0;
+}
+
+// Single "image" of n rows (stand-alone kmeans / assign entry points).
+__global__ void flat_table_kernel(int64_t n, ChunkTable t, int max_chunks,
+                                  hsgk_segkm_meta *meta) {
+  const int32_t nc = (int32_t)((n + HSGK_CHUNK - 1) / HSGK_CHUNK);
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    t.img_row0[0] = 0;
+    t.img_row0[1] = n;
+    t.img_chunk0[0] = 0;
+    t.img_chunk0[1] = nc;
+    meta->n_rows = n;
+    meta->n_chunks = nc;
+    meta->error = 0;
+  }
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < nc && c < max_chunks;
+       c += gridDim.x * blockDim.x) {
+    int64_t off = (int64_t)c * HSGK_CHUNK;
+    int64_t left = n - off;
+    t.chunk_row0[c] = off;
+    t.chunk_rows[c] = (int32_t)(left < HSGK_CHUNK ? left : HSGK_CHUNK);
+    t.chunk_img[c] = 0;
+  }
+}
+
+int launch_flat_table(int64_t n, ChunkTable t, int max_chunks, hsgk_segkm_meta *meta,
+                      hipStream_t s) {
+  int blocks = (max_chunks + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(flat_table_kernel, dim3(blocks), dim3(256), 0, s, n, t, max_chunks,
+                     meta);
+  HSGK_LAUNCH_CHECK();
+  return 0;
+}
+
+// --------------------------------------------------------------------------
+// prep kernel: one workgroup (256 threads) per 64-pixel tile of one image.
+//
+// LDS holds the tile pixel-major, tile[j][c] at j*S + c with S = C|1 (odd
+// stride: 32 consecutive pixels hit 32 distinct banks both when lanes walk
+// pixels (load, chains) and when lanes walk channels (store)).
+//
+//   phase 1  wave w loads channels w, w+4, ... : lanes = pixels, 256 B per
+//            wave-instruction straight out of the NCHW plane.
+//   phase 2a thread j<64 runs the canonical sum-of-squares chain of pixel j.
+//   phase 2b all threads: e = x / norm in place.
+//   phase 2c thread j<64: second chain over (e_0..e_{C-1}, ly, lx).
+//   phase 3  wave w writes rows of pixels w, w+4, ... : lanes = channels.
+__global__ __launch_bounds__(256) void prep_kernel(
+    const float *__restrict__ in, int C, int64_t HW, int ntiles,
+    const float *__restrict__ loc, int64_t loc_sb, const int64_t *__restrict__ labels,
+    int has_ignore, int64_t ignore, const int32_t *__restrict__ tile_off,
+    const int64_t *__restrict__ img_row0, const int32_t *__restrict__ seed_map,
+    float eps, float *__restrict__ emb, float *__restrict__ emb_loc,
+    int64_t *__restrict__ labels_out, int32_t *__restrict__ klab) {
+  extern __shared__ float lds[];
+  const int S = C | 1;
+  float *tile = lds;                       // [64][S]
+  float *nrm1 = lds + 64 * S;              // [64]
+  float *nrm2 = nrm1 + 64;                 // [64]
+  float *locv = nrm2 + 64;                 // [64][2]
+  int64_t *rowi = reinterpret_cast<int64_t *>(locv + 128);  // [64] (8B aligned: see launcher)
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int t = blockIdx.x, b = blockIdx.y;
+  const int64_t p0 = (int64_t)t * kTilePix;
+  const int D = C + 2;
+
+  if (w == 0) {
+    const int64_t pix = p0 + lane;
+    bool keep = false;
+    int64_t lab = 0;
+    if (pix < HW) {
+      lab = labels ? labels[(int64_t)b * HW + pix] : 0;
+      keep = !(has_ignore && lab == ignore);
+    }
+    unsigned long long m = __ballot(keep);
+    int rank = __popcll(m & ((1ull << lane) - 1ull));
+    int64_t base = img_row0[b] + (tile_off ? (int64_t)tile_off[(int64_t)b * ntiles + t] : p0);
+    int64_t row = keep ? base + rank : -1;
+    rowi[lane] = row;
+    if (keep) {
+      labels_out[row] = lab;
+      klab[row] = seed_map[pix];
+      locv[2 * lane + 0] = loc[(int64_t)b * loc_sb + pix * 2 + 0];
+      locv[2 * lane + 1] = loc[(int64_t)b * loc_sb + pix * 2 + 1];
+    }
+    if (lane == 0) nrm1[0] = m ? 1.0f : 0.0f;   // "tile has work" flag, overwritten in 2a
+  }
+  __syncthreads();
+  if (nrm1[0] == 0.0f) return;
+  __syncthreads();
+
+  // phase 1
+  {
+    const int64_t pix = p0 + lane;
+    const bool ok = pix < HW;
+    const float *src = in + (int64_t)b * C * HW + pix;
+    for (int c = w; c < C; c += 4) {
+      float v = ok ? src[(int64_t)c * HW] : 0.0f;
+      tile[lane * S + c] = v;
+    }
+  }
+  __syncthreads();
+  // phase 2a
+  if (w == 0) {
+    const float *r = tile + lane * S;
+    float ss = 0.0f;
+    for (int c = 0; c < C; ++c) ss = fmaf(r[c], r[c], ss);
+    float n1 = sqrtf(ss);
+    if (!(n1 >= eps)) n1 = eps;
+    nrm1[lane] = n1;
+  }
+  __syncthreads();
+  // phase 2b
+  for (int idx = tid; idx < 64 * C; idx += 256) {
+    int c = idx >> 6, j = idx & 63;
+    tile[j * S + c] = tile[j * S + c] / nrm1[j];
+  }
+  __syncthreads();
+  // phase 2c
+  if (w == 0) {
+    const float *r = tile + lane * S;
+    float ss = 0.0f;
+    for (int c = 0; c < C; ++c) ss = fmaf(r[c], r[c], ss);
+    float ly = locv[2 * lane], lx = locv[2 * lane + 1];
+    ss = fmaf(ly, ly, ss);
+    ss = fmaf(lx, lx, ss);
+    float n2 = sqrtf(ss);
+    if (!(n2 >= eps)) n2 = eps;
+    nrm2[lane] = n2;
+  }
+  __syncthreads();
+  // phase 3
+  for (int j = w; j < 64; j += 4) {
+    const int64_t row = rowi[j];
+    if (row < 0) continue;
+    const float n2 = nrm2[j];
+    const float *r = tile + j * S;
+    float *eo = emb + row * C;
+    float *lo = emb_loc + row * D;
+    for (int c = lane; c < C; c += 64) {
+      float e = r[c];
+      eo[c] = e;
+      lo[c] = e / n2;
+    }
+    if (lane < 2) lo[C + lane] = locv[2 * j + lane] / n2;
+  }
+}
+
+int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTable &t,
+                int32_t *klab, hipStream_t s) {
+  const int64_t HW = (int64_t)a.H * a.W;
+  const int ntiles = (int)((HW + kTilePix - 1) / kTilePix);
+  const int S = a.C | 1;
+  size_t floats = (size_t)64 * S + 64 + 64 + 128;
+  floats = (floats + 1) & ~(size_t)1;     // keep the int64 row table 8-byte aligned
+  size_t lds = floats * 4 + 64 * 8;
+  HSGK_REQUIRE(lds <= 160 * 1024, "embedding dimension too large for the prep tile");
+  HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(prep_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+  dim3 grid(ntiles, a.B);
+  hipLaunchKernelGGL(prep_kernel, grid, dim3(256), lds, s, a.embeddings, a.C, HW, ntiles,
+                     a.loc, a.loc_batch_stride, a.labels, a.has_ignore, a.ignore_index,
+                     tile_off, t.img_row0, a.seed_map, HSGK_EPS, a.out_embeddings,
+                     a.out_embeddings_loc, a.out_labels, klab);
+  HSGK_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace hsgk

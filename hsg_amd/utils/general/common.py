@@ -1,0 +1,37 @@
+"""Drop-in for `hsg.utils.general.common` (hot-path members only).
+
+Same names, argument meaning and return conventions as the reference
+(hsg/utils/general/common.py); the arithmetic runs in libhsgk's gfx950
+kernels.  Tensors must live on a ROCm device: like the reference's multi-GPU
+code path, CPU tensors are not a supported device here.
+"""
+import ctypes
+
+import torch
+
+from hsg_amd import _lib
+
+
+def _require_gpu(t, name):
+  if not t.is_cuda:
+    raise _lib.HsgkError('%s must be a ROCm device tensor (got %s); hsg_amd has '
+                         'no CPU path' % (name, t.device))
+
+
+def normalize_embedding(embeddings, eps=1e-12):
+  """L2-normalises the last dimension (reference general/common.py:101-120).
+
+  x / where(||x|| >= eps, ||x||, eps); forward only (the differentiable use
+  inside segment_by_kmeans has its own fused kernels).
+  """
+  _require_gpu(embeddings, 'embeddings')
+  if embeddings.dtype != torch.float32:
+    raise TypeError('embeddings must be float32')
+  x = embeddings.contiguous()
+  out = torch.empty_like(x)
+  d = x.shape[-1]
+  n = x.numel() // d if d else 0
+  with torch.cuda.device(x.device):
+    _lib.check(_lib.lib().hsgk_normalize_rows(
+        x.data_ptr(), n, d, ctypes.c_float(eps), out.data_ptr(), _lib.stream_ptr()))
+  return out

@@ -1,0 +1,210 @@
+"""Drop-in for `hsg.utils.segsort.common` on MI355X.
+
+Mirrors the reference module's call surface (hsg/utils/segsort/common.py):
+`segment_by_kmeans`, `kmeans_with_initial_labels`, `find_nearest_prototypes`,
+`calculate_prototypes_from_labels`, `prepare_prototype_labels`,
+`initialize_cluster_labels`, `generate_location_features`.  The arithmetic is
+done by libhsgk (hand-written gfx950 kernels, C ABI in include/hsgk.h); this
+file only validates arguments, allocates outputs/workspace on the caller's
+device and stream, and shapes the results like the reference does.
+
+Thread-safe: no global mutable state apart from two read-only caches of tiny
+per-(H,W) tables; every call allocates its own workspace and launches on the
+calling thread's current device/stream (the reference's DataParallel shell
+calls these from one Python thread per GPU).
+"""
+import ctypes
+import threading
+
+import torch
+
+from hsg_amd import _lib
+from hsg_amd.utils.general import common as common_utils
+
+_cache_lock = threading.Lock()
+_seed_cache = {}
+_loc_cache = {}
+_TABLE_CAP_MAX = 1 << 24
+
+
+def _require_gpu(t, name):
+  if not t.is_cuda:
+    raise _lib.HsgkError('%s must be a ROCm device tensor (got %s); hsg_amd has '
+                         'no CPU path' % (name, t.device))
+
+
+def initialize_cluster_labels(num_clusters, img_dimensions, device):
+  """Uniform grid seed labels (reference common.py:129-153).
+
+  The float32 `linspace(...).round_()` is evaluated by torch on the host --
+  its bit pattern is part of the reference's behaviour -- and the tiny [H,W]
+  result is moved to `device`.
+  """
+  y = torch.linspace(0, num_clusters[0] - 1, img_dimensions[0]).round_().long()
+  x = torch.linspace(0, num_clusters[1] - 1, img_dimensions[1]).round_().long()
+  labels = y.view(-1, 1) + (y.max() + 1) * x.view(1, -1)
+  return labels.to(device)
+
+
+def generate_location_features(img_dimensions, device, feature_type='int'):
+  """[H,W,2] (y,x) location features (reference common.py:156-189)."""
+  if feature_type == 'int':
+    y = torch.arange(img_dimensions[0])
+    x = torch.arange(img_dimensions[1])
+  elif feature_type == 'float':
+    y = torch.linspace(0, 1, img_dimensions[0])
+    x = torch.linspace(0, 1, img_dimensions[1])
+  else:
+    raise ValueError('Type of location features should be either int or float.')
+  yy, xx = torch.meshgrid(y, x, indexing='ij')
+  return torch.stack([yy, xx], dim=2).to(device)
+
+
+def _seed_map(num_clusters, H, W, device):
+  """Dense int32 seed label per pixel + cluster count (common.py:320-345)."""
+  key = (int(num_clusters[0]), int(num_clusters[1]), H, W, str(device))
+  with _cache_lock:
+    hit = _seed_cache.get(key)
+  if hit is None:
+    grid = initialize_cluster_labels(num_clusters, (H, W), 'cpu').view(-1)
+    _, dense = torch.unique(grid, return_inverse=True)
+    hit = (dense.to(torch.int32).to(device), int(dense.max()) + 1)
+    with _cache_lock:
+      _seed_cache[key] = hit
+  return hit
+
+
+def _default_loc(H, W, device):
+  key = (H, W, str(device))
+  with _cache_lock:
+    hit = _loc_cache.get(key)
+  if hit is None:
+    loc = generate_location_features((H, W), 'cpu', 'float')
+    loc -= 0.5
+    hit = loc.contiguous().to(device)
+    with _cache_lock:
+      _loc_cache[key] = hit
+  return hit
+
+
+def segment_by_kmeans(embeddings,
+                      labels=None,
+                      num_clusters=[5, 5],
+                      cluster_indices=None,
+                      local_features=None,
+                      ignore_index=None,
+                      iterations=10):
+  """Per-image spherical k-means over pixel embeddings.
+
+  Contract of reference common.py:270-408.  `embeddings` is [B,C,H,W] float32
+  on a ROCm device.  Returns (embeddings [N,C], embeddings_with_loc [N,C+2],
+  labels [N], cluster_indices [N], batch_indices [N]) over the N pixels whose
+  label differs from `ignore_index`, image-major, row-major inside an image.
+  """
+  _require_gpu(embeddings, 'embeddings')
+  if embeddings.dim() != 4:
+    raise ValueError('embeddings must be [batch, channels, height, width]')
+  if embeddings.dtype != torch.float32:
+    raise TypeError('embeddings must be float32')
+  if cluster_indices is not None:
+    raise NotImplementedError(
+        'explicit cluster_indices are not supported (no caller in the reference '
+        'passes them); seeds come from num_clusters')
+  dev = embeddings.device
+  B, C, H, W = embeddings.shape
+  x = embeddings.detach().contiguous()
+  seed_map, K = _seed_map(num_clusters, H, W, dev)
+
+  if local_features is None:
+    loc, loc_sb = _default_loc(H, W, dev), 0
+  else:
+    _require_gpu(local_features, 'local_features')
+    lf = local_features.detach().to(torch.float32)
+    if lf.dim() == 4 and lf.stride(0) == 0:
+      lf = lf[0]
+    loc = lf.contiguous()
+    loc_sb = 0 if loc.dim() == 3 else H * W * 2
+    if tuple(loc.shape[-3:]) != (H, W, 2):
+      raise ValueError('local_features must be [batch, height, width, 2]')
+
+  lab = None
+  if labels is not None:
+    _require_gpu(labels, 'labels')
+    lab = labels.detach().to(torch.int64).contiguous()
+    if tuple(lab.shape) != (B, H, W):
+      raise ValueError('labels must be [batch, height, width]')
+  elif ignore_index is not None:
+    lab = torch.zeros((B, H, W), dtype=torch.int64, device=dev)   # common.py:326-329
+  has_ignore = ignore_index is not None
+  ign = int(ignore_index) if has_ignore else 0
+
+  n_max = B * H * W
+  table_cap = B * K if lab is None else max(B * K, min(B * K * 4096, _TABLE_CAP_MAX))
+  L = _lib.lib()
+  with torch.cuda.device(dev):
+    out_emb = torch.empty((n_max, C), dtype=torch.float32, device=dev)
+    out_loc = torch.empty((n_max, C + 2), dtype=torch.float32, device=dev)
+    out_lab = torch.empty((n_max,), dtype=torch.int64, device=dev)
+    out_cluster = torch.empty((n_max,), dtype=torch.int64, device=dev)
+    out_batch = torch.empty((n_max,), dtype=torch.int64, device=dev)
+    meta = torch.empty((8,), dtype=torch.int64, device=dev)
+    ws_bytes = L.hsgk_segment_by_kmeans_workspace_bytes(B, C, H, W, K, table_cap)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    args = _lib.SegkmArgs(
+        embeddings=x.data_ptr(), labels=lab.data_ptr() if lab is not None else None,
+        loc=loc.data_ptr(), loc_batch_stride=loc_sb, seed_map=seed_map.data_ptr(),
+        B=B, C=C, H=H, W=W, K=K, iterations=int(iterations), has_ignore=int(has_ignore),
+        ignore_index=ign, batch_offset=B * (dev.index or 0), table_cap=table_cap,
+        out_embeddings=out_emb.data_ptr(), out_embeddings_loc=out_loc.data_ptr(),
+        out_labels=out_lab.data_ptr(), out_cluster=out_cluster.data_ptr(),
+        out_batch=out_batch.data_ptr(), meta=meta.data_ptr(),
+        workspace=ws.data_ptr(), workspace_bytes=ws_bytes)
+    _lib.check(L.hsgk_segment_by_kmeans(ctypes.byref(args), _lib.stream_ptr()))
+    m = meta.cpu().tolist()          # the operator's single host sync
+  n, err = m[0], m[5]
+  if err == 1:
+    raise ValueError('segment_by_kmeans: negative labels are not supported')
+  if err == 2:
+    raise _lib.HsgkError('segment_by_kmeans: label range too large for the relabel '
+                         'table (label_max=%d)' % m[3])
+  return out_emb[:n], out_loc[:n], out_lab[:n], out_cluster[:n], out_batch[:n]
+
+
+def kmeans_with_initial_labels(embeddings, initial_labels, max_label=None, iterations=10):
+  """Lloyd iterations from given labels (reference common.py:67-97)."""
+  _require_gpu(embeddings, 'embeddings')
+  x = embeddings.detach().to(torch.float32).contiguous()
+  if x.dim() != 2:
+    raise ValueError('embeddings must be [num_pixels, embedding_dim]')
+  lab = initial_labels.detach().to(torch.int64).contiguous().clone()
+  n, d = x.shape
+  if n == 0:
+    return lab
+  K = int(initial_labels.max()) + 1 if max_label is None else int(max_label)
+  L = _lib.lib()
+  with torch.cuda.device(x.device):
+    ws_bytes = L.hsgk_kmeans_workspace_bytes(n, d, K)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+    _lib.check(L.hsgk_kmeans_with_initial_labels(
+        x.data_ptr(), n, d, lab.data_ptr(), K, int(iterations), ws.data_ptr(), ws_bytes,
+        _lib.stream_ptr()))
+  return lab
+
+
+def find_nearest_prototypes(embeddings, prototypes):
+  """argmax_k <embedding, prototype_k> (reference common.py:44-64)."""
+  _require_gpu(embeddings, 'embeddings')
+  p = prototypes.detach().to(torch.float32).contiguous()
+  x = embeddings.detach().to(torch.float32).contiguous().view(-1, p.shape[-1])
+  n, d = x.shape
+  out = torch.empty((n,), dtype=torch.int64, device=x.device)
+  if n == 0:
+    return out
+  L = _lib.lib()
+  with torch.cuda.device(x.device):
+    ws_bytes = L.hsgk_assign_workspace_bytes(n, d, p.shape[0])
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+    _lib.check(L.hsgk_find_nearest_prototypes(
+        x.data_ptr(), n, d, p.data_ptr(), p.shape[0], out.data_ptr(), ws.data_ptr(),
+        ws_bytes, _lib.stream_ptr()))
+  return out

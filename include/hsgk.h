@@ -1,0 +1,120 @@
+/*
+ * hsgk.h -- C ABI of libhsgk.so: MI355X (gfx950) kernels for the HSG
+ * dense-pixel clustering / pixel-contrast hot path.
+ *
+ * The reference (twke18/HSG) is pure Python on torch tensors, so "the FFI a
+ * maintainer would bind" is a ctypes stub.  Every entry
+ * point below names the reference callable it replaces (paths relative to the
+ * reference root).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in _host;
+ *   - float = IEEE binary32, labels/indices at the boundary are int64 (torch
+ *     `long`), internal working labels are int32;
+ *   - every function enqueues work on `stream` (a hipStream_t passed as
+ *     void*) and returns immediately: no allocation, no synchronisation;
+ *     scratch comes from the caller (`*_workspace_bytes`);
+ *   - return value 0 = ok, negative = error; hsgk_last_error() gives the
+ *     thread-local message.  Errors detected on the device (label range too
+ *     large for the relabel table, negative labels) are reported through the
+ *     `meta` block, see hsgk_segkm_meta.
+ *   - floating-point summation orders are fixed ("canonical order", DESIGN.md
+ *     section 4) so results are run-to-run deterministic and bit-identical to
+ *     oracle/hsg_oracle.c.
+ */
+#ifndef HSGK_H_
+#define HSGK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HSGK_VERSION 100
+#define HSGK_CHUNK 2048          /* rows per segment-sum chunk (order C2)      */
+#define HSGK_EPS 1e-12f          /* normalize_embedding eps (general/common.py:101) */
+
+typedef void *hsgk_stream_t;     /* hipStream_t */
+
+#if defined(__GNUC__)
+#define HSGK_API __attribute__((visibility("default")))
+#else
+#define HSGK_API
+#endif
+
+HSGK_API int hsgk_version(void);
+HSGK_API const char *hsgk_last_error(void);
+
+/* ---- device-side result block of hsgk_segment_by_kmeans ------------------ */
+typedef struct hsgk_segkm_meta {
+  int64_t n_rows;        /* N: kept pixels over the whole batch                */
+  int64_t n_segments;    /* number of distinct (image, cluster, label) ids     */
+  int64_t label_min;     /* min / max of kept labels (0 / 0 when no labels)    */
+  int64_t label_max;
+  int64_t n_chunks;      /* chunks actually used                               */
+  int64_t error;         /* 0 ok; 1 negative label; 2 relabel table too small  */
+  int64_t relabel_mode;  /* 0 direct table, 1 label-ranked table               */
+  int64_t relabel_L;     /* effective label extent used by the table           */
+} hsgk_segkm_meta;
+
+/* ---- hsg/utils/general/common.py:101-120 normalize_embedding ------------- */
+/* rows [n,d] -> out [n,d] (may alias x).                                      */
+HSGK_API int hsgk_normalize_rows(const float *x, int64_t n, int d, float eps, float *out,
+                        hsgk_stream_t stream);
+
+/* ---- hsg/utils/segsort/common.py:270-408 segment_by_kmeans ---------------- */
+typedef struct hsgk_segkm_args {
+  /* inputs */
+  const float *embeddings;     /* [B,C,H,W] f32 (NCHW, contiguous)            */
+  const int64_t *labels;       /* [B,H,W] i64 or NULL (-> all zero)           */
+  const float *loc;            /* location features, element (b,p,i) at
+                                  loc[b*loc_batch_stride + p*2 + i]           */
+  int64_t loc_batch_stride;    /* 0 when one [H,W,2] map is shared            */
+  const int32_t *seed_map;     /* [H*W] i32: dense grid-seed label per pixel
+                                  (common.py:320-323,341-345)                 */
+  int32_t B, C, H, W;
+  int32_t K;                   /* number of seed clusters (max seed + 1)      */
+  int32_t iterations;
+  int32_t has_ignore;          /* ignore_index is not None                    */
+  int64_t ignore_index;
+  int64_t batch_offset;        /* B * gpu_id (common.py:375-377)              */
+  int64_t table_cap;           /* entries available for the relabel table     */
+  /* outputs (sized for the worst case B*H*W rows; first meta->n_rows valid)  */
+  float *out_embeddings;       /* [N,C]                                       */
+  float *out_embeddings_loc;   /* [N,C+2]                                     */
+  int64_t *out_labels;         /* [N]                                         */
+  int64_t *out_cluster;        /* [N] dense segment ids                       */
+  int64_t *out_batch;          /* [N]                                         */
+  hsgk_segkm_meta *meta;       /* device                                      */
+  /* scratch */
+  void *workspace;
+  size_t workspace_bytes;
+} hsgk_segkm_args;
+
+HSGK_API size_t hsgk_segment_by_kmeans_workspace_bytes(int B, int C, int H, int W, int K,
+                                              int64_t table_cap);
+HSGK_API int hsgk_segment_by_kmeans(const hsgk_segkm_args *args, hsgk_stream_t stream);
+
+/* ---- hsg/utils/segsort/common.py:67-97 kmeans_with_initial_labels --------- */
+/* One row set x[n,d]; labels_io holds the initial labels on entry (int64,
+ * values in [0,K)) and the final labels on return.                            */
+HSGK_API size_t hsgk_kmeans_workspace_bytes(int64_t n, int d, int K);
+HSGK_API int hsgk_kmeans_with_initial_labels(const float *x, int64_t n, int d,
+                                    int64_t *labels_io, int K, int iterations,
+                                    void *workspace, size_t workspace_bytes,
+                                    hsgk_stream_t stream);
+
+/* ---- hsg/utils/segsort/common.py:44-64 find_nearest_prototypes ------------ */
+/* labels_out[n] = argmax_k <x_r, proto_k>, first index on ties.               */
+HSGK_API size_t hsgk_assign_workspace_bytes(int64_t n, int d, int K);
+HSGK_API int hsgk_find_nearest_prototypes(const float *x, int64_t n, int d,
+                                 const float *prototypes, int K,
+                                 int64_t *labels_out, void *workspace,
+                                 size_t workspace_bytes, hsgk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSGK_H_ */

@@ -1,0 +1,116 @@
+"""GPU parity: libhsgk (through the hsg_amd drop-in surface -> C ABI) against
+(1) the golden vectors captured from the reference and (2) the CPU oracle on
+the same seeded inputs.  Integer outputs bit-exact; float outputs bit-exact
+against the oracle (shared canonical arithmetic) and <= 2e-6 against the
+reference's own floats."""
+import numpy as np
+import pytest
+
+from tests import util
+from hsg_amd.utils import synth
+
+pytestmark = pytest.mark.gpu
+FTOL = 2e-6
+
+
+@pytest.fixture(scope='module')
+def dev():
+  import torch
+  assert torch.cuda.is_available(), 'needs a ROCm GPU'
+  return torch.device('cuda:0')
+
+
+def _run_segkm(dev, x, lab, grid, ign, iters, loc=None):
+  import torch
+  from hsg_amd.utils.segsort import common as sc
+  lf = None
+  if loc is not None:
+    B = x.shape[0]
+    lf = torch.from_numpy(loc).to(dev).unsqueeze(0).expand(B, -1, -1, -1)
+  out = sc.segment_by_kmeans(
+      torch.from_numpy(x).to(dev), None if lab is None else torch.from_numpy(lab).to(dev),
+      list(grid), local_features=lf, ignore_index=ign, iterations=iters)
+  return [t.cpu().numpy() for t in out]
+
+
+@pytest.mark.parametrize('case', util.F4_CASES)
+def test_segment_by_kmeans_vs_golden_and_oracle(dev, oracle, case):
+  g = util.load('f4_segkm_' + case)
+  x, lab, grid, ign, iters, loc = util.f4_inputs(g)
+  emb, emb_loc, labels, cluster, batch = _run_segkm(dev, x, lab, grid, ign, iters)
+  # (1) reference golden vectors
+  assert np.array_equal(labels, g['labels'].astype(np.int64))
+  assert np.array_equal(batch, g['batch'].astype(np.int64))
+  assert np.array_equal(cluster, g['cluster'].astype(np.int64))
+  assert np.abs(emb[::util.ROW_STRIDE] - g['emb_rows']).max() <= FTOL
+  assert np.abs(emb_loc[::util.ROW_STRIDE] - g['emb_loc_rows']).max() <= FTOL
+  # (2) oracle, bit-exact including floats
+  ref = oracle.segment_by_kmeans(x, lab, grid, loc, ign, iters)
+  for name, a, b in zip(('emb', 'emb_loc', 'labels', 'cluster', 'batch'),
+                        (emb, emb_loc, labels, cluster, batch), ref):
+    assert a.shape == b.shape, name
+    assert np.array_equal(a, b), '%s: %d mismatching elements' % (name, int((a != b).sum()))
+
+
+def test_explicit_local_features_match_default(dev):
+  g = util.load('f4_segkm_ragged')
+  x, lab, grid, ign, iters, loc = util.f4_inputs(g)
+  a = _run_segkm(dev, x, lab, grid, ign, iters)
+  b = _run_segkm(dev, x, lab, grid, ign, iters, loc=loc)
+  for u, v in zip(a, b):
+    assert np.array_equal(u, v)
+
+
+@pytest.mark.parametrize('case', util.F3_CASES)
+def test_kmeans_with_initial_labels(dev, oracle, case):
+  import torch
+  from hsg_amd.utils.segsort import common as sc
+  g = util.load('f3_kmeans_' + case)
+  shape = tuple(int(v) for v in g['shape'])
+  grid = tuple(int(v) for v in g['grid'])
+  x = synth.embeddings_nchw(int(g['seed']), shape, str(g['flavour']))
+  B, C, H, W = shape
+  loc = util.loc_from_lin(g['ylin'], g['xlin'])
+  _, emb_loc, _, _, _ = oracle.segment_by_kmeans(x, None, grid, loc, None, 0)
+  seeds = oracle.dense_relabel(oracle.initialize_cluster_labels(grid, (H, W)).reshape(-1))
+  K = int(g['K'])
+  for b in range(B):
+    rows = np.ascontiguousarray(emb_loc[b * H * W:(b + 1) * H * W])
+    for it in (1, 2, 10, 15):
+      lab = sc.kmeans_with_initial_labels(
+          torch.from_numpy(rows).to(dev), torch.from_numpy(seeds).to(dev), K, it)
+      lab = lab.cpu().numpy()
+      assert np.array_equal(lab, g['b%d_it%d' % (b, it)].astype(np.int64)), (case, b, it)
+
+
+@pytest.mark.parametrize('n,d,K', [(1, 4, 1), (63, 7, 3), (2049, 34, 8), (5000, 258, 64),
+                                   (3000, 130, 100), (777, 66, 256)])
+def test_find_nearest_prototypes_vs_oracle(dev, oracle, n, d, K):
+  import torch
+  from hsg_amd.utils.segsort import common as sc
+  x = oracle.normalize_embedding(synth.gaussish(11 + n, n * d).reshape(n, d))
+  p = oracle.normalize_embedding(synth.gaussish(13 + K, K * d).reshape(K, d))
+  if K > 2:
+    p[1] = p[0]                      # exact tie -> first index must win
+    p[K - 1] = 0.0                   # empty-cluster style zero prototype
+  got = sc.find_nearest_prototypes(torch.from_numpy(x).to(dev), torch.from_numpy(p).to(dev))
+  ref = oracle.find_nearest_prototypes(x, p)
+  assert np.array_equal(got.cpu().numpy(), ref)
+
+
+def test_normalize_embedding_bit_exact(dev, oracle):
+  import torch
+  from hsg_amd.utils.general import common as gc
+  x = synth.gaussish(5, 300 * 70).reshape(300, 70).copy()
+  x[3] = 0.0
+  x[7] *= np.float32(1e-20)
+  y = gc.normalize_embedding(torch.from_numpy(x).to(dev)).cpu().numpy()
+  assert np.array_equal(y, oracle.normalize_embedding(x))
+  g = util.load('f1_normalize')
+  n, d = (int(v) for v in g['shape'])
+  x = synth.gaussish(int(g['seed']), n * d).reshape(n, d).copy()
+  x[3] = 0.0
+  x[7] *= np.float32(1e-20)
+  x[11] *= np.float32(1e-9)
+  y = gc.normalize_embedding(torch.from_numpy(x).to(dev)).cpu().numpy()
+  assert np.abs(y - g['y']).max() <= FTOL
