@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Headline benchmark: pixel-embeddings clustered per second (BASELINE.json).
+
+One "step" = one segment_by_kmeans-equivalent pass (NCHW f32 in -> normalise ->
++location -> 10 Lloyd iterations from the grid seed -> 5 output tensors) over a
+synthetic batch already resident in HBM.  N=1 workload = BASELINE.json
+configs[1] (VOC12 stage-2 shape: 48x256x448x448, K=8x8).  N>1: every rank
+clusters its own shard of the same per-GPU shape (weak scaling; images are
+independent, the only exchange is the prototype-table step).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline      assign (E-step) kernel: algorithmic bytes (4D+8 per pixel) over
+                its average launch time, measured with HIP events on the launch
+                stream inside the timed region (libhsgk's event profiler);
+  cpu_baseline  oracle/torch_ref.py (same ATen op sequence as the reference's
+                CPU path) timed on the host cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (B per GPU, C, H, W, grid, iterations)
+    'cfg2': (48, 256, 448, 448, (8, 8), 10),
+    'cfg3': (16, 256, 224, 224, (8, 8), 10),
+    'cfg5': (24, 384, 224, 224, (8, 16), 10),
+    'cfg1': (4, 32, 64, 64, (2, 4), 10),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=3)
+  ap.add_argument('--warmup', type=int, default=1)
+  ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
+  ap.add_argument('--cpu-images', type=int, default=4,
+                  help='images of the workload shape timed on the host CPU (0 = skip)')
+  args = ap.parse_args()
+
+  import torch
+  rank = int(os.environ.get('RANK', '0'))
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  local = int(os.environ.get('LOCAL_RANK', '0'))
+  dist = None
+  if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    torch.cuda.set_device(local)
+    dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+  dev = torch.device('cuda', local)
+  torch.cuda.set_device(dev)
+
+  from hsg_amd import _lib
+  from hsg_amd.utils.segsort import common as segsort_common
+
+  B, C, H, W, grid, iters = WORKLOADS[args.workload]
+  D = C + 2
+  gen = torch.Generator(device=dev)
+  gen.manual_seed(0x48534700 + 2 + 1000 * rank)
+  x = torch.randn((B, C, H, W), device=dev, dtype=torch.float32, generator=gen)
+
+  def step():
+    out = segsort_common.segment_by_kmeans(x, None, list(grid), iterations=iters)
+    return out
+
+  def fence():
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+      dist.barrier()
+      torch.cuda.synchronize(dev)
+
+  for _ in range(args.warmup):
+    out = step()
+    del out
+  fence()
+  _lib.profile_enable(True)
+  _lib.profile_collect()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    out = step()
+    del out
+  fence()
+  elapsed = time.perf_counter() - t0
+  prof = _lib.profile_collect()
+  _lib.profile_enable(False)
+
+  if dist is not None:
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+  px_per_step = B * H * W * world
+  value = px_per_step * args.steps / elapsed
+
+  a_ms, a_n = prof['assign']
+  roofline = None
+  if a_n:
+    avg_s = a_ms / a_n * 1e-3
+    bytes_per_launch = (4 * D + 8) * B * H * W           # 4D+8 B / pixel
+    achieved = bytes_per_launch / avg_s / 1e9
+    roofline = {'bound': 'hbm', 'kernel': 'assign_kernel (E-step)',
+                'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                'avg_launch_ms': round(a_ms / a_n, 4), 'launches': int(a_n),
+                'mfma_tflops': round(2.0 * D * (grid[0] * grid[1]) * B * H * W / avg_s / 1e12, 2)}
+  phases = {k: round(v[0] / max(1, args.steps), 3) for k, v in prof.items()}
+
+  cpu = None
+  if rank == 0 and world == 1 and args.cpu_images > 0:
+    from oracle import torch_ref
+    nb = min(args.cpu_images, B)
+    xc = x[:nb].cpu()
+    torch.set_num_threads(os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    torch_ref.segment_by_kmeans(xc, None, grid, None, None, iters)
+    dt = time.perf_counter() - t0
+    cpu = {'value': round(nb * H * W / dt, 1), 'unit': 'pixels/s',
+           'cores': torch.get_num_threads(), 'kind': 'port',
+           'sample': '%d of %d images of the same %dx%dx%d shape, %d iterations, '
+                     'oracle/torch_ref.py (ATen op sequence of the reference CPU path), %.1f s'
+                     % (nb, B, C, H, W, iters, dt)}
+
+  if rank == 0:
+    print(json.dumps({
+        'metric': 'pixel-embeddings clustered/sec', 'value': round(value, 1),
+        'unit': 'pixels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': '%s: segment_by_kmeans %dx%dx%dx%d per GPU, K=%dx%d, %d Lloyd '
+                               'iterations, no labels' % (args.workload, B, C, H, W, grid[0],
+                                                          grid[1], iters),
+                   'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world,
+                   'phase_ms_per_step': phases},
+        'roofline': roofline, 'cpu_baseline': cpu}))
+  if dist is not None:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -53,6 +53,11 @@ SIGNATURES = {
     'hsgk_segment_by_kmeans': (_i32, [ctypes.POINTER(SegkmArgs), _vp]),
     'hsgk_kmeans_workspace_bytes': (_sz, [_i64, _i32, _i32]),
     'hsgk_kmeans_with_initial_labels': (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _sz, _vp]),
+    'hsgk_profile_enable': (None, [_i32]),
+    'hsgk_profile_collect': (_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
+    'hsgk_lloyd_workspace_bytes': (_sz, [_i32, _i64, _i32, _i32]),
+    'hsgk_lloyd_mstep': (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    'hsgk_lloyd_estep': (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     'hsgk_assign_workspace_bytes': (_sz, [_i64, _i32, _i32]),
     'hsgk_find_nearest_prototypes': (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
 }
@@ -66,6 +71,9 @@ def lib():
       raise HsgkError(
           'libhsgk.so is not built (%s). Run `python -c "import __graft_entry__ as g; '
           'g.build()"` or `make -C hsg_amd/csrc`. There is no fallback path.' % SO_PATH)
+    # torch ships its own libamdhip64; load it FIRST so libhsgk binds to the
+    # same HIP runtime instance (streams and device pointers are then shared).
+    import torch  # noqa: F401
     try:
       L = ctypes.CDLL(SO_PATH)
     except OSError as e:
@@ -81,6 +89,21 @@ def lib():
 def check(rc):
   if rc != 0:
     raise HsgkError('libhsgk error %d: %s' % (rc, lib().hsgk_last_error().decode()))
+
+
+PROF_KINDS = ('prep', 'accumulate', 'finalize', 'assign', 'relabel')
+
+
+def profile_enable(on):
+  lib().hsgk_profile_enable(int(bool(on)))
+
+
+def profile_collect():
+  """{kind: (total_ms, launches)} since the last collect; waits for the events."""
+  ms = (ctypes.c_double * len(PROF_KINDS))()
+  cnt = (ctypes.c_int64 * len(PROF_KINDS))()
+  check(lib().hsgk_profile_collect(ms, cnt))
+  return {k: (ms[i], cnt[i]) for i, k in enumerate(PROF_KINDS)}
 
 
 def stream_ptr():

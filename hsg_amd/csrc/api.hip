@@ -4,6 +4,10 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
+#include <vector>
+
 #include "common.h"
 
 namespace hsgk {
@@ -16,6 +20,27 @@ void set_error(const char *fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+// ---- optional event profiling of the kernel groups ------------------------
+struct ProfRec { int kind; hipEvent_t a, b; };
+static std::mutex g_prof_mu;
+static std::vector<ProfRec> g_prof;
+static std::atomic<int> g_prof_on{0};
+
+struct ProfScope {
+  int kind; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; bool on;
+  ProfScope(int k, hipStream_t st) : kind(k), s(st), on(g_prof_on.load() != 0) {
+    if (!on) return;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+    (void)hipEventRecord(a, s);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(b, s);
+    std::lock_guard<std::mutex> g(g_prof_mu);
+    g_prof.push_back({kind, a, b});
+  }
+};
 
 struct KmeansScratch {
   ChunkTable t;
@@ -49,9 +74,12 @@ static void carve_kmeans(Carver &cv, int B, int64_t rows_per_img, int d, int K,
 static int lloyd(const float *x, int d, int K, int B, int iterations,
                  const KmeansScratch &k, const hsgk_segkm_meta *meta, hipStream_t s) {
   for (int it = 0; it < iterations; ++it) {
-    if (int rc = launch_accumulate(x, d, k.klab, k.t, k.max_chunks, K, k.partial, meta, s)) return rc;
-    if (int rc = launch_finalize(k.partial, d, K, B, k.t, HSGK_EPS, k.cent, s)) return rc;
-    if (int rc = launch_assign(x, d, k.cent, K, k.t, k.max_chunks, k.klab, k.best, meta, s)) return rc;
+    { ProfScope p(HSGK_PROF_ACCUMULATE, s);
+      if (int rc = launch_accumulate(x, d, k.klab, k.t, k.max_chunks, K, k.partial, meta, s)) return rc; }
+    { ProfScope p(HSGK_PROF_FINALIZE, s);
+      if (int rc = launch_finalize(k.partial, d, K, B, k.t, HSGK_EPS, k.cent, s)) return rc; }
+    { ProfScope p(HSGK_PROF_ASSIGN, s);
+      if (int rc = launch_assign(x, d, k.cent, K, k.t, k.max_chunks, k.klab, k.best, meta, s)) return rc; }
   }
   return 0;
 }
@@ -64,6 +92,28 @@ extern "C" {
 
 int hsgk_version(void) { return HSGK_VERSION; }
 const char *hsgk_last_error(void) { return g_err; }
+
+void hsgk_profile_enable(int on) { g_prof_on.store(on ? 1 : 0); }
+
+int hsgk_profile_collect(double *ms_sum, int64_t *count) {
+  std::vector<ProfRec> recs;
+  {
+    std::lock_guard<std::mutex> g(g_prof_mu);
+    recs.swap(g_prof);
+  }
+  for (int i = 0; i < HSGK_PROF_KINDS; ++i) { ms_sum[i] = 0.0; count[i] = 0; }
+  for (auto &r : recs) {
+    float ms = 0.0f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess &&
+        r.kind >= 0 && r.kind < HSGK_PROF_KINDS) {
+      ms_sum[r.kind] += ms;
+      count[r.kind] += 1;
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  return 0;
+}
 
 int hsgk_normalize_rows(const float *x, int64_t n, int d, float eps, float *out,
                         hsgk_stream_t stream) {
@@ -112,13 +162,20 @@ int hsgk_segment_by_kmeans(const hsgk_segkm_args *a, hsgk_stream_t stream) {
   int32_t *scan_tmp = cv.take<int32_t>((size_t)a->table_cap / 2048 + 2);
 
   const bool compact = a->labels != nullptr && a->has_ignore;
-  if (int rc = launch_count_valid(a->labels, a->B, HW, a->has_ignore, a->ignore_index,
-                                  tile_cnt, a->meta, s)) return rc;
-  if (int rc = launch_build_tables(compact ? tile_cnt : nullptr, a->B, HW, ntiles, tile_off,
-                                   k.t, k.max_chunks, a->meta, s)) return rc;
-  if (int rc = launch_prep(*a, compact ? tile_off : nullptr, k.t, k.klab, s)) return rc;
+  (void)hipGetLastError();   // drop stale errors left by other users of the runtime
+  {
+    ProfScope p(HSGK_PROF_PREP, s);
+    if (int rc = launch_count_valid(a->labels, a->B, HW, a->has_ignore, a->ignore_index,
+                                    tile_cnt, a->meta, s)) return rc;
+    if (int rc = launch_build_tables(compact ? tile_cnt : nullptr, a->B, HW, ntiles, tile_off,
+                                     k.t, k.max_chunks, a->meta, s)) return rc;
+    if (int rc = launch_prep(*a, compact ? tile_off : nullptr, k.t, k.klab, s)) return rc;
+  }
   if (int rc = lloyd(a->out_embeddings_loc, D, a->K, a->B, a->iterations, k, a->meta, s)) return rc;
-  if (int rc = launch_relabel(*a, k.t, k.max_chunks, k.klab, table, scan_tmp, s)) return rc;
+  {
+    ProfScope p(HSGK_PROF_RELABEL, s);
+    if (int rc = launch_relabel(*a, k.t, k.max_chunks, k.klab, table, scan_tmp, s)) return rc;
+  }
   return 0;
 }
 
@@ -146,6 +203,51 @@ int hsgk_kmeans_with_initial_labels(const float *x, int64_t n, int d, int64_t *l
   if (int rc = launch_i64_to_i32(labels_io, n, k.klab, s)) return rc;
   if (int rc = lloyd(x, d, K, 1, iterations, k, meta, s)) return rc;
   return launch_i32_to_i64(k.klab, n, labels_io, s);
+}
+
+// ---------------------------------------------------------------------------
+// Batch-level Lloyd half-steps over B images of `rows_per_image` rows each.
+size_t hsgk_lloyd_workspace_bytes(int B, int64_t rows_per_image, int d, int K) {
+  Carver cv(nullptr);
+  cv.take<hsgk_segkm_meta>(1);
+  KmeansScratch k;
+  carve_kmeans(cv, B, rows_per_image, d, K, &k);
+  return cv.off + 256;
+}
+
+static int lloyd_setup(int B, int64_t rows, int d, int K, void *workspace, size_t bytes,
+                       KmeansScratch *k, hsgk_segkm_meta **meta, hipStream_t s) {
+  HSGK_REQUIRE(B >= 1 && rows >= 1 && d >= 1 && K >= 1, "bad shape");
+  HSGK_REQUIRE(bytes >= hsgk_lloyd_workspace_bytes(B, rows, d, K), "workspace too small");
+  Carver cv(workspace);
+  *meta = cv.take<hsgk_segkm_meta>(1);
+  carve_kmeans(cv, B, rows, d, K, k);
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(init_meta_kernel, dim3(1), dim3(1), 0, s, *meta, 0);
+  HSGK_LAUNCH_CHECK();
+  return launch_build_tables(nullptr, B, rows, 0, nullptr, k->t, k->max_chunks, *meta, s);
+}
+
+int hsgk_lloyd_mstep(const float *x, int B, int64_t rows_per_image, int d, int K,
+                     const int32_t *labels, float *centroids, void *workspace,
+                     size_t workspace_bytes, hsgk_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  KmeansScratch k; hsgk_segkm_meta *meta;
+  if (int rc = lloyd_setup(B, rows_per_image, d, K, workspace, workspace_bytes, &k, &meta, s)) return rc;
+  { ProfScope p(HSGK_PROF_ACCUMULATE, s);
+    if (int rc = launch_accumulate(x, d, labels, k.t, k.max_chunks, K, k.partial, meta, s)) return rc; }
+  ProfScope p(HSGK_PROF_FINALIZE, s);
+  return launch_finalize(k.partial, d, K, B, k.t, HSGK_EPS, centroids, s);
+}
+
+int hsgk_lloyd_estep(const float *x, int B, int64_t rows_per_image, int d, int K,
+                     const float *centroids, int32_t *labels_out, void *workspace,
+                     size_t workspace_bytes, hsgk_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  KmeansScratch k; hsgk_segkm_meta *meta;
+  if (int rc = lloyd_setup(B, rows_per_image, d, K, workspace, workspace_bytes, &k, &meta, s)) return rc;
+  ProfScope p(HSGK_PROF_ASSIGN, s);
+  return launch_assign(x, d, centroids, K, k.t, k.max_chunks, labels_out, k.best, meta, s);
 }
 
 size_t hsgk_assign_workspace_bytes(int64_t n, int d, int K) {

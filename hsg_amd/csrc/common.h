@@ -67,6 +67,7 @@ constexpr int kTilePix = 64;      // prep kernel tile (pixels)
 constexpr int kAssignTile = 256;  // assign kernel tile (rows)
 
 // ---- kernels implemented across the .hip files (host launchers) -----------
+__global__ void init_meta_kernel(hsgk_segkm_meta *meta, int has_labels);
 int launch_count_valid(const int64_t *labels, int B, int64_t HW, int has_ignore,
                        int64_t ignore, int32_t *tile_cnt, hsgk_segkm_meta *meta,
                        hipStream_t s);

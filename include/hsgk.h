@@ -47,6 +47,19 @@ typedef void *hsgk_stream_t;     /* hipStream_t */
 HSGK_API int hsgk_version(void);
 HSGK_API const char *hsgk_last_error(void);
 
+/* ---- optional HIP-event profiling of the kernel groups --------------------
+ * While enabled, every group launch is bracketed by hipEvents on the caller's
+ * stream; hsgk_profile_collect waits for them, returns summed milliseconds and
+ * launch counts per kind, and clears the log.                                 */
+#define HSGK_PROF_PREP 0        /* count + tables + prep kernels              */
+#define HSGK_PROF_ACCUMULATE 1  /* M-step chunk partial sums                  */
+#define HSGK_PROF_FINALIZE 2    /* M-step partial combine + normalise         */
+#define HSGK_PROF_ASSIGN 3      /* E-step (the roofline kernel)               */
+#define HSGK_PROF_RELABEL 4
+#define HSGK_PROF_KINDS 5
+HSGK_API void hsgk_profile_enable(int on);
+HSGK_API int hsgk_profile_collect(double *ms_sum, int64_t *count);
+
 /* ---- device-side result block of hsgk_segment_by_kmeans ------------------ */
 typedef struct hsgk_segkm_meta {
   int64_t n_rows;        /* N: kept pixels over the whole batch                */
@@ -105,6 +118,18 @@ HSGK_API int hsgk_kmeans_with_initial_labels(const float *x, int64_t n, int d,
                                     int64_t *labels_io, int K, int iterations,
                                     void *workspace, size_t workspace_bytes,
                                     hsgk_stream_t stream);
+
+/* ---- batch-level Lloyd half-steps (common.py:92 and :95) -------------------
+ * x [B*rows_per_image, d]; labels int32 [B*rows_per_image] in [0,K);
+ * centroids [B,K,d].  mstep = calculate_prototypes_from_labels per image,
+ * estep = find_nearest_prototypes per image.                                  */
+HSGK_API size_t hsgk_lloyd_workspace_bytes(int B, int64_t rows_per_image, int d, int K);
+HSGK_API int hsgk_lloyd_mstep(const float *x, int B, int64_t rows_per_image, int d, int K,
+                              const int32_t *labels, float *centroids, void *workspace,
+                              size_t workspace_bytes, hsgk_stream_t stream);
+HSGK_API int hsgk_lloyd_estep(const float *x, int B, int64_t rows_per_image, int d, int K,
+                              const float *centroids, int32_t *labels_out, void *workspace,
+                              size_t workspace_bytes, hsgk_stream_t stream);
 
 /* ---- hsg/utils/segsort/common.py:44-64 find_nearest_prototypes ------------ */
 /* labels_out[n] = argmax_k <x_r, proto_k>, first index on ties.               */

@@ -97,3 +97,21 @@ def test_f6_segsort_loss(oracle):
       assert np.abs(nll - g[key + '_nll']).max() <= 1e-4
       assert np.abs(ge[::7] - g[key + '_gemb']).max() <= 1e-6
       assert np.abs(gp - g[key + '_gproto']).max() <= 1e-5
+
+
+@pytest.mark.parametrize('case', ['cfg1_overseg', 'ragged', 'k1_it1'])
+def test_torch_restatement_matches_golden(case):
+  """The timed CPU baseline (oracle/torch_ref.py) reproduces the reference."""
+  import torch
+  from oracle import torch_ref
+  g = util.load('f4_segkm_' + case)
+  x, lab, grid, ign, iters, loc = util.f4_inputs(g)
+  out = torch_ref.segment_by_kmeans(
+      torch.from_numpy(x), None if lab is None else torch.from_numpy(lab), grid,
+      torch.from_numpy(loc), ign, iters)
+  emb, emb_loc, labels, cluster, batch = (t.numpy() for t in out)
+  assert np.array_equal(labels, g['labels'].astype(np.int64))
+  assert np.array_equal(cluster, g['cluster'].astype(np.int64))
+  assert np.array_equal(batch, g['batch'].astype(np.int64))
+  assert np.abs(emb[::util.ROW_STRIDE] - g['emb_rows']).max() <= FTOL
+  assert np.abs(emb_loc[::util.ROW_STRIDE] - g['emb_loc_rows']).max() <= FTOL
