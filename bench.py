@@ -41,7 +41,7 @@ def main():
   ap.add_argument('--steps', type=int, default=3)
   ap.add_argument('--warmup', type=int, default=1)
   ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
-  ap.add_argument('--cpu-images', type=int, default=4,
+  ap.add_argument('--cpu-images', type=int, default=1,
                   help='images of the workload shape timed on the host CPU (0 = skip)')
   args = ap.parse_args()
 
@@ -118,15 +118,23 @@ def main():
     from oracle import torch_ref
     nb = min(args.cpu_images, B)
     xc = x[:nb].cpu()
-    torch.set_num_threads(os.cpu_count() or 1)
-    t0 = time.perf_counter()
-    torch_ref.segment_by_kmeans(xc, None, grid, None, None, iters)
-    dt = time.perf_counter() - t0
-    cpu = {'value': round(nb * H * W / dt, 1), 'unit': 'pixels/s',
-           'cores': torch.get_num_threads(), 'kind': 'port',
+    ncpu = os.cpu_count() or 1
+    runs = []
+    for threads in sorted({min(32, ncpu), ncpu}):
+      torch.set_num_threads(threads)
+      t0 = time.perf_counter()
+      torch_ref.segment_by_kmeans(xc, None, grid, None, None, iters)
+      runs.append((time.perf_counter() - t0, threads))
+      if runs[-1][0] > 40.0:
+        break
+    dt, threads = min(runs)
+    cpu = {'value': round(nb * H * W / dt, 1), 'unit': 'pixels/s', 'cores': threads,
+           'kind': 'port',
            'sample': '%d of %d images of the same %dx%dx%d shape, %d iterations, '
-                     'oracle/torch_ref.py (ATen op sequence of the reference CPU path), %.1f s'
-                     % (nb, B, C, H, W, iters, dt)}
+                     'oracle/torch_ref.py (ATen op sequence of the reference CPU path); '
+                     'host has %d logical CPUs; runs (seconds@threads): %s'
+                     % (nb, B, C, H, W, iters, ncpu,
+                        ', '.join('%.1f@%d' % r for r in runs))}
 
   if rank == 0:
     print(json.dumps({

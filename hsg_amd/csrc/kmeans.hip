@@ -18,20 +18,31 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ===========================================================================
 // M-step, stage 1: chunk partial sums.
-// One workgroup per chunk.  Thread t owns columns t, t+256, ... of EVERY
-// cluster row, so a given LDS word is only ever touched by one thread, in
-// program (= row) order: ds_add_f32 gives the sequential sum of order C2
-// without any cross-thread ordering question.
-template <int UNROLL>
+// One workgroup (4 waves) per chunk.  Every cluster is OWNED by one wave
+// (hash of the label), and a wave walks the chunk's rows in order, so each LDS
+// word only ever receives ds_add_f32 from one wave, in row order: the result
+// is the sequential sum of order C2, independent of scheduling.  A wave reads
+// a whole row with VEC floats per lane (1 KiB per load instruction at VEC=4)
+// and keeps up to UNROLL rows in flight.
+//
+// LDS layout of one cluster row (d floats): "full passes" of 64*VEC columns
+// are stored component-major ([pass][i][lane]) so the VEC ds_adds of a row are
+// bank-conflict free; the d % (64*VEC) tail columns follow in natural order.
+__device__ inline int owner_wave(int label) {
+  return (label ^ (label >> 2) ^ (label >> 4) ^ (label >> 6)) & 3;
+}
+
+template <int VEC, int UNROLL>
 __global__ __launch_bounds__(256) void accumulate_kernel(
     const float *__restrict__ x, int d, const int32_t *__restrict__ klab,
     const int64_t *__restrict__ chunk_row0, const int32_t *__restrict__ chunk_rows,
     int K, int kb0, int kbn, float *__restrict__ partial,
     const hsgk_segkm_meta *__restrict__ meta) {
+  typedef float vec_t __attribute__((ext_vector_type(VEC), aligned(4)));
   extern __shared__ float sums[];   // [kbn][d]
   const int c = blockIdx.x;
   if (c >= meta->n_chunks) return;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int tot = kbn * d;
   for (int i = tid; i < tot; i += 256) sums[i] = 0.0f;
   __syncthreads();
@@ -40,35 +51,80 @@ __global__ __launch_bounds__(256) void accumulate_kernel(
   const int n = chunk_rows[c];
   const int32_t *lab = klab + row0;
   const float *xr = x + row0 * d;
+  constexpr int PW = 64 * VEC;
+  const int npass = d / PW;
+  const int tail0 = npass * PW;
+  const int tail = d - tail0;          // < 64*VEC columns, one float per lane, looped
 
-  for (int dcol = tid; dcol < d; dcol += 256) {
-    int r = 0;
-    for (; r + UNROLL <= n; r += UNROLL) {
-      float v[UNROLL];
-      int l[UNROLL];
+  for (int base = 0; base < n; base += 64) {
+    int l = -1;
+    if (base + lane < n) l = lab[base + lane] - kb0;
+    const bool mine = l >= 0 && l < kbn && owner_wave(l + kb0) == w;
+    unsigned long long mask = __ballot(mine);
+    while (mask) {
+      int rr[UNROLL], ll[UNROLL];
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
-        l[u] = lab[r + u] - kb0;
-        v[u] = xr[(int64_t)(r + u) * d + dcol];
+        rr[u] = -1;
+        ll[u] = 0;
+        if (mask) {
+          const int bit = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          rr[u] = base + bit;
+          ll[u] = __builtin_amdgcn_readlane(l, bit);
+        }
+      }
+      // tail columns (d % (64*VEC), at most one float per lane here) are
+      // requested first so they share the latency of the wide row loads
+      float tv[UNROLL];
+      const bool on = lane < tail;
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u)
+        if (rr[u] >= 0 && on) tv[u] = xr[(int64_t)rr[u] * d + tail0 + lane];
+      for (int p = 0; p < npass; ++p) {
+        vec_t v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+          if (rr[u] >= 0)
+            v[u] = *reinterpret_cast<const vec_t *>(xr + (int64_t)rr[u] * d + p * PW + lane * VEC);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+          if (rr[u] >= 0) {
+            float *dst = sums + ll[u] * d + p * PW + lane;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+              __hip_atomic_fetch_add(dst + i * 64, v[u][i], __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
       }
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        if (l[u] >= 0 && l[u] < kbn)
-          __hip_atomic_fetch_add(&sums[l[u] * d + dcol], v[u], __ATOMIC_RELAXED,
+      for (int u = 0; u < UNROLL; ++u)
+        if (rr[u] >= 0 && on)
+          __hip_atomic_fetch_add(sums + ll[u] * d + tail0 + lane, tv[u], __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_WORKGROUP);
+      for (int t0 = 64; t0 < tail; t0 += 64) {       // wider tails (VEC > 1 only)
+        if (t0 + lane < tail) {
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u)
+            if (rr[u] >= 0)
+              __hip_atomic_fetch_add(sums + ll[u] * d + tail0 + t0 + lane,
+                                     xr[(int64_t)rr[u] * d + tail0 + t0 + lane],
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       }
-    }
-    for (; r < n; ++r) {
-      int l = lab[r] - kb0;
-      float v = xr[(int64_t)r * d + dcol];
-      if (l >= 0 && l < kbn)
-        __hip_atomic_fetch_add(&sums[l * d + dcol], v, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
   __syncthreads();
   float *out = partial + ((int64_t)c * K + kb0) * d;
-  for (int i = tid; i < tot; i += 256) out[i] = sums[i];
+  for (int i = tid; i < tot; i += 256) {
+    const int k = i / d, pos = i - k * d;
+    int col = pos;
+    if (pos < tail0) {
+      const int p = pos / PW, q = pos - p * PW;
+      col = p * PW + (q & 63) * VEC + (q >> 6);
+    }
+    out[k * d + col] = sums[i];
+  }
 }
 
 int launch_accumulate(const float *x, int d, const int32_t *klab, const ChunkTable &t,
@@ -85,7 +141,8 @@ int launch_accumulate(const float *x, int d, const int32_t *klab, const ChunkTab
     if ((size_t)K * d * 4 <= budget1) kbn = K;
   }
   HSGK_REQUIRE(kbn >= 1, "row too long for the LDS segment table");
-  auto kern = accumulate_kernel<16>;
+  // 16-byte loads only need dword alignment on gfx950 global memory.
+  auto kern = (d >= 256) ? accumulate_kernel<4, 8> : accumulate_kernel<1, 16>;
   size_t lds = (size_t)kbn * d * 4;
   HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -150,7 +207,7 @@ int launch_finalize(const float *partial, int d, int K, int B, const ChunkTable 
 //
 // v_mfma_f32_32x32x2_f32 operand map: A[i = l&31][k = l>>5], B[k = l>>5][j = l&31];
 // D[i][j] at lane (j, h = l>>5), register r <-> i = (r&3) + 8*(r>>2) + 4*h.
-template <int KB, int NW, int KC>
+template <int KB, int NW, int KC, bool EVEN_D>
 __global__ __launch_bounds__(NW * 64) void assign_kernel(
     const float *__restrict__ x, int d, const float *__restrict__ cent, int K, int kb0,
     const int64_t *__restrict__ chunk_row0, const int32_t *__restrict__ chunk_rows,
@@ -191,7 +248,9 @@ __global__ __launch_bounds__(NW * 64) void assign_kernel(
       cent_s[i * DP + dd] = (k < K && dd < d) ? src[dd] : 0.0f;
   }
 
-  const bool even_d = (d & 1) == 0;
+  // Staging loads are branch-free: out-of-range rows / columns are clamped to
+  // a valid address and zeroed by a select, so all LOADS loads of a chunk are
+  // in flight together.
   float2 pre[LOADS];
   auto load_chunk = [&](int q) {
 #pragma unroll
@@ -199,17 +258,19 @@ __global__ __launch_bounds__(NW * 64) void assign_kernel(
       const int e = tid + NT * i;
       const int px = e / F2_PER_ROW, f2 = e % F2_PER_ROW;
       const int dd = q * KC + 2 * f2;
-      float2 v = make_float2(0.0f, 0.0f);
-      if (px < n && dd < d) {
-        const float *src = x + (row0 + px) * (int64_t)d + dd;
-        if (even_d) {
-          v = *reinterpret_cast<const float2 *>(src);
-        } else {
-          v.x = src[0];
-          if (dd + 1 < d) v.y = src[1];
-        }
+      const bool ok = px < n && dd < d;
+      const int pxc = px < n ? px : n - 1;
+      const int ddc = dd < d ? dd : 0;
+      const float *src = x + (row0 + pxc) * (int64_t)d + ddc;
+      float2 v;
+      if constexpr (EVEN_D) {
+        v = *reinterpret_cast<const float2 *>(src);
+      } else {
+        v.x = src[0];
+        v.y = src[ddc + 1 < d ? 1 : 0];
+        if (dd + 1 >= d) v.y = 0.0f;
       }
-      pre[i] = v;
+      pre[i] = ok ? v : make_float2(0.0f, 0.0f);
     }
   };
   auto store_chunk = [&](int buf) {
@@ -236,6 +297,8 @@ __global__ __launch_bounds__(NW * 64) void assign_kernel(
 
   for (int q = 0; q < nq; ++q) {
     if (q + 1 < nq) load_chunk(q + 1);
+    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of, and its LDS
+                                         // write-back behind, this chunk's MFMAs
     const float *xb = xs + (q & 1) * (TPX * XS) + (w * 32 + j) * XS + h;
     const float *cb = cent_s + j * DP + q * KC + h;
     const int rem = dpad - q * KC;
@@ -259,6 +322,7 @@ __global__ __launch_bounds__(NW * 64) void assign_kernel(
         }
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (q + 1 < nq) store_chunk((q + 1) & 1);
     __syncthreads();
   }
@@ -292,15 +356,15 @@ __global__ __launch_bounds__(NW * 64) void assign_kernel(
   }
 }
 
-template <int KB, int NW, int KC>
-static int launch_assign_cfg(const float *x, int d, const float *cent, int K,
+template <int KB, int NW, int KC, bool EVEN_D>
+static int launch_assign_cfg2(const float *x, int d, const float *cent, int K,
                              const ChunkTable &t, int max_chunks, int32_t *klab,
                              float *best, const hsgk_segkm_meta *meta, hipStream_t s) {
   constexpr int TPX = NW * 32;
   const int dpad = (d + 1) & ~1;
   const int DP = dpad | 1;
   size_t lds = ((size_t)KB * DP + (size_t)2 * TPX * (KC + 1)) * 4;
-  auto kern = assign_kernel<KB, NW, KC>;
+  auto kern = assign_kernel<KB, NW, KC, EVEN_D>;
   HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));
@@ -313,6 +377,15 @@ static int launch_assign_cfg(const float *x, int d, const float *cent, int K,
     HSGK_LAUNCH_CHECK();
   }
   return 0;
+}
+
+template <int KB, int NW, int KC>
+static int launch_assign_cfg(const float *x, int d, const float *cent, int K,
+                             const ChunkTable &t, int max_chunks, int32_t *klab,
+                             float *best, const hsgk_segkm_meta *meta, hipStream_t s) {
+  if ((d & 1) == 0)
+    return launch_assign_cfg2<KB, NW, KC, true>(x, d, cent, K, t, max_chunks, klab, best, meta, s);
+  return launch_assign_cfg2<KB, NW, KC, false>(x, d, cent, K, t, max_chunks, klab, best, meta, s);
 }
 
 int launch_assign(const float *x, int d, const float *cent, int K, const ChunkTable &t,

@@ -336,20 +336,167 @@ __global__ __launch_bounds__(256) void prep_kernel(
   }
 }
 
+// --------------------------------------------------------------------------
+// Fast path of the prep kernel for C % 64 == 0 (C = 64, 128, 256, 384, 512):
+// same phases and the same canonical arithmetic, but every LDS access moves
+// 16 bytes.  tile[j][c] lives at j*C + (((c>>2) ^ (j&15)) << 2) + (c&3): the
+// 16-byte quad index is XOR-swizzled with the pixel index, which makes
+// ds_write_b128 (lanes = pixels, 8-lane groups), ds_read_b128 (lanes = pixels,
+// 16-lane groups) and ds_read_b128 (lanes = quads of one pixel) conflict free.
+// Global traffic: 256 B per wave-load on the NCHW side (plane rows), 1 KiB
+// (float4) per wave-store for `embeddings`, 512 B (float2) for
+// `embeddings_with_loc` whose rows are only 8-byte aligned (D = C+2).
+__global__ __launch_bounds__(256) void prep_fast_kernel(
+    const float *__restrict__ in, int C, int64_t HW, int ntiles,
+    const float *__restrict__ loc, int64_t loc_sb, const int64_t *__restrict__ labels,
+    int has_ignore, int64_t ignore, const int32_t *__restrict__ tile_off,
+    const int64_t *__restrict__ img_row0, const int32_t *__restrict__ seed_map,
+    float eps, float *__restrict__ emb, float *__restrict__ emb_loc,
+    int64_t *__restrict__ labels_out, int32_t *__restrict__ klab) {
+  extern __shared__ float lds[];
+  float *tile = lds;                       // [64][C] swizzled
+  float *nrm1 = lds + 64 * C;              // [64]
+  float *nrm2 = nrm1 + 64;                 // [64]
+  float *locv = nrm2 + 64;                 // [64][2]
+  int64_t *rowi = reinterpret_cast<int64_t *>(locv + 128);
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int t = blockIdx.x, b = blockIdx.y;
+  const int64_t p0 = (int64_t)t * kTilePix;
+  const int D = C + 2;
+  const int NQ = C >> 2;
+
+  if (w == 0) {
+    const int64_t pix = p0 + lane;
+    bool keep = false;
+    int64_t lab = 0;
+    if (pix < HW) {
+      lab = labels ? labels[(int64_t)b * HW + pix] : 0;
+      keep = !(has_ignore && lab == ignore);
+    }
+    unsigned long long m = __ballot(keep);
+    int rank = __popcll(m & ((1ull << lane) - 1ull));
+    int64_t base = img_row0[b] + (tile_off ? (int64_t)tile_off[(int64_t)b * ntiles + t] : p0);
+    int64_t row = keep ? base + rank : -1;
+    rowi[lane] = row;
+    if (keep) {
+      labels_out[row] = lab;
+      klab[row] = seed_map[pix];
+      locv[2 * lane + 0] = loc[(int64_t)b * loc_sb + pix * 2 + 0];
+      locv[2 * lane + 1] = loc[(int64_t)b * loc_sb + pix * 2 + 1];
+    }
+    if (lane == 0) nrm1[0] = m ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+  if (nrm1[0] == 0.0f) return;
+  __syncthreads();
+
+  const int sw = lane & 15;
+  // phase 1: 4 channel planes -> one 16-byte LDS write per pixel
+  {
+    const int64_t pix = p0 + lane;
+    const bool ok = pix < HW;
+    const float *src = in + (int64_t)b * C * HW + (ok ? pix : HW - 1);
+    for (int q = w; q < NQ; q += 4) {
+      float4 v;
+      v.x = src[(int64_t)(4 * q + 0) * HW];
+      v.y = src[(int64_t)(4 * q + 1) * HW];
+      v.z = src[(int64_t)(4 * q + 2) * HW];
+      v.w = src[(int64_t)(4 * q + 3) * HW];
+      if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4 *>(tile + lane * C + ((q ^ sw) << 2)) = v;
+    }
+  }
+  __syncthreads();
+  // phase 2a
+  if (w == 0) {
+    const float *r = tile + lane * C;
+    float ss = 0.0f;
+    for (int q = 0; q < NQ; ++q) {
+      const float4 v = *reinterpret_cast<const float4 *>(r + ((q ^ sw) << 2));
+      ss = fmaf(v.x, v.x, ss);
+      ss = fmaf(v.y, v.y, ss);
+      ss = fmaf(v.z, v.z, ss);
+      ss = fmaf(v.w, v.w, ss);
+    }
+    float n1 = sqrtf(ss);
+    if (!(n1 >= eps)) n1 = eps;
+    nrm1[lane] = n1;
+  }
+  __syncthreads();
+  // phase 2b
+  {
+    const float n1 = nrm1[lane];
+    float *r = tile + lane * C;
+    for (int q = w; q < NQ; q += 4) {
+      float4 *pv = reinterpret_cast<float4 *>(r + ((q ^ sw) << 2));
+      float4 v = *pv;
+      v.x = v.x / n1; v.y = v.y / n1; v.z = v.z / n1; v.w = v.w / n1;
+      *pv = v;
+    }
+  }
+  __syncthreads();
+  // phase 2c
+  if (w == 0) {
+    const float *r = tile + lane * C;
+    float ss = 0.0f;
+    for (int q = 0; q < NQ; ++q) {
+      const float4 v = *reinterpret_cast<const float4 *>(r + ((q ^ sw) << 2));
+      ss = fmaf(v.x, v.x, ss);
+      ss = fmaf(v.y, v.y, ss);
+      ss = fmaf(v.z, v.z, ss);
+      ss = fmaf(v.w, v.w, ss);
+    }
+    const float ly = locv[2 * lane], lx = locv[2 * lane + 1];
+    ss = fmaf(ly, ly, ss);
+    ss = fmaf(lx, lx, ss);
+    float n2 = sqrtf(ss);
+    if (!(n2 >= eps)) n2 = eps;
+    nrm2[lane] = n2;
+  }
+  __syncthreads();
+  // phase 3
+  for (int j = w; j < 64; j += 4) {
+    const int64_t row = rowi[j];
+    if (row < 0) continue;
+    const float n2 = nrm2[j];
+    const float *r = tile + j * C;
+    float *eo = emb + row * C;
+    float *lo = emb_loc + row * D;
+    const int sj = j & 15;
+    for (int q = lane; q < NQ; q += 64) {
+      const float4 v = *reinterpret_cast<const float4 *>(r + ((q ^ sj) << 2));
+      *reinterpret_cast<float4 *>(eo + 4 * q) = v;
+      float2 a, c2;
+      a.x = v.x / n2; a.y = v.y / n2; c2.x = v.z / n2; c2.y = v.w / n2;
+      *reinterpret_cast<float2 *>(lo + 4 * q) = a;
+      *reinterpret_cast<float2 *>(lo + 4 * q + 2) = c2;
+    }
+    if (lane == 0) {
+      float2 lv;
+      lv.x = locv[2 * j] / n2;
+      lv.y = locv[2 * j + 1] / n2;
+      *reinterpret_cast<float2 *>(lo + C) = lv;
+    }
+  }
+}
+
 int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTable &t,
                 int32_t *klab, hipStream_t s) {
   const int64_t HW = (int64_t)a.H * a.W;
   const int ntiles = (int)((HW + kTilePix - 1) / kTilePix);
-  const int S = a.C | 1;
+  const bool fast = (a.C % 64) == 0;
+  const int S = fast ? a.C : (a.C | 1);
   size_t floats = (size_t)64 * S + 64 + 64 + 128;
   floats = (floats + 1) & ~(size_t)1;     // keep the int64 row table 8-byte aligned
   size_t lds = floats * 4 + 64 * 8;
   HSGK_REQUIRE(lds <= 160 * 1024, "embedding dimension too large for the prep tile");
-  HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(prep_kernel),
+  auto kern = fast ? prep_fast_kernel : prep_kernel;
+  HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));
   dim3 grid(ntiles, a.B);
-  hipLaunchKernelGGL(prep_kernel, grid, dim3(256), lds, s, a.embeddings, a.C, HW, ntiles,
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a.embeddings, a.C, HW, ntiles,
                      a.loc, a.loc_batch_stride, a.labels, a.has_ignore, a.ignore_index,
                      tile_off, t.img_row0, a.seed_map, HSGK_EPS, a.out_embeddings,
                      a.out_embeddings_loc, a.out_labels, klab);
