@@ -19,15 +19,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ===========================================================================
 // M-step, stage 1: chunk partial sums.
 // One workgroup (4 waves) per chunk.  Every cluster is OWNED by one wave
-// (hash of the label), and a wave walks the chunk's rows in order, so each LDS
-// word only ever receives ds_add_f32 from one wave, in row order: the result
-// is the sequential sum of order C2, independent of scheduling.  A wave reads
-// a whole row with VEC floats per lane (1 KiB per load instruction at VEC=4)
-// and keeps up to UNROLL rows in flight.
+// (hash of the label) and a wave walks the chunk's rows in order, so each LDS
+// word is only ever updated by one wave, in row order: plain LDS
+// read-add-write (the LDS executes one wave's DS instructions in issue order)
+// gives the sequential sum of order C2 independent of scheduling.  LDS float
+// atomics were measured ~160 cycles per wave-instruction on gfx950 and are not
+// used.  A wave reads a whole row with VEC floats per lane (1 KiB per load
+// instruction at VEC=4) and keeps UNROLL rows in flight.
 //
-// LDS layout of one cluster row (d floats): "full passes" of 64*VEC columns
-// are stored component-major ([pass][i][lane]) so the VEC ds_adds of a row are
-// bank-conflict free; the d % (64*VEC) tail columns follow in natural order.
+// LDS row stride DS = d rounded up to VEC floats so the per-lane VEC-wide
+// LDS accesses stay naturally aligned.
 __device__ inline int owner_wave(int label) {
   return (label ^ (label >> 2) ^ (label >> 4) ^ (label >> 6)) & 3;
 }
@@ -38,12 +39,14 @@ __global__ __launch_bounds__(256) void accumulate_kernel(
     const int64_t *__restrict__ chunk_row0, const int32_t *__restrict__ chunk_rows,
     int K, int kb0, int kbn, float *__restrict__ partial,
     const hsgk_segkm_meta *__restrict__ meta) {
-  typedef float vec_t __attribute__((ext_vector_type(VEC), aligned(4)));
-  extern __shared__ float sums[];   // [kbn][d]
+  typedef float gvec_t __attribute__((ext_vector_type(VEC), aligned(4)));       // global: dword aligned
+  typedef float lvec_t __attribute__((ext_vector_type(VEC), aligned(4 * VEC))); // LDS: natural
+  extern __shared__ float sums[];   // [kbn][DS]
   const int c = blockIdx.x;
   if (c >= meta->n_chunks) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int tot = kbn * d;
+  const int DS = (d + VEC - 1) / VEC * VEC;
+  const int tot = kbn * DS;
   for (int i = tid; i < tot; i += 256) sums[i] = 0.0f;
   __syncthreads();
 
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(
   constexpr int PW = 64 * VEC;
   const int npass = d / PW;
   const int tail0 = npass * PW;
-  const int tail = d - tail0;          // < 64*VEC columns, one float per lane, looped
+  const int tail = d - tail0;          // < 64*VEC columns, one float per lane per step
 
   for (int base = 0; base < n; base += 64) {
     int l = -1;
@@ -74,76 +77,71 @@ __global__ __launch_bounds__(256) void accumulate_kernel(
           ll[u] = __builtin_amdgcn_readlane(l, bit);
         }
       }
-      // tail columns (d % (64*VEC), at most one float per lane here) are
-      // requested first so they share the latency of the wide row loads
+      // tail columns are requested first so they share the latency of the
+      // wide row loads
       float tv[UNROLL];
       const bool on = lane < tail;
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u)
         if (rr[u] >= 0 && on) tv[u] = xr[(int64_t)rr[u] * d + tail0 + lane];
       for (int p = 0; p < npass; ++p) {
-        vec_t v[UNROLL];
+        gvec_t v[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
           if (rr[u] >= 0)
-            v[u] = *reinterpret_cast<const vec_t *>(xr + (int64_t)rr[u] * d + p * PW + lane * VEC);
+            v[u] = *reinterpret_cast<const gvec_t *>(xr + (int64_t)rr[u] * d + p * PW + lane * VEC);
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
           if (rr[u] >= 0) {
-            float *dst = sums + ll[u] * d + p * PW + lane;
+            lvec_t *dst = reinterpret_cast<lvec_t *>(sums + ll[u] * DS + p * PW + lane * VEC);
+            lvec_t acc = *dst;
 #pragma unroll
-            for (int i = 0; i < VEC; ++i)
-              __hip_atomic_fetch_add(dst + i * 64, v[u][i], __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int i = 0; i < VEC; ++i) acc[i] = acc[i] + v[u][i];
+            *dst = acc;
           }
       }
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u)
-        if (rr[u] >= 0 && on)
-          __hip_atomic_fetch_add(sums + ll[u] * d + tail0 + lane, tv[u], __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (rr[u] >= 0 && on) {
+          float *dst = sums + ll[u] * DS + tail0 + lane;
+          *dst = *dst + tv[u];
+        }
       for (int t0 = 64; t0 < tail; t0 += 64) {       // wider tails (VEC > 1 only)
         if (t0 + lane < tail) {
 #pragma unroll
           for (int u = 0; u < UNROLL; ++u)
-            if (rr[u] >= 0)
-              __hip_atomic_fetch_add(sums + ll[u] * d + tail0 + t0 + lane,
-                                     xr[(int64_t)rr[u] * d + tail0 + t0 + lane],
-                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (rr[u] >= 0) {
+              float *dst = sums + ll[u] * DS + tail0 + t0 + lane;
+              *dst = *dst + xr[(int64_t)rr[u] * d + tail0 + t0 + lane];
+            }
         }
       }
     }
   }
   __syncthreads();
   float *out = partial + ((int64_t)c * K + kb0) * d;
-  for (int i = tid; i < tot; i += 256) {
-    const int k = i / d, pos = i - k * d;
-    int col = pos;
-    if (pos < tail0) {
-      const int p = pos / PW, q = pos - p * PW;
-      col = p * PW + (q & 63) * VEC + (q >> 6);
-    }
-    out[k * d + col] = sums[i];
-  }
+  for (int k = w; k < kbn; k += 4)
+    for (int i = lane; i < d; i += 64) out[k * d + i] = sums[k * DS + i];
 }
 
 int launch_accumulate(const float *x, int d, const int32_t *klab, const ChunkTable &t,
                       int max_chunks, int K, float *partial,
                       const hsgk_segkm_meta *meta, hipStream_t s) {
   if (max_chunks <= 0) return 0;
+  const bool wide = d >= 256;
+  const int DS = wide ? (d + 3) / 4 * 4 : d;
   // cluster rows per pass so that the table fits LDS (two workgroups per CU
-  // when possible: <= 72 KiB each).
-  const size_t budget2 = 72 * 1024, budget1 = 150 * 1024;
+  // when possible: <= 76 KiB each).
+  const size_t budget2 = 76 * 1024, budget1 = 150 * 1024;
   int kbn = K;
-  if ((size_t)kbn * d * 4 > budget2) {
-    kbn = (int)(budget1 / ((size_t)d * 4));
+  if ((size_t)kbn * DS * 4 > budget2) {
+    kbn = (int)(budget1 / ((size_t)DS * 4));
     if (kbn > K) kbn = K;
-    if ((size_t)K * d * 4 <= budget1) kbn = K;
   }
   HSGK_REQUIRE(kbn >= 1, "row too long for the LDS segment table");
-  // 16-byte loads only need dword alignment on gfx950 global memory.
-  auto kern = (d >= 256) ? accumulate_kernel<4, 8> : accumulate_kernel<1, 16>;
-  size_t lds = (size_t)kbn * d * 4;
+  // 16-byte global loads only need dword alignment on gfx950.
+  auto kern = wide ? accumulate_kernel<4, 8> : accumulate_kernel<1, 16>;
+  size_t lds = (size_t)kbn * DS * 4;
   HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)(150 * 1024)));
@@ -212,24 +210,28 @@ __global__ __launch_bounds__(NW * 64) void assign_kernel(
     const float *__restrict__ x, int d, const float *__restrict__ cent, int K, int kb0,
     const int64_t *__restrict__ chunk_row0, const int32_t *__restrict__ chunk_rows,
     const int32_t *__restrict__ chunk_img, int32_t *__restrict__ klab,
-    float *__restrict__ best, int first_block,
+    float *__restrict__ best, int first_block, int split,
     const hsgk_segkm_meta *__restrict__ meta) {
   constexpr int NT = NW * 64;
   constexpr int TPX = NW * 32;
   constexpr int XS = KC + 1;
   constexpr int MB = KB / 32;
-  constexpr int TILES_PER_CHUNK = HSGK_CHUNK / TPX;
   constexpr int F2_PER_ROW = KC / 2;
   constexpr int LOADS = (TPX * F2_PER_ROW) / NT;
   static_assert((TPX * F2_PER_ROW) % NT == 0, "staging must divide evenly");
 
   extern __shared__ float lds[];
-  const int c = blockIdx.x / TILES_PER_CHUNK;
+  // `split` workgroups share one chunk (split = 1 when there are plenty of
+  // chunks; > 1 keeps all CUs busy on small batches); each takes a contiguous
+  // range of the chunk's tiles and stages the centroid block once.
+  const int c = blockIdx.x / split;
   if (c >= meta->n_chunks) return;
-  const int tt = blockIdx.x % TILES_PER_CHUNK;
-  const int n = min(TPX, chunk_rows[c] - tt * TPX);
-  if (n <= 0) return;
-  const int64_t row0 = chunk_row0[c] + (int64_t)tt * TPX;
+  const int part = blockIdx.x - c * split;
+  const int tps = (HSGK_CHUNK / TPX + split - 1) / split;      // tiles per workgroup
+  const int all_rows = chunk_rows[c];
+  const int nrows = min(all_rows - part * tps * TPX, tps * TPX);
+  if (nrows <= 0) return;
+  const int64_t crow0 = chunk_row0[c] + (int64_t)part * tps * TPX;
   const int b = chunk_img[c];
 
   const int dpad = (d + 1) & ~1;
@@ -240,19 +242,52 @@ __global__ __launch_bounds__(NW * 64) void assign_kernel(
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
 
-  // ---- stage the centroid block (rows >= K and the pad column are zero)
-  for (int i = w; i < KB; i += NW) {
-    const int k = kb0 + i;
-    const float *src = cent + ((int64_t)b * K + k) * d;
-    for (int dd = lane; dd < dpad; dd += 64)
-      cent_s[i * DP + dd] = (k < K && dd < d) ? src[dd] : 0.0f;
+  // ---- stage the centroid block once per chunk (rows >= K and the pad
+  //      column are zero); batches of 8 independent 8-byte loads per thread
+  {
+    const float *src = cent + ((int64_t)b * K + kb0) * d;
+    const int kvalid = min(KB, K - kb0);
+    if constexpr (EVEN_D) {
+      const int half = d >> 1;
+      const int total = KB * half;                     // float2 elements
+      for (int f0 = 0; f0 < total; f0 += NT * 8) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int f = f0 + tid + NT * u;
+          const int k = f / half;
+          v[u] = (f < total && k < kvalid) ? *reinterpret_cast<const float2 *>(src + 2 * (int64_t)f)
+                                           : make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int f = f0 + tid + NT * u;
+          if (f < total) {
+            const int k = f / half, col = 2 * (f - k * half);
+            cent_s[k * DP + col] = v[u].x;
+            cent_s[k * DP + col + 1] = v[u].y;
+          }
+        }
+      }
+    } else {
+      for (int i = w; i < KB; i += NW)
+        for (int dd = lane; dd < dpad; dd += 64)
+          cent_s[i * DP + dd] = (i < kvalid && dd < d) ? src[(int64_t)i * d + dd] : 0.0f;
+    }
   }
+
+  const int nq = (dpad + KC - 1) / KC;
+  const int ntile = (nrows + TPX - 1) / TPX;
+  const int nsteps = ntile * nq;
 
   // Staging loads are branch-free: out-of-range rows / columns are clamped to
   // a valid address and zeroed by a select, so all LOADS loads of a chunk are
   // in flight together.
   float2 pre[LOADS];
-  auto load_chunk = [&](int q) {
+  auto load_chunk = [&](int g) {
+    const int tile = g / nq, q = g - tile * nq;
+    const int n = min(TPX, nrows - tile * TPX);
+    const int64_t row0 = crow0 + (int64_t)tile * TPX;
 #pragma unroll
     for (int i = 0; i < LOADS; ++i) {
       const int e = tid + NT * i;
@@ -284,74 +319,76 @@ __global__ __launch_bounds__(NW * 64) void assign_kernel(
     }
   };
 
-  f32x16 acc[MB];
-#pragma unroll
-  for (int m = 0; m < MB; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
-
-  const int nq = (dpad + KC - 1) / KC;
   load_chunk(0);
   store_chunk(0);
   __syncthreads();
 
-  for (int q = 0; q < nq; ++q) {
-    if (q + 1 < nq) load_chunk(q + 1);
-    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of, and its LDS
-                                         // write-back behind, this chunk's MFMAs
-    const float *xb = xs + (q & 1) * (TPX * XS) + (w * 32 + j) * XS + h;
-    const float *cb = cent_s + j * DP + q * KC + h;
-    const int rem = dpad - q * KC;
-    if (rem >= KC) {
+  int g = 0;
+  for (int tile = 0; tile < ntile; ++tile) {
+    f32x16 acc[MB];
 #pragma unroll
-      for (int st = 0; st < KC / 2; ++st) {
-        const float bv = xb[2 * st];
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-          const float av = cb[m * 32 * DP + 2 * st];
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
+      for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+
+    for (int q = 0; q < nq; ++q, ++g) {
+      if (g + 1 < nsteps) load_chunk(g + 1);
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of, and its LDS
+                                           // write-back behind, this chunk's MFMAs
+      const float *xb = xs + (g & 1) * (TPX * XS) + (w * 32 + j) * XS + h;
+      const float *cb = cent_s + j * DP + q * KC + h;
+      const int rem = dpad - q * KC;
+      if (rem >= KC) {
+#pragma unroll
+        for (int st = 0; st < KC / 2; ++st) {
+          const float bv = xb[2 * st];
+#pragma unroll
+          for (int m = 0; m < MB; ++m) {
+            const float av = cb[m * 32 * DP + 2 * st];
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
+          }
+        }
+      } else {
+        for (int st = 0; st < rem / 2; ++st) {
+          const float bv = xb[2 * st];
+#pragma unroll
+          for (int m = 0; m < MB; ++m) {
+            const float av = cb[m * 32 * DP + 2 * st];
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
+          }
         }
       }
-    } else {
-      for (int st = 0; st < rem / 2; ++st) {
-        const float bv = xb[2 * st];
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 1 < nsteps) store_chunk((g + 1) & 1);
+      __syncthreads();
+    }
+
+    // ---- argmax over this lane's rows (ascending index, strict >)
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-          const float av = cb[m * 32 * DP + 2 * st];
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
-        }
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = kb0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = acc[m][r];
+        if (k < K && v > bv) { bv = v; bi = k; }
       }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (q + 1 < nq) store_chunk((q + 1) & 1);
-    __syncthreads();
-  }
+    const float ov = __shfl_xor(bv, 32);
+    const int oi = __shfl_xor(bi, 32);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
 
-  // ---- argmax over this lane's rows (ascending index, strict >)
-  float bv = -INFINITY;
-  int bi = 0x7fffffff;
-#pragma unroll
-  for (int m = 0; m < MB; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int k = kb0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      const float v = acc[m][r];
-      if (k < K && v > bv) { bv = v; bi = k; }
-    }
-  const float ov = __shfl_xor(bv, 32);
-  const int oi = __shfl_xor(bi, 32);
-  if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-
-  const int px = w * 32 + j;
-  if (h == 0 && px < n) {
-    const int64_t row = row0 + px;
-    if (bi == 0x7fffffff) bi = kb0;           // every score NaN: keep first index
-    if (first_block) {
-      klab[row] = bi;
-      if (best) best[row] = bv;
-    } else if (bv > best[row]) {              // later blocks win only strictly
-      klab[row] = bi;
-      best[row] = bv;
+    const int px = tile * TPX + w * 32 + j;
+    if (h == 0 && px < nrows) {
+      const int64_t row = crow0 + px;
+      if (bi == 0x7fffffff) bi = kb0;           // every score NaN: keep first index
+      if (first_block) {
+        klab[row] = bi;
+        if (best) best[row] = bv;
+      } else if (bv > best[row]) {              // later blocks win only strictly
+        klab[row] = bi;
+        best[row] = bv;
+      }
     }
   }
 }
@@ -368,12 +405,15 @@ static int launch_assign_cfg2(const float *x, int d, const float *cent, int K,
   HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));
-  const int grid = max_chunks * (HSGK_CHUNK / TPX);
+  constexpr int kTiles = HSGK_CHUNK / TPX;
+  int split = 1;
+  while (split < kTiles && (int64_t)max_chunks * split < 2048) split *= 2;
+  const int grid = max_chunks * split;
   const bool multi = K > KB;
   for (int kb0 = 0; kb0 < K; kb0 += KB) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, x, d, cent, K, kb0,
                        t.chunk_row0, t.chunk_rows, t.chunk_img, klab,
-                       multi ? best : nullptr, kb0 == 0 ? 1 : 0, meta);
+                       multi ? best : nullptr, kb0 == 0 ? 1 : 0, split, meta);
     HSGK_LAUNCH_CHECK();
   }
   return 0;
