@@ -41,81 +41,112 @@ __global__ __launch_bounds__(256) void accumulate_kernel(
     const hsgk_segkm_meta *__restrict__ meta) {
   typedef float gvec_t __attribute__((ext_vector_type(VEC), aligned(4)));       // global: dword aligned
   typedef float lvec_t __attribute__((ext_vector_type(VEC), aligned(4 * VEC))); // LDS: natural
-  extern __shared__ float sums[];   // [kbn][DS]
+  extern __shared__ float sums[];   // [kbn][DS] then the row lists
   const int c = blockIdx.x;
   if (c >= meta->n_chunks) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int DS = (d + VEC - 1) / VEC * VEC;
   const int tot = kbn * DS;
+  uint32_t *rlist = reinterpret_cast<uint32_t *>(sums + tot);   // [HSGK_CHUNK] (row << 8 | label)
+  __shared__ int wcount[4];
   for (int i = tid; i < tot; i += 256) sums[i] = 0.0f;
-  __syncthreads();
 
   const int64_t row0 = chunk_row0[c];
   const int n = chunk_rows[c];
   const int32_t *lab = klab + row0;
   const float *xr = x + row0 * d;
-  constexpr int PW = 64 * VEC;
-  const int npass = d / PW;
-  const int tail0 = npass * PW;
-  const int tail = d - tail0;          // < 64*VEC columns, one float per lane per step
 
+  // ---- pass 1: every wave counts the rows it owns; pass 2: ordered row list
+  int cnt = 0;
   for (int base = 0; base < n; base += 64) {
     int l = -1;
     if (base + lane < n) l = lab[base + lane] - kb0;
     const bool mine = l >= 0 && l < kbn && owner_wave(l + kb0) == w;
-    unsigned long long mask = __ballot(mine);
-    while (mask) {
-      int rr[UNROLL], ll[UNROLL];
+    cnt += __popcll(__ballot(mine));
+  }
+  if (lane == 0) wcount[w] = cnt;
+  __syncthreads();
+  int lbeg = 0;
+  for (int i = 0; i < w; ++i) lbeg += wcount[i];
+  {
+    int pos = lbeg;
+    for (int base = 0; base < n; base += 64) {
+      int l = -1;
+      if (base + lane < n) l = lab[base + lane] - kb0;
+      const bool mine = l >= 0 && l < kbn && owner_wave(l + kb0) == w;
+      const unsigned long long m = __ballot(mine);
+      if (mine) rlist[pos + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)(base + lane) << 8) | (uint32_t)l;
+      pos += __popcll(m);
+    }
+  }
+  // (a wave reads back only its own list entries: in-order LDS, no barrier)
+
+  constexpr int PW = 64 * VEC;
+  const int npass = d / PW;
+  const int tail0 = npass * PW;
+  const int tail = d - tail0;          // < 64*VEC columns, one float per lane per step
+  const uint32_t *mylist = rlist + lbeg;
+
+  // Batches of UNROLL rows; the loads of batch i+1 are issued before batch i is
+  // folded into LDS (only the first column pass is double buffered: npass == 1
+  // for d < 2*64*VEC, the shapes this kernel is tuned for).
+  gvec_t va[UNROLL], vb[UNROLL];
+  float ta[UNROLL], tb[UNROLL];
+  const bool on = lane < tail;
+  auto issue = [&](int b0, gvec_t (&v)[UNROLL], float (&t)[UNROLL]) {
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        rr[u] = -1;
-        ll[u] = 0;
-        if (mask) {
-          const int bit = __builtin_ctzll(mask);
-          mask &= mask - 1;
-          rr[u] = base + bit;
-          ll[u] = __builtin_amdgcn_readlane(l, bit);
+    for (int u = 0; u < UNROLL; ++u) {
+      const int idx = min(b0 + u, cnt - 1);
+      const int r = (int)(mylist[idx] >> 8);
+      if (npass > 0) v[u] = *reinterpret_cast<const gvec_t *>(xr + (int64_t)r * d + lane * VEC);
+      t[u] = on ? xr[(int64_t)r * d + tail0 + lane] : 0.0f;
+    }
+  };
+  auto fold = [&](int b0, const gvec_t (&v)[UNROLL], const float (&t)[UNROLL]) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      if (b0 + u < cnt) {
+        const uint32_t e = mylist[b0 + u];
+        const int r = (int)(e >> 8), l = (int)(e & 255u);
+        if (npass > 0) {
+          lvec_t *dst = reinterpret_cast<lvec_t *>(sums + l * DS + lane * VEC);
+          lvec_t acc = *dst;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] = acc[i] + v[u][i];
+          *dst = acc;
         }
-      }
-      // tail columns are requested first so they share the latency of the
-      // wide row loads
-      float tv[UNROLL];
-      const bool on = lane < tail;
+        for (int p = 1; p < npass; ++p) {                     // further full passes (wide rows)
+          const gvec_t vv = *reinterpret_cast<const gvec_t *>(xr + (int64_t)r * d + p * PW + lane * VEC);
+          lvec_t *dst = reinterpret_cast<lvec_t *>(sums + l * DS + p * PW + lane * VEC);
+          lvec_t acc = *dst;
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u)
-        if (rr[u] >= 0 && on) tv[u] = xr[(int64_t)rr[u] * d + tail0 + lane];
-      for (int p = 0; p < npass; ++p) {
-        gvec_t v[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-          if (rr[u] >= 0)
-            v[u] = *reinterpret_cast<const gvec_t *>(xr + (int64_t)rr[u] * d + p * PW + lane * VEC);
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-          if (rr[u] >= 0) {
-            lvec_t *dst = reinterpret_cast<lvec_t *>(sums + ll[u] * DS + p * PW + lane * VEC);
-            lvec_t acc = *dst;
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) acc[i] = acc[i] + v[u][i];
-            *dst = acc;
+          for (int i = 0; i < VEC; ++i) acc[i] = acc[i] + vv[i];
+          *dst = acc;
+        }
+        if (on) {
+          float *dst = sums + l * DS + tail0 + lane;
+          *dst = *dst + t[u];
+        }
+        for (int t0 = 64; t0 < tail; t0 += 64)                // wider tails (VEC > 1 only)
+          if (t0 + lane < tail) {
+            float *dst = sums + l * DS + tail0 + t0 + lane;
+            *dst = *dst + xr[(int64_t)r * d + tail0 + t0 + lane];
           }
       }
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u)
-        if (rr[u] >= 0 && on) {
-          float *dst = sums + ll[u] * DS + tail0 + lane;
-          *dst = *dst + tv[u];
-        }
-      for (int t0 = 64; t0 < tail; t0 += 64) {       // wider tails (VEC > 1 only)
-        if (t0 + lane < tail) {
-#pragma unroll
-          for (int u = 0; u < UNROLL; ++u)
-            if (rr[u] >= 0) {
-              float *dst = sums + ll[u] * DS + tail0 + t0 + lane;
-              *dst = *dst + xr[(int64_t)rr[u] * d + tail0 + t0 + lane];
-            }
-        }
-      }
+    }
+  };
+  if (cnt > 0) {
+    issue(0, va, ta);
+    for (int b0 = 0; b0 < cnt; b0 += 2 * UNROLL) {
+      if (b0 + UNROLL < cnt) issue(b0 + UNROLL, vb, tb);
+      __builtin_amdgcn_sched_barrier(0);
+      fold(b0, va, ta);
+      __builtin_amdgcn_sched_barrier(0);
+      if (b0 + UNROLL >= cnt) break;
+      if (b0 + 2 * UNROLL < cnt) issue(b0 + 2 * UNROLL, va, ta);
+      __builtin_amdgcn_sched_barrier(0);
+      fold(b0 + UNROLL, vb, tb);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   __syncthreads();
@@ -132,19 +163,21 @@ int launch_accumulate(const float *x, int d, const int32_t *klab, const ChunkTab
   const int DS = wide ? (d + 3) / 4 * 4 : d;
   // cluster rows per pass so that the table fits LDS (two workgroups per CU
   // when possible: <= 76 KiB each).
-  const size_t budget2 = 76 * 1024, budget1 = 150 * 1024;
+  const size_t list_bytes = (size_t)HSGK_CHUNK * 4;
+  const size_t budget2 = 78 * 1024 - list_bytes, budget1 = 156 * 1024 - list_bytes;
   int kbn = K;
   if ((size_t)kbn * DS * 4 > budget2) {
     kbn = (int)(budget1 / ((size_t)DS * 4));
     if (kbn > K) kbn = K;
   }
+  if (kbn > 256) kbn = 256;                 // label field of the row list is 8 bits
   HSGK_REQUIRE(kbn >= 1, "row too long for the LDS segment table");
   // 16-byte global loads only need dword alignment on gfx950.
   auto kern = wide ? accumulate_kernel<4, 8> : accumulate_kernel<1, 16>;
-  size_t lds = (size_t)kbn * DS * 4;
+  size_t lds = (size_t)kbn * DS * 4 + list_bytes;
   HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)(150 * 1024)));
+                                     (int)(158 * 1024)));
   for (int kb0 = 0; kb0 < K; kb0 += kbn) {
     int cur = K - kb0 < kbn ? K - kb0 : kbn;
     hipLaunchKernelGGL(kern, dim3(max_chunks), dim3(256), lds, s, x, d, klab,
@@ -195,13 +228,21 @@ int launch_finalize(const float *partial, int d, int K, int B, const ChunkTable 
 // ===========================================================================
 // E-step: fp32 MFMA assign kernel.
 //
-// Workgroup = NW waves; tile = NW*32 rows.  Centroid block (KB rows, KB = 32
-// or 64) is staged once per workgroup in LDS with an odd row stride (bank
-// conflict free A-operand reads).  Pixel rows stream through LDS in column
-// chunks of KC floats, double buffered, padded to KC+1 floats per row.
-// Per wave: 32 rows on the MFMA N dimension, centroids on M, so every lane
-// ends with all KB scores of ONE row split between lanes l and l^32: the
+// One workgroup (NW waves) per chunk (or per 1/split of a chunk).  The
+// centroid block (KB rows, KB = 32 or 64) is staged ONCE per workgroup in LDS
+// with an odd row stride (bank-conflict-free A-operand reads).  Each wave owns
+// 32-row tiles: rows sit on the MFMA N dimension, centroids on M, so a lane
+// ends with all KB scores of ONE row split between lanes l and l^32 and the
 // argmax is in-register plus one cross-half exchange.
+//
+// Pixel rows stream through a WAVE-PRIVATE, double-buffered LDS window in
+// column chunks of KC floats (padded to KC+1 per row): a wave parks and reads
+// back only its own rows, so the column loop needs no workgroup barrier and
+// the two waves of a SIMD overlap each other's staging with MFMAs.  Global
+// loads run two chunks ahead of their use; LDS operand reads one k-step ahead.
+// Columns past the last full chunk (d mod KC, the 2 location channels when
+// C is a multiple of KC) are fed straight from global memory, one float per
+// lane per k-step.
 //
 // v_mfma_f32_32x32x2_f32 operand map: A[i = l&31][k = l>>5], B[k = l>>5][j = l&31];
 // D[i][j] at lane (j, h = l>>5), register r <-> i = (r&3) + 8*(r>>2) + 4*h.
@@ -217,8 +258,10 @@ __global__ __launch_bounds__(NW * 64) void assign_kernel(
   constexpr int XS = KC + 1;
   constexpr int MB = KB / 32;
   constexpr int F2_PER_ROW = KC / 2;
-  constexpr int LOADS = (TPX * F2_PER_ROW) / NT;
-  static_assert((TPX * F2_PER_ROW) % NT == 0, "staging must divide evenly");
+  constexpr int LOADS = (32 * F2_PER_ROW) / 64;       // float2 per lane per chunk
+  constexpr int ROWS_PER_LOAD = 64 / F2_PER_ROW;
+  constexpr int MAXT = 4;                             // preloaded tail k-steps
+  static_assert((32 * F2_PER_ROW) % 64 == 0 && 64 % F2_PER_ROW == 0, "staging must divide evenly");
 
   extern __shared__ float lds[];
   // `split` workgroups share one chunk (split = 1 when there are plenty of
@@ -237,13 +280,13 @@ __global__ __launch_bounds__(NW * 64) void assign_kernel(
   const int dpad = (d + 1) & ~1;
   const int DP = dpad | 1;
   float *cent_s = lds;                     // [KB][DP]
-  float *xs = lds + KB * DP;               // [2][TPX][XS]
+  float *xs = lds + KB * DP;               // [NW][2][32][XS]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
 
-  // ---- stage the centroid block once per chunk (rows >= K and the pad
-  //      column are zero); batches of 8 independent 8-byte loads per thread
+  // ---- stage the centroid block once (rows >= K and the pad column are
+  //      zero); batches of 8 independent 8-byte loads per thread
   {
     const float *src = cent + ((int64_t)b * K + kb0) * d;
     const int kvalid = min(KB, K - kb0);
@@ -276,94 +319,97 @@ __global__ __launch_bounds__(NW * 64) void assign_kernel(
     }
   }
 
-  const int nq = (dpad + KC - 1) / KC;
+  const int nfull = d / KC;                 // full column chunks, staged via LDS
+  const int tcol0 = nfull * KC;
+  const int tsteps = (dpad - tcol0) / 2;    // tail k-steps, fed from global
   const int ntile = (nrows + TPX - 1) / TPX;
-  const int nsteps = ntile * nq;
+  const int nsteps = ntile * nfull;
 
-  // Staging loads are branch-free: out-of-range rows / columns are clamped to
-  // a valid address and zeroed by a select, so all LOADS loads of a chunk are
-  // in flight together.
-  float2 pre[LOADS];
-  auto load_chunk = [&](int g) {
-    const int tile = g / nq, q = g - tile * nq;
-    const int n = min(TPX, nrows - tile * TPX);
-    const int64_t row0 = crow0 + (int64_t)tile * TPX;
+  float *xw = xs + w * (2 * 32 * XS);
+  const int lpx = lane / F2_PER_ROW, lf2 = lane % F2_PER_ROW;
+
+  // issue the LOADS 8-byte loads of global chunk g (tile g / nfull, chunk g % nfull)
+  auto load_chunk = [&](int g, float2 (&pre)[LOADS]) {
+    const int tile = g / nfull, q = g - tile * nfull;
+    const int n = nrows - tile * TPX - w * 32;       // rows this wave owns in the tile
+    const float *tb = x + (crow0 + (int64_t)tile * TPX + w * 32) * d + q * KC;   // wave-uniform
 #pragma unroll
     for (int i = 0; i < LOADS; ++i) {
-      const int e = tid + NT * i;
-      const int px = e / F2_PER_ROW, f2 = e % F2_PER_ROW;
-      const int dd = q * KC + 2 * f2;
-      const bool ok = px < n && dd < d;
-      const int pxc = px < n ? px : n - 1;
-      const int ddc = dd < d ? dd : 0;
-      const float *src = x + (row0 + pxc) * (int64_t)d + ddc;
+      const int px = lpx + ROWS_PER_LOAD * i;
+      const int pxc = max(min(px, n - 1), -(tile * TPX + w * 32));   // stay inside the chunk
+      const float *src = tb + pxc * d + 2 * lf2;
       float2 v;
       if constexpr (EVEN_D) {
         v = *reinterpret_cast<const float2 *>(src);
       } else {
         v.x = src[0];
-        v.y = src[ddc + 1 < d ? 1 : 0];
-        if (dd + 1 >= d) v.y = 0.0f;
+        v.y = src[1];                                 // q*KC + 2*lf2 + 1 < tcol0 <= d
       }
-      pre[i] = ok ? v : make_float2(0.0f, 0.0f);
+      pre[i] = px < n ? v : make_float2(0.0f, 0.0f);
     }
   };
-  auto store_chunk = [&](int buf) {
-    float *dst = xs + buf * (TPX * XS);
+  auto store_chunk = [&](int buf, const float2 (&pre)[LOADS]) {
+    float *dst = xw + buf * (32 * XS);
 #pragma unroll
     for (int i = 0; i < LOADS; ++i) {
-      const int e = tid + NT * i;
-      const int px = e / F2_PER_ROW, f2 = e % F2_PER_ROW;
-      dst[px * XS + 2 * f2] = pre[i].x;
-      dst[px * XS + 2 * f2 + 1] = pre[i].y;
+      const int px = lpx + ROWS_PER_LOAD * i;
+      dst[px * XS + 2 * lf2] = pre[i].x;
+      dst[px * XS + 2 * lf2 + 1] = pre[i].y;
     }
   };
 
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-
-  int g = 0;
-  for (int tile = 0; tile < ntile; ++tile) {
-    f32x16 acc[MB];
+  f32x16 acc[MB];
+  auto zero_acc = [&]() {
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+  };
 
-    for (int q = 0; q < nq; ++q, ++g) {
-      if (g + 1 < nsteps) load_chunk(g + 1);
-      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of, and its LDS
-                                           // write-back behind, this chunk's MFMAs
-      const float *xb = xs + (g & 1) * (TPX * XS) + (w * 32 + j) * XS + h;
-      const float *cb = cent_s + j * DP + q * KC + h;
-      const int rem = dpad - q * KC;
-      if (rem >= KC) {
+  // tail operand of (tile, k-step st): column tcol0 + 2*st + h of row j
+  auto load_tail = [&](int tile, int st) -> float {
+    const int n = nrows - tile * TPX - w * 32;
+    const int col = tcol0 + 2 * st + h;
+    const int jc = max(min(j, n - 1), -(tile * TPX + w * 32));
+    const float v = x[(crow0 + (int64_t)tile * TPX + w * 32 + jc) * d + min(col, d - 1)];
+    return (j < n && col < d) ? v : 0.0f;
+  };
+
+  // all MFMAs of one staged chunk; LDS operands are read one k-step ahead
+  auto compute_chunk = [&](int buf, int q) {
+    const float *xb = xw + buf * (32 * XS) + j * XS + h;
+    const float *cb = cent_s + j * DP + q * KC + h;
+    float bc = xb[0], ac[MB];
 #pragma unroll
-        for (int st = 0; st < KC / 2; ++st) {
-          const float bv = xb[2 * st];
+    for (int m = 0; m < MB; ++m) ac[m] = cb[m * 32 * DP];
 #pragma unroll
-          for (int m = 0; m < MB; ++m) {
-            const float av = cb[m * 32 * DP + 2 * st];
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
-          }
-        }
-      } else {
-        for (int st = 0; st < rem / 2; ++st) {
-          const float bv = xb[2 * st];
+    for (int st = 0; st < KC / 2; ++st) {
+      float bn = 0.0f, an[MB];
+      if (st + 1 < KC / 2) {
+        bn = xb[2 * st + 2];
 #pragma unroll
-          for (int m = 0; m < MB; ++m) {
-            const float av = cb[m * 32 * DP + 2 * st];
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
-          }
-        }
+        for (int m = 0; m < MB; ++m) an[m] = cb[m * 32 * DP + 2 * st + 2];
       }
-      __builtin_amdgcn_sched_barrier(0);
-      if (g + 1 < nsteps) store_chunk((g + 1) & 1);
-      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);     // next operands are in flight ...
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[m], bc, acc[m], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);     // ... while these MFMAs occupy the pipe
+      bc = bn;
+#pragma unroll
+      for (int m = 0; m < MB; ++m) ac[m] = an[m];
     }
+  };
 
-    // ---- argmax over this lane's rows (ascending index, strict >)
+  // tail k-steps + argmax + label store of one finished tile
+  auto finish_tile = [&](int tile, const float (&bt)[MAXT]) {
+    const float *cb = cent_s + j * DP + tcol0 + h;
+    for (int st = 0; st < tsteps; ++st) {
+      const float bv = st < MAXT ? bt[st < MAXT ? st : 0] : load_tail(tile, st);
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[m * 32 * DP + 2 * st], bv, acc[m], 0, 0, 0);
+    }
     float bv = -INFINITY;
     int bi = 0x7fffffff;
 #pragma unroll
@@ -372,12 +418,11 @@ __global__ __launch_bounds__(NW * 64) void assign_kernel(
       for (int r = 0; r < 16; ++r) {
         const int k = kb0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const float v = acc[m][r];
-        if (k < K && v > bv) { bv = v; bi = k; }
+        if (k < K && v > bv) { bv = v; bi = k; }      // ascending k, strict >: first maximum
       }
     const float ov = __shfl_xor(bv, 32);
     const int oi = __shfl_xor(bi, 32);
     if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-
     const int px = tile * TPX + w * 32 + j;
     if (h == 0 && px < nrows) {
       const int64_t row = crow0 + px;
@@ -389,6 +434,61 @@ __global__ __launch_bounds__(NW * 64) void assign_kernel(
         klab[row] = bi;
         best[row] = bv;
       }
+    }
+  };
+
+  __syncthreads();                         // centroid block visible to all waves
+  zero_acc();
+
+  float bt[MAXT];
+  auto preload_tail = [&](int tile) {
+#pragma unroll
+    for (int st = 0; st < MAXT; ++st) bt[st] = st < tsteps ? load_tail(tile, st) : 0.0f;
+  };
+
+  if (nfull == 0) {                         // rows shorter than one chunk
+    for (int tile = 0; tile < ntile; ++tile) {
+      preload_tail(tile);
+      finish_tile(tile, bt);
+      zero_acc();
+    }
+    return;
+  }
+
+  // software pipeline over global chunk index g = tile * nfull + q: register
+  // sets A / B alternate, each loaded two chunks ahead of its use.
+  float2 preA[LOADS], preB[LOADS];
+  load_chunk(0, preA);
+  if (nsteps > 1) load_chunk(1, preB);
+  preload_tail(0);
+  int tile = 0, q = 0;
+  for (int g = 0; g < nsteps; g += 2) {
+    // ---- even step: set A, LDS buffer 0
+    store_chunk(0, preA);
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 2 < nsteps) load_chunk(g + 2, preA);
+    __builtin_amdgcn_sched_barrier(0);
+    compute_chunk(0, q);
+    if (++q == nfull) {
+      finish_tile(tile, bt);
+      zero_acc();
+      q = 0;
+      ++tile;
+      if (tile < ntile) preload_tail(tile);
+    }
+    if (g + 1 >= nsteps) break;
+    // ---- odd step: set B, LDS buffer 1
+    store_chunk(1, preB);
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 3 < nsteps) load_chunk(g + 3, preB);
+    __builtin_amdgcn_sched_barrier(0);
+    compute_chunk(1, q);
+    if (++q == nfull) {
+      finish_tile(tile, bt);
+      zero_acc();
+      q = 0;
+      ++tile;
+      if (tile < ntile) preload_tail(tile);
     }
   }
 }
