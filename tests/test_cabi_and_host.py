@@ -1,0 +1,78 @@
+"""CPU-only checks: the C-ABI library loads, exports every symbol that
+include/hsgk.h declares (no compute calls without a GPU), and the host-side
+helpers of the Python mirror agree with the oracle / golden tables."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+  text = open(os.path.join(ROOT, 'include', 'hsgk.h')).read()
+  return sorted(set(re.findall(r'HSGK_API\s+[\w\s\*]+?\b(hsgk_\w+)\s*\(', text)))
+
+
+def test_header_symbols_exported_and_bound():
+  from hsg_amd import _lib
+  L = _lib.lib()
+  names = _declared_symbols()
+  assert len(names) >= 10
+  for n in names:
+    assert hasattr(L, n), 'libhsgk.so does not export %s' % n
+    assert n in _lib.SIGNATURES, 'hsg_amd/_lib.py does not bind %s' % n
+  assert L.hsgk_version() >= 100
+  assert set(_lib.SIGNATURES) == set(names)
+
+
+def test_workspace_queries_run_on_cpu():
+  from hsg_amd import _lib
+  L = _lib.lib()
+  a = L.hsgk_segment_by_kmeans_workspace_bytes(4, 32, 64, 64, 8, 32)
+  b = L.hsgk_segment_by_kmeans_workspace_bytes(48, 256, 448, 448, 64, 48 * 64)
+  assert 0 < a < b < (1 << 31)
+  assert L.hsgk_kmeans_workspace_bytes(5000, 258, 64) > 0
+  assert L.hsgk_lloyd_workspace_bytes(2, 4096, 34, 8) > 0
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+  from hsg_amd import _lib
+  monkeypatch.setattr(_lib, '_lib', None)
+  monkeypatch.setattr(_lib, 'SO_PATH', '/nonexistent/libhsgk.so')
+  with pytest.raises(_lib.HsgkError):
+    _lib.lib()
+
+
+def test_cpu_tensors_rejected():
+  import torch
+  from hsg_amd import _lib
+  from hsg_amd.utils.segsort import common as sc
+  with pytest.raises(_lib.HsgkError):
+    sc.segment_by_kmeans(torch.zeros(1, 4, 8, 8), None, [2, 2])
+
+
+def test_seed_axis_matches_torch_and_oracle(oracle):
+  """Host seed labels (torch linspace().round_()) == exact half-even formula."""
+  import torch
+  from hsg_amd.utils.segsort import common as sc
+  for n in (1, 2, 5, 14, 28, 37, 56, 64, 100, 224, 448, 449, 768, 1024):
+    for k in (1, 2, 3, 4, 5, 6, 8, 12, 16, 24):
+      t = torch.linspace(0, k - 1, n).round_().long().numpy()
+      assert np.array_equal(t, oracle.grid_seed_axis(k, n)), (n, k)
+  lab = sc.initialize_cluster_labels([8, 8], (448, 448), 'cpu').numpy()
+  assert np.array_equal(lab, oracle.initialize_cluster_labels((8, 8), (448, 448)))
+  assert np.bincount(lab.reshape(-1)).min() == 1024          # edge cells half width
+
+
+def test_default_location_features_match_golden():
+  from hsg_amd.utils.segsort import common as sc
+  g = util.load('f2_linspace01')
+  for key in ('n56', 'n448', 'n768'):
+    n = int(key[1:])
+    loc = sc.generate_location_features((n, 3), 'cpu', 'float').numpy()
+    assert np.array_equal(loc[:, 0, 0], g[key])
