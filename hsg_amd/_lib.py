@@ -58,6 +58,9 @@ SIGNATURES = {
     'hsgk_lloyd_workspace_bytes': (_sz, [_i32, _i64, _i32, _i32]),
     'hsgk_lloyd_mstep': (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     'hsgk_lloyd_estep': (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    'hsgk_segment_reduce_workspace_bytes': (_sz, [_i64, _i32, _i64]),
+    'hsgk_segment_reduce': (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'hsgk_segment_reduce_bwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _f32, _vp, _vp, _vp]),
     'hsgk_assign_workspace_bytes': (_sz, [_i64, _i32, _i32]),
     'hsgk_find_nearest_prototypes': (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
 }

@@ -1,0 +1,122 @@
+// accumulate.h -- device-side chunk accumulation shared by the k-means M-step
+// (kmeans.hip) and segment_reduce (segreduce.hip).  See kmeans.hip for the
+// ordering argument (canonical order C2).
+#pragma once
+#include "common.h"
+
+namespace hsgk {
+
+__device__ inline int owner_wave(int label) {
+  return (label ^ (label >> 2) ^ (label >> 4) ^ (label >> 6)) & 3;
+}
+
+// Accumulates the rows of one chunk whose label lies in [lo, lo+cnt_lab) into
+// the zeroed LDS table sums[cnt_lab][DS].  Shared by the k-means M-step
+// (int32 working labels, window = cluster block) and segment_reduce (int64
+// labels, window = the chunk's own label range).
+template <int VEC, int UNROLL, typename LabT>
+__device__ inline void chunk_accumulate(const float *__restrict__ xr, int d, int DS,
+                                        const LabT *__restrict__ lab, int n, int64_t lo,
+                                        int cnt_lab, float *sums, uint32_t *rlist,
+                                        int *wcount) {
+  typedef float gvec_t __attribute__((ext_vector_type(VEC), aligned(4)));       // global: dword aligned
+  typedef float lvec_t __attribute__((ext_vector_type(VEC), aligned(4 * VEC))); // LDS: natural
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+
+  // ---- pass 1: every wave counts the rows it owns; pass 2: ordered row list
+  int cnt = 0;
+  for (int base = 0; base < n; base += 64) {
+    int64_t l = -1;
+    if (base + lane < n) l = (int64_t)lab[base + lane] - lo;
+    const bool mine = l >= 0 && l < cnt_lab && owner_wave((int)l) == w;
+    cnt += __popcll(__ballot(mine));
+  }
+  if (lane == 0) wcount[w] = cnt;
+  __syncthreads();
+  int lbeg = 0;
+  for (int i = 0; i < w; ++i) lbeg += wcount[i];
+  {
+    int pos = lbeg;
+    for (int base = 0; base < n; base += 64) {
+      int64_t l = -1;
+      if (base + lane < n) l = (int64_t)lab[base + lane] - lo;
+      const bool mine = l >= 0 && l < cnt_lab && owner_wave((int)l) == w;
+      const unsigned long long m = __ballot(mine);
+      if (mine) rlist[pos + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)(base + lane) << 10) | (uint32_t)l;
+      pos += __popcll(m);
+    }
+  }
+  // (a wave reads back only its own list entries: in-order LDS, no barrier)
+
+  constexpr int PW = 64 * VEC;
+  const int npass = d / PW;
+  const int tail0 = npass * PW;
+  const int tail = d - tail0;          // < 64*VEC columns, one float per lane per step
+  const uint32_t *mylist = rlist + lbeg;
+
+  // Batches of UNROLL rows; the loads of batch i+1 are issued before batch i is
+  // folded into LDS (only the first column pass is double buffered: npass == 1
+  // for d < 2*64*VEC, the shapes this kernel is tuned for).
+  gvec_t va[UNROLL], vb[UNROLL];
+  float ta[UNROLL], tb[UNROLL];
+  const bool on = lane < tail;
+  auto issue = [&](int b0, gvec_t (&v)[UNROLL], float (&t)[UNROLL]) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int idx = min(b0 + u, cnt - 1);
+      const int r = (int)(mylist[idx] >> 10);
+      if (npass > 0) v[u] = *reinterpret_cast<const gvec_t *>(xr + (int64_t)r * d + lane * VEC);
+      t[u] = on ? xr[(int64_t)r * d + tail0 + lane] : 0.0f;
+    }
+  };
+  auto fold = [&](int b0, const gvec_t (&v)[UNROLL], const float (&t)[UNROLL]) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      if (b0 + u < cnt) {
+        const uint32_t e = mylist[b0 + u];
+        const int r = (int)(e >> 10), l = (int)(e & 1023u);
+        if (npass > 0) {
+          lvec_t *dst = reinterpret_cast<lvec_t *>(sums + l * DS + lane * VEC);
+          lvec_t acc = *dst;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] = acc[i] + v[u][i];
+          *dst = acc;
+        }
+        for (int p = 1; p < npass; ++p) {                     // further full passes (wide rows)
+          const gvec_t vv = *reinterpret_cast<const gvec_t *>(xr + (int64_t)r * d + p * PW + lane * VEC);
+          lvec_t *dst = reinterpret_cast<lvec_t *>(sums + l * DS + p * PW + lane * VEC);
+          lvec_t acc = *dst;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] = acc[i] + vv[i];
+          *dst = acc;
+        }
+        if (on) {
+          float *dst = sums + l * DS + tail0 + lane;
+          *dst = *dst + t[u];
+        }
+        for (int t0 = 64; t0 < tail; t0 += 64)                // wider tails (VEC > 1 only)
+          if (t0 + lane < tail) {
+            float *dst = sums + l * DS + tail0 + t0 + lane;
+            *dst = *dst + xr[(int64_t)r * d + tail0 + t0 + lane];
+          }
+      }
+    }
+  };
+  if (cnt > 0) {
+    issue(0, va, ta);
+    for (int b0 = 0; b0 < cnt; b0 += 2 * UNROLL) {
+      if (b0 + UNROLL < cnt) issue(b0 + UNROLL, vb, tb);
+      __builtin_amdgcn_sched_barrier(0);
+      fold(b0, va, ta);
+      __builtin_amdgcn_sched_barrier(0);
+      if (b0 + UNROLL >= cnt) break;
+      if (b0 + 2 * UNROLL < cnt) issue(b0 + 2 * UNROLL, va, ta);
+      __builtin_amdgcn_sched_barrier(0);
+      fold(b0 + UNROLL, vb, tb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+
+}  // namespace hsgk

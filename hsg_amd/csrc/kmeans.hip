@@ -11,6 +11,7 @@
 //      exactly what v_mfma_f32_32x32x2_f32 computes (k-ordered fmaf chain) --
 //      argmax takes the first maximal index.
 #include "common.h"
+#include "accumulate.h"
 
 namespace hsgk {
 
@@ -29,126 +30,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //
 // LDS row stride DS = d rounded up to VEC floats so the per-lane VEC-wide
 // LDS accesses stay naturally aligned.
-__device__ inline int owner_wave(int label) {
-  return (label ^ (label >> 2) ^ (label >> 4) ^ (label >> 6)) & 3;
-}
-
 template <int VEC, int UNROLL>
 __global__ __launch_bounds__(256) void accumulate_kernel(
     const float *__restrict__ x, int d, const int32_t *__restrict__ klab,
     const int64_t *__restrict__ chunk_row0, const int32_t *__restrict__ chunk_rows,
     int K, int kb0, int kbn, float *__restrict__ partial,
     const hsgk_segkm_meta *__restrict__ meta) {
-  typedef float gvec_t __attribute__((ext_vector_type(VEC), aligned(4)));       // global: dword aligned
-  typedef float lvec_t __attribute__((ext_vector_type(VEC), aligned(4 * VEC))); // LDS: natural
-  extern __shared__ float sums[];   // [kbn][DS] then the row lists
+  extern __shared__ float sums[];   // [kbn][DS] then the row list
+  __shared__ int wcount[4];
   const int c = blockIdx.x;
   if (c >= meta->n_chunks) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int DS = (d + VEC - 1) / VEC * VEC;
   const int tot = kbn * DS;
-  uint32_t *rlist = reinterpret_cast<uint32_t *>(sums + tot);   // [HSGK_CHUNK] (row << 8 | label)
-  __shared__ int wcount[4];
+  uint32_t *rlist = reinterpret_cast<uint32_t *>(sums + tot);   // [HSGK_CHUNK] (row << 10 | label)
   for (int i = tid; i < tot; i += 256) sums[i] = 0.0f;
-
   const int64_t row0 = chunk_row0[c];
-  const int n = chunk_rows[c];
-  const int32_t *lab = klab + row0;
-  const float *xr = x + row0 * d;
-
-  // ---- pass 1: every wave counts the rows it owns; pass 2: ordered row list
-  int cnt = 0;
-  for (int base = 0; base < n; base += 64) {
-    int l = -1;
-    if (base + lane < n) l = lab[base + lane] - kb0;
-    const bool mine = l >= 0 && l < kbn && owner_wave(l + kb0) == w;
-    cnt += __popcll(__ballot(mine));
-  }
-  if (lane == 0) wcount[w] = cnt;
-  __syncthreads();
-  int lbeg = 0;
-  for (int i = 0; i < w; ++i) lbeg += wcount[i];
-  {
-    int pos = lbeg;
-    for (int base = 0; base < n; base += 64) {
-      int l = -1;
-      if (base + lane < n) l = lab[base + lane] - kb0;
-      const bool mine = l >= 0 && l < kbn && owner_wave(l + kb0) == w;
-      const unsigned long long m = __ballot(mine);
-      if (mine) rlist[pos + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)(base + lane) << 8) | (uint32_t)l;
-      pos += __popcll(m);
-    }
-  }
-  // (a wave reads back only its own list entries: in-order LDS, no barrier)
-
-  constexpr int PW = 64 * VEC;
-  const int npass = d / PW;
-  const int tail0 = npass * PW;
-  const int tail = d - tail0;          // < 64*VEC columns, one float per lane per step
-  const uint32_t *mylist = rlist + lbeg;
-
-  // Batches of UNROLL rows; the loads of batch i+1 are issued before batch i is
-  // folded into LDS (only the first column pass is double buffered: npass == 1
-  // for d < 2*64*VEC, the shapes this kernel is tuned for).
-  gvec_t va[UNROLL], vb[UNROLL];
-  float ta[UNROLL], tb[UNROLL];
-  const bool on = lane < tail;
-  auto issue = [&](int b0, gvec_t (&v)[UNROLL], float (&t)[UNROLL]) {
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const int idx = min(b0 + u, cnt - 1);
-      const int r = (int)(mylist[idx] >> 8);
-      if (npass > 0) v[u] = *reinterpret_cast<const gvec_t *>(xr + (int64_t)r * d + lane * VEC);
-      t[u] = on ? xr[(int64_t)r * d + tail0 + lane] : 0.0f;
-    }
-  };
-  auto fold = [&](int b0, const gvec_t (&v)[UNROLL], const float (&t)[UNROLL]) {
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      if (b0 + u < cnt) {
-        const uint32_t e = mylist[b0 + u];
-        const int r = (int)(e >> 8), l = (int)(e & 255u);
-        if (npass > 0) {
-          lvec_t *dst = reinterpret_cast<lvec_t *>(sums + l * DS + lane * VEC);
-          lvec_t acc = *dst;
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[i] = acc[i] + v[u][i];
-          *dst = acc;
-        }
-        for (int p = 1; p < npass; ++p) {                     // further full passes (wide rows)
-          const gvec_t vv = *reinterpret_cast<const gvec_t *>(xr + (int64_t)r * d + p * PW + lane * VEC);
-          lvec_t *dst = reinterpret_cast<lvec_t *>(sums + l * DS + p * PW + lane * VEC);
-          lvec_t acc = *dst;
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[i] = acc[i] + vv[i];
-          *dst = acc;
-        }
-        if (on) {
-          float *dst = sums + l * DS + tail0 + lane;
-          *dst = *dst + t[u];
-        }
-        for (int t0 = 64; t0 < tail; t0 += 64)                // wider tails (VEC > 1 only)
-          if (t0 + lane < tail) {
-            float *dst = sums + l * DS + tail0 + t0 + lane;
-            *dst = *dst + xr[(int64_t)r * d + tail0 + t0 + lane];
-          }
-      }
-    }
-  };
-  if (cnt > 0) {
-    issue(0, va, ta);
-    for (int b0 = 0; b0 < cnt; b0 += 2 * UNROLL) {
-      if (b0 + UNROLL < cnt) issue(b0 + UNROLL, vb, tb);
-      __builtin_amdgcn_sched_barrier(0);
-      fold(b0, va, ta);
-      __builtin_amdgcn_sched_barrier(0);
-      if (b0 + UNROLL >= cnt) break;
-      if (b0 + 2 * UNROLL < cnt) issue(b0 + 2 * UNROLL, va, ta);
-      __builtin_amdgcn_sched_barrier(0);
-      fold(b0 + UNROLL, vb, tb);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
+  chunk_accumulate<VEC, UNROLL, int32_t>(x + row0 * d, d, DS, klab + row0, chunk_rows[c], kb0,
+                                         kbn, sums, rlist, wcount);
   __syncthreads();
   float *out = partial + ((int64_t)c * K + kb0) * d;
   for (int k = w; k < kbn; k += 4)
@@ -170,7 +69,7 @@ int launch_accumulate(const float *x, int d, const int32_t *klab, const ChunkTab
     kbn = (int)(budget1 / ((size_t)DS * 4));
     if (kbn > K) kbn = K;
   }
-  if (kbn > 256) kbn = 256;                 // label field of the row list is 8 bits
+  if (kbn > 1024) kbn = 1024;               // label field of the row list is 10 bits
   HSGK_REQUIRE(kbn >= 1, "row too long for the LDS segment table");
   // 16-byte global loads only need dword alignment on gfx950.
   auto kern = wide ? accumulate_kernel<4, 8> : accumulate_kernel<1, 16>;

@@ -1,0 +1,72 @@
+"""torch.autograd glue over the libhsgk C ABI (internal; the public surface is
+the reference-shaped modules under hsg_amd/utils and hsg_amd/models)."""
+import ctypes
+
+import torch
+
+from hsg_amd import _lib
+
+EPS = 1e-12
+
+
+def require_gpu(t, name):
+  if not t.is_cuda:
+    raise _lib.HsgkError('%s must be a ROCm device tensor (got %s); hsg_amd has '
+                         'no CPU path' % (name, t.device))
+
+
+def _segment_reduce_fwd(x, labels, P, mode):
+  n, d = x.shape
+  L = _lib.lib()
+  dev = x.device
+  with torch.cuda.device(dev):
+    out = torch.empty((P, d), dtype=torch.float32, device=dev)
+    aux = torch.empty((max(P, 1),), dtype=torch.float32, device=dev)
+    status = torch.empty((1,), dtype=torch.int32, device=dev)
+    wsb = L.hsgk_segment_reduce_workspace_bytes(n, d, P)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    _lib.check(L.hsgk_segment_reduce(
+        x.data_ptr(), n, d, labels.data_ptr(), P, mode, ctypes.c_float(EPS), out.data_ptr(),
+        aux.data_ptr(), status.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr()))
+    if int(status.item()) != 0:
+      raise _lib.HsgkError(
+          'segment_reduce: one 2048-row chunk spans more than 512 consecutive segment ids; '
+          'rows must be grouped by segment id range (image-major rows, sorted ids)')
+  return out, aux
+
+
+class SegmentReduce(torch.autograd.Function):
+  """mode 0 prototypes (normalised sums), 1 means, 2 raw sums."""
+
+  @staticmethod
+  def forward(ctx, x, labels, P, mode):
+    x = x.contiguous()
+    out, aux = _segment_reduce_fwd(x.detach(), labels, P, mode)
+    ctx.save_for_backward(out, aux, labels)
+    ctx.meta = (x.shape[0], x.shape[1], P, mode)
+    return out
+
+  @staticmethod
+  def backward(ctx, gout):
+    out, aux, labels = ctx.saved_tensors
+    n, d, P, mode = ctx.meta
+    gout = gout.contiguous().to(torch.float32)
+    dev = gout.device
+    with torch.cuda.device(dev):
+      gseg = torch.empty((max(P, 1), d), dtype=torch.float32, device=dev)
+      gx = torch.empty((n, d), dtype=torch.float32, device=dev)
+      _lib.check(_lib.lib().hsgk_segment_reduce_bwd(
+          gout.data_ptr(), out.data_ptr(), aux.data_ptr(), labels.data_ptr(), n, d, P, mode,
+          ctypes.c_float(EPS), gseg.data_ptr(), gx.data_ptr(), _lib.stream_ptr()))
+    return gx, None, None, None
+
+
+def segment_reduce(x, labels, P, mode):
+  require_gpu(x, 'x')
+  if x.dtype != torch.float32:
+    raise TypeError('x must be float32')
+  x2 = x.reshape(-1, x.shape[-1])
+  lab = labels.reshape(-1).to(torch.int64).contiguous()
+  if lab.shape[0] != x2.shape[0]:
+    raise ValueError('labels and rows disagree: %d vs %d' % (lab.shape[0], x2.shape[0]))
+  return SegmentReduce.apply(x2, lab, int(P), int(mode))

@@ -9,7 +9,7 @@ import ctypes
 
 import torch
 
-from hsg_amd import _lib
+from hsg_amd import _lib, ops
 
 
 def _require_gpu(t, name):
@@ -35,3 +35,20 @@ def normalize_embedding(embeddings, eps=1e-12):
     _lib.check(_lib.lib().hsgk_normalize_rows(
         x.data_ptr(), n, d, ctypes.c_float(eps), out.data_ptr(), _lib.stream_ptr()))
   return out
+
+
+def segment_mean(x, index):
+  """tf.segment_mean look-alike (reference general/common.py:123-147):
+  per-index mean of the rows of x, empty indices give zero rows."""
+  max_index = int(index.max()) + 1
+  return ops.segment_reduce(x, index, max_index, 1)
+
+
+def one_hot(labels, max_label=None):
+  """Reference general/common.py:76-98 (bookkeeping helper, stays on ATen)."""
+  if max_label is None:
+    max_label = int(labels.max()) + 1
+  flat = labels.reshape(-1, 1)
+  out = torch.zeros((flat.shape[0], max_label), dtype=torch.long, device=labels.device)
+  out.scatter_(1, flat, 1)
+  return out.view(list(labels.shape) + [max_label])

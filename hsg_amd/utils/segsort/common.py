@@ -18,7 +18,7 @@ import threading
 
 import torch
 
-from hsg_amd import _lib
+from hsg_amd import _lib, ops
 from hsg_amd.utils.general import common as common_utils
 
 _cache_lock = threading.Lock()
@@ -208,3 +208,20 @@ def find_nearest_prototypes(embeddings, prototypes):
         x.data_ptr(), n, d, p.data_ptr(), p.shape[0], out.data_ptr(), ws.data_ptr(),
         ws_bytes, _lib.stream_ptr()))
   return out
+
+
+def calculate_prototypes_from_labels(embeddings, labels, max_label=None):
+  """Mean direction per label (reference common.py:11-41): zeros ->
+  scatter_add_ -> normalize_embedding.  Differentiable w.r.t. `embeddings`
+  (prototypes carry gradient in the reference's training step)."""
+  if max_label is None:
+    max_label = int(labels.max()) + 1
+  return ops.segment_reduce(embeddings, labels, int(max_label), 0)
+
+
+def prepare_prototype_labels(semantic_labels, instance_labels, offset=256):
+  """Reference common.py:192-218: dense ids of (instance, semantic) pairs in
+  sorted order and the semantic label of every id."""
+  panoptic = semantic_labels + instance_labels * offset
+  proto_panoptic, unique_instance = torch.unique(panoptic, return_inverse=True)
+  return proto_panoptic % offset, unique_instance

@@ -139,6 +139,24 @@ HSGK_API int hsgk_find_nearest_prototypes(const float *x, int64_t n, int d,
                                  int64_t *labels_out, void *workspace,
                                  size_t workspace_bytes, hsgk_stream_t stream);
 
+/* ---- hsg/utils/segsort/common.py:11-41 calculate_prototypes_from_labels and
+ *      hsg/utils/general/common.py:123-147 segment_mean -----------------------
+ * x [n,d], labels int64 [n] (rows with labels outside [0,P) are skipped).
+ * mode 0: L2-normalised segment sums; mode 1: means (count 0 -> 1); mode 2: raw
+ * sums.  out [P,d]; aux [P] (nullable) receives the clamped norm (mode 0) or
+ * the count (mode 1) for the backward pass.  *status (device int32) becomes 1
+ * if one 2048-row chunk spans more than 512 consecutive segment ids.          */
+HSGK_API size_t hsgk_segment_reduce_workspace_bytes(int64_t n, int d, int64_t P);
+HSGK_API int hsgk_segment_reduce(const float *x, int64_t n, int d, const int64_t *labels,
+                                 int64_t P, int mode, float eps, float *out, float *aux,
+                                 int32_t *status, void *workspace, size_t workspace_bytes,
+                                 hsgk_stream_t stream);
+/* gx [n,d] = d(loss)/d(x) given gout [P,d]; gseg [P,d] is scratch.             */
+HSGK_API int hsgk_segment_reduce_bwd(const float *gout, const float *out, const float *aux,
+                                     const int64_t *labels, int64_t n, int d, int64_t P,
+                                     int mode, float eps, float *gseg, float *gx,
+                                     hsgk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,3 +114,85 @@ def test_normalize_embedding_bit_exact(dev, oracle):
   x[11] *= np.float32(1e-9)
   y = gc.normalize_embedding(torch.from_numpy(x).to(dev)).cpu().numpy()
   assert np.abs(y - g['y']).max() <= FTOL
+
+
+def test_prototypes_and_segment_mean_vs_golden_and_oracle(dev, oracle):
+  import torch
+  from hsg_amd.utils.segsort import common as sc
+  from hsg_amd.utils.general import common as gc
+  g = util.load('f5_prototypes')
+  n, d = int(g['n']), int(g['d'])
+  x = oracle.normalize_embedding(synth.gaussish(int(g['seed']), n * d).reshape(n, d))
+  lab = g['labels'].astype(np.int64)
+  xt, lt = torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)
+  p_auto = sc.calculate_prototypes_from_labels(xt, lt).cpu().numpy()
+  p_pad = sc.calculate_prototypes_from_labels(xt, lt, 64).cpu().numpy()
+  sm = gc.segment_mean(xt, lt).cpu().numpy()
+  assert np.abs(p_auto - g['p_auto']).max() <= FTOL
+  assert np.abs(p_pad - g['p_pad']).max() <= FTOL
+  assert np.abs(sm - g['seg_mean']).max() <= FTOL
+  assert np.array_equal(p_auto, oracle.calculate_prototypes_from_labels(x, lab))
+  assert np.array_equal(p_pad, oracle.calculate_prototypes_from_labels(x, lab, 64))
+  assert np.array_equal(sm, oracle.segment_mean(x, lab))
+  assert np.all(p_pad[5] == 0) and np.all(p_pad[37:] == 0)
+
+
+@pytest.mark.parametrize('n,d,P', [(1, 3, 1), (2047, 34, 7), (2049, 258, 64), (30000, 130, 700),
+                                   (9000, 258, 300), (5000, 66, 1000)])
+def test_segment_reduce_sorted_ids_vs_oracle(dev, oracle, n, d, P):
+  """Large P with image-major style (monotone, locally clustered) ids."""
+  import torch
+  from hsg_amd import ops
+  x = oracle.normalize_embedding(synth.gaussish(7 + n, n * d).reshape(n, d))
+  base = (np.arange(n, dtype=np.int64) * P) // n               # monotone 0..P-1
+  jitter = (synth.hash_u64(3 + n, n) % np.uint64(5)).astype(np.int64)
+  lab = np.clip(base + jitter - 2, 0, P - 1)
+  lab[::97] = -1                                               # skipped rows
+  xt, lt = torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)
+  for mode in (0, 1, 2):
+    got = ops.segment_reduce(xt, lt, P, mode).cpu().numpy()
+    if mode == 0:
+      ref = oracle.calculate_prototypes_from_labels(x, lab, P)
+    else:
+      import ctypes
+      ref = np.empty((P, d), np.float32)
+      oracle.lib().orc_segment_sums(
+          x.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), ctypes.c_int64(n), d,
+          lab.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), ctypes.c_int64(P), oracle.CHUNK,
+          ref.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+      if mode == 1:
+        cnt = np.bincount(lab[lab >= 0], minlength=P).astype(np.float32)
+        cnt[cnt == 0] = 1
+        ref = ref / cnt[:, None]
+    assert np.array_equal(got, ref), (mode, int((got != ref).sum()))
+
+
+def test_prototype_gradients_match_torch_autograd(dev):
+  """Backward of calculate_prototypes_from_labels / segment_mean against a
+  plain torch (ATen, fp32) restatement of the same op on the GPU."""
+  import torch
+  from hsg_amd.utils.segsort import common as sc
+  from hsg_amd.utils.general import common as gc
+  n, d, P = 4000, 66, 37
+  x = torch.from_numpy(synth.gaussish(21, n * d).reshape(n, d)).to(dev)
+  lab = torch.from_numpy((synth.hash_u64(22, n) % np.uint64(P)).astype(np.int64)).to(dev)
+  w = torch.from_numpy(synth.gaussish(23, P * d).reshape(P, d)).to(dev)
+
+  def ref_proto(xx):
+    acc = torch.zeros((P, d), device=dev).index_add_(0, lab, xx)
+    nrm = acc.norm(dim=1, keepdim=True)
+    return acc / torch.where(nrm >= 1e-12, nrm, torch.full_like(nrm, 1e-12))
+
+  def ref_mean(xx):
+    acc = torch.zeros((P, d), device=dev).index_add_(0, lab, xx)
+    cnt = torch.bincount(lab, minlength=P).clamp(min=1).float()
+    return acc / cnt[:, None]
+
+  for ours, ref in ((lambda t: sc.calculate_prototypes_from_labels(t, lab, P), ref_proto),
+                    (lambda t: gc.segment_mean(t, lab), ref_mean)):
+    a = x.clone().requires_grad_(True)
+    b = x.clone().requires_grad_(True)
+    (ours(a) * w).sum().backward()
+    (ref(b) * w).sum().backward()
+    scale = b.grad.abs().max().item()
+    assert (a.grad - b.grad).abs().max().item() <= 1e-5 * max(scale, 1.0)
