@@ -61,6 +61,11 @@ SIGNATURES = {
     'hsgk_segment_reduce_workspace_bytes': (_sz, [_i64, _i32, _i64]),
     'hsgk_segment_reduce': (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
     'hsgk_segment_reduce_bwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _f32, _vp, _vp, _vp]),
+    'hsgk_segsort_loss_workspace_bytes': (_sz, [_i64, _i32, _i64]),
+    'hsgk_segsort_loss_fwd': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _f32, _i32, _vp, _vp,
+                                     _vp, _vp, _vp, _sz, _vp]),
+    'hsgk_segsort_loss_bwd_weights': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _f32, _i32,
+                                             _vp, _vp, _vp, _vp, _vp, _vp]),
     'hsgk_assign_workspace_bytes': (_sz, [_i64, _i32, _i32]),
     'hsgk_find_nearest_prototypes': (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
 }

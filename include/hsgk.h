@@ -157,6 +157,26 @@ HSGK_API int hsgk_segment_reduce_bwd(const float *gout, const float *out, const 
                                      int mode, float eps, float *gseg, float *gx,
                                      hsgk_stream_t stream);
 
+/* ---- hsg/utils/segsort/loss.py:15-82,149-190 SegSortLoss --------------------
+ * emb [n,c] f32, sem/inst int64 [n] (inst indexes the prototype table),
+ * proto [P,c] f32, psem int64 [P], kappa = concentration, group_plus = 1 for
+ * 'segsort+', 0 for 'segsort'.  fwd writes the per-pixel negative log
+ * likelihood nll[n] and the backward state num[n], den[n], use_same[n].
+ * bwd_weights writes W^T [P,n] with W^T[p][i] = gscale[i] * dnll_i/d(e_i.p_p);
+ * the caller finishes with two plain GEMMs: g_emb = W proto, g_proto = W^T emb. */
+HSGK_API size_t hsgk_segsort_loss_workspace_bytes(int64_t n, int c, int64_t P);
+HSGK_API int hsgk_segsort_loss_fwd(const float *emb, int64_t n, int c, const int64_t *sem,
+                                   const int64_t *inst, const float *proto, int64_t P,
+                                   const int64_t *psem, float kappa, int group_plus, float *nll,
+                                   float *num, float *den, int32_t *use_same, void *workspace,
+                                   size_t workspace_bytes, hsgk_stream_t stream);
+HSGK_API int hsgk_segsort_loss_bwd_weights(const float *emb, int64_t n, int c, const int64_t *sem,
+                                           const int64_t *inst, const float *proto, int64_t P,
+                                           const int64_t *psem, float kappa, int group_plus,
+                                           const float *num, const float *den,
+                                           const int32_t *use_same, const float *gscale,
+                                           float *wt, hsgk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

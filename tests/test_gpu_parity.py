@@ -196,3 +196,53 @@ def test_prototype_gradients_match_torch_autograd(dev):
     (ref(b) * w).sum().backward()
     scale = b.grad.abs().max().item()
     assert (a.grad - b.grad).abs().max().item() <= 1e-5 * max(scale, 1.0)
+
+
+def test_segsort_loss_vs_golden_and_oracle(dev, oracle):
+  """Loss value within 1e-4 (north_star), per-pixel nll and gradients vs the
+  reference's autograd captured in tests/golden/f6_segsort_loss.npz."""
+  import torch
+  from hsg_amd.utils.segsort import common as sc
+  from hsg_amd.utils.segsort.loss import SegSortLoss
+  g = util.load('f6_segsort_loss')
+  n, c, P = int(g['n']), int(g['c']), int(g['P'])
+  e_np = oracle.normalize_embedding(synth.gaussish(int(g['seed']), n * c).reshape(n, c))
+  inst = torch.from_numpy(g['inst'].astype(np.int64)).to(dev)
+  psem = torch.from_numpy(g['psem'].astype(np.int64)).to(dev)
+  sem = psem[inst]
+  for kappa in (10, 16):
+    for mode, tag in (('segsort+', 'plus'), ('segsort', 'plain')):
+      key = 'k%d_%s' % (kappa, tag)
+      e = torch.from_numpy(e_np).to(dev).requires_grad_(True)
+      proto = sc.calculate_prototypes_from_labels(e, inst, P)
+      assert np.abs(proto.detach().cpu().numpy() - g['proto']).max() <= FTOL
+      pp = proto.detach().clone().requires_grad_(True)
+      loss = SegSortLoss(kappa, mode)(e, sem, inst, pp, psem)
+      loss.backward()
+      assert abs(loss.item() - float(g[key + '_loss'])) <= 1e-4
+      nll = SegSortLoss(kappa, mode, reduction='none')(e.detach(), sem, inst, proto.detach(), psem)
+      assert nll.shape == (n, 1)
+      assert np.abs(nll.view(-1).cpu().numpy() - g[key + '_nll']).max() <= 1e-4
+      assert np.abs(e.grad.cpu().numpy()[::7] - g[key + '_gemb']).max() <= 2e-6
+      assert np.abs(pp.grad.cpu().numpy() - g[key + '_gproto']).max() <= 2e-5
+      ref = oracle.segsort_nll(e_np, sem.cpu().numpy(), inst.cpu().numpy(),
+                               proto.detach().cpu().numpy(), psem.cpu().numpy(), float(kappa), mode)
+      assert abs(loss.item() - ref.mean()) <= 1e-4
+
+
+def test_segsort_loss_large_shapes_vs_oracle(dev, oracle):
+  """C=256 pixels against several prototype blocks incl. a ragged last block
+  and a multi-chunk pixel range."""
+  import torch
+  from hsg_amd.utils.segsort.loss import SegSortLoss
+  n, c, P = 5000, 256, 150
+  e = oracle.normalize_embedding(synth.gaussish(91, n * c).reshape(n, c))
+  p = oracle.normalize_embedding(synth.gaussish(92, P * c).reshape(P, c))
+  inst = (synth.hash_u64(93, n) % np.uint64(P)).astype(np.int64)
+  psem = (synth.hash_u64(94, P) % np.uint64(11)).astype(np.int64)
+  sem = psem[inst]
+  t = lambda a: torch.from_numpy(a).to(dev)
+  for mode in ('segsort+', 'segsort'):
+    nll = SegSortLoss(16, mode, reduction='none')(t(e), t(sem), t(inst), t(p), t(psem))
+    ref = oracle.segsort_nll(e, sem, inst, p, psem, 16.0, mode)
+    assert np.abs(nll.view(-1).cpu().numpy() - ref).max() <= 1e-4
