@@ -36,6 +36,7 @@ class SegkmArgs(ctypes.Structure):
       ('out_embeddings', ctypes.c_void_p), ('out_embeddings_loc', ctypes.c_void_p),
       ('out_labels', ctypes.c_void_p), ('out_cluster', ctypes.c_void_p),
       ('out_batch', ctypes.c_void_p), ('meta', ctypes.c_void_p),
+      ('out_norms', ctypes.c_void_p), ('out_rowmap', ctypes.c_void_p),
       ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t)]
 
 
@@ -51,6 +52,8 @@ SIGNATURES = {
     'hsgk_normalize_rows': (_i32, [_vp, _i64, _i32, _f32, _vp, _vp]),
     'hsgk_segment_by_kmeans_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32, _i32, _i64]),
     'hsgk_segment_by_kmeans': (_i32, [ctypes.POINTER(SegkmArgs), _vp]),
+    'hsgk_segment_by_kmeans_bwd': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32,
+                                          _vp, _vp]),
     'hsgk_kmeans_workspace_bytes': (_sz, [_i64, _i32, _i32]),
     'hsgk_kmeans_with_initial_labels': (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _sz, _vp]),
     'hsgk_profile_enable': (None, [_i32]),

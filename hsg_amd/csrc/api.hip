@@ -179,6 +179,17 @@ int hsgk_segment_by_kmeans(const hsgk_segkm_args *a, hsgk_stream_t stream) {
   return 0;
 }
 
+int hsgk_segment_by_kmeans_bwd(const float *g_emb, const float *g_emb_loc, const float *emb,
+                               const float *emb_loc, const float *norms, const int64_t *rowmap,
+                               int B, int C, int H, int W, float eps, float *gx,
+                               hsgk_stream_t stream) {
+  HSGK_REQUIRE(B >= 1 && C >= 1 && H >= 1 && W >= 1, "bad shape");
+  HSGK_REQUIRE(emb && emb_loc && norms && gx, "null input");
+  (void)hipGetLastError();
+  return launch_prep_bwd(g_emb, g_emb_loc, emb, emb_loc, norms, rowmap, B, C, H, W, eps, gx,
+                         static_cast<hipStream_t>(stream));
+}
+
 // ---------------------------------------------------------------------------
 size_t hsgk_kmeans_workspace_bytes(int64_t n, int d, int K) {
   Carver cv(nullptr);

@@ -76,6 +76,9 @@ int launch_build_tables(const int32_t *tile_cnt, int B, int64_t HW, int ntiles,
                         hsgk_segkm_meta *meta, hipStream_t s);
 int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off,
                 const ChunkTable &t, int32_t *klab, hipStream_t s);
+int launch_prep_bwd(const float *g_emb, const float *g_emb_loc, const float *emb,
+                    const float *emb_loc, const float *norms, const int64_t *rowmap, int B, int C,
+                    int H, int W, float eps, float *gx, hipStream_t s);
 int launch_normalize_rows(const float *x, int64_t n, int d, float eps, float *out,
                           hipStream_t s);
 

@@ -240,7 +240,8 @@ __global__ __launch_bounds__(256) void prep_kernel(
     int has_ignore, int64_t ignore, const int32_t *__restrict__ tile_off,
     const int64_t *__restrict__ img_row0, const int32_t *__restrict__ seed_map,
     float eps, float *__restrict__ emb, float *__restrict__ emb_loc,
-    int64_t *__restrict__ labels_out, int32_t *__restrict__ klab) {
+    int64_t *__restrict__ labels_out, int32_t *__restrict__ klab,
+    float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out) {
   extern __shared__ float lds[];
   const int S = C | 1;
   float *tile = lds;                       // [64][S]
@@ -267,6 +268,7 @@ __global__ __launch_bounds__(256) void prep_kernel(
     int64_t base = img_row0[b] + (tile_off ? (int64_t)tile_off[(int64_t)b * ntiles + t] : p0);
     int64_t row = keep ? base + rank : -1;
     rowi[lane] = row;
+    if (rowmap_out && pix < HW) rowmap_out[(int64_t)b * HW + pix] = row;
     if (keep) {
       labels_out[row] = lab;
       klab[row] = seed_map[pix];
@@ -324,6 +326,7 @@ __global__ __launch_bounds__(256) void prep_kernel(
     const int64_t row = rowi[j];
     if (row < 0) continue;
     const float n2 = nrm2[j];
+    if (norms_out && lane == 0) { norms_out[2 * row] = nrm1[j]; norms_out[2 * row + 1] = n2; }
     const float *r = tile + j * S;
     float *eo = emb + row * C;
     float *lo = emb_loc + row * D;
@@ -352,7 +355,8 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(
     int has_ignore, int64_t ignore, const int32_t *__restrict__ tile_off,
     const int64_t *__restrict__ img_row0, const int32_t *__restrict__ seed_map,
     float eps, float *__restrict__ emb, float *__restrict__ emb_loc,
-    int64_t *__restrict__ labels_out, int32_t *__restrict__ klab) {
+    int64_t *__restrict__ labels_out, int32_t *__restrict__ klab,
+    float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out) {
   extern __shared__ float lds[];
   float *tile = lds;                       // [64][C] swizzled
   float *nrm1 = lds + 64 * C;              // [64]
@@ -379,6 +383,7 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(
     int64_t base = img_row0[b] + (tile_off ? (int64_t)tile_off[(int64_t)b * ntiles + t] : p0);
     int64_t row = keep ? base + rank : -1;
     rowi[lane] = row;
+    if (rowmap_out && pix < HW) rowmap_out[(int64_t)b * HW + pix] = row;
     if (keep) {
       labels_out[row] = lab;
       klab[row] = seed_map[pix];
@@ -460,6 +465,7 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(
     const int64_t row = rowi[j];
     if (row < 0) continue;
     const float n2 = nrm2[j];
+    if (norms_out && lane == 0) { norms_out[2 * row] = nrm1[j]; norms_out[2 * row + 1] = n2; }
     const float *r = tile + j * C;
     float *eo = emb + row * C;
     float *lo = emb_loc + row * D;
@@ -499,7 +505,78 @@ int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTa
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a.embeddings, a.C, HW, ntiles,
                      a.loc, a.loc_batch_stride, a.labels, a.has_ignore, a.ignore_index,
                      tile_off, t.img_row0, a.seed_map, HSGK_EPS, a.out_embeddings,
-                     a.out_embeddings_loc, a.out_labels, klab);
+                     a.out_embeddings_loc, a.out_labels, klab, a.out_norms, a.out_rowmap);
+  HSGK_LAUNCH_CHECK();
+  return 0;
+}
+
+// --------------------------------------------------------------------------
+// Backward of the prep stage.  Same 64-pixel tiling as the forward pass.
+//   el = v / n2, v = (e, loc)      g_v = (g_el - el <el, g_el>) / n2
+//   e  = x / n1                    g_x = (g   - e  <e , g   >) / n1,  g = g_e + g_v[:C]
+// (the eps-clamped branches are linear: g / eps).  Wave per row for the two
+// dot products (shuffle reduction; gradients are tolerance quantities), LDS
+// transpose, then coalesced NCHW plane writes with lanes = pixels.
+__global__ __launch_bounds__(256) void prep_bwd_kernel(
+    const float *__restrict__ g_emb, const float *__restrict__ g_emb_loc,
+    const float *__restrict__ emb, const float *__restrict__ emb_loc,
+    const float *__restrict__ norms, const int64_t *__restrict__ rowmap, int C, int64_t HW,
+    float eps, float *__restrict__ gx) {
+  extern __shared__ float lds[];
+  const int S = C | 1;
+  float *tile = lds;                        // [64][S]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int t = blockIdx.x, b = blockIdx.y;
+  const int64_t p0 = (int64_t)t * kTilePix;
+  const int D = C + 2;
+  for (int j = w; j < 64; j += 4) {
+    const int64_t pix = p0 + j;
+    int64_t row = -1;
+    if (pix < HW) row = rowmap ? rowmap[(int64_t)b * HW + pix] : (int64_t)b * HW + pix;
+    float *dst = tile + j * S;
+    if (row < 0) {
+      for (int c = lane; c < C; c += 64) dst[c] = 0.0f;
+      continue;
+    }
+    const float n1 = norms[2 * row], n2 = norms[2 * row + 1];
+    const float *e = emb + row * C, *el = emb_loc + row * D;
+    const float *ge = g_emb ? g_emb + row * C : nullptr;
+    const float *gl = g_emb_loc ? g_emb_loc + row * D : nullptr;
+    float dot2 = 0.0f;
+    if (gl && n2 > eps) {
+      for (int c = lane; c < D; c += 64) dot2 += el[c] * gl[c];
+      for (int off = 32; off > 0; off >>= 1) dot2 += __shfl_xor(dot2, off);
+    }
+    float dot1 = 0.0f;
+    for (int c = lane; c < C; c += 64) {
+      float g = ge ? ge[c] : 0.0f;
+      if (gl) g += (gl[c] - el[c] * dot2) / n2;
+      dst[c] = g;                            // g = g_e + g_v[c]
+      dot1 += e[c] * g;
+    }
+    for (int off = 32; off > 0; off >>= 1) dot1 += __shfl_xor(dot1, off);
+    if (!(n1 > eps)) dot1 = 0.0f;
+    for (int c = lane; c < C; c += 64) dst[c] = (dst[c] - e[c] * dot1) / n1;
+  }
+  __syncthreads();
+  const int64_t pix = p0 + lane;
+  if (pix < HW) {
+    float *out = gx + (int64_t)b * C * HW + pix;
+    for (int c = w; c < C; c += 4) out[(int64_t)c * HW] = tile[lane * S + c];
+  }
+}
+
+int launch_prep_bwd(const float *g_emb, const float *g_emb_loc, const float *emb,
+                    const float *emb_loc, const float *norms, const int64_t *rowmap, int B, int C,
+                    int H, int W, float eps, float *gx, hipStream_t s) {
+  const int64_t HW = (int64_t)H * W;
+  const int ntiles = (int)((HW + kTilePix - 1) / kTilePix);
+  const size_t lds = (size_t)64 * (C | 1) * 4;
+  HSGK_REQUIRE(lds <= 160 * 1024, "embedding dimension too large for the prep tile");
+  HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(prep_bwd_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(prep_bwd_kernel, dim3(ntiles, B), dim3(256), lds, s, g_emb, g_emb_loc, emb,
+                     emb_loc, norms, rowmap, C, HW, eps, gx);
   HSGK_LAUNCH_CHECK();
   return 0;
 }

@@ -87,6 +87,76 @@ def _default_loc(H, W, device):
   return hit
 
 
+class _SegmentByKmeans(torch.autograd.Function):
+  """One libhsgk call; `embeddings` / `embeddings_with_loc` are differentiable
+  w.r.t. the NCHW input (normalise -> concat -> normalise -> index_select),
+  the three index outputs are not."""
+
+  @staticmethod
+  def forward(ctx, x, lab, loc, loc_sb, seed_map, K, has_ignore, ign, iterations):
+    dev = x.device
+    B, C, H, W = x.shape
+    n_max = B * H * W
+    want_grad = x.requires_grad
+    xd = x.detach()
+    table_cap = B * K if lab is None else max(B * K, min(B * K * 4096, _TABLE_CAP_MAX))
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+      out_emb = torch.empty((n_max, C), dtype=torch.float32, device=dev)
+      out_loc = torch.empty((n_max, C + 2), dtype=torch.float32, device=dev)
+      out_lab = torch.empty((n_max,), dtype=torch.int64, device=dev)
+      out_cluster = torch.empty((n_max,), dtype=torch.int64, device=dev)
+      out_batch = torch.empty((n_max,), dtype=torch.int64, device=dev)
+      meta = torch.empty((8,), dtype=torch.int64, device=dev)
+      norms = torch.empty((n_max, 2), dtype=torch.float32, device=dev) if want_grad else None
+      rowmap = (torch.empty((n_max,), dtype=torch.int64, device=dev)
+                if want_grad and has_ignore else None)
+      ws_bytes = L.hsgk_segment_by_kmeans_workspace_bytes(B, C, H, W, K, table_cap)
+      ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+      args = _lib.SegkmArgs(
+          embeddings=xd.data_ptr(), labels=lab.data_ptr() if lab is not None else None,
+          loc=loc.data_ptr(), loc_batch_stride=loc_sb, seed_map=seed_map.data_ptr(),
+          B=B, C=C, H=H, W=W, K=K, iterations=int(iterations), has_ignore=int(has_ignore),
+          ignore_index=ign, batch_offset=B * (dev.index or 0), table_cap=table_cap,
+          out_embeddings=out_emb.data_ptr(), out_embeddings_loc=out_loc.data_ptr(),
+          out_labels=out_lab.data_ptr(), out_cluster=out_cluster.data_ptr(),
+          out_batch=out_batch.data_ptr(), meta=meta.data_ptr(),
+          out_norms=norms.data_ptr() if norms is not None else None,
+          out_rowmap=rowmap.data_ptr() if rowmap is not None else None,
+          workspace=ws.data_ptr(), workspace_bytes=ws_bytes)
+      _lib.check(L.hsgk_segment_by_kmeans(ctypes.byref(args), _lib.stream_ptr()))
+      m = meta.cpu().tolist()          # the operator's single host sync
+    n, err = m[0], m[5]
+    if err == 1:
+      raise ValueError('segment_by_kmeans: negative labels are not supported')
+    if err == 2:
+      raise _lib.HsgkError('segment_by_kmeans: label range too large for the relabel '
+                           'table (label_max=%d)' % m[3])
+    emb, eloc = out_emb[:n], out_loc[:n]
+    labels, cluster, batch = out_lab[:n], out_cluster[:n], out_batch[:n]
+    if want_grad:
+      ctx.save_for_backward(emb, eloc, norms, rowmap)
+      ctx.shape = (B, C, H, W)
+    ctx.mark_non_differentiable(labels, cluster, batch)
+    return emb, eloc, labels, cluster, batch
+
+  @staticmethod
+  def backward(ctx, g_emb, g_eloc, _gl, _gc, _gb):
+    emb, eloc, norms, rowmap = ctx.saved_tensors
+    B, C, H, W = ctx.shape
+    dev = emb.device
+    ge = g_emb.contiguous().to(torch.float32) if g_emb is not None else None
+    gl = g_eloc.contiguous().to(torch.float32) if g_eloc is not None else None
+    with torch.cuda.device(dev):
+      gx = torch.empty((B, C, H, W), dtype=torch.float32, device=dev)
+      _lib.check(_lib.lib().hsgk_segment_by_kmeans_bwd(
+          ge.data_ptr() if ge is not None else None, gl.data_ptr() if gl is not None else None,
+          emb.data_ptr(), eloc.data_ptr(), norms.data_ptr(),
+          rowmap.data_ptr() if rowmap is not None else None, B, C, H, W,
+          ctypes.c_float(_lib.EPS), gx.data_ptr(), _lib.stream_ptr()))
+    return gx, None, None, None, None, None, None, None, None
+
+
 def segment_by_kmeans(embeddings,
                       labels=None,
                       num_clusters=[5, 5],
@@ -100,6 +170,8 @@ def segment_by_kmeans(embeddings,
   on a ROCm device.  Returns (embeddings [N,C], embeddings_with_loc [N,C+2],
   labels [N], cluster_indices [N], batch_indices [N]) over the N pixels whose
   label differs from `ignore_index`, image-major, row-major inside an image.
+  The two float outputs carry gradient back to `embeddings` (location
+  features are treated as constants).
   """
   _require_gpu(embeddings, 'embeddings')
   if embeddings.dim() != 4:
@@ -112,7 +184,7 @@ def segment_by_kmeans(embeddings,
         'passes them); seeds come from num_clusters')
   dev = embeddings.device
   B, C, H, W = embeddings.shape
-  x = embeddings.detach().contiguous()
+  x = embeddings.contiguous()
   seed_map, K = _seed_map(num_clusters, H, W, dev)
 
   if local_features is None:
@@ -137,37 +209,8 @@ def segment_by_kmeans(embeddings,
     lab = torch.zeros((B, H, W), dtype=torch.int64, device=dev)   # common.py:326-329
   has_ignore = ignore_index is not None
   ign = int(ignore_index) if has_ignore else 0
-
-  n_max = B * H * W
-  table_cap = B * K if lab is None else max(B * K, min(B * K * 4096, _TABLE_CAP_MAX))
-  L = _lib.lib()
-  with torch.cuda.device(dev):
-    out_emb = torch.empty((n_max, C), dtype=torch.float32, device=dev)
-    out_loc = torch.empty((n_max, C + 2), dtype=torch.float32, device=dev)
-    out_lab = torch.empty((n_max,), dtype=torch.int64, device=dev)
-    out_cluster = torch.empty((n_max,), dtype=torch.int64, device=dev)
-    out_batch = torch.empty((n_max,), dtype=torch.int64, device=dev)
-    meta = torch.empty((8,), dtype=torch.int64, device=dev)
-    ws_bytes = L.hsgk_segment_by_kmeans_workspace_bytes(B, C, H, W, K, table_cap)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-    args = _lib.SegkmArgs(
-        embeddings=x.data_ptr(), labels=lab.data_ptr() if lab is not None else None,
-        loc=loc.data_ptr(), loc_batch_stride=loc_sb, seed_map=seed_map.data_ptr(),
-        B=B, C=C, H=H, W=W, K=K, iterations=int(iterations), has_ignore=int(has_ignore),
-        ignore_index=ign, batch_offset=B * (dev.index or 0), table_cap=table_cap,
-        out_embeddings=out_emb.data_ptr(), out_embeddings_loc=out_loc.data_ptr(),
-        out_labels=out_lab.data_ptr(), out_cluster=out_cluster.data_ptr(),
-        out_batch=out_batch.data_ptr(), meta=meta.data_ptr(),
-        workspace=ws.data_ptr(), workspace_bytes=ws_bytes)
-    _lib.check(L.hsgk_segment_by_kmeans(ctypes.byref(args), _lib.stream_ptr()))
-    m = meta.cpu().tolist()          # the operator's single host sync
-  n, err = m[0], m[5]
-  if err == 1:
-    raise ValueError('segment_by_kmeans: negative labels are not supported')
-  if err == 2:
-    raise _lib.HsgkError('segment_by_kmeans: label range too large for the relabel '
-                         'table (label_max=%d)' % m[3])
-  return out_emb[:n], out_loc[:n], out_lab[:n], out_cluster[:n], out_batch[:n]
+  return _SegmentByKmeans.apply(x, lab, loc, loc_sb, seed_map, K, has_ignore, ign,
+                                int(iterations))
 
 
 def kmeans_with_initial_labels(embeddings, initial_labels, max_label=None, iterations=10):

@@ -101,6 +101,9 @@ typedef struct hsgk_segkm_args {
   int64_t *out_cluster;        /* [N] dense segment ids                       */
   int64_t *out_batch;          /* [N]                                         */
   hsgk_segkm_meta *meta;       /* device                                      */
+  /* optional state for the backward pass (NULL = not needed)                 */
+  float *out_norms;            /* [N,2]: clamped ||x|| and ||(e,loc)|| per row */
+  int64_t *out_rowmap;         /* [B*H*W]: output row of each pixel, -1 = dropped */
   /* scratch */
   void *workspace;
   size_t workspace_bytes;
@@ -109,6 +112,15 @@ typedef struct hsgk_segkm_args {
 HSGK_API size_t hsgk_segment_by_kmeans_workspace_bytes(int B, int C, int H, int W, int K,
                                               int64_t table_cap);
 HSGK_API int hsgk_segment_by_kmeans(const hsgk_segkm_args *args, hsgk_stream_t stream);
+/* Backward of the two float outputs w.r.t. the NCHW input (common.py:306-365:
+ * normalise -> concat loc -> normalise -> index_select).  g_emb [N,C] and/or
+ * g_emb_loc [N,C+2] may be NULL (= zero).  gx [B,C,H,W] is fully written
+ * (dropped pixels get 0).  rowmap may be NULL when nothing was dropped.       */
+HSGK_API int hsgk_segment_by_kmeans_bwd(const float *g_emb, const float *g_emb_loc,
+                                        const float *emb, const float *emb_loc,
+                                        const float *norms, const int64_t *rowmap, int B,
+                                        int C, int H, int W, float eps, float *gx,
+                                        hsgk_stream_t stream);
 
 /* ---- hsg/utils/segsort/common.py:67-97 kmeans_with_initial_labels --------- */
 /* One row set x[n,d]; labels_io holds the initial labels on entry (int64,

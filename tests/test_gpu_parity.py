@@ -246,3 +246,38 @@ def test_segsort_loss_large_shapes_vs_oracle(dev, oracle):
     nll = SegSortLoss(16, mode, reduction='none')(t(e), t(sem), t(inst), t(p), t(psem))
     ref = oracle.segsort_nll(e, sem, inst, p, psem, 16.0, mode)
     assert np.abs(nll.view(-1).cpu().numpy() - ref).max() <= 1e-4
+
+
+@pytest.mark.parametrize('case', ['ragged', 'cfg1_overseg', 'c256k64'])
+def test_segment_by_kmeans_backward_vs_torch_autograd(dev, case):
+  """Gradients of the two float outputs w.r.t. the NCHW input against a plain
+  torch fp32 restatement (normalise -> cat -> normalise -> index_select)."""
+  import torch
+  from hsg_amd.utils.segsort import common as sc
+  g = util.load('f4_segkm_' + case)
+  x, lab, grid, ign, iters, loc = util.f4_inputs(g)
+  B, C, H, W = x.shape
+  xt = torch.from_numpy(x).to(dev)
+  lt = None if lab is None else torch.from_numpy(lab).to(dev)
+  a = xt.clone().requires_grad_(True)
+  emb, eloc, labels, cluster, batch = sc.segment_by_kmeans(a, lt, list(grid), ignore_index=ign,
+                                                           iterations=2)
+  n = emb.shape[0]
+  w1 = torch.from_numpy(synth.gaussish(5, n * C).reshape(n, C)).to(dev)
+  w2 = torch.from_numpy(synth.gaussish(6, n * (C + 2)).reshape(n, C + 2)).to(dev)
+  ((emb * w1).sum() + (eloc * w2).sum()).backward()
+
+  b = xt.clone().requires_grad_(True)
+  e = b.permute(0, 2, 3, 1).reshape(-1, C)
+  e = e / e.norm(dim=1, keepdim=True).clamp_min(1e-12)
+  lc = torch.from_numpy(loc).to(dev).view(1, H * W, 2).expand(B, H * W, 2).reshape(-1, 2)
+  el = torch.cat([e, lc], 1)
+  el = el / el.norm(dim=1, keepdim=True).clamp_min(1e-12)
+  if ign is not None and lt is not None:
+    keep = (lt.view(-1) != ign).nonzero().view(-1)
+    e, el = e.index_select(0, keep), el.index_select(0, keep)
+  assert e.shape[0] == n
+  ((e * w1).sum() + (el * w2).sum()).backward()
+  scale = b.grad.abs().max().item()
+  assert (a.grad - b.grad).abs().max().item() <= 2e-5 * max(scale, 1.0)
+  assert not labels.requires_grad and not cluster.requires_grad
