@@ -41,6 +41,8 @@ def main():
   ap.add_argument('--steps', type=int, default=3)
   ap.add_argument('--warmup', type=int, default=1)
   ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
+  ap.add_argument('--no-exchange', action='store_true',
+                  help='skip the untimed prototype-table exchange measurement')
   ap.add_argument('--cpu-images', type=int, default=1,
                   help='images of the workload shape timed on the host CPU (0 = skip)')
   args = ap.parse_args()
@@ -84,13 +86,35 @@ def main():
   _lib.profile_enable(True)
   _lib.profile_collect()
   t0 = time.perf_counter()
+  out = None
   for _ in range(args.steps):
-    out = step()
     del out
+    out = step()
   fence()
   elapsed = time.perf_counter() - t0
   prof = _lib.profile_collect()
   _lib.profile_enable(False)
+
+  # Untimed side measurement: the batch-wide prototype table of the step's
+  # output (local segment sums + ONE RCCL all_reduce over xGMI when N > 1,
+  # hsg_amd/models/utils.py).  Not part of `value` (BASELINE.md metric = the
+  # segment_by_kmeans call), reported in config for the multi-GPU runs.
+  exch = None
+  if not args.no_exchange:
+    from hsg_amd.models import utils as model_utils
+    emb, emb_loc, lab, cidx, bidx = out
+    zeros = torch.zeros_like(lab)
+    times = []
+    for _ in range(3):
+      fence()
+      t1 = time.perf_counter()
+      res = model_utils.gather_clustering_and_update_prototypes(emb, emb_loc, cidx, bidx, lab, zeros)
+      fence()
+      times.append(time.perf_counter() - t1)
+    exch = {'ms': round(min(times) * 1e3, 3), 'segments': int(res[0].shape[0]),
+            'payload_MB': round(res[0].shape[0] * (2 * C + 2) * 4 / 1e6, 2)}
+    del res, emb, emb_loc, lab, cidx, bidx
+  del out
 
   if dist is not None:
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -146,7 +170,7 @@ def main():
                                'iterations, no labels' % (args.workload, B, C, H, W, grid[0],
                                                           grid[1], iters),
                    'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world,
-                   'phase_ms_per_step': phases},
+                   'phase_ms_per_step': phases, 'prototype_exchange_untimed': exch},
         'roofline': roofline, 'cpu_baseline': cpu}))
   if dist is not None:
     dist.destroy_process_group()

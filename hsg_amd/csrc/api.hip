@@ -115,10 +115,11 @@ int hsgk_profile_collect(double *ms_sum, int64_t *count) {
   return 0;
 }
 
-int hsgk_normalize_rows(const float *x, int64_t n, int d, float eps, float *out,
+int hsgk_normalize_rows(const float *x, int64_t n, int d, float eps, float *out, float *norms,
                         hsgk_stream_t stream) {
   HSGK_REQUIRE(n >= 0 && d >= 1, "bad shape");
-  return launch_normalize_rows(x, n, d, eps, out, static_cast<hipStream_t>(stream));
+  (void)hipGetLastError();
+  return launch_normalize_rows(x, n, d, eps, out, norms, static_cast<hipStream_t>(stream));
 }
 
 // ---------------------------------------------------------------------------

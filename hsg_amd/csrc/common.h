@@ -80,7 +80,7 @@ int launch_prep_bwd(const float *g_emb, const float *g_emb_loc, const float *emb
                     const float *emb_loc, const float *norms, const int64_t *rowmap, int B, int C,
                     int H, int W, float eps, float *gx, hipStream_t s);
 int launch_normalize_rows(const float *x, int64_t n, int d, float eps, float *out,
-                          hipStream_t s);
+                          float *norms, hipStream_t s);
 
 int launch_accumulate(const float *x, int d, const int32_t *klab,
                       const ChunkTable &t, int max_chunks, int K, float *partial,

@@ -16,7 +16,8 @@ namespace hsgk {
 // chain, so one THREAD owns one row and waves stream 64 rows at a time; this
 // entry point serves small tables (prototypes, tests), not the pixel stream.
 __global__ void normalize_rows_kernel(const float *__restrict__ x, int64_t n, int d,
-                                      float eps, float *__restrict__ out) {
+                                      float eps, float *__restrict__ out,
+                                      float *__restrict__ norms) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   const float *xr = x + r * d;
@@ -24,16 +25,17 @@ __global__ void normalize_rows_kernel(const float *__restrict__ x, int64_t n, in
   for (int i = 0; i < d; ++i) ss = fmaf(xr[i], xr[i], ss);
   float nrm = sqrtf(ss);
   if (!(nrm >= eps)) nrm = eps;
+  if (norms) norms[r] = nrm;
   float *yr = out + r * d;
   for (int i = 0; i < d; ++i) yr[i] = xr[i] / nrm;
 }
 
 int launch_normalize_rows(const float *x, int64_t n, int d, float eps, float *out,
-                          hipStream_t s) {
+                          float *norms, hipStream_t s) {
   if (n <= 0) return 0;
   int64_t blocks = (n + 63) / 64;
   hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)blocks), dim3(64), 0, s, x,
-                     n, d, eps, out);
+                     n, d, eps, out, norms);
   HSGK_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,239 @@
+"""Drop-in for the cross-GPU glue of `hsg.models.utils` (reference
+hsg/models/utils.py:41-240), re-designed for one process per GPU.
+
+The reference runs ONE process, gathers every pixel embedding of every GPU to
+an anchor GPU (`scatter_gather.gather`), computes the batch-wide prototype
+table there and copies it back (3x per iteration, train.py:190,219).  Here
+each rank reduces its own pixels to per-segment SUMS with libhsgk
+(segment_reduce, mode 2) and only the small segment table crosses xGMI:
+
+    keys      all_gather of the sorted unique (image, cluster, sem, inst) keys
+    sums      one RCCL all_reduce(sum) over the zero-padded [P_total, C + D] table
+    labels    decoded from the keys (identical on every rank)
+
+A segment normally lives on one rank (an image is never split), so the
+all_reduce only adds zeros to each row and the result is independent of the
+reduction order; if the same image id does occur on two ranks its rows merge,
+exactly as in the reference.  Payload ~ P_total * (2C+2) * 4 B (a few MB):
+latency-bound on xGMI, which is why it is ONE collective.
+
+Every function accepts what the reference accepts -- a list with one tensor per
+GPU of this process -- and also a bare tensor (the natural form with one process
+per GPU); it returns the same structure it was given.  With
+`torch.distributed` initialised the exchange spans all ranks of `group`.
+"""
+import torch
+import torch.distributed as dist
+
+from hsg_amd import ops
+
+
+# ---- hooks (replaced by the CPU gloo tests with oracle-backed versions) ------
+def _segment_sums(rows, ids, count):
+  """Raw per-segment sums [count, d] of the local rows (libhsgk, mode 2)."""
+  return ops.segment_reduce(rows, ids, count, 2)
+
+
+def _normalize(table):
+  return ops.normalize_rows(table)
+
+
+# ---- small helpers -----------------------------------------------------------
+def _world(group):
+  if dist.is_available() and dist.is_initialized():
+    return dist.get_world_size(group)
+  return 1
+
+
+def _as_list(v):
+  return (list(v), True) if isinstance(v, (list, tuple)) else ([v], False)
+
+
+def _cat_to(tensors, device):
+  return torch.cat([t.to(device) for t in tensors], 0)
+
+
+def _all_max(value, group):
+  """Global max of a 0-d integer tensor over the ranks of `group`."""
+  if _world(group) > 1:
+    value = value.clone()
+    dist.all_reduce(value, op=dist.ReduceOp.MAX, group=group)
+  return value
+
+
+def _all_gather_varlen(t, group):
+  """Concatenation over ranks (rank order) of 1-D/2-D tensors whose first
+  dimension differs per rank; also returns this rank's offset."""
+  world = _world(group)
+  if world == 1:
+    return t, 0
+  n = torch.tensor([t.shape[0]], dtype=torch.long, device=t.device)
+  counts = [torch.zeros_like(n) for _ in range(world)]
+  dist.all_gather(counts, n, group=group)
+  counts = [int(c.item()) for c in counts]
+  cap = max(max(counts), 1)
+  pad = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+  pad[:t.shape[0]] = t
+  bufs = [torch.empty_like(pad) for _ in range(world)]
+  dist.all_gather(bufs, pad, group=group)
+  rank = dist.get_rank(group)
+  return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0), sum(counts[:rank])
+
+
+class _AllReduceSum(torch.autograd.Function):
+  """y = sum over ranks of x; dL/dx = sum over ranks of dL/dy (every rank's
+  loss sees the whole table)."""
+
+  @staticmethod
+  def forward(ctx, x, group):
+    ctx.group = group
+    y = x.detach().clone()
+    dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
+    return y
+
+  @staticmethod
+  def backward(ctx, g):
+    g = g.contiguous().clone()
+    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+    return g, None
+
+
+# ---- hsg/models/utils.py:127-217 -----------------------------------------------
+def exchange_prototypes(embeddings, embeddings_with_loc, cluster_indices, batch_indices,
+                        semantic_labels, instance_labels, group=None):
+  """Per-rank tensors in, batch-wide prototype tables out (same 6 results as
+  the reference's gather_clustering_and_update_prototypes, un-listed)."""
+  dev = cluster_indices.device
+  c = cluster_indices.view(-1).long()
+  b = batch_indices.view(-1).long()
+  sem = semantic_labels.view(-1).long()
+  inst = instance_labels.view(-1).long()
+  zero = torch.zeros((), dtype=torch.long, device=dev)
+
+  # utils.py:181-189: key order = (batch, cluster, semantic, instance)
+  divisor = _all_max(c.max() + 1 if c.numel() else zero + 1, group)
+  lab_div = _all_max(torch.maximum(inst.max(), sem.max()) + 1 if c.numel() else zero + 1, group)
+  keys = ((b * divisor + c) * lab_div + sem) * lab_div + inst
+  local_keys, local_ids = torch.unique(keys, return_inverse=True)
+
+  gathered, _ = _all_gather_varlen(local_keys, group)
+  global_keys = torch.unique(gathered) if _world(group) > 1 else local_keys
+  P = global_keys.shape[0]
+  slot = torch.searchsorted(global_keys, local_keys)          # local segment -> global id
+  updated_cluster_indices = slot[local_ids]
+
+  # utils.py:193-197: labels of every prototype, decoded from the keys
+  prototype_instance_labels = global_keys % lab_div
+  prototype_semantic_labels = (global_keys // lab_div) % lab_div
+  prototype_batch_indices = (global_keys // (lab_div * lab_div)) // divisor
+
+  # utils.py:199-202: segment sums -> (exchange) -> normalise
+  C = embeddings.shape[-1]
+  local = torch.cat([
+      _segment_sums(embeddings.reshape(-1, C), local_ids, local_keys.shape[0]),
+      _segment_sums(embeddings_with_loc.reshape(-1, embeddings_with_loc.shape[-1]), local_ids,
+                    local_keys.shape[0])], 1)
+  if _world(group) > 1:
+    table = torch.zeros((P, local.shape[1]), dtype=local.dtype, device=dev)
+    table = table.index_add(0, slot, local)
+    table = _AllReduceSum.apply(table, group)
+  else:
+    table = local
+  prototypes = _normalize(table[:, :C].contiguous())
+  prototypes_with_loc = _normalize(table[:, C:].contiguous())
+  return (prototypes, prototypes_with_loc, prototype_semantic_labels,
+          prototype_instance_labels, prototype_batch_indices, updated_cluster_indices)
+
+
+def gather_clustering_and_update_prototypes(embeddings, embeddings_with_loc, cluster_indices,
+                                            batch_indices, semantic_labels, instance_labels,
+                                            anchor_device=None, group=None):
+  """Reference hsg/models/utils.py:127-217 (same arguments and results)."""
+  embs, listed = _as_list(embeddings)
+  embs_loc, _ = _as_list(embeddings_with_loc)
+  c_inds, _ = _as_list(cluster_indices)
+  b_inds, _ = _as_list(batch_indices)
+  sems, _ = _as_list(semantic_labels)
+  insts, _ = _as_list(instance_labels)
+  devices = [t.device for t in c_inds]
+  sections = [t.shape[0] for t in c_inds]
+  anchor = torch.device(anchor_device) if anchor_device is not None else devices[0]
+  if len(c_inds) > 1:            # several GPUs driven by this one process
+    args = [_cat_to(v, anchor) for v in (embs, embs_loc, c_inds, b_inds, sems, insts)]
+  else:
+    args = [embs[0], embs_loc[0], c_inds[0], b_inds[0], sems[0], insts[0]]
+  protos, protos_loc, psem, pinst, pbatch, updated = exchange_prototypes(*args, group=group)
+  if not listed:
+    return protos, protos_loc, psem, pinst, pbatch, updated
+  updated = [u.to(d) for u, d in zip(torch.split(updated, sections), devices)]
+  fan = lambda t: [t.to(d) for d in devices]
+  return fan(protos), fan(protos_loc), fan(psem), fan(pinst), fan(pbatch), updated
+
+
+# ---- hsg/models/utils.py:41-74 ---------------------------------------------------
+def reorder_image_indices(image_ids_all):
+  """Dense image index by first-occurrence order over the gathered id list."""
+  uniq, inv = torch.unique(image_ids_all, return_inverse=True)
+  n = image_ids_all.shape[0]
+  pos = torch.arange(n, dtype=torch.long, device=image_ids_all.device)
+  first = torch.full((uniq.shape[0],), n, dtype=torch.long, device=image_ids_all.device)
+  first = first.scatter_reduce(0, inv, pos, reduce='amin')
+  rank_of = torch.empty_like(first)
+  rank_of[torch.argsort(first)] = torch.arange(uniq.shape[0], dtype=torch.long,
+                                               device=image_ids_all.device)
+  return rank_of[inv]
+
+
+def gather_and_reorder_image_indices(image_indices, anchor_device=None, group=None):
+  """Reference hsg/models/utils.py:41-74: every GPU receives the WHOLE
+  re-indexed vector (it is later indexed with `batch_index + B * gpu_id`,
+  train.py:208-212)."""
+  ids, listed = _as_list(image_indices)
+  devices = [t.device for t in ids]
+  anchor = torch.device(anchor_device) if anchor_device is not None else devices[0]
+  local = _cat_to(ids, anchor).long() if len(ids) > 1 else ids[0].long()
+  gathered, _ = _all_gather_varlen(local, group)
+  full = reorder_image_indices(gathered)
+  if not listed:
+    return full
+  return [full.to(d) for d in devices]
+
+
+# ---- hsg/models/utils.py:78-124 --------------------------------------------------
+def gather_and_update_cluster_mappings(cluster_indices_1, cluster_indices_2,
+                                       anchor_device=None, group=None):
+  """mapping[i] = the cluster_indices_2 value co-occurring with index i of
+  cluster_indices_1 (largest one if several), over all ranks."""
+  c1, listed = _as_list(cluster_indices_1)
+  c2, _ = _as_list(cluster_indices_2)
+  devices = [t.device for t in c1]
+  anchor = torch.device(anchor_device) if anchor_device is not None else devices[0]
+  a = _cat_to(c1, anchor).long() if len(c1) > 1 else c1[0].long()
+  b = _cat_to(c2, anchor).long() if len(c2) > 1 else c2[0].long()
+  max_ind = _all_max(b.max() + 1, group)
+  size = _all_max(a.max() + 1, group)
+  pairs, _ = _all_gather_varlen(torch.unique(a * max_ind + b), group)
+  pairs = torch.unique(pairs)                                   # ascending: later writes win
+  mapping = torch.zeros((int(size),), dtype=torch.long, device=a.device)
+  # sorted order + last-write-wins == the reference's advanced-index assignment
+  keep = torch.ones_like(pairs, dtype=torch.bool)
+  keep[:-1] = (pairs[1:] // max_ind) != (pairs[:-1] // max_ind)
+  mapping[(pairs // max_ind)[keep]] = (pairs % max_ind)[keep]
+  if not listed:
+    return mapping
+  return [mapping.to(d) for d in devices]
+
+
+# ---- hsg/models/utils.py:220-240 -------------------------------------------------
+def gather_and_update_datas(datas, anchor_device=None, group=None):
+  """Concatenation along dim 0 over all GPUs, replicated everywhere."""
+  items, listed = _as_list(datas)
+  devices = [t.device for t in items]
+  anchor = torch.device(anchor_device) if anchor_device is not None else devices[0]
+  local = _cat_to(items, anchor) if len(items) > 1 else items[0]
+  flat = local.reshape(local.shape[0], -1)
+  gathered, _ = _all_gather_varlen(flat, group)
+  out = gathered.reshape((gathered.shape[0],) + tuple(local.shape[1:]))
+  if not listed:
+    return out
+  return [out.to(d) for d in devices]

@@ -70,3 +70,44 @@ def segment_reduce(x, labels, P, mode):
   if lab.shape[0] != x2.shape[0]:
     raise ValueError('labels and rows disagree: %d vs %d' % (lab.shape[0], x2.shape[0]))
   return SegmentReduce.apply(x2, lab, int(P), int(mode))
+
+
+class NormalizeRows(torch.autograd.Function):
+  """normalize_embedding with the norm-clamp semantics of the reference."""
+
+  @staticmethod
+  def forward(ctx, x, eps):
+    x2 = x.detach().contiguous()
+    d = x2.shape[-1]
+    n = x2.numel() // d if d else 0
+    dev = x2.device
+    with torch.cuda.device(dev):
+      out = torch.empty_like(x2)
+      norms = torch.empty((max(n, 1),), dtype=torch.float32, device=dev)
+      _lib.check(_lib.lib().hsgk_normalize_rows(
+          x2.data_ptr(), n, d, ctypes.c_float(eps), out.data_ptr(), norms.data_ptr(),
+          _lib.stream_ptr()))
+    ctx.save_for_backward(out, norms)
+    ctx.eps = eps
+    return out
+
+  @staticmethod
+  def backward(ctx, gout):
+    out, norms = ctx.saved_tensors
+    d = out.shape[-1]
+    n = out.numel() // d if d else 0
+    g = gout.contiguous().to(torch.float32)
+    with torch.cuda.device(out.device):
+      gx = torch.empty_like(out)
+      # a normalised row is a prototype row: reuse the mode-0 segment backward
+      _lib.check(_lib.lib().hsgk_segment_reduce_bwd(
+          g.data_ptr(), out.data_ptr(), norms.data_ptr(), None, 0, d, n, 0,
+          ctypes.c_float(ctx.eps), gx.data_ptr(), None, _lib.stream_ptr()))
+    return gx, None
+
+
+def normalize_rows(x, eps=EPS):
+  require_gpu(x, 'embeddings')
+  if x.dtype != torch.float32:
+    raise TypeError('embeddings must be float32')
+  return NormalizeRows.apply(x, float(eps))

@@ -5,8 +5,6 @@ Same names, argument meaning and return conventions as the reference
 kernels.  Tensors must live on a ROCm device: like the reference's multi-GPU
 code path, CPU tensors are not a supported device here.
 """
-import ctypes
-
 import torch
 
 from hsg_amd import _lib, ops
@@ -19,22 +17,9 @@ def _require_gpu(t, name):
 
 
 def normalize_embedding(embeddings, eps=1e-12):
-  """L2-normalises the last dimension (reference general/common.py:101-120).
-
-  x / where(||x|| >= eps, ||x||, eps); forward only (the differentiable use
-  inside segment_by_kmeans has its own fused kernels).
-  """
-  _require_gpu(embeddings, 'embeddings')
-  if embeddings.dtype != torch.float32:
-    raise TypeError('embeddings must be float32')
-  x = embeddings.contiguous()
-  out = torch.empty_like(x)
-  d = x.shape[-1]
-  n = x.numel() // d if d else 0
-  with torch.cuda.device(x.device):
-    _lib.check(_lib.lib().hsgk_normalize_rows(
-        x.data_ptr(), n, d, ctypes.c_float(eps), out.data_ptr(), _lib.stream_ptr()))
-  return out
+  """L2-normalises the last dimension (reference general/common.py:101-120):
+  x / where(||x|| >= eps, ||x||, eps).  Differentiable."""
+  return ops.normalize_rows(embeddings, eps)
 
 
 def segment_mean(x, index):

@@ -73,9 +73,11 @@ typedef struct hsgk_segkm_meta {
 } hsgk_segkm_meta;
 
 /* ---- hsg/utils/general/common.py:101-120 normalize_embedding ------------- */
-/* rows [n,d] -> out [n,d] (may alias x).                                      */
+/* rows [n,d] -> out [n,d] (may alias x); norms [n] (nullable) receives the
+ * clamped norms.  Backward = hsgk_segment_reduce_bwd(mode 0, n = 0) on the
+ * rows (same formula as a prototype row).                                     */
 HSGK_API int hsgk_normalize_rows(const float *x, int64_t n, int d, float eps, float *out,
-                        hsgk_stream_t stream);
+                                 float *norms, hsgk_stream_t stream);
 
 /* ---- hsg/utils/segsort/common.py:270-408 segment_by_kmeans ---------------- */
 typedef struct hsgk_segkm_args {

@@ -281,3 +281,25 @@ def test_segment_by_kmeans_backward_vs_torch_autograd(dev, case):
   scale = b.grad.abs().max().item()
   assert (a.grad - b.grad).abs().max().item() <= 2e-5 * max(scale, 1.0)
   assert not labels.requires_grad and not cluster.requires_grad
+
+
+def test_exchange_list_api_on_gpu_vs_reference(dev):
+  """hsg_amd.models.utils with the libhsgk kernels (segment sums, normalise)
+  against the reference's outputs for the two-'GPU' fixture."""
+  import torch
+  from hsg_amd.models import utils as mu
+  g = util.load('f8_exchange')
+  parts = util.exchange_inputs(int(g['seed']))
+  T = lambda k: [torch.from_numpy(p[k]).to(dev) for p in parts]
+  embs = [t.requires_grad_(True) for t in T('emb')]
+  protos, protos_loc, psem, pinst, pbatch, upd = mu.gather_clustering_and_update_prototypes(
+      embs, T('emb_loc'), T('cluster'), T('batch'), T('sem'), T('inst'), dev)
+  assert np.array_equal(psem[0].cpu().numpy(), g['psem'])
+  assert np.array_equal(pinst[0].cpu().numpy(), g['pinst'])
+  assert np.array_equal(pbatch[0].cpu().numpy(), g['pbatch'])
+  assert np.array_equal(upd[0].cpu().numpy(), g['upd0'])
+  assert np.array_equal(upd[1].cpu().numpy(), g['upd1'])
+  assert np.abs(protos[0].detach().cpu().numpy() - g['protos']).max() <= FTOL
+  assert np.abs(protos_loc[1].detach().cpu().numpy() - g['protos_loc']).max() <= FTOL
+  protos[0].sum().backward()
+  assert embs[0].grad is not None and embs[1].grad is not None

@@ -44,3 +44,26 @@ def f4_inputs(g):
 F4_CASES = ['cfg1_nolabel', 'cfg1_overseg', 'k1_it1', 'mix_overseg', 'c256k64',
             'ragged', 'noignore_labels']
 F3_CASES = ['cfg1', 'c256k64', 'c384k128', 'mix']
+
+
+def exchange_inputs(seed, n_gpus=2, imgs_per_gpu=3, C=16, K=6):
+  """Per-'GPU' pixel sets of the f8_exchange fixture (tools/gen_golden.py f8)."""
+  out = []
+  for g in range(n_gpus):
+    n = 900 + 137 * g
+    e = synth.gaussish(seed + 10 * g, n * C).reshape(n, C).astype(np.float64)
+    e = (e / np.sqrt((e * e).sum(1, keepdims=True))).astype(np.float32)
+    l = synth.gaussish(seed + 10 * g + 1, n * 2).reshape(n, 2) * np.float32(0.3)
+    el = np.concatenate([e, l], 1).astype(np.float64)
+    el = (el / np.sqrt((el * el).sum(1, keepdims=True))).astype(np.float32)
+    img = np.sort((synth.hash_u64(seed + 10 * g + 2, n) % np.uint64(imgs_per_gpu)).astype(np.int64))
+    out.append(dict(
+        emb=e, emb_loc=el,
+        cluster=(synth.hash_u64(seed + 10 * g + 3, n) % np.uint64(K)).astype(np.int64),
+        batch=img + imgs_per_gpu * g,
+        sem=(synth.hash_u64(seed + 10 * g + 4, n) % np.uint64(4)).astype(np.int64),
+        inst=(synth.hash_u64(seed + 10 * g + 5, n) % np.uint64(3)).astype(np.int64),
+        image_id=np.array([7, 3, 7, 9, 3, 11][3 * g:3 * g + 3] * 2, np.int64)))
+  return out
+
+

@@ -212,8 +212,35 @@ def f6():
   save('f6_segsort_loss', **rec)
 
 
+# ---- F8 cross-GPU glue (hsg/models/utils.py) with 2 simulated GPUs ------------
+def f8():
+  import torch.nn.parallel.scatter_gather as sg
+  import hsg.models.utils as ref_mu
+  sg_gather = sg.gather
+  sg.gather = lambda xs, dev=None, dim=0: torch.cat(list(xs), 0)   # CPU stand-in for device gather
+  ref_mu.scatter_gather.gather = sg.gather
+  try:
+    seed = synth.SEED_BASE + 51
+    from tests import util as tutil
+    parts = tutil.exchange_inputs(seed)
+    T = lambda k: [torch.from_numpy(p[k]) for p in parts]
+    outs = ref_mu.gather_clustering_and_update_prototypes(
+        T('emb'), T('emb_loc'), T('cluster'), T('batch'), T('sem'), T('inst'), 'cpu')
+    protos, protos_loc, psem, pinst, pbatch, upd = outs
+    img = ref_mu.gather_and_reorder_image_indices(T('image_id'), 'cpu')
+    mapping = ref_mu.gather_and_update_cluster_mappings(
+        [u for u in upd], [torch.from_numpy(p['cluster']) for p in parts], 'cpu')
+    datas = ref_mu.gather_and_update_datas([torch.from_numpy(p['emb'][:5]) for p in parts], 'cpu')
+    save('f8_exchange', seed=seed, protos=protos[0].numpy(), protos_loc=protos_loc[0].numpy(),
+         psem=psem[0].numpy(), pinst=pinst[0].numpy(), pbatch=pbatch[0].numpy(),
+         upd0=upd[0].numpy(), upd1=upd[1].numpy(), img0=img[0].numpy(), img1=img[1].numpy(),
+         mapping=mapping[0].numpy(), datas=datas[0].numpy())
+  finally:
+    sg.gather = sg_gather
+
+
 if __name__ == '__main__':
   os.makedirs(OUT, exist_ok=True)
-  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6']
+  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f8']
   for w in which:
     globals()[w]()
