@@ -60,7 +60,7 @@ SIGNATURES = {
     'hsgk_profile_collect': (_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     'hsgk_lloyd_workspace_bytes': (_sz, [_i32, _i64, _i32, _i32]),
     'hsgk_lloyd_mstep': (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
-    'hsgk_lloyd_estep': (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    'hsgk_lloyd_estep': (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _sz, _vp]),
     'hsgk_segment_reduce_workspace_bytes': (_sz, [_i64, _i32, _i64]),
     'hsgk_segment_reduce': (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
     'hsgk_segment_reduce_bwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _f32, _vp, _vp, _vp]),
@@ -69,6 +69,7 @@ SIGNATURES = {
                                      _vp, _vp, _vp, _sz, _vp]),
     'hsgk_segsort_loss_bwd_weights': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _f32, _i32,
                                              _vp, _vp, _vp, _vp, _vp, _vp]),
+    'hsgk_lloyd_requeued_rows': (_i32, [_i32, _i64, _i32, _i32, _vp, _sz, _vp, _vp]),
     'hsgk_assign_workspace_bytes': (_sz, [_i64, _i32, _i32]),
     'hsgk_find_nearest_prototypes': (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
 }

@@ -48,6 +48,8 @@ struct KmeansScratch {
   float *best;
   float *partial;
   float *cent;
+  int2 *qrows;         // [max_chunks * HSGK_CHUNK] (row, image) exact re-score queue (split E-step)
+  int32_t *qcount;     // [1] queue length
   int max_chunks;
 };
 
@@ -69,17 +71,26 @@ static void carve_kmeans(Carver &cv, int B, int64_t rows_per_img, int d, int K,
   k->best = cv.take<float>((size_t)B * rows_per_img + 1);
   k->partial = cv.take<float>(mcs * K * d);
   k->cent = cv.take<float>((size_t)B * K * d + 1);
+  k->qrows = cv.take<int2>(mcs * HSGK_CHUNK);
+  k->qcount = cv.take<int32_t>(4);
 }
 
+// unit_rows: rows of x and centroids are L2-normalised (enables the bf16 split
+// filter of the E-step; results are identical either way)
 static int lloyd(const float *x, int d, int K, int B, int iterations,
-                 const KmeansScratch &k, const hsgk_segkm_meta *meta, hipStream_t s) {
+                 const KmeansScratch &k, const hsgk_segkm_meta *meta, hipStream_t s,
+                 bool unit_rows = false) {
   for (int it = 0; it < iterations; ++it) {
     { ProfScope p(HSGK_PROF_ACCUMULATE, s);
       if (int rc = launch_accumulate(x, d, k.klab, k.t, k.max_chunks, K, k.partial, meta, s)) return rc; }
     { ProfScope p(HSGK_PROF_FINALIZE, s);
       if (int rc = launch_finalize(k.partial, d, K, B, k.t, HSGK_EPS, k.cent, s)) return rc; }
     { ProfScope p(HSGK_PROF_ASSIGN, s);
-      if (int rc = launch_assign(x, d, k.cent, K, k.t, k.max_chunks, k.klab, k.best, meta, s)) return rc; }
+      if (int rc = unit_rows
+                       ? launch_assign_fast(x, d, k.cent, K, k.t, k.max_chunks, k.klab, k.best,
+                                            k.qrows, k.qcount, meta, s)
+                       : launch_assign(x, d, k.cent, K, k.t, k.max_chunks, k.klab, k.best, meta, s))
+        return rc; }
   }
   return 0;
 }
@@ -172,7 +183,8 @@ int hsgk_segment_by_kmeans(const hsgk_segkm_args *a, hsgk_stream_t stream) {
                                      k.t, k.max_chunks, a->meta, s)) return rc;
     if (int rc = launch_prep(*a, compact ? tile_off : nullptr, k.t, k.klab, s)) return rc;
   }
-  if (int rc = lloyd(a->out_embeddings_loc, D, a->K, a->B, a->iterations, k, a->meta, s)) return rc;
+  if (int rc = lloyd(a->out_embeddings_loc, D, a->K, a->B, a->iterations, k, a->meta, s,
+                     /*unit_rows=*/true)) return rc;
   {
     ProfScope p(HSGK_PROF_RELABEL, s);
     if (int rc = launch_relabel(*a, k.t, k.max_chunks, k.klab, table, scan_tmp, s)) return rc;
@@ -253,13 +265,42 @@ int hsgk_lloyd_mstep(const float *x, int B, int64_t rows_per_image, int d, int K
 }
 
 int hsgk_lloyd_estep(const float *x, int B, int64_t rows_per_image, int d, int K,
-                     const float *centroids, int32_t *labels_out, void *workspace,
+                     const float *centroids, int32_t *labels_out, int unit_rows, void *workspace,
                      size_t workspace_bytes, hsgk_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   KmeansScratch k; hsgk_segkm_meta *meta;
   if (int rc = lloyd_setup(B, rows_per_image, d, K, workspace, workspace_bytes, &k, &meta, s)) return rc;
   ProfScope p(HSGK_PROF_ASSIGN, s);
+  if (unit_rows)
+    return launch_assign_fast(x, d, centroids, K, k.t, k.max_chunks, labels_out, k.best, k.qrows,
+                              k.qcount, meta, s);
   return launch_assign(x, d, centroids, K, k.t, k.max_chunks, labels_out, k.best, meta, s);
+}
+
+// Number of rows the last hsgk_lloyd_estep(unit_rows=1) on this workspace sent
+// to the exact re-score pass (diagnostics for the bf16 split filter).
+__global__ void sum_qcount_kernel(const int32_t *__restrict__ qcount, int n,
+                                  int64_t *__restrict__ out) {
+  __shared__ long long ws[4];
+  long long s = 0;
+  for (int i = threadIdx.x; i < n; i += 256) s += qcount[i];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+int hsgk_lloyd_requeued_rows(int B, int64_t rows_per_image, int d, int K, void *workspace,
+                             size_t workspace_bytes, int64_t *out, hsgk_stream_t stream) {
+  HSGK_REQUIRE(workspace_bytes >= hsgk_lloyd_workspace_bytes(B, rows_per_image, d, K), "workspace too small");
+  Carver cv(workspace);
+  cv.take<hsgk_segkm_meta>(1);
+  KmeansScratch k;
+  carve_kmeans(cv, B, rows_per_image, d, K, &k);
+  hipLaunchKernelGGL(sum_qcount_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     k.qcount, 1, out);
+  HSGK_LAUNCH_CHECK();
+  return 0;
 }
 
 size_t hsgk_assign_workspace_bytes(int64_t n, int d, int K) {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/hsgk.h"
 
@@ -90,6 +91,12 @@ int launch_finalize(const float *partial, int d, int K, int B, const ChunkTable 
 int launch_assign(const float *x, int d, const float *cent, int K,
                   const ChunkTable &t, int max_chunks, int32_t *klab, float *best,
                   const hsgk_segkm_meta *meta, hipStream_t s);
+
+// unit-norm fast path (bf16 split filter + exact re-score); falls back to
+// launch_assign when the shape is not eligible or HSGK_ASSIGN=fp32
+int launch_assign_fast(const float *x, int d, const float *cent, int K, const ChunkTable &t,
+                       int max_chunks, int32_t *klab, float *best, int2 *qrows,
+                       int32_t *qcount, const hsgk_segkm_meta *meta, hipStream_t s);
 
 int launch_relabel(const hsgk_segkm_args &a, const ChunkTable &t, int max_chunks,
                    const int32_t *klab, int32_t *table, int32_t *scan_tmp,

@@ -13,6 +13,7 @@
 #include "common.h"
 #include "accumulate.h"
 #include "score_tiles.h"
+#include "score_tiles_bf16.h"
 
 namespace hsgk {
 
@@ -190,6 +191,201 @@ __global__ __launch_bounds__(NW * 64) void assign_kernel(
   ArgmaxEpi epi{kb0, K, nrows, first_block, crow0, klab, best};
   score_tiles<KB, NW, KC, EVEN_D>(x, d, cent + ((int64_t)b * K + kb0) * d, min(KB, K - kb0),
                                   crow0, nrows, lds, epi);
+}
+
+// ===========================================================================
+// E-step, fast path: bf16x3 split filter (score_tiles_bf16.h) + exact re-score
+// of the rows whose two best approximate scores are closer than kSplitGap.
+// Requires unit-norm rows and centroids (true inside the Lloyd loop), K <= 64,
+// even d.  Both kernels use the same (chunk, part) -> row-range mapping.
+struct SplitEpi {
+  int K, nrows;
+  int64_t crow0;
+  int32_t *klab;
+  uint16_t *qrows;       // LDS: this workgroup's queue (row offsets inside its range)
+  int *qn;               // LDS counter
+  __device__ inline void operator()(int tile, const f32x16 (&mainacc)[2],
+                                    const f32x16 (&corracc)[2]) const {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int TPX = (int)(blockDim.x >> 1);
+    // branch-free running top-2: b2 = max(b2, min(b1, v)); b1 = max(b1, v)
+    float b1 = -INFINITY, b2 = -INFINITY;
+    int bi = 0;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = k < K ? mainacc[m][r] + corracc[m][r] : -INFINITY;
+        b2 = fmaxf(b2, fminf(b1, v));
+        bi = v > b1 ? k : bi;
+        b1 = fmaxf(b1, v);
+      }
+    const float o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
+    const int oi = __shfl_xor(bi, 32);
+    // merged top-2 of the two halves
+    float t1, t2;
+    int ti;
+    if (o1 > b1) { t1 = o1; ti = oi; t2 = fmaxf(b1, o2); }
+    else { t1 = b1; ti = bi; t2 = fmaxf(o1, b2); }
+    const int px = tile * TPX + w * 32 + j;
+    if (h == 0 && px < nrows) {
+      klab[crow0 + px] = ti;
+      if (!(t1 - t2 > kSplitGap)) {           // ambiguous (or NaN): exact pass decides
+        const int pos = atomicAdd(qn, 1);
+        qrows[pos] = (uint16_t)px;
+      }
+    }
+  }
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void assign_split_kernel(
+    const float *__restrict__ x, int d, const float *__restrict__ cent, int K,
+    const int64_t *__restrict__ chunk_row0, const int32_t *__restrict__ chunk_rows,
+    const int32_t *__restrict__ chunk_img, int32_t *__restrict__ klab,
+    int2 *__restrict__ gqueue, int32_t *__restrict__ gcount, int split,
+    const hsgk_segkm_meta *__restrict__ meta) {
+  constexpr int TPX = NW * 32;
+  // All LDS comes from ONE dynamic array: a static __shared__ object in front
+  // of it would leave the base only 4-byte aligned and every ds_read_b128 of the
+  // engine would be split (measured: LDS 87 % busy, 2x slower kernel).
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  unsigned char *tail = lds_raw + split_lds_bytes<NW>(d);
+  int *qnp = reinterpret_cast<int *>(tail - 16);            // [0] count, [1] global base
+  uint16_t *qlist = reinterpret_cast<uint16_t *>(tail);     // [HSGK_CHUNK]
+  if (threadIdx.x == 0) qnp[0] = 0;
+  const int c = blockIdx.x / split;
+  if (c >= meta->n_chunks) return;
+  const int part = blockIdx.x - c * split;
+  const int tps = (HSGK_CHUNK / TPX + split - 1) / split;
+  const int nrows = min(chunk_rows[c] - part * tps * TPX, tps * TPX);
+  if (nrows <= 0) return;
+  const int64_t crow0 = chunk_row0[c] + (int64_t)part * tps * TPX;
+  const int b = chunk_img[c];
+  SplitEpi epi{K, nrows, crow0, klab, qlist, qnp};
+  score_tiles_split<NW>(x, d, cent + (int64_t)b * K * d, K, crow0, nrows, lds_raw, epi);
+  __syncthreads();
+  // publish this workgroup's ambiguous rows to the global queue (one atomic per
+  // workgroup); the re-score pass balances them over the whole chip
+  const int qn = qnp[0];
+  if (qn > 0) {
+    if (threadIdx.x == 0) qnp[1] = atomicAdd(gcount, qn);
+    __syncthreads();
+    const int base = qnp[1];
+    for (int i = threadIdx.x; i < qn; i += NW * 64)
+      gqueue[base + i] = make_int2((int)(crow0 + qlist[i]), b);
+  }
+}
+
+// Exact re-score of the queued rows (typically < 1 % of a chunk): one WAVE per
+// row, lane k owns centroid k and runs the canonical C1 chain
+// acc = fmaf(c_k[dd], x[dd], acc) over ascending dd -- bit-identical to the
+// fp32 MFMA engine.  The row is held across the wave (4 floats per lane) and
+// broadcast one element at a time with v_readlane; centroid rows are read
+// straight from global memory as 16-byte pieces (64 rows x 128-byte lines = an
+// 8 KiB working set that lives in the CU's L1), so there is no LDS staging and
+// no per-workgroup setup cost.  Ties keep the lowest index.
+__global__ __launch_bounds__(256) void assign_requeue_rows_kernel(
+    const float *__restrict__ x, int d, const float *__restrict__ cent, int K,
+    int32_t *__restrict__ klab, const int2 *__restrict__ gqueue,
+    const int32_t *__restrict__ gcount) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+  const int total = *gcount;
+  const int d4 = d & ~3;
+  for (int e = wave; e < total; e += nwaves) {
+    const int2 ent = gqueue[e];
+    const int64_t row = ent.x;
+    const float *xr = x + row * d;
+    const float *ck = cent + ((int64_t)ent.y * K + min(lane, K - 1)) * d;   // this lane's centroid
+    float acc = 0.0f;
+    for (int base = 0; base < d4; base += 256) {
+      // lanes hold 256 consecutive row elements, 4 per lane
+      const int mine = base + 4 * lane;
+      float xv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (mine < d4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xv[i] = xr[mine + i];
+      }
+      const int cnt = min(256, d4 - base);
+      typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));    // rows are 8-byte aligned
+      for (int t0 = 0; t0 < cnt; t0 += 32) {                                 // 8 pieces in flight
+        f4u cv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          cv[u] = *reinterpret_cast<const f4u *>(ck + base + min(t0 + 4 * u, cnt - 4));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int t = t0 + 4 * u;
+          if (t < cnt) {
+            const int src = t >> 2;
+            acc = fmaf(cv[u].x, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[0]), src)), acc);
+            acc = fmaf(cv[u].y, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[1]), src)), acc);
+            acc = fmaf(cv[u].z, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[2]), src)), acc);
+            acc = fmaf(cv[u].w, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[3]), src)), acc);
+          }
+        }
+      }
+    }
+    for (int dd = d4; dd < d; ++dd) acc = fmaf(ck[dd], xr[dd], acc);
+    // wave argmax, first index on ties
+    float bv = lane < K ? acc : -INFINITY;
+    int bi = lane;
+    if (!(bv == bv)) bv = -INFINITY;               // NaN never wins
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(bv, off);
+      const int oi = __shfl_xor(bi, off);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) klab[row] = bi < K ? bi : 0;
+  }
+}
+
+static int launch_assign_split(const float *x, int d, const float *cent, int K,
+                               const ChunkTable &t, int max_chunks, int32_t *klab,
+                               int2 *gqueue, int32_t *gcount, const hsgk_segkm_meta *meta,
+                               hipStream_t s) {
+  constexpr int NW = 8, TPX = NW * 32, kTiles = HSGK_CHUNK / TPX;
+  int split = 1;
+  while (split < kTiles && (int64_t)max_chunks * split < 2048) split *= 2;
+  const int grid = max_chunks * split;
+  HSGK_CHECK_HIP(hipMemsetAsync(gcount, 0, sizeof(int32_t), s));
+  {
+    auto kern = assign_split_kernel<NW>;
+    const size_t lds = split_lds_bytes<NW>(d) + (size_t)HSGK_CHUNK * sizeof(uint16_t);
+    HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, x, d, cent, K, t.chunk_row0,
+                       t.chunk_rows, t.chunk_img, klab, gqueue, gcount, split, meta);
+    HSGK_LAUNCH_CHECK();
+  }
+  // exact pass over the (chip-wide balanced) queue; its length is only known on
+  // the device, so a fixed grid strides over it
+  hipLaunchKernelGGL(assign_requeue_rows_kernel, dim3(2048), dim3(256), 0, s, x, d, cent, K, klab,
+                     gqueue, gcount);
+  HSGK_LAUNCH_CHECK();
+  return 0;
+}
+
+bool assign_split_eligible(int d, int K) {
+  return K <= 64 && split_shape_ok(d) &&
+         split_lds_bytes<8>(d) + (size_t)HSGK_CHUNK * sizeof(uint16_t) <= 160 * 1024;
+}
+
+int launch_assign_fast(const float *x, int d, const float *cent, int K, const ChunkTable &t,
+                       int max_chunks, int32_t *klab, float *best, int2 *qrows,
+                       int32_t *qcount, const hsgk_segkm_meta *meta, hipStream_t s) {
+  if (max_chunks <= 0) return 0;
+  static const int mode = [] {
+    const char *e = getenv("HSGK_ASSIGN");          // "fp32" forces the exact kernel only
+    return (e && e[0] == 'f') ? 0 : 1;
+  }();
+  if (mode == 1 && qrows && assign_split_eligible(d, K))
+    return launch_assign_split(x, d, cent, K, t, max_chunks, klab, qrows, qcount, meta, s);
+  return launch_assign(x, d, cent, K, t, max_chunks, klab, best, meta, s);
 }
 
 template <int KB, int NW, int KC, bool EVEN_D>

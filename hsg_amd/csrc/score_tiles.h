@@ -38,10 +38,14 @@ __host__ __device__ constexpr size_t score_tiles_lds_bytes(int d) {
   return ((size_t)KB * ((((d + 1) & ~1)) | 1) + (size_t)2 * NW * 32 * (KC + 1)) * 4;
 }
 
+// rowlist (nullable): when given, logical row r of the range is the physical
+// row crow0 + rowlist[r] (used by the exact re-scoring pass of the bf16-split
+// E-step, which only visits the queued rows of a chunk).
 template <int KB, int NW, int KC, bool EVEN_D, class Epi>
 __device__ inline void score_tiles(const float *__restrict__ x, int d,
                                    const float *__restrict__ table, int kvalid,
-                                   int64_t crow0, int nrows, float *lds, Epi &epi) {
+                                   int64_t crow0, int nrows, float *lds, Epi &epi,
+                                   const uint16_t *__restrict__ rowlist = nullptr) {
   constexpr int NT = NW * 64;
   constexpr int TPX = NW * 32;
   constexpr int XS = KC + 1;
@@ -112,6 +116,8 @@ __device__ inline void score_tiles(const float *__restrict__ x, int d,
       const int px = lpx + ROWS_PER_LOAD * i;
       const int pxc = max(min(px, n - 1), -(tile * TPX + w * 32));   // stay inside the chunk
       const float *src = tb + pxc * d + 2 * lf2;
+      if (rowlist)
+        src = x + (crow0 + rowlist[tile * TPX + w * 32 + pxc]) * d + q * KC + 2 * lf2;
       float2 v;
       if constexpr (EVEN_D) {
         v = *reinterpret_cast<const float2 *>(src);
@@ -145,7 +151,8 @@ __device__ inline void score_tiles(const float *__restrict__ x, int d,
     const int n = nrows - tile * TPX - w * 32;
     const int col = tcol0 + 2 * st + h;
     const int jc = max(min(j, n - 1), -(tile * TPX + w * 32));
-    const float v = x[(crow0 + (int64_t)tile * TPX + w * 32 + jc) * d + min(col, d - 1)];
+    const int64_t lr = (int64_t)tile * TPX + w * 32 + jc;
+    const float v = x[(crow0 + (rowlist ? (int64_t)rowlist[lr] : lr)) * d + min(col, d - 1)];
     return (j < n && col < d) ? v : 0.0f;
   };
 

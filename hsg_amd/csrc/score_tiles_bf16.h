@@ -1,0 +1,250 @@
+// score_tiles_bf16.h -- bf16x3 "split" scoring engine: a fast, rigorously
+// bounded FILTER in front of the exact fp32 engine (score_tiles.h).
+//
+// fp32 MFMA costs 64 cycles / instruction / SIMD and caps the E-step at the
+// MFMA roof (~50 % of HBM peak at the clock the chip sustains).  Here every
+// fp32 operand is split on the fly into two bf16 values, x = xh + xl + ex with
+// xh = bf16(x), xl = bf16(x - xh) (|ex| <= 2^-16 |x|), and the score is
+// approximated by three bf16 MFMAs per 16 columns
+//
+//     main += ch * xh          corr += cl * xh + ch * xl
+//
+// (v_mfma_f32_32x32x16_bf16: 32 cycles each -> 16/3 times cheaper than the fp32
+// chain).  The approximation error against the canonical fp32 chain is bounded
+// for unit-norm rows and centroids:
+//
+//     dropped products (xl cl, ex c, x ec)      <= 3.02 * 2^-16           = 4.62e-5
+//     bf16 MFMA accumulation, 17 instructions   <= 17 * 2^-22 * 1.01      = 0.41e-5
+//        (measured on gfx950: |D - exact| <= 2^-23.1 * sum|terms| per instruction,
+//         tools/probes/mfma_bf16_probe.hip; 2^-22 used)
+//     corr accumulator + final add                                         < 0.02e-5
+//     fp32 chain of the oracle vs the real number  gamma_258               = 1.54e-5
+//                                                              E           <= 6.6e-5
+//
+// A row whose two best approximate scores are more than kSplitGap = 1.4e-4 (> 2E)
+// apart has a strictly unique exact argmax and gets its label here; every other
+// row (a few per cent on i.i.d. data) is queued and re-scored EXACTLY by the fp32
+// engine, so the labels are bit-identical to the canonical arithmetic.
+//
+// Layout: one workgroup (8 waves) per chunk part, table block (<= 64 rows) as
+// two bf16 planes [64][RS] in LDS (RS = ceil16(d) + 8 elements: 16-byte aligned
+// rows, conflict-free ds_read_b128), rows stream through wave-private double
+// buffered hi/lo planes [32][40] exactly like the fp32 engine (no barrier in the
+// column loop, global loads two chunks ahead).
+#pragma once
+#include "common.h"
+#include "score_tiles.h"
+
+namespace hsgk {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr float kSplitGap = 1.4e-4f;
+
+// (a, b) -> packed hi pair and packed lo pair; v_cvt_pk_bf16_f32 rounds to
+// nearest even, the residual subtraction is exact
+__device__ inline void bf16_split2(float a, float b, uint32_t &hi, uint32_t &lo) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {a, b};
+  const bf16x2 h = __builtin_convertvector(v, bf16x2);
+  const f32x2 r = v - __builtin_convertvector(h, f32x2);
+  const bf16x2 l = __builtin_convertvector(r, bf16x2);
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+
+template <int NW>
+__host__ __device__ constexpr size_t split_lds_bytes(int d) {
+  return (size_t)2 * 64 * (((d + 15) / 16) * 16 + 8) * 2 + (size_t)NW * 2 * 2 * 32 * 40 * 2 + 16;
+}
+
+// Epi(tile, main, corr): lane (j, h) holds main[m][r] + corr[m][r] = approximate
+// score of table row m*32 + (r&3) + 8*(r>>2) + 4*h for x row tile*NW*32 + w*32 + j.
+template <int NW, class Epi>
+__device__ inline void score_tiles_split(const float *__restrict__ x, int d,
+                                         const float *__restrict__ table, int kvalid,
+                                         int64_t crow0, int nrows, unsigned char *lds_raw,
+                                         Epi &epi) {
+  constexpr int NT = NW * 64;
+  constexpr int TPX = NW * 32;
+  constexpr int KC = 32;               // columns per staged chunk (2 k-blocks)
+  constexpr int XSB = 40;              // bf16 elements per staged row (32 + 8 pad)
+  constexpr int LOADS = 8;             // float2 per lane per chunk
+  const int dk16 = ((d + 15) / 16) * 16;
+  const int RS = dk16 + 8;             // bf16 elements per table row
+
+  uint16_t *chs = reinterpret_cast<uint16_t *>(lds_raw);          // [64][RS]
+  uint16_t *cls = chs + 64 * RS;                                   // [64][RS]
+  uint16_t *xs = cls + 64 * RS;                                    // [NW][2 buf][2 plane][32][XSB]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int j = lane & 31, g = lane >> 5;
+
+  // ---- table block -> bf16 hi / lo planes (zero padded)
+  {
+    uint32_t *z = reinterpret_cast<uint32_t *>(chs);
+    for (int i = tid; i < 64 * RS; i += NT) z[i] = 0u;            // 2 planes * 64*RS*2 B / 4
+    __syncthreads();
+    const int half = d >> 1;
+    const int total = kvalid * half;
+    for (int f0 = 0; f0 < total; f0 += NT * 8) {
+      float2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int f = min(f0 + tid + NT * u, total - 1);
+        v[u] = *reinterpret_cast<const float2 *>(table + 2 * (int64_t)f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int f = f0 + tid + NT * u;
+        if (f < total) {
+          const int k = f / half, col = 2 * (f - k * half);
+          uint32_t hi, lo;
+          bf16_split2(v[u].x, v[u].y, hi, lo);
+          *reinterpret_cast<uint32_t *>(chs + k * RS + col) = hi;
+          *reinterpret_cast<uint32_t *>(cls + k * RS + col) = lo;
+        }
+      }
+    }
+  }
+
+  const int nfull = d / KC;
+  const int tcol0 = nfull * KC;
+  const int tblocks = (d - tcol0 + 15) / 16;      // tail k-blocks fed from global (<= 2)
+  const int ntile = (nrows + TPX - 1) / TPX;
+  const int nsteps = ntile * nfull;
+
+  uint16_t *xw = xs + w * (2 * 2 * 32 * XSB);
+  const int lpx = lane >> 4, lf2 = lane & 15;
+
+  auto load_chunk = [&](int gidx, float2 (&pre)[LOADS]) {
+    const int tile = gidx / nfull, q = gidx - tile * nfull;
+    const int n = nrows - tile * TPX - w * 32;
+    const float *tb = x + (crow0 + (int64_t)tile * TPX + w * 32) * d + q * KC;
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      const int px = lpx + 4 * i;
+      const int pxc = max(min(px, n - 1), -(tile * TPX + w * 32));
+      const float2 v = *reinterpret_cast<const float2 *>(tb + pxc * d + 2 * lf2);
+      pre[i] = px < n ? v : make_float2(0.0f, 0.0f);
+    }
+  };
+  auto store_chunk = [&](int buf, const float2 (&pre)[LOADS]) {
+    uint16_t *hp = xw + buf * (2 * 32 * XSB);
+    uint16_t *lp = hp + 32 * XSB;
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      const int px = lpx + 4 * i;
+      uint32_t hi, lo;
+      bf16_split2(pre[i].x, pre[i].y, hi, lo);
+      *reinterpret_cast<uint32_t *>(hp + px * XSB + 2 * lf2) = hi;
+      *reinterpret_cast<uint32_t *>(lp + px * XSB + 2 * lf2) = lo;
+    }
+  };
+
+  f32x16 mainacc[2], corracc[2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { mainacc[m][r] = 0.0f; corracc[m][r] = 0.0f; }
+  };
+  auto kblock = [&](const bf16x8 &bh, const bf16x8 &bl, int col0) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(chs + (m * 32 + j) * RS + col0 + 8 * g);
+      const bf16x8 al = *reinterpret_cast<const bf16x8 *>(cls + (m * 32 + j) * RS + col0 + 8 * g);
+      mainacc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, mainacc[m], 0, 0, 0);
+      corracc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, corracc[m], 0, 0, 0);
+      corracc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, corracc[m], 0, 0, 0);
+    }
+  };
+  auto compute_chunk = [&](int buf, int q) {
+    const uint16_t *hp = xw + buf * (2 * 32 * XSB) + j * XSB + 8 * g;
+    const uint16_t *lp = hp + 32 * XSB;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(hp + kb * 16);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(lp + kb * 16);
+      kblock(bh, bl, q * KC + kb * 16);
+    }
+  };
+  // tail k-block kb of a tile: columns tcol0 + 16 kb + 8 g + 0..7 of row j, from global
+  auto tail_operands = [&](int tile, int kb, bf16x8 &bh, bf16x8 &bl) {
+    const int n = nrows - tile * TPX - w * 32;
+    const int jc = max(min(j, n - 1), -(tile * TPX + w * 32));
+    const float *src = x + (crow0 + (int64_t)tile * TPX + w * 32 + jc) * d;
+    const int c0 = tcol0 + 16 * kb + 8 * g;
+    uint32_t hw[4], lw[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ca = c0 + 2 * p;
+      const float a = (j < n && ca < d) ? src[min(ca, d - 1)] : 0.0f;
+      const float b = (j < n && ca + 1 < d) ? src[min(ca + 1, d - 1)] : 0.0f;
+      bf16_split2(a, b, hw[p], lw[p]);
+    }
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 hv = {hw[0], hw[1], hw[2], hw[3]}, lv = {lw[0], lw[1], lw[2], lw[3]};
+    bh = __builtin_bit_cast(bf16x8, hv);
+    bl = __builtin_bit_cast(bf16x8, lv);
+  };
+  auto finish_tile = [&](int tile) {
+    for (int kb = 0; kb < tblocks; ++kb) {
+      bf16x8 bh, bl;
+      tail_operands(tile, kb, bh, bl);
+      kblock(bh, bl, tcol0 + 16 * kb);
+    }
+    epi(tile, mainacc, corracc);
+  };
+
+  __syncthreads();                         // table planes visible to all waves
+  zero_acc();
+  // The caller guarantees nfull % 4 == 0 (split_shape_ok): four register sets
+  // rotate, each loaded FOUR chunks (4 KiB per wave each) ahead of its use --
+  // with the MFMA work this cheap the kernel is latency-bound unless ~100 KiB
+  // per CU are in flight -- and a tile always ends on the last set, so there is
+  // ONE epilogue site and the accumulators never move between code paths.
+  float2 preA[LOADS], preB[LOADS], preC[LOADS], preD[LOADS];
+  load_chunk(0, preA);
+  load_chunk(1, preB);
+  load_chunk(2, preC);
+  load_chunk(3, preD);
+  int gidx = 0;
+  for (int tile = 0; tile < ntile; ++tile) {
+    for (int q = 0; q < nfull; q += 4, gidx += 4) {
+      store_chunk(0, preA);
+      __builtin_amdgcn_sched_barrier(0);
+      if (gidx + 4 < nsteps) load_chunk(gidx + 4, preA);
+      __builtin_amdgcn_sched_barrier(0);
+      compute_chunk(0, q);
+      __builtin_amdgcn_sched_barrier(0);
+      store_chunk(1, preB);
+      __builtin_amdgcn_sched_barrier(0);
+      if (gidx + 5 < nsteps) load_chunk(gidx + 5, preB);
+      __builtin_amdgcn_sched_barrier(0);
+      compute_chunk(1, q + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      store_chunk(0, preC);
+      __builtin_amdgcn_sched_barrier(0);
+      if (gidx + 6 < nsteps) load_chunk(gidx + 6, preC);
+      __builtin_amdgcn_sched_barrier(0);
+      compute_chunk(0, q + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      store_chunk(1, preD);
+      __builtin_amdgcn_sched_barrier(0);
+      if (gidx + 7 < nsteps) load_chunk(gidx + 7, preD);
+      __builtin_amdgcn_sched_barrier(0);
+      compute_chunk(1, q + 3);
+    }
+    finish_tile(tile);
+    zero_acc();
+  }
+}
+
+// shapes the split engine accepts (number of 32-column chunks divisible by 4)
+__host__ __device__ inline bool split_shape_ok(int d) {
+  return (d & 1) == 0 && d >= 128 && ((d / 32) & 3) == 0;
+}
+
+}  // namespace hsgk

@@ -141,9 +141,16 @@ HSGK_API size_t hsgk_lloyd_workspace_bytes(int B, int64_t rows_per_image, int d,
 HSGK_API int hsgk_lloyd_mstep(const float *x, int B, int64_t rows_per_image, int d, int K,
                               const int32_t *labels, float *centroids, void *workspace,
                               size_t workspace_bytes, hsgk_stream_t stream);
+/* unit_rows != 0 promises L2-normalised rows and centroids and enables the
+ * bf16-split filter + exact re-score E-step (same labels, faster).            */
 HSGK_API int hsgk_lloyd_estep(const float *x, int B, int64_t rows_per_image, int d, int K,
-                              const float *centroids, int32_t *labels_out, void *workspace,
-                              size_t workspace_bytes, hsgk_stream_t stream);
+                              const float *centroids, int32_t *labels_out, int unit_rows,
+                              void *workspace, size_t workspace_bytes, hsgk_stream_t stream);
+
+/* diagnostics: rows the last unit_rows E-step on this workspace re-scored exactly */
+HSGK_API int hsgk_lloyd_requeued_rows(int B, int64_t rows_per_image, int d, int K,
+                                      void *workspace, size_t workspace_bytes, int64_t *out,
+                                      hsgk_stream_t stream);
 
 /* ---- hsg/utils/segsort/common.py:44-64 find_nearest_prototypes ------------ */
 /* labels_out[n] = argmax_k <x_r, proto_k>, first index on ties.               */

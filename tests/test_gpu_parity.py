@@ -303,3 +303,38 @@ def test_exchange_list_api_on_gpu_vs_reference(dev):
   assert np.abs(protos_loc[1].detach().cpu().numpy() - g['protos_loc']).max() <= FTOL
   protos[0].sum().backward()
   assert embs[0].grad is not None and embs[1].grad is not None
+
+
+@pytest.mark.parametrize('B,HW,C,K', [(2, 4096, 32, 8), (1, 5000, 256, 64), (3, 2500, 128, 37),
+                                      (1, 300, 64, 64)])
+def test_split_estep_matches_exact_labels(dev, oracle, B, HW, C, K):
+  """bf16-split filter + exact re-score == canonical fp32 argmax, including
+  exact ties (duplicate centroids), near ties (perturbed copies) and zero
+  centroids; also equals the pure fp32 kernel (unit_rows = 0)."""
+  import torch
+  from hsg_amd import _lib
+  D = C + 2
+  n = B * HW
+  x = oracle.normalize_embedding(synth.gaussish(31 + C, n * D).reshape(n, D))
+  cent = oracle.normalize_embedding(synth.gaussish(37 + K, B * K * D).reshape(B * K, D))
+  cent = cent.reshape(B, K, D).copy()
+  if K >= 8:
+    cent[:, 3] = cent[:, 1]                                   # exact tie -> first index
+    near = cent[:, 2] + np.float32(3e-6) * cent[:, 5]
+    cent[:, 6] = oracle.normalize_embedding(near)             # gap ~1e-6: must be re-scored
+    cent[:, K - 1] = 0.0                                      # empty cluster
+  L = _lib.lib()
+  xt = torch.from_numpy(x).to(dev)
+  ct = torch.from_numpy(cent).to(dev)
+  wsb = L.hsgk_lloyd_workspace_bytes(B, HW, D, K)
+  ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+  got = {}
+  for unit in (1, 0):
+    out = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    _lib.check(L.hsgk_lloyd_estep(xt.data_ptr(), B, HW, D, K, ct.data_ptr(), out.data_ptr(), unit,
+                                  ws.data_ptr(), wsb, _lib.stream_ptr()))
+    got[unit] = out.cpu().numpy().astype(np.int64)
+  for b in range(B):
+    ref = oracle.find_nearest_prototypes(x[b * HW:(b + 1) * HW], cent[b])
+    assert np.array_equal(got[0][b * HW:(b + 1) * HW], ref), 'fp32 kernel'
+    assert np.array_equal(got[1][b * HW:(b + 1) * HW], ref), 'split kernel'

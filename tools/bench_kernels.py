@@ -23,6 +23,8 @@ def main():
   ap.add_argument('--K', type=int, default=64)
   ap.add_argument('--reps', type=int, default=5)
   ap.add_argument('--only', default='em')
+  ap.add_argument('--lloyd-warm', type=int, default=3)
+  ap.add_argument('--unit', type=int, default=1, help='1 = bf16 split fast path, 0 = fp32 kernel')
   a = ap.parse_args()
   import torch
   from hsg_amd import _lib
@@ -46,8 +48,14 @@ def main():
 
   def e():
     _lib.check(L.hsgk_lloyd_estep(x.data_ptr(), a.B, a.HW, a.D, a.K, cent.data_ptr(),
-                                  out.data_ptr(), ws.data_ptr(), wsb, st))
+                                  out.data_ptr(), a.unit, ws.data_ptr(), wsb, st))
 
+  # a few real Lloyd iterations first so that labels / centroids look like the
+  # operator's steady state (random labels give 64 near-identical centroids)
+  def relabel():
+    lab.copy_(out)
+  for _ in range(a.lloyd_warm):
+    m(); e(); relabel()
   m(); e(); torch.cuda.synchronize()
   _lib.profile_enable(True)
   _lib.profile_collect()
@@ -65,6 +73,10 @@ def main():
       res[k] = {'ms': round(ms / cnt, 4), 'GB/s(4D+8)': round(gb / (ms / cnt) * 1e3, 1)}
   if 'assign' in res:
     res['assign']['TFLOP/s'] = round(2.0 * a.D * a.K * n / (res['assign']['ms'] * 1e-3) / 1e12, 1)
+  if a.unit:
+    q = torch.zeros((1,), dtype=torch.int64, device=dev)
+    _lib.check(L.hsgk_lloyd_requeued_rows(a.B, a.HW, a.D, a.K, ws.data_ptr(), wsb, q.data_ptr(), st))
+    res['requeued_fraction'] = round(q.item() / n, 5)
   print(json.dumps({'shape': vars(a), 'result': res}))
 
 
