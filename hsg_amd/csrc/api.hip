@@ -48,7 +48,7 @@ struct KmeansScratch {
   float *best;
   float *partial;
   float *cent;
-  int2 *qrows;         // [max_chunks * HSGK_CHUNK] (row, image) exact re-score queue (split E-step)
+  void *qrows;         // [max_chunks * HSGK_CHUNK] 12-byte entries: exact re-score queue (split E-step)
   int32_t *qcount;     // [1] queue length
   int max_chunks;
 };
@@ -71,7 +71,7 @@ static void carve_kmeans(Carver &cv, int B, int64_t rows_per_img, int d, int K,
   k->best = cv.take<float>((size_t)B * rows_per_img + 1);
   k->partial = cv.take<float>(mcs * K * d);
   k->cent = cv.take<float>((size_t)B * K * d + 1);
-  k->qrows = cv.take<int2>(mcs * HSGK_CHUNK);
+  k->qrows = cv.take<char>(mcs * HSGK_CHUNK * 12);
   k->qcount = cv.take<int32_t>(4);
 }
 

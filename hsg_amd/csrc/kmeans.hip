@@ -198,18 +198,30 @@ __global__ __launch_bounds__(NW * 64) void assign_kernel(
 // of the rows whose two best approximate scores are closer than kSplitGap.
 // Requires unit-norm rows and centroids (true inside the Lloyd loop), K <= 64,
 // even d.  Both kernels use the same (chunk, part) -> row-range mapping.
+// Queue entry of the exact pass: the row, its image and the CANDIDATE centroids
+// (every k whose approximate score is within kSplitGap of the best one -- a
+// superset of all exact maximisers, see score_tiles_bf16.h).  cand = up to three
+// indices in bytes 0..2 and their count in byte 3; count 255 = "more than three,
+// re-score all K".
+struct SplitEntry { int32_t row; uint32_t cand; int32_t img; };
+constexpr int kSplitLdsList = 1024;      // per-workgroup staging of entries (6 B each)
+
 struct SplitEpi {
-  int K, nrows;
+  int K, nrows, img;
   int64_t crow0;
   int32_t *klab;
-  uint16_t *qrows;       // LDS: this workgroup's queue (row offsets inside its range)
+  uint16_t *qpx;         // LDS [kSplitLdsList]
+  uint32_t *qcand;       // LDS [kSplitLdsList]
   int *qn;               // LDS counter
+  SplitEntry *gqueue;    // global queue (overflow path)
+  int32_t *gcount;
   __device__ inline void operator()(int tile, const f32x16 (&mainacc)[2],
                                     const f32x16 (&corracc)[2]) const {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int TPX = (int)(blockDim.x >> 1);
     // branch-free running top-2: b2 = max(b2, min(b1, v)); b1 = max(b1, v)
+    float sc[2][16];
     float b1 = -INFINITY, b2 = -INFINITY;
     int bi = 0;
 #pragma unroll
@@ -218,6 +230,7 @@ struct SplitEpi {
       for (int r = 0; r < 16; ++r) {
         const int k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const float v = k < K ? mainacc[m][r] + corracc[m][r] : -INFINITY;
+        sc[m][r] = v;
         b2 = fmaxf(b2, fminf(b1, v));
         bi = v > b1 ? k : bi;
         b1 = fmaxf(b1, v);
@@ -230,11 +243,37 @@ struct SplitEpi {
     if (o1 > b1) { t1 = o1; ti = oi; t2 = fmaxf(b1, o2); }
     else { t1 = b1; ti = bi; t2 = fmaxf(o1, b2); }
     const int px = tile * TPX + w * 32 + j;
-    if (h == 0 && px < nrows) {
-      klab[crow0 + px] = ti;
-      if (!(t1 - t2 > kSplitGap)) {           // ambiguous (or NaN): exact pass decides
-        const int pos = atomicAdd(qn, 1);
-        qrows[pos] = (uint16_t)px;
+    const bool valid = px < nrows;
+    const bool amb = valid && !(t1 - t2 > kSplitGap);       // ambiguous (or NaN)
+    if (h == 0 && valid) klab[crow0 + px] = ti;
+    if (!__any(amb)) return;
+    // candidate list of this lane's half, then merged with the partner half
+    const float thr = t1 - kSplitGap;
+    uint32_t list = 0;
+    int cnt = 0;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool hit = sc[m][r] >= thr;                    // NaN scores never hit
+        list = hit ? ((list << 8) | k) : list;
+        cnt += hit ? 1 : 0;
+      }
+    const uint32_t olist = __shfl_xor(list, 32);
+    const int ocnt = __shfl_xor(cnt, 32);
+    const int tot = cnt + ocnt;
+    uint32_t cand = 255u << 24;
+    if (tot <= 3 && tot >= 1 && t1 == t1)
+      cand = (list & ((1u << (8 * cnt)) - 1u)) | (olist << (8 * cnt)) | ((uint32_t)tot << 24);
+    if (h == 0 && amb) {
+      const int pos = atomicAdd(qn, 1);
+      if (pos < kSplitLdsList) {
+        qpx[pos] = (uint16_t)px;
+        qcand[pos] = cand;
+      } else {                                               // staging full: straight to global
+        const int g = atomicAdd(gcount, 1);
+        gqueue[g] = SplitEntry{(int32_t)(crow0 + px), cand, img};
       }
     }
   }
@@ -245,7 +284,7 @@ __global__ __launch_bounds__(NW * 64) void assign_split_kernel(
     const float *__restrict__ x, int d, const float *__restrict__ cent, int K,
     const int64_t *__restrict__ chunk_row0, const int32_t *__restrict__ chunk_rows,
     const int32_t *__restrict__ chunk_img, int32_t *__restrict__ klab,
-    int2 *__restrict__ gqueue, int32_t *__restrict__ gcount, int split,
+    SplitEntry *__restrict__ gqueue, int32_t *__restrict__ gcount, int split,
     const hsgk_segkm_meta *__restrict__ meta) {
   constexpr int TPX = NW * 32;
   // All LDS comes from ONE dynamic array: a static __shared__ object in front
@@ -254,7 +293,8 @@ __global__ __launch_bounds__(NW * 64) void assign_split_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   unsigned char *tail = lds_raw + split_lds_bytes<NW>(d);
   int *qnp = reinterpret_cast<int *>(tail - 16);            // [0] count, [1] global base
-  uint16_t *qlist = reinterpret_cast<uint16_t *>(tail);     // [HSGK_CHUNK]
+  uint32_t *qcand = reinterpret_cast<uint32_t *>(tail);     // [kSplitLdsList]
+  uint16_t *qpx = reinterpret_cast<uint16_t *>(qcand + kSplitLdsList);
   if (threadIdx.x == 0) qnp[0] = 0;
   const int c = blockIdx.x / split;
   if (c >= meta->n_chunks) return;
@@ -264,89 +304,103 @@ __global__ __launch_bounds__(NW * 64) void assign_split_kernel(
   if (nrows <= 0) return;
   const int64_t crow0 = chunk_row0[c] + (int64_t)part * tps * TPX;
   const int b = chunk_img[c];
-  SplitEpi epi{K, nrows, crow0, klab, qlist, qnp};
+  SplitEpi epi{K, nrows, b, crow0, klab, qpx, qcand, qnp, gqueue, gcount};
   score_tiles_split<NW>(x, d, cent + (int64_t)b * K * d, K, crow0, nrows, lds_raw, epi);
   __syncthreads();
-  // publish this workgroup's ambiguous rows to the global queue (one atomic per
-  // workgroup); the re-score pass balances them over the whole chip
-  const int qn = qnp[0];
+  // publish the staged entries with ONE global atomic per workgroup; the exact
+  // pass then balances the queue over the whole chip
+  const int qn = min(qnp[0], kSplitLdsList);
   if (qn > 0) {
     if (threadIdx.x == 0) qnp[1] = atomicAdd(gcount, qn);
     __syncthreads();
     const int base = qnp[1];
     for (int i = threadIdx.x; i < qn; i += NW * 64)
-      gqueue[base + i] = make_int2((int)(crow0 + qlist[i]), b);
+      gqueue[base + i] = SplitEntry{(int32_t)(crow0 + qpx[i]), qcand[i], b};
   }
 }
 
-// Exact re-score of the queued rows (typically < 1 % of a chunk): one WAVE per
-// row, lane k owns centroid k and runs the canonical C1 chain
-// acc = fmaf(c_k[dd], x[dd], acc) over ascending dd -- bit-identical to the
-// fp32 MFMA engine.  The row is held across the wave (4 floats per lane) and
-// broadcast one element at a time with v_readlane; centroid rows are read
-// straight from global memory as 16-byte pieces (64 rows x 128-byte lines = an
-// 8 KiB working set that lives in the CU's L1), so there is no LDS staging and
-// no per-workgroup setup cost.  Ties keep the lowest index.
+// Exact pass over the queue.  Lane group of 4 = one entry, lane = one candidate:
+// each lane runs the canonical C1 chain acc = fmaf(c_k[dd], x[dd], acc) over
+// ascending dd for ITS (row, centroid) pair -- bit-identical to the fp32 MFMA
+// engine -- streaming both rows with 16-byte loads (8 in flight).  The group
+// keeps the largest exact score, lowest index on ties.  Entries with more than
+// three candidates (count 255: duplicate / empty clusters) take the whole wave:
+// lane k = centroid k, row elements broadcast with v_readlane.
+__device__ inline float exact_chain(const float *__restrict__ ck, const float *__restrict__ xr, int d) {
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));    // rows are 8-byte aligned
+  float acc = 0.0f;
+  const int d4 = d & ~3;
+  int t0 = 0;
+  for (; t0 + 32 <= d4; t0 += 32) {
+    f4u cv[8], xv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      cv[u] = *reinterpret_cast<const f4u *>(ck + t0 + 4 * u);
+      xv[u] = *reinterpret_cast<const f4u *>(xr + t0 + 4 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc = fmaf(cv[u].x, xv[u].x, acc);
+      acc = fmaf(cv[u].y, xv[u].y, acc);
+      acc = fmaf(cv[u].z, xv[u].z, acc);
+      acc = fmaf(cv[u].w, xv[u].w, acc);
+    }
+  }
+  for (int dd = t0; dd < d; ++dd) acc = fmaf(ck[dd], xr[dd], acc);
+  return acc;
+}
+
 __global__ __launch_bounds__(256) void assign_requeue_rows_kernel(
     const float *__restrict__ x, int d, const float *__restrict__ cent, int K,
-    int32_t *__restrict__ klab, const int2 *__restrict__ gqueue,
+    int32_t *__restrict__ klab, const SplitEntry *__restrict__ gqueue,
     const int32_t *__restrict__ gcount) {
   const int lane = threadIdx.x & 63;
   const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
   const int total = *gcount;
-  const int d4 = d & ~3;
-  for (int e = wave; e < total; e += nwaves) {
-    const int2 ent = gqueue[e];
-    const int64_t row = ent.x;
-    const float *xr = x + row * d;
-    const float *ck = cent + ((int64_t)ent.y * K + min(lane, K - 1)) * d;   // this lane's centroid
-    float acc = 0.0f;
-    for (int base = 0; base < d4; base += 256) {
-      // lanes hold 256 consecutive row elements, 4 per lane
-      const int mine = base + 4 * lane;
-      float xv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (mine < d4) {
+  const int grp = lane >> 2, ci = lane & 3;
+  for (int e0 = wave * 16; e0 < total; e0 += nwaves * 16) {
+    const int e = e0 + grp;
+    SplitEntry ent{0, 0u, 0};
+    if (e < total) ent = gqueue[e];
+    const int n = e < total ? (int)(ent.cand >> 24) : 0;
+    const int k = (int)((ent.cand >> (8 * ci)) & 255u);
+    const bool act = n != 255 && ci < n;
+    float acc = -INFINITY;
+    if (act) acc = exact_chain(cent + ((int64_t)ent.img * K + k) * d, x + (int64_t)ent.row * d, d);
+    float bv = (act && acc == acc) ? acc : -INFINITY;     // NaN never wins
+    int bi = act ? k : 0x7fffffff;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xv[i] = xr[mine + i];
-      }
-      const int cnt = min(256, d4 - base);
-      typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));    // rows are 8-byte aligned
-      for (int t0 = 0; t0 < cnt; t0 += 32) {                                 // 8 pieces in flight
-        f4u cv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          cv[u] = *reinterpret_cast<const f4u *>(ck + base + min(t0 + 4 * u, cnt - 4));
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int t = t0 + 4 * u;
-          if (t < cnt) {
-            const int src = t >> 2;
-            acc = fmaf(cv[u].x, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[0]), src)), acc);
-            acc = fmaf(cv[u].y, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[1]), src)), acc);
-            acc = fmaf(cv[u].z, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[2]), src)), acc);
-            acc = fmaf(cv[u].w, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[3]), src)), acc);
-          }
-        }
-      }
-    }
-    for (int dd = d4; dd < d; ++dd) acc = fmaf(ck[dd], xr[dd], acc);
-    // wave argmax, first index on ties
-    float bv = lane < K ? acc : -INFINITY;
-    int bi = lane;
-    if (!(bv == bv)) bv = -INFINITY;               // NaN never wins
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int off = 1; off <= 2; off <<= 1) {
       const float ov = __shfl_xor(bv, off);
       const int oi = __shfl_xor(bi, off);
       if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
-    if (lane == 0) klab[row] = bi < K ? bi : 0;
+    if (ci == 0 && n >= 1 && n <= 3) klab[ent.row] = bi == 0x7fffffff ? 0 : bi;
+    // rare: entries that need all K centroids, one at a time on the whole wave
+    unsigned long long hard = __ballot(ci == 0 && n == 255);
+    while (hard) {
+      const int src = __builtin_ctzll(hard);
+      hard &= hard - 1;
+      const int row = __builtin_amdgcn_readlane(ent.row, src);
+      const int img = __builtin_amdgcn_readlane(ent.img, src);
+      float a = -INFINITY;
+      if (lane < K) a = exact_chain(cent + ((int64_t)img * K + lane) * d, x + (int64_t)row * d, d);
+      float hv = (lane < K && a == a) ? a : -INFINITY;
+      int hi = lane;
+      for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(hv, off);
+        const int oi = __shfl_xor(hi, off);
+        if (ov > hv || (ov == hv && oi < hi)) { hv = ov; hi = oi; }
+      }
+      if (lane == 0) klab[row] = hi < K ? hi : 0;
+    }
   }
 }
 
 static int launch_assign_split(const float *x, int d, const float *cent, int K,
                                const ChunkTable &t, int max_chunks, int32_t *klab,
-                               int2 *gqueue, int32_t *gcount, const hsgk_segkm_meta *meta,
+                               SplitEntry *gqueue, int32_t *gcount, const hsgk_segkm_meta *meta,
                                hipStream_t s) {
   constexpr int NW = 8, TPX = NW * 32, kTiles = HSGK_CHUNK / TPX;
   int split = 1;
@@ -355,7 +409,7 @@ static int launch_assign_split(const float *x, int d, const float *cent, int K,
   HSGK_CHECK_HIP(hipMemsetAsync(gcount, 0, sizeof(int32_t), s));
   {
     auto kern = assign_split_kernel<NW>;
-    const size_t lds = split_lds_bytes<NW>(d) + (size_t)HSGK_CHUNK * sizeof(uint16_t);
+    const size_t lds = split_lds_bytes<NW>(d) + (size_t)kSplitLdsList * 6;
     HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, x, d, cent, K, t.chunk_row0,
@@ -372,11 +426,11 @@ static int launch_assign_split(const float *x, int d, const float *cent, int K,
 
 bool assign_split_eligible(int d, int K) {
   return K <= 64 && split_shape_ok(d) &&
-         split_lds_bytes<8>(d) + (size_t)HSGK_CHUNK * sizeof(uint16_t) <= 160 * 1024;
+         split_lds_bytes<8>(d) + (size_t)kSplitLdsList * 6 <= 160 * 1024;
 }
 
 int launch_assign_fast(const float *x, int d, const float *cent, int K, const ChunkTable &t,
-                       int max_chunks, int32_t *klab, float *best, int2 *qrows,
+                       int max_chunks, int32_t *klab, float *best, void *qrows,
                        int32_t *qcount, const hsgk_segkm_meta *meta, hipStream_t s) {
   if (max_chunks <= 0) return 0;
   static const int mode = [] {
@@ -384,7 +438,8 @@ int launch_assign_fast(const float *x, int d, const float *cent, int K, const Ch
     return (e && e[0] == 'f') ? 0 : 1;
   }();
   if (mode == 1 && qrows && assign_split_eligible(d, K))
-    return launch_assign_split(x, d, cent, K, t, max_chunks, klab, qrows, qcount, meta, s);
+    return launch_assign_split(x, d, cent, K, t, max_chunks, klab,
+                               reinterpret_cast<SplitEntry *>(qrows), qcount, meta, s);
   return launch_assign(x, d, cent, K, t, max_chunks, klab, best, meta, s);
 }
 
