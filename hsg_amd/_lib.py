@@ -70,6 +70,9 @@ SIGNATURES = {
     'hsgk_segsort_loss_bwd_weights': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _f32, _i32,
                                              _vp, _vp, _vp, _vp, _vp, _vp]),
     'hsgk_lloyd_requeued_rows': (_i32, [_i32, _i64, _i32, _i32, _vp, _sz, _vp, _vp]),
+    'hsgk_hier_assign': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'hsgk_group_mean': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
+    'hsgk_gather_labels': (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _vp]),
     'hsgk_assign_workspace_bytes': (_sz, [_i64, _i32, _i32]),
     'hsgk_find_nearest_prototypes': (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
 }

@@ -1,0 +1,167 @@
+// hier.hip -- hierarchical segment assignment (reference
+// hsg/models/embeddings/resnet_fcn_hsg.py):
+//   hier_assign   :638-672  softmax over clusters, argmax -> fine labels;
+//                           coarse probs = softmax(coarse) x fine probs
+//                           (Bayes chain, einsum 'bij,bjk->bik'), argmax
+//   group_mean    :683-748  _collect_nd_coarser_prototype: masked scatter-mean
+//                           of [B,C,N] node features into groups (+ optional
+//                           L2 normalisation)
+//   gather_labels :751-780  pixel -> segment -> group label lookup
+// All three are launch-bound in the reference (tens of tiny ATen ops and a
+// Python loop per image); here each is one launch, one workgroup per image.
+// Canonical arithmetic: sums run sequentially in ascending index, dot products
+// are fmaf chains (C1), softmax = exp(x - max) / sum with expf.
+#include "common.h"
+
+namespace hsgk {
+
+__global__ __launch_bounds__(256) void hier_assign_kernel(
+    const float *__restrict__ fine_logits, const float *__restrict__ coarse_logits, int KF, int KC,
+    int N, float *__restrict__ fine_prob, int64_t *__restrict__ fine_lab,
+    float *__restrict__ coarse_prob, int64_t *__restrict__ coarse_lab) {
+  extern __shared__ float pc[];              // [KC][KF] coarse softmax (over KC, per fine column)
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float *fl = fine_logits + (int64_t)b * KF * N;
+  float *fp = fine_prob + (int64_t)b * KF * N;
+  if (coarse_logits) {
+    const float *cl = coarse_logits + (int64_t)b * KC * KF;
+    for (int c1 = tid; c1 < KF; c1 += 256) {
+      float m = -INFINITY;
+      for (int c2 = 0; c2 < KC; ++c2) m = fmaxf(m, cl[c2 * KF + c1]);
+      float s = 0.0f;
+      for (int c2 = 0; c2 < KC; ++c2) s = s + expf(cl[c2 * KF + c1] - m);
+      for (int c2 = 0; c2 < KC; ++c2) pc[c2 * KF + c1] = expf(cl[c2 * KF + c1] - m) / s;
+    }
+  }
+  __syncthreads();
+  for (int n = tid; n < N; n += 256) {
+    float m = -INFINITY;
+    for (int c = 0; c < KF; ++c) m = fmaxf(m, fl[c * N + n]);
+    float s = 0.0f;
+    for (int c = 0; c < KF; ++c) s = s + expf(fl[c * N + n] - m);
+    float best = -INFINITY;
+    int bi = 0;
+    for (int c = 0; c < KF; ++c) {
+      const float p = expf(fl[c * N + n] - m) / s;
+      fp[c * N + n] = p;
+      if (p > best) { best = p; bi = c; }
+    }
+    fine_lab[(int64_t)b * N + n] = bi;
+    if (coarse_logits) {
+      float *cp = coarse_prob + (int64_t)b * KC * N;
+      float cbest = -INFINITY;
+      int ci = 0;
+      for (int c2 = 0; c2 < KC; ++c2) {
+        float acc = 0.0f;
+        for (int c = 0; c < KF; ++c) acc = fmaf(pc[c2 * KF + c], fp[c * N + n], acc);
+        cp[c2 * N + n] = acc;
+        if (acc > cbest) { cbest = acc; ci = c2; }
+      }
+      coarse_lab[(int64_t)b * N + n] = ci;
+    }
+  }
+}
+
+// prototypes [B,C,N]; labels [B,N]; masks [B,N] (uint8, nullable: nothing
+// padded); out [B,C,G].  Node n contributes to group labels[n] unless padded.
+__global__ __launch_bounds__(256) void group_mean_kernel(
+    const float *__restrict__ protos, const int64_t *__restrict__ labels,
+    const uint8_t *__restrict__ masks, int C, int N, int G, int normalized, float eps,
+    float *__restrict__ out) {
+  extern __shared__ float sm[];              // [G][C] means, then [G] norms, then int labels [N]
+  float *means = sm;
+  float *norms = sm + (size_t)G * C;
+  int *lab = reinterpret_cast<int *>(norms + G);
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int n = tid; n < N; n += 256) {
+    const bool pad = masks ? masks[(int64_t)b * N + n] != 0 : false;
+    const int64_t l = labels[(int64_t)b * N + n];
+    lab[n] = (pad || l < 0 || l >= G) ? -1 : (int)l;
+  }
+  __syncthreads();
+  const float *p = protos + (int64_t)b * C * N;
+  for (int c = tid; c < C; c += 256) {
+    for (int g = 0; g < G; ++g) {
+      float s = 0.0f, cnt = 0.0f;
+      for (int n = 0; n < N; ++n)
+        if (lab[n] == g) { s = s + p[(int64_t)c * N + n]; cnt = cnt + 1.0f; }
+      means[g * C + c] = s / fmaxf(cnt, 1e-12f);
+    }
+  }
+  __syncthreads();
+  if (normalized) {
+    for (int g = tid; g < G; g += 256) {
+      float ss = 0.0f;
+      for (int c = 0; c < C; ++c) ss = fmaf(means[g * C + c], means[g * C + c], ss);
+      float nrm = sqrtf(ss);
+      if (!(nrm >= eps)) nrm = eps;
+      norms[g] = nrm;
+    }
+    __syncthreads();
+  }
+  float *o = out + (int64_t)b * C * G;
+  for (int i = tid; i < C * G; i += 256) {
+    const int c = i / G, g = i - c * G;
+    const float v = means[g * C + c];
+    o[(int64_t)c * G + g] = normalized ? v / norms[g] : v;
+  }
+}
+
+__global__ void gather_labels_kernel(const int64_t *__restrict__ table, int M,
+                                     const int64_t *__restrict__ img, const int64_t *__restrict__ seg,
+                                     int64_t n, int64_t *__restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = table[img[i] * M + seg[i]];
+}
+
+}  // namespace hsgk
+
+using namespace hsgk;
+
+extern "C" {
+
+int hsgk_hier_assign(const float *fine_logits, const float *coarse_logits, int B, int KF, int KC,
+                     int N, float *fine_prob, int64_t *fine_lab, float *coarse_prob,
+                     int64_t *coarse_lab, hsgk_stream_t stream) {
+  HSGK_REQUIRE(B >= 0 && KF >= 1 && N >= 1, "bad shape");
+  HSGK_REQUIRE(fine_logits && fine_prob && fine_lab, "null argument");
+  HSGK_REQUIRE(!coarse_logits || (KC >= 1 && coarse_prob && coarse_lab), "null coarse output");
+  if (B == 0) return 0;
+  (void)hipGetLastError();
+  const size_t lds = (size_t)(coarse_logits ? KC : 0) * KF * 4 + 16;
+  HSGK_REQUIRE(lds <= 64 * 1024, "hierarchy too large");
+  hipLaunchKernelGGL(hier_assign_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream),
+                     fine_logits, coarse_logits, KF, KC, N, fine_prob, fine_lab, coarse_prob, coarse_lab);
+  HSGK_LAUNCH_CHECK();
+  return 0;
+}
+
+int hsgk_group_mean(const float *protos, const int64_t *labels, const uint8_t *masks, int B, int C,
+                    int N, int G, int normalized, float eps, float *out, hsgk_stream_t stream) {
+  HSGK_REQUIRE(B >= 0 && C >= 1 && N >= 1 && G >= 1, "bad shape");
+  if (B == 0) return 0;
+  (void)hipGetLastError();
+  const size_t lds = ((size_t)G * C + G) * 4 + (size_t)N * 4;
+  HSGK_REQUIRE(lds <= 150 * 1024, "groups x channels too large for one workgroup");
+  HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(group_mean_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(group_mean_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream),
+                     protos, labels, masks, C, N, G, normalized, eps, out);
+  HSGK_LAUNCH_CHECK();
+  return 0;
+}
+
+int hsgk_gather_labels(const int64_t *table, int M, const int64_t *img, const int64_t *seg, int64_t n,
+                       int64_t *out, hsgk_stream_t stream) {
+  HSGK_REQUIRE(n >= 0 && M >= 1, "bad shape");
+  if (n == 0) return 0;
+  (void)hipGetLastError();
+  int64_t g = (n + 255) / 256;
+  hipLaunchKernelGGL(gather_labels_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), table, M, img, seg, n, out);
+  HSGK_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,209 @@
+"""Hierarchical segment prototypes and grouping -- the hot-path methods of the
+reference's embedding models (hsg/models/embeddings/resnet_fcn_hsg.py),
+as free functions with the same argument / return conventions:
+
+  calculate_kmeans_prototypes                 :455-577  (_calculate_kmeans_prototypes)
+  hierarchical_grouping_from_logits           :638-672  (tail of _hierarchical_grouping)
+  collect_nd_coarser_prototype                :683-748
+  collect_pixel_hierarchical_clustering_indices :751-780
+
+The transformer stacks that produce the logits stay stock PyTorch-ROCm
+(out of scope); everything downstream of them runs in libhsgk:
+one launch per operator instead of tens of ATen calls and a Python loop per
+image.  Differentiable outputs (probabilities, group means, prototypes) keep
+their autograd connection: the fused forward values are produced by the HIP
+kernels and the backward pass re-derives the tiny local graph with ATen ops.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from hsg_amd import _lib, ops
+
+
+# ---------------------------------------------------------------------------
+def calculate_kmeans_prototypes(cluster_embeddings, cluster_indices, cluster_batch_indices,
+                                cluster_pos_embeddings, cluster_labels, label_divisor=256,
+                                max_num_clusters=256):
+  """Per-image padded prototypes of the k-means segments (reference :455-577).
+
+  Returns (prototypes [B,C,M], pos_prototypes [B,C,M] or None, padding masks
+  [B,M] bool, prototype_labels [B,M], prototype_batch_indices [B,M],
+  cluster_indices_by_image [N]); padded entries are 0 / True / -1 / -1.
+  Segment ids inside an image are the ranks of (cluster index, label) pairs.
+  """
+  ops.require_gpu(cluster_embeddings, 'cluster_embeddings')
+  dev = cluster_embeddings.device
+  M = int(max_num_clusters)
+  b = cluster_batch_indices.view(-1).long()
+  c = cluster_indices.view(-1).long()
+  lab = cluster_labels.view(-1).long()
+  # one sorted unique over (batch, cluster, label) replaces the per-image loop:
+  # rows of one image are ranked by (cluster, batch*div^2 + label) there (:519-523)
+  ldiv = int(label_divisor) ** 2
+  cdiv = int(c.max()) + 1 if c.numel() else 1
+  lmax = int(lab.max()) + 1 if lab.numel() else 1
+  keys = (b * cdiv + c) * max(lmax, 1) + lab
+  ukeys, gid = torch.unique(keys, return_inverse=True)
+  ubatch = ukeys // (cdiv * max(lmax, 1))
+  ulab = ukeys % max(lmax, 1)
+  images, img_of_seg = torch.unique(ubatch, return_inverse=True)      # ascending batch index
+  B = images.shape[0]
+  first = torch.searchsorted(ubatch, images)                           # first global id per image
+  local = torch.arange(ukeys.shape[0], device=dev) - first[img_of_seg]
+  if int(local.max()) >= M if local.numel() else False:
+    raise IndexError('an image has more than max_num_clusters=%d segments' % M)
+  slot = img_of_seg * M + local                                        # position in the padded table
+  cluster_indices_by_image = local[gid]
+
+  P = ukeys.shape[0]
+  C = cluster_embeddings.shape[-1]
+  protos = ops.segment_reduce(cluster_embeddings, gid, P, 0)           # normalised segment sums
+  table = torch.zeros((B * M, C), dtype=torch.float32, device=dev).index_copy(0, slot, protos)
+  prototypes = table.view(B, M, C).permute(0, 2, 1)
+  pos_prototypes = None
+  if cluster_pos_embeddings is not None:
+    pos = ops.segment_reduce(cluster_pos_embeddings, gid, P, 1)        # segment means
+    ptab = torch.zeros((B * M, pos.shape[1]), dtype=torch.float32, device=dev).index_copy(0, slot, pos)
+    pos_prototypes = ptab.view(B, M, -1).permute(0, 2, 1)
+  masks = torch.ones((B * M,), dtype=torch.bool, device=dev)
+  masks[slot] = False
+  plabs = torch.full((B * M,), -1, dtype=torch.long, device=dev)
+  plabs[slot] = (ubatch * ldiv + ulab) % ldiv                          # (:524-525)
+  pbatch = torch.full((B * M,), -1, dtype=torch.long, device=dev)
+  pbatch[slot] = (ubatch * ldiv + ulab) // ldiv
+  return (prototypes, pos_prototypes, masks.view(B, M), plabs.view(B, M), pbatch.view(B, M),
+          cluster_indices_by_image)
+
+
+# ---------------------------------------------------------------------------
+class _HierAssign(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, fine_logits, coarse_logits):
+    fl = fine_logits.detach().contiguous().float()
+    B, KF, N = fl.shape
+    dev = fl.device
+    cl = coarse_logits.detach().contiguous().float() if coarse_logits is not None else None
+    KC = cl.shape[1] if cl is not None else 0
+    with torch.cuda.device(dev):
+      fprob = torch.empty_like(fl)
+      flab = torch.empty((B, N), dtype=torch.long, device=dev)
+      cprob = torch.empty((B, max(KC, 1), N), dtype=torch.float32, device=dev)
+      clab = torch.empty((B, N), dtype=torch.long, device=dev)
+      _lib.check(_lib.lib().hsgk_hier_assign(
+          fl.data_ptr(), cl.data_ptr() if cl is not None else None, B, KF, KC, N,
+          fprob.data_ptr(), flab.data_ptr(), cprob.data_ptr() if cl is not None else None,
+          clab.data_ptr() if cl is not None else None, _lib.stream_ptr()))
+    ctx.save_for_backward(fl, cl if cl is not None else fl.new_empty(0))
+    ctx.has_coarse = cl is not None
+    ctx.mark_non_differentiable(flab, clab)
+    return fprob, flab, cprob, clab
+
+  @staticmethod
+  def backward(ctx, g_fprob, _g1, g_cprob, _g2):
+    fl, cl = ctx.saved_tensors
+    with torch.enable_grad():
+      a = fl.detach().requires_grad_(True)
+      pf = torch.softmax(a, dim=1)
+      outs, grads = [pf], [g_fprob]
+      c = None
+      if ctx.has_coarse:
+        c = cl.detach().requires_grad_(True)
+        outs.append(torch.einsum('bij,bjk->bik', torch.softmax(c, dim=1), pf))
+        grads.append(g_cprob)
+      ins = [a] + ([c] if c is not None else [])
+      res = torch.autograd.grad(outs, ins, grads, allow_unused=True)
+    return res[0], (res[1] if c is not None else None)
+
+
+def hierarchical_grouping_from_logits(fine_logits, coarse_logits=None):
+  """Tail of _hierarchical_grouping (reference :638-672).
+
+  fine_logits [B, fine_clusters, nodes] -> probabilities over dim 1 and argmax
+  labels [B, nodes]; with coarse_logits [B, coarse_clusters, fine_clusters] also
+  the Bayes-chained coarse probabilities [B, coarse_clusters, nodes] and labels.
+  Returns (fine_labels, fine_probs, coarse_labels, coarse_probs).
+  """
+  ops.require_gpu(fine_logits, 'fine_logits')
+  fprob, flab, cprob, clab = _HierAssign.apply(fine_logits, coarse_logits)
+  if coarse_logits is None:
+    return flab, fprob, None, None
+  return flab, fprob, clab, cprob
+
+
+# ---------------------------------------------------------------------------
+def _group_mean_torch(prototypes, labels, masks, num_groups, normalized):
+  """ATen restatement used only to derive gradients (reference :706-746)."""
+  B, C, N = prototypes.shape
+  lab = labels.masked_fill(masks, num_groups) if masks is not None else labels
+  idx = lab.unsqueeze(2).expand(B, N, C)
+  pt = prototypes.permute(0, 2, 1)
+  acc = torch.zeros((B, num_groups + 1, C), dtype=prototypes.dtype, device=prototypes.device)
+  cnt = torch.zeros_like(acc)
+  acc = acc.scatter_add(1, idx, pt)
+  cnt = cnt.scatter_add(1, idx, torch.ones_like(pt))
+  out = (acc / cnt.clamp(min=1e-12))[:, :-1, :]
+  if normalized:
+    nrm = out.norm(dim=-1, keepdim=True)
+    out = out / torch.where(nrm >= 1e-12, nrm, torch.full_like(nrm, 1e-12))
+  return out.permute(0, 2, 1)
+
+
+class _GroupMean(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, prototypes, labels, masks, num_groups, normalized):
+    p = prototypes.detach().contiguous().float()
+    B, C, N = p.shape
+    lab = labels.contiguous().long()
+    mk = masks.contiguous().to(torch.uint8) if masks is not None else None
+    with torch.cuda.device(p.device):
+      out = torch.empty((B, C, num_groups), dtype=torch.float32, device=p.device)
+      _lib.check(_lib.lib().hsgk_group_mean(
+          p.data_ptr(), lab.data_ptr(), mk.data_ptr() if mk is not None else None, B, C, N,
+          int(num_groups), int(bool(normalized)), ctypes.c_float(1e-12), out.data_ptr(),
+          _lib.stream_ptr()))
+    ctx.save_for_backward(p, lab, masks if masks is not None else lab.new_empty(0))
+    ctx.cfg = (int(num_groups), bool(normalized), masks is not None)
+    return out
+
+  @staticmethod
+  def backward(ctx, g):
+    p, lab, masks = ctx.saved_tensors
+    G, normalized, has_mask = ctx.cfg
+    with torch.enable_grad():
+      a = p.detach().requires_grad_(True)
+      out = _group_mean_torch(a, lab, masks.bool() if has_mask else None, G, normalized)
+      (ga,) = torch.autograd.grad(out, a, g)
+    return ga, None, None, None, None
+
+
+def collect_nd_coarser_prototype(prototypes, prototype_grouping_labels,
+                                 prototype_padding_masks=None, num_groups=None, normalized=True):
+  """Mean node feature of every group (reference :683-748): [B,C,N] -> [B,C,G]."""
+  ops.require_gpu(prototypes, 'prototypes')
+  if num_groups is None:
+    num_groups = int(prototype_grouping_labels.max()) + 1
+  return _GroupMean.apply(prototypes, prototype_grouping_labels, prototype_padding_masks,
+                          int(num_groups), bool(normalized))
+
+
+# ---------------------------------------------------------------------------
+def collect_pixel_hierarchical_clustering_indices(cluster_indices_by_batch,
+                                                  cluster_batch_indices,
+                                                  finehrchy_prototype_grouping_labels):
+  """Group label of every pixel (reference :751-780): the i-th distinct batch
+  index (ascending) reads row i of the [B, M] grouping-label table."""
+  ops.require_gpu(cluster_indices_by_batch, 'cluster_indices_by_batch')
+  seg = cluster_indices_by_batch.view(-1).long().contiguous()
+  _, img = torch.unique(cluster_batch_indices.view(-1).long(), return_inverse=True)
+  img = img.contiguous()
+  table = finehrchy_prototype_grouping_labels.long().contiguous()
+  out = torch.empty_like(seg)
+  with torch.cuda.device(seg.device):
+    _lib.check(_lib.lib().hsgk_gather_labels(table.data_ptr(), table.shape[1], img.data_ptr(),
+                                             seg.data_ptr(), seg.shape[0], out.data_ptr(),
+                                             _lib.stream_ptr()))
+  return out

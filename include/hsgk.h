@@ -198,6 +198,24 @@ HSGK_API int hsgk_segsort_loss_bwd_weights(const float *emb, int64_t n, int c, c
                                            const int32_t *use_same, const float *gscale,
                                            float *wt, hsgk_stream_t stream);
 
+/* ---- hsg/models/embeddings/resnet_fcn_hsg.py:638-672 _hierarchical_grouping tail
+ * fine_logits [B,KF,N], coarse_logits [B,KC,KF] (nullable).  fine_prob = softmax
+ * over KF, fine_lab = argmax; coarse_prob [B,KC,N] = softmax_KC(coarse) x fine_prob,
+ * coarse_lab = argmax.                                                          */
+HSGK_API int hsgk_hier_assign(const float *fine_logits, const float *coarse_logits, int B, int KF,
+                              int KC, int N, float *fine_prob, int64_t *fine_lab,
+                              float *coarse_prob, int64_t *coarse_lab, hsgk_stream_t stream);
+/* ---- resnet_fcn_hsg.py:683-748 _collect_nd_coarser_prototype ------------------
+ * protos [B,C,N], labels int64 [B,N], masks uint8 [B,N] (nullable) -> out [B,C,G]:
+ * mean of the unpadded nodes of every group, optionally L2-normalised over C.   */
+HSGK_API int hsgk_group_mean(const float *protos, const int64_t *labels, const uint8_t *masks,
+                             int B, int C, int N, int G, int normalized, float eps, float *out,
+                             hsgk_stream_t stream);
+/* ---- resnet_fcn_hsg.py:751-780 pixel -> segment -> group label ---------------
+ * out[i] = table[img[i] * M + seg[i]]                                           */
+HSGK_API int hsgk_gather_labels(const int64_t *table, int M, const int64_t *img,
+                                const int64_t *seg, int64_t n, int64_t *out, hsgk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -241,3 +241,90 @@ def segsort_loss(*args, reduction='mean', **kw):
   if reduction == 'sum':
     return float(nll.sum())
   return nll
+
+
+# ---- hierarchical grouping (hsg/models/embeddings/resnet_fcn_hsg.py) ----------
+def _softmax_dim1(x):
+  """float32 softmax over axis 1: exp(x - max) / sequential sum (canonical)."""
+  x = x.astype(np.float32)
+  e = np.exp(x - x.max(axis=1, keepdims=True), dtype=np.float32)
+  s = np.zeros_like(e[:, 0])
+  for c in range(e.shape[1]):
+    s = (s + e[:, c]).astype(np.float32)
+  return (e / s[:, None]).astype(np.float32)
+
+
+def hierarchical_grouping_from_logits(fine_logits, coarse_logits=None):
+  """resnet_fcn_hsg.py:638-672: (fine_labels, fine_probs, coarse_labels, coarse_probs)."""
+  pf = _softmax_dim1(np.asarray(fine_logits))
+  flab = pf.argmax(axis=1).astype(np.int64)
+  if coarse_logits is None:
+    return flab, pf, None, None
+  pc = _softmax_dim1(np.asarray(coarse_logits))                    # [B,KC,KF]
+  B, KC, KF = pc.shape
+  out = np.zeros((B, KC, pf.shape[2]), np.float32)
+  for c in range(KF):                                              # fmaf chain over fine clusters
+    out = (pc[:, :, c, None].astype(np.float64) * pf[:, None, c, :].astype(np.float64)
+           + out.astype(np.float64)).astype(np.float32)
+  return flab, pf, out.argmax(axis=1).astype(np.int64), out
+
+
+def collect_nd_coarser_prototype(prototypes, labels, masks=None, num_groups=None, normalized=True):
+  """resnet_fcn_hsg.py:683-748: [B,C,N] -> [B,C,G] masked group means."""
+  p = _f32(prototypes)
+  B, C, N = p.shape
+  lab = _i64(labels)
+  G = int(lab.max()) + 1 if num_groups is None else int(num_groups)
+  out = np.zeros((B, C, G), np.float32)
+  for b in range(B):
+    for g in range(G):
+      sel = lab[b] == g
+      if masks is not None:
+        sel &= ~np.asarray(masks[b], bool)
+      s = np.zeros(C, np.float32)
+      for n in np.nonzero(sel)[0]:
+        s = (s + p[b, :, n]).astype(np.float32)
+      out[b, :, g] = s / np.float32(max(float(sel.sum()), 1e-12))
+    if normalized:
+      out[b] = normalize_embedding(out[b].T.copy()).T
+  return out
+
+
+def collect_pixel_hierarchical_clustering_indices(cluster_indices_by_batch, cluster_batch_indices,
+                                                  grouping_labels):
+  """resnet_fcn_hsg.py:751-780."""
+  _, img = np.unique(_i64(cluster_batch_indices), return_inverse=True)
+  return _i64(grouping_labels)[img, _i64(cluster_indices_by_batch)]
+
+
+def calculate_kmeans_prototypes(emb, cluster_indices, cluster_batch_indices, pos_emb, labels,
+                                label_divisor=256, max_num_clusters=256):
+  """resnet_fcn_hsg.py:455-577, per-image loop as in the reference."""
+  emb = _f32(emb)
+  c, b, lab = _i64(cluster_indices), _i64(cluster_batch_indices), _i64(labels)
+  M = int(max_num_clusters)
+  outs = ([], [], [], [], [], [])
+  for bi in np.unique(b):
+    sel = np.nonzero(b == bi)[0]
+    cl = b[sel] * label_divisor ** 2 + lab[sel]
+    plab, ci = prepare_prototype_labels(cl, c[sel], int(cl.max()) + 1)
+    n = plab.shape[0]
+    outs[0].append(calculate_prototypes_from_labels(emb[sel], ci, M))
+    if pos_emb is not None:
+      pm = np.zeros((M, pos_emb.shape[1]), np.float32)
+      pm[:n] = segment_mean(_f32(pos_emb)[sel], ci)
+      outs[1].append(pm)
+    mk = np.ones(M, bool)
+    mk[:n] = False
+    outs[2].append(mk)
+    pl = np.full(M, -1, np.int64)
+    pl[:n] = plab % label_divisor ** 2
+    outs[3].append(pl)
+    pb = np.full(M, -1, np.int64)
+    pb[:n] = plab // label_divisor ** 2
+    outs[4].append(pb)
+    outs[5].append(ci)
+  protos = np.stack(outs[0]).transpose(0, 2, 1)
+  pos = np.stack(outs[1]).transpose(0, 2, 1) if outs[1] else None
+  return (protos, pos, np.stack(outs[2]), np.stack(outs[3]), np.stack(outs[4]),
+          np.concatenate(outs[5]))

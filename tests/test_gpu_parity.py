@@ -338,3 +338,61 @@ def test_split_estep_matches_exact_labels(dev, oracle, B, HW, C, K):
     ref = oracle.find_nearest_prototypes(x[b * HW:(b + 1) * HW], cent[b])
     assert np.array_equal(got[0][b * HW:(b + 1) * HW], ref), 'fp32 kernel'
     assert np.array_equal(got[1][b * HW:(b + 1) * HW], ref), 'split kernel'
+
+
+def test_hierarchy_ops_vs_reference_golden(dev):
+  """a10-a14: padded per-image prototypes, softmax/argmax/Bayes-chain grouping,
+  group means and the pixel label lookup against the reference's own methods
+  (tests/golden/f7_hierarchy.npz, generated by calling them with stub selves)."""
+  import torch
+  from hsg_amd.models.embeddings import hierarchy as hz
+  g = util.load('f7_hierarchy')
+  M, KF, KC = int(g['M']), int(g['KF']), int(g['KC'])
+  seed = int(g['seed'])
+  B, C, H, W = (int(v) for v in g['shape'])
+  emb = torch.from_numpy(g['emb']).to(dev).requires_grad_(True)
+  n = emb.shape[0]
+  pos = torch.from_numpy(synth.gaussish(seed + 1, n * C).reshape(n, C).copy()).to(dev)
+  T = lambda k: torch.from_numpy(g[k]).to(dev)
+  protos, pos_protos, masks, plabs, pbatch, c_by_img = hz.calculate_kmeans_prototypes(
+      emb, T('cidx'), T('bidx'), pos, T('labels'), label_divisor=256, max_num_clusters=M)
+  assert np.array_equal(masks.cpu().numpy(), g['masks'])
+  assert np.array_equal(plabs.cpu().numpy(), g['plabs'])
+  assert np.array_equal(pbatch.cpu().numpy(), g['pbatch'])
+  assert np.array_equal(c_by_img.cpu().numpy(), g['c_by_img'])
+  assert np.abs(protos.detach().cpu().numpy() - g['protos']).max() <= FTOL
+  assert np.abs(pos_protos.cpu().numpy() - g['pos_protos']).max() <= 1e-5
+  protos.sum().backward()
+  assert emb.grad is not None and torch.isfinite(emb.grad).all()
+
+  fine_logits = (torch.from_numpy(synth.gaussish(seed + 2, B * KF * M).reshape(B, KF, M).copy()) * 2).to(dev)
+  coarse_logits = (torch.from_numpy(synth.gaussish(seed + 3, B * KC * KF).reshape(B, KC, KF).copy()) * 2).to(dev)
+  fl = fine_logits.clone().requires_grad_(True)
+  cl = coarse_logits.clone().requires_grad_(True)
+  f_lab, f_prob, c_lab, c_prob = hz.hierarchical_grouping_from_logits(fl, cl)
+  assert np.array_equal(f_lab.cpu().numpy(), g['f_lab'])
+  assert np.array_equal(c_lab.cpu().numpy(), g['c_lab'])
+  assert np.abs(f_prob.detach().cpu().numpy() - g['f_prob']).max() <= 1e-6
+  assert np.abs(c_prob.detach().cpu().numpy() - g['c_prob']).max() <= 1e-6
+  # gradients of the fused op == gradients of the ATen formulation
+  w = torch.from_numpy(synth.gaussish(seed + 9, B * KC * M).reshape(B, KC, M).copy()).to(dev)
+  (c_prob * w).sum().backward()
+  a = fine_logits.clone().requires_grad_(True)
+  b2 = coarse_logits.clone().requires_grad_(True)
+  ref = torch.einsum('bij,bjk->bik', torch.softmax(b2, 1), torch.softmax(a, 1))
+  (ref * w).sum().backward()
+  assert (fl.grad - a.grad).abs().max().item() <= 1e-6
+  assert (cl.grad - b2.grad).abs().max().item() <= 1e-6
+
+  fine_pos = hz.collect_nd_coarser_prototype(T('pos_protos'), T('f_lab'), T('masks'), KF, False)
+  fine_pos_n = hz.collect_nd_coarser_prototype(T('protos'), T('f_lab'), T('masks'), KF, True)
+  assert np.abs(fine_pos.cpu().numpy() - g['fine_pos']).max() <= 1e-5
+  assert np.abs(fine_pos_n.cpu().numpy() - g['fine_pos_n']).max() <= 2e-6
+  pp = T('protos').requires_grad_(True)
+  hz.collect_nd_coarser_prototype(pp, T('f_lab'), T('masks'), KF, True).sum().backward()
+  assert torch.isfinite(pp.grad).all()
+
+  px_fine = hz.collect_pixel_hierarchical_clustering_indices(T('c_by_img'), T('bidx'), T('f_lab'))
+  px_coarse = hz.collect_pixel_hierarchical_clustering_indices(T('c_by_img'), T('bidx'), T('c_lab'))
+  assert np.array_equal(px_fine.cpu().numpy(), g['px_fine'])
+  assert np.array_equal(px_coarse.cpu().numpy(), g['px_coarse'])

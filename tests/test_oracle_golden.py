@@ -115,3 +115,29 @@ def test_torch_restatement_matches_golden(case):
   assert np.array_equal(batch, g['batch'].astype(np.int64))
   assert np.abs(emb[::util.ROW_STRIDE] - g['emb_rows']).max() <= FTOL
   assert np.abs(emb_loc[::util.ROW_STRIDE] - g['emb_loc_rows']).max() <= FTOL
+
+
+def test_f7_hierarchy(oracle):
+  g = util.load('f7_hierarchy')
+  M, KF, KC = int(g['M']), int(g['KF']), int(g['KC'])
+  seed = int(g['seed'])
+  B, C, H, W = (int(v) for v in g['shape'])
+  n = g['emb'].shape[0]
+  pos = synth.gaussish(seed + 1, n * C).reshape(n, C)
+  protos, pos_protos, masks, plabs, pbatch, c_by_img = oracle.calculate_kmeans_prototypes(
+      g['emb'], g['cidx'], g['bidx'], pos, g['labels'], 256, M)
+  assert np.array_equal(masks, g['masks']) and np.array_equal(plabs, g['plabs'])
+  assert np.array_equal(pbatch, g['pbatch']) and np.array_equal(c_by_img, g['c_by_img'])
+  assert np.abs(protos - g['protos']).max() <= FTOL
+  assert np.abs(pos_protos - g['pos_protos']).max() <= 1e-5
+  fl = synth.gaussish(seed + 2, B * KF * M).reshape(B, KF, M) * np.float32(2)
+  cl = synth.gaussish(seed + 3, B * KC * KF).reshape(B, KC, KF) * np.float32(2)
+  f_lab, f_prob, c_lab, c_prob = oracle.hierarchical_grouping_from_logits(fl, cl)
+  assert np.array_equal(f_lab, g['f_lab']) and np.array_equal(c_lab, g['c_lab'])
+  assert np.abs(f_prob - g['f_prob']).max() <= 1e-6 and np.abs(c_prob - g['c_prob']).max() <= 1e-6
+  assert np.abs(oracle.collect_nd_coarser_prototype(g['pos_protos'], g['f_lab'], g['masks'], KF, False)
+                - g['fine_pos']).max() <= 1e-5
+  assert np.abs(oracle.collect_nd_coarser_prototype(g['protos'], g['f_lab'], g['masks'], KF, True)
+                - g['fine_pos_n']).max() <= 2e-6
+  assert np.array_equal(oracle.collect_pixel_hierarchical_clustering_indices(
+      g['c_by_img'], g['bidx'], g['f_lab']), g['px_fine'])

@@ -239,8 +239,51 @@ def f8():
     sg.gather = sg_gather
 
 
+# ---- F7 hierarchical prototypes / grouping (resnet_fcn_hsg.py:455-780) ----------
+def f7():
+  import types
+  import hsg.models.embeddings.resnet_fcn_hsg as ref_model
+  cls = ref_model.ResnetFcn
+  seed = synth.SEED_BASE + 61
+  B, C, H, W, grid = 3, 16, 24, 20, (3, 3)
+  x = synth.embeddings_nchw(seed, (B, C, H, W), 'mixture')
+  lab = synth.overseg_labels(seed + 7, B, H, W, regions=5, ignore_rows=2, ignore_index=255)
+  emb, emb_loc, labels, cidx, bidx = ref_segment_by_kmeans(
+      torch.from_numpy(x), torch.from_numpy(lab), list(grid), ignore_index=255, iterations=4)
+  n = emb.shape[0]
+  pos = torch.from_numpy(synth.gaussish(seed + 1, n * C).reshape(n, C).copy())
+  M, KF, KC2 = 64, 6, 3
+  stub = types.SimpleNamespace(label_divisor=256, max_num_clusters=M, fine_hrchy_clusters=KF)
+  protos, pos_protos, masks, plabs, pbatch, c_by_img = cls._calculate_kmeans_prototypes(
+      stub, emb, cidx, bidx, pos, labels)
+  fine_logits = torch.from_numpy(synth.gaussish(seed + 2, B * KF * M).reshape(B, KF, M).copy()) * 2
+  coarse_logits = torch.from_numpy(synth.gaussish(seed + 3, B * KC2 * KF).reshape(B, KC2, KF).copy()) * 2
+  cent_f = torch.from_numpy(synth.gaussish(seed + 4, B * C * KF).reshape(B, C, KF).copy())
+  cent_c = torch.from_numpy(synth.gaussish(seed + 5, B * C * KC2).reshape(B, C, KC2).copy())
+  stub.fine_query_embed = lambda: None
+  stub.coarse_query_embed = lambda: None
+  stub.fine_hrchy_transformer = lambda **kw: (cent_f, cent_f, fine_logits, kw['src'])
+  stub.coarse_hrchy_transformer = lambda **kw: (cent_c, cent_c, coarse_logits, kw['src'])
+  stub._collect_nd_coarser_prototype = types.MethodType(cls._collect_nd_coarser_prototype, stub)
+  (f_lab, _, f_prob, _, c_lab, _, c_prob, _) = cls._hierarchical_grouping(stub, protos, pos_protos, masks)
+  fine_pos = cls._collect_nd_coarser_prototype(stub, pos_protos, f_lab, masks, num_groups=KF,
+                                               normalized=False)
+  fine_pos_n = cls._collect_nd_coarser_prototype(stub, protos, f_lab, masks, num_groups=KF,
+                                                 normalized=True)
+  px_fine = cls._collect_pixel_hierarchical_clustering_indices(stub, c_by_img, bidx, f_lab)
+  px_coarse = cls._collect_pixel_hierarchical_clustering_indices(stub, c_by_img, bidx, c_lab)
+  save('f7_hierarchy', seed=seed, shape=np.array([B, C, H, W]), grid=np.array(grid), M=M, KF=KF, KC=KC2,
+       label_seed=seed + 7, ylin=lin01(H), xlin=lin01(W),
+       emb=emb.numpy(), cidx=cidx.numpy(), bidx=bidx.numpy(), labels=labels.numpy(),
+       protos=protos.numpy(), pos_protos=pos_protos.numpy(), masks=masks.numpy(),
+       plabs=plabs.numpy(), pbatch=pbatch.numpy(), c_by_img=c_by_img.numpy(),
+       f_lab=f_lab.numpy(), f_prob=f_prob.numpy(), c_lab=c_lab.numpy(), c_prob=c_prob.numpy(),
+       fine_pos=fine_pos.numpy(), fine_pos_n=fine_pos_n.numpy(), px_fine=px_fine.numpy(),
+       px_coarse=px_coarse.numpy())
+
+
 if __name__ == '__main__':
   os.makedirs(OUT, exist_ok=True)
-  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f8']
+  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8']
   for w in which:
     globals()[w]()
