@@ -7,21 +7,20 @@
 // xh = bf16(x), xl = bf16(x - xh) (|ex| <= 2^-16 |x|), and the score is
 // approximated by three bf16 MFMAs per 16 columns
 //
-//     main += ch * xh          corr += cl * xh + ch * xl
+//     acc += ch * xh + cl * xh + ch * xl          (one fp32 accumulator)
 //
 // (v_mfma_f32_32x32x16_bf16: 32 cycles each -> 16/3 times cheaper than the fp32
 // chain).  The approximation error against the canonical fp32 chain is bounded
 // for unit-norm rows and centroids:
 //
 //     dropped products (xl cl, ex c, x ec)      <= 3.02 * 2^-16           = 4.62e-5
-//     bf16 MFMA accumulation, 17 instructions   <= 17 * 2^-22 * 1.01      = 0.41e-5
+//     bf16 MFMA accumulation, 3*17 instructions <= 51 * 2^-22 * 1.01      = 1.23e-5
 //        (measured on gfx950: |D - exact| <= 2^-23.1 * sum|terms| per instruction,
 //         tools/probes/mfma_bf16_probe.hip; 2^-22 used)
-//     corr accumulator + final add                                         < 0.02e-5
 //     fp32 chain of the oracle vs the real number  gamma_258               = 1.54e-5
-//                                                              E           <= 6.6e-5
+//                                                              E           <= 7.4e-5
 //
-// A row whose two best approximate scores are more than kSplitGap = 1.4e-4 (> 2E)
+// A row whose two best approximate scores are more than kSplitGap = 1.6e-4 (> 2E)
 // apart has a strictly unique exact argmax and gets its label here; every other
 // row (a few per cent on i.i.d. data) is queued and re-scored EXACTLY by the fp32
 // engine, so the labels are bit-identical to the canonical arithmetic.
@@ -39,7 +38,7 @@ namespace hsgk {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr float kSplitGap = 1.4e-4f;
+constexpr float kSplitGap = 1.6e-4f;
 
 // (a, b) -> packed hi pair and packed lo pair; v_cvt_pk_bf16_f32 rounds to
 // nearest even, the residual subtraction is exact
@@ -59,10 +58,10 @@ __host__ __device__ constexpr size_t split_lds_bytes(int d) {
   return (size_t)2 * 64 * (((d + 15) / 16) * 16 + 8) * 2 + (size_t)NW * 2 * 2 * 32 * 40 * 2 + 16;
 }
 
-// Epi(tile, main, corr): lane (j, h) holds main[m][r] + corr[m][r] = approximate
-// score of table row m*32 + (r&3) + 8*(r>>2) + 4*h for x row tile*NW*32 + w*32 + j.
-template <int NW, class Epi>
-__device__ inline void score_tiles_split(const float *__restrict__ x, int d,
+// Epi(tile, acc): lane (j, h) holds acc[m][r] = approximate score of table row
+// m*32 + (r&3) + 8*(r>>2) + 4*h for x row tile*NW*32 + w*32 + j.
+template <int NW, int DEPTH, class Epi>
+__device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, int d,
                                          const float *__restrict__ table, int kvalid,
                                          int64_t crow0, int nrows, unsigned char *lds_raw,
                                          Epi &epi) {
@@ -143,21 +142,21 @@ __device__ inline void score_tiles_split(const float *__restrict__ x, int d,
     }
   };
 
-  f32x16 mainacc[2], corracc[2];
+  f32x16 acc[2];
   auto zero_acc = [&]() {
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { mainacc[m][r] = 0.0f; corracc[m][r] = 0.0f; }
+      for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
   };
   auto kblock = [&](const bf16x8 &bh, const bf16x8 &bl, int col0) {
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(chs + (m * 32 + j) * RS + col0 + 8 * g);
       const bf16x8 al = *reinterpret_cast<const bf16x8 *>(cls + (m * 32 + j) * RS + col0 + 8 * g);
-      mainacc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, mainacc[m], 0, 0, 0);
-      corracc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, corracc[m], 0, 0, 0);
-      corracc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, corracc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[m], 0, 0, 0);
     }
   };
   auto compute_chunk = [&](int buf, int q) {
@@ -195,7 +194,7 @@ __device__ inline void score_tiles_split(const float *__restrict__ x, int d,
       tail_operands(tile, kb, bh, bl);
       kblock(bh, bl, tcol0 + 16 * kb);
     }
-    epi(tile, mainacc, corracc);
+    epi(tile, acc);
   };
 
   __syncthreads();                         // table planes visible to all waves
@@ -205,41 +204,47 @@ __device__ inline void score_tiles_split(const float *__restrict__ x, int d,
   // with the MFMA work this cheap the kernel is latency-bound unless ~100 KiB
   // per CU are in flight -- and a tile always ends on the last set, so there is
   // ONE epilogue site and the accumulators never move between code paths.
-  float2 preA[LOADS], preB[LOADS], preC[LOADS], preD[LOADS];
+  static_assert(DEPTH == 2 || DEPTH == 4, "prefetch depth");
+  float2 preA[LOADS], preB[LOADS], preC[DEPTH == 4 ? LOADS : 1], preD[DEPTH == 4 ? LOADS : 1];
   load_chunk(0, preA);
   load_chunk(1, preB);
-  load_chunk(2, preC);
-  load_chunk(3, preD);
+  if constexpr (DEPTH == 4) {
+    load_chunk(2, preC);
+    load_chunk(3, preD);
+  }
   int gidx = 0;
+  // epi.chunk_begin() / chunk_end() bracket every chunk's MFMA work: the fused
+  // Lloyd epilogue uses them to trickle the previous tile's M-step row loads
+  // through the pipeline (issue before, consume after the MFMAs).
+#define HSGK_SPLIT_STEP(BUF, PRE, STEP, QQ)                                   \
+  store_chunk(BUF, PRE);                                                      \
+  __builtin_amdgcn_sched_barrier(0);                                          \
+  if (gidx + (STEP) + DEPTH < nsteps) load_chunk(gidx + (STEP) + DEPTH, PRE); \
+  epi.chunk_begin();                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                          \
+  compute_chunk(BUF, QQ);                                                     \
+  __builtin_amdgcn_sched_barrier(0);                                          \
+  epi.chunk_end();                                                            \
+  __builtin_amdgcn_sched_barrier(0);
   for (int tile = 0; tile < ntile; ++tile) {
     for (int q = 0; q < nfull; q += 4, gidx += 4) {
-      store_chunk(0, preA);
-      __builtin_amdgcn_sched_barrier(0);
-      if (gidx + 4 < nsteps) load_chunk(gidx + 4, preA);
-      __builtin_amdgcn_sched_barrier(0);
-      compute_chunk(0, q);
-      __builtin_amdgcn_sched_barrier(0);
-      store_chunk(1, preB);
-      __builtin_amdgcn_sched_barrier(0);
-      if (gidx + 5 < nsteps) load_chunk(gidx + 5, preB);
-      __builtin_amdgcn_sched_barrier(0);
-      compute_chunk(1, q + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      store_chunk(0, preC);
-      __builtin_amdgcn_sched_barrier(0);
-      if (gidx + 6 < nsteps) load_chunk(gidx + 6, preC);
-      __builtin_amdgcn_sched_barrier(0);
-      compute_chunk(0, q + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      store_chunk(1, preD);
-      __builtin_amdgcn_sched_barrier(0);
-      if (gidx + 7 < nsteps) load_chunk(gidx + 7, preD);
-      __builtin_amdgcn_sched_barrier(0);
-      compute_chunk(1, q + 3);
+      if constexpr (DEPTH == 4) {
+        HSGK_SPLIT_STEP(0, preA, 0, q)
+        HSGK_SPLIT_STEP(1, preB, 1, q + 1)
+        HSGK_SPLIT_STEP(0, preC, 2, q + 2)
+        HSGK_SPLIT_STEP(1, preD, 3, q + 3)
+      } else {
+        HSGK_SPLIT_STEP(0, preA, 0, q)
+        HSGK_SPLIT_STEP(1, preB, 1, q + 1)
+        HSGK_SPLIT_STEP(0, preA, 2, q + 2)
+        HSGK_SPLIT_STEP(1, preB, 3, q + 3)
+      }
     }
     finish_tile(tile);
     zero_acc();
   }
+#undef HSGK_SPLIT_STEP
+  epi.drain();
 }
 
 // shapes the split engine accepts (number of 32-column chunks divisible by 4)
