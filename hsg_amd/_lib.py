@@ -106,7 +106,7 @@ def check(rc):
     raise HsgkError('libhsgk error %d: %s' % (rc, lib().hsgk_last_error().decode()))
 
 
-PROF_KINDS = ('prep', 'accumulate', 'finalize', 'assign', 'relabel', 'fused')
+PROF_KINDS = ('prep', 'accumulate', 'finalize', 'assign', 'relabel')
 
 
 def profile_enable(on):

@@ -80,27 +80,11 @@ static void carve_kmeans(Carver &cv, int B, int64_t rows_per_img, int d, int K,
 static int lloyd(const float *x, int d, int K, int B, int iterations,
                  const KmeansScratch &k, const hsgk_segkm_meta *meta, hipStream_t s,
                  bool unit_rows = false) {
-  static const int fused_on = [] {
-    const char *e = getenv("HSGK_FUSED");            // "0" disables the fused E+M pass
-    return (e && e[0] == '0') ? 0 : 1;
-  }();
-  const bool fuse = unit_rows && fused_on && lloyd_fused_eligible(d, K, k.max_chunks);
-  bool have_partial = false;          // chunk partials of the coming M-step already written
   for (int it = 0; it < iterations; ++it) {
-    if (!have_partial) {
-      ProfScope p(HSGK_PROF_ACCUMULATE, s);
-      if (int rc = launch_accumulate(x, d, k.klab, k.t, k.max_chunks, K, k.partial, meta, s)) return rc;
-    }
+    { ProfScope p(HSGK_PROF_ACCUMULATE, s);
+      if (int rc = launch_accumulate(x, d, k.klab, k.t, k.max_chunks, K, k.partial, meta, s)) return rc; }
     { ProfScope p(HSGK_PROF_FINALIZE, s);
       if (int rc = launch_finalize(k.partial, d, K, B, k.t, HSGK_EPS, k.cent, s)) return rc; }
-    have_partial = false;
-    if (fuse && it + 1 < iterations) {
-      // E-step(it) and the partial sums of M-step(it+1) in one pass over the rows
-      ProfScope p(HSGK_PROF_FUSED, s);
-      if (int rc = launch_lloyd_fused(x, d, k.cent, K, k.t, k.max_chunks, k.klab, k.partial, meta, s)) return rc;
-      have_partial = true;
-      continue;
-    }
     { ProfScope p(HSGK_PROF_ASSIGN, s);
       if (int rc = unit_rows
                        ? launch_assign_fast(x, d, k.cent, K, k.t, k.max_chunks, k.klab, k.best,

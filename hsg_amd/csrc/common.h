@@ -98,12 +98,6 @@ int launch_assign_fast(const float *x, int d, const float *cent, int K, const Ch
                        int max_chunks, int32_t *klab, float *best, void *qrows,
                        int32_t *qcount, const hsgk_segkm_meta *meta, hipStream_t s);
 
-// fused E-step + next M-step chunk partials (one read of the rows)
-bool lloyd_fused_eligible(int d, int K, int max_chunks);
-int launch_lloyd_fused(const float *x, int d, const float *cent, int K, const ChunkTable &t,
-                       int max_chunks, int32_t *klab, float *partial,
-                       const hsgk_segkm_meta *meta, hipStream_t s);
-
 int launch_relabel(const hsgk_segkm_args &a, const ChunkTable &t, int max_chunks,
                    const int32_t *klab, int32_t *table, int32_t *scan_tmp,
                    hipStream_t s);

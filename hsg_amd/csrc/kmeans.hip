@@ -400,291 +400,6 @@ __global__ __launch_bounds__(256) void assign_requeue_rows_kernel(
   }
 }
 
-// ===========================================================================
-// Fused Lloyd pass: E-step(t) + chunk partial sums of M-step(t+1) in ONE read
-// of the rows from HBM.  The split engine scores a 256-row tile; ambiguous rows
-// are resolved EXACTLY inside the kernel (same candidate chains as the re-score
-// kernel) so the tile's final labels exist when it ends; after one workgroup
-// barrier per tile the 8 waves add the tile's rows into REGISTER accumulators:
-// wave (slice = w & 3, half = w >> 2) owns columns [64*slice, 64*slice+64) of
-// clusters [32*half, 32*half+32) as one 32-wide vector indexed with the
-// (wave-uniform) label -- s_set_gpr_idx addressing, no LDS table, no atomics.
-// Rows are re-read as 256-byte slices from L2 / Infinity Cache (the tile was
-// streamed a few microseconds earlier) in row order, so every (cluster, column)
-// is summed sequentially over the chunk exactly like accumulate_kernel (order
-// C2; one workgroup = one chunk).  The d - 256 tail columns (the 2 location
-// channels) are owned by wave 0 with lanes = clusters.
-// Shape envelope: K <= 64, 256 <= d <= 260, d % 2 == 0.
-typedef float v32f __attribute__((ext_vector_type(32)));
-constexpr int kFusedTailMax = 4;
-
-struct FusedEpi {
-  // E-step state
-  int K, nrows, img, d;
-  int64_t crow0;
-  const float *x, *cent;
-  int32_t *klab;
-  unsigned char *tlab;     // LDS [2][256] final labels of the current / previous tile
-  uint32_t *scratch;       // LDS, this wave's [16][3] words for the exact-resolve pass
-  // M-step state (the accumulator vector is a kernel local: as a struct member
-  // its dynamic indexing was lowered through scratch memory)
-  v32f &acc;
-  float acct[kFusedTailMax];
-  uint16_t *mlist;         // LDS, this wave's [256] (row | label << 8) entries of the queued tile
-  int mcount, mpos, mtile, tpos;
-  int ment, tlb;
-  float mv[16];
-  float tvv[kFusedTailMax];
-
-  __device__ __forceinline__ void operator()(int tile, const f32x16 (&sacc)[2]) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    constexpr int TPX = 256;
-    // ---- approximate top-2 and candidate set (see SplitEpi)
-    float b1 = -INFINITY, b2 = -INFINITY;
-    int bi = 0;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float v = k < K ? sacc[m][r] : -INFINITY;
-        b2 = fmaxf(b2, fminf(b1, v));
-        bi = v > b1 ? k : bi;
-        b1 = fmaxf(b1, v);
-      }
-    const float o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
-    const int oi = __shfl_xor(bi, 32);
-    float t1, t2;
-    int ti;
-    if (o1 > b1) { t1 = o1; ti = oi; t2 = fmaxf(b1, o2); }
-    else { t1 = b1; ti = bi; t2 = fmaxf(o1, b2); }
-    const int px = tile * TPX + w * 32 + j;
-    const bool valid = px < nrows;
-    const bool amb = valid && !(t1 - t2 > kSplitGap);
-    int label = ti;
-    unsigned long long am = __ballot(amb && h == 0);
-    if (am) {
-      const float thr = t1 - kSplitGap;
-      uint32_t list = 0;
-      int cnt = 0;
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const uint32_t k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const float v = k < (uint32_t)K ? sacc[m][r] : -INFINITY;
-          const bool hit = v >= thr;
-          list = hit ? ((list << 8) | k) : list;
-          cnt += hit ? 1 : 0;
-        }
-      const uint32_t olist = __shfl_xor(list, 32);
-      const int ocnt = __shfl_xor(cnt, 32);
-      const int tot = cnt + ocnt;
-      uint32_t cand = 255u << 24;
-      if (tot <= 3 && tot >= 1 && t1 == t1)
-        cand = (list & ((1u << (8 * cnt)) - 1u)) | (olist << (8 * cnt)) | ((uint32_t)tot << 24);
-      // exact resolve, 16 ambiguous rows per round: 4 lanes per row, lane = candidate
-      while (am) {
-        const int rank = __popcll(am & ((1ull << lane) - 1ull));
-        const bool me = amb && h == 0 && ((am >> lane) & 1ull) && rank < 16;   // still unresolved
-        if (me) {
-          scratch[rank * 2 + 0] = (uint32_t)j;
-          scratch[rank * 2 + 1] = cand;
-        }
-        const int nr = min(16, (int)__popcll(am));
-        const int grp = lane >> 2, ci = lane & 3;
-        uint32_t ej = 0, ec = 0;
-        if (grp < nr) { ej = scratch[grp * 2]; ec = scratch[grp * 2 + 1]; }
-        const int n = grp < nr ? (int)(ec >> 24) : 0;
-        const int k = (int)((ec >> (8 * ci)) & 255u);
-        const int64_t row = crow0 + tile * TPX + w * 32 + (int)ej;
-        const bool act = n != 255 && ci < n;
-        float a = -INFINITY;
-        if (act) a = exact_chain(cent + (int64_t)k * d, x + row * d, d);
-        float bv = (act && a == a) ? a : -INFINITY;
-        int bk = act ? k : 0x7fffffff;
-#pragma unroll
-        for (int off = 1; off <= 2; off <<= 1) {
-          const float ov = __shfl_xor(bv, off);
-          const int ok = __shfl_xor(bk, off);
-          if (ov > bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
-        }
-        if (ci == 0 && n >= 1 && n <= 3) scratch[32 + grp] = (uint32_t)(bk == 0x7fffffff ? 0 : bk);
-        unsigned long long hard = __ballot(ci == 0 && n == 255);
-        while (hard) {                                   // > 3 candidates: all K on the whole wave
-          const int src = __builtin_ctzll(hard);
-          hard &= hard - 1;
-          const int hj = __builtin_amdgcn_readlane((int)ej, src);
-          const int64_t hrow = crow0 + tile * TPX + w * 32 + hj;
-          float hs = -INFINITY;
-          if (lane < K) hs = exact_chain(cent + (int64_t)lane * d, x + hrow * d, d);
-          float hv = (lane < K && hs == hs) ? hs : -INFINITY;
-          int hk = lane;
-          for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(hv, off);
-            const int ok = __shfl_xor(hk, off);
-            if (ov > hv || (ov == hv && ok < hk)) { hv = ov; hk = ok; }
-          }
-          if (lane == 0) scratch[32 + (src >> 2)] = (uint32_t)(hk < K ? hk : 0);
-        }
-        // hand the resolved labels back to their rows
-        if (me) label = (int)scratch[32 + rank];
-        // drop the 16 lowest set bits
-        for (int i = 0; i < nr; ++i) am &= am - 1;
-      }
-    }
-    unsigned char *tl = tlab + (tile & 1) * 256;
-    if (h == 0) {
-      if (valid) klab[crow0 + px] = label;
-      tl[w * 32 + j] = valid ? (unsigned char)label : (unsigned char)255;
-    }
-    __syncthreads();                       // the tile's 256 final labels are visible
-
-    // ---- queue this tile's rows for the M-step; they are consumed 16 per
-    //      chunk-step while the NEXT tile's MFMAs run (chunk_begin / chunk_end)
-    const int half = w >> 2;
-    int count = 0;
-#pragma unroll
-    for (int r0 = 0; r0 < TPX; r0 += 64) {
-      const int lb = tl[r0 + lane];
-      const bool mine = lb != 255 && (lb >> 5) == half;
-      const unsigned long long m = __ballot(mine);
-      if (mine) mlist[count + __popcll(m & ((1ull << lane) - 1ull))] =
-          (uint16_t)((r0 + lane) | ((lb & 31) << 8));
-      count += __popcll(m);
-    }
-    mcount = count;
-    mpos = 0;
-    mtile = tile;
-    tpos = 0;
-  }
-
-  // issue: next 16 rows of my (column slice, cluster half), one float per lane
-  __device__ __forceinline__ void chunk_begin() {
-    if (mtile < 0) return;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (mpos < mcount) {
-      const int e = min(mpos + (lane & 15), mcount - 1);
-      ment = mlist[e];
-      const float *xt = x + (crow0 + (int64_t)mtile * 256) * d + (w & 3) * 64 + lane;
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int row = __builtin_amdgcn_readlane(ment, u) & 255;
-        mv[u] = xt[(int64_t)row * d];
-      }
-    }
-    if (w == 0 && tpos < 256) {              // tail columns: lanes = rows of this 64-row block
-      const int r = tpos + lane;
-      const int nr = min(256, nrows - mtile * 256);
-      const float *xr = x + (crow0 + (int64_t)mtile * 256 + min(r, nr - 1)) * d + 256;
-      tlb = r < nr ? tlab[(mtile & 1) * 256 + r] : 255;
-#pragma unroll
-      for (int t = 0; t < kFusedTailMax; ++t) tvv[t] = (t < d - 256) ? xr[t] : 0.0f;
-    }
-  }
-  // consume in row order: acc[label] += value (wave-uniform register index)
-  __device__ __forceinline__ void chunk_end() {
-    if (mtile < 0) return;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (mpos < mcount) {
-      const int n = min(16, mcount - mpos);
-#pragma unroll
-      for (int u = 0; u < 16; ++u)
-        if (u < n) acc[(__builtin_amdgcn_readlane(ment, u) >> 8) & 31] += mv[u];
-      mpos += 16;
-    }
-    if (w == 0 && tpos < 256) {
-      for (int i = 0; i < 64; ++i) {
-        const int lb = __builtin_amdgcn_readlane(tlb, i);
-#pragma unroll
-        for (int t = 0; t < kFusedTailMax; ++t) {
-          const float tv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tvv[t]), i));
-          if (lane == lb) acct[t] += tv;
-        }
-      }
-      tpos += 64;
-    }
-  }
-  // after the last tile: finish its rows
-  __device__ __forceinline__ void drain() {
-    while (mtile >= 0 && (mpos < mcount || ((threadIdx.x >> 6) == 0 && tpos < 256))) {
-      chunk_begin();
-      chunk_end();
-    }
-  }
-};
-
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void lloyd_fused_kernel(
-    const float *__restrict__ x, int d, const float *__restrict__ cent, int K,
-    const int64_t *__restrict__ chunk_row0, const int32_t *__restrict__ chunk_rows,
-    const int32_t *__restrict__ chunk_img, int32_t *__restrict__ klab,
-    float *__restrict__ partial, const hsgk_segkm_meta *__restrict__ meta) {
-  static_assert(NW == 8, "roles are laid out for 8 waves");
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  unsigned char *tail = lds_raw + split_lds_bytes<NW>(d);
-  const int c = blockIdx.x;                 // one workgroup = one chunk (order C2)
-  if (c >= meta->n_chunks) return;
-  const int nrows = chunk_rows[c];
-  if (nrows <= 0) return;
-  const int64_t crow0 = chunk_row0[c];
-  const int b = chunk_img[c];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  v32f macc;
-#pragma unroll
-  for (int i = 0; i < 32; ++i) macc[i] = 0.0f;
-  FusedEpi epi{.acc = macc};
-  epi.K = K; epi.nrows = nrows; epi.img = b; epi.d = d; epi.crow0 = crow0;
-  epi.x = x; epi.cent = cent + (int64_t)b * K * d; epi.klab = klab;
-  epi.tlab = tail;                                                   // 512 B
-  epi.scratch = reinterpret_cast<uint32_t *>(tail + 512) + w * 48;   // 48 words per wave
-  epi.mlist = reinterpret_cast<uint16_t *>(tail + 512 + 8 * 48 * 4) + w * 256;
-  epi.mcount = 0; epi.mpos = 0; epi.mtile = -1; epi.tpos = 256; epi.ment = 0; epi.tlb = 255;
-#pragma unroll
-  for (int t = 0; t < kFusedTailMax; ++t) epi.acct[t] = 0.0f;
-  score_tiles_split<NW, 2>(x, d, cent + (int64_t)b * K * d, K, crow0, nrows, lds_raw, epi);
-  // chunk partial sums -> partial[c][k][col]
-  float *out = partial + (int64_t)c * K * d;
-  const int slice = w & 3, half = w >> 2;
-#pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    const int k = half * 32 + i;
-    if (k < K) out[(int64_t)k * d + slice * 64 + lane] = macc[i];
-  }
-  if (w == 0 && lane < K) {
-    const int tw = d - 256;
-#pragma unroll
-    for (int t = 0; t < kFusedTailMax; ++t)
-      if (t < tw) out[(int64_t)lane * d + 256 + t] = epi.acct[t];
-  }
-}
-
-bool lloyd_fused_eligible(int d, int K, int max_chunks) {
-  // below ~one chunk per CU the unfused kernels (which can split a chunk over
-  // several workgroups) keep the chip busier; HSGK_FUSED_MIN_CHUNKS overrides
-  static const int min_chunks = [] {
-    const char *e = getenv("HSGK_FUSED_MIN_CHUNKS");
-    return e ? atoi(e) : 256;
-  }();
-  return K <= 64 && (d & 1) == 0 && d >= 256 && d <= 256 + kFusedTailMax && split_shape_ok(d) &&
-         max_chunks >= min_chunks &&
-         split_lds_bytes<8>(d) + 512 + 8 * 48 * 4 + 8 * 256 * 2 <= 160 * 1024;
-}
-
-int launch_lloyd_fused(const float *x, int d, const float *cent, int K, const ChunkTable &t,
-                       int max_chunks, int32_t *klab, float *partial,
-                       const hsgk_segkm_meta *meta, hipStream_t s) {
-  auto kern = lloyd_fused_kernel<8>;
-  const size_t lds = split_lds_bytes<8>(d) + 512 + 8 * 48 * 4 + 8 * 256 * 2;
-  HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(max_chunks), dim3(512), lds, s, x, d, cent, K, t.chunk_row0,
-                     t.chunk_rows, t.chunk_img, klab, partial, meta);
-  HSGK_LAUNCH_CHECK();
-  return 0;
-}
-
 static int launch_assign_split(const float *x, int d, const float *cent, int K,
                                const ChunkTable &t, int max_chunks, int32_t *klab,
                                SplitEntry *gqueue, int32_t *gcount, const hsgk_segkm_meta *meta,

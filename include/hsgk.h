@@ -56,8 +56,7 @@ HSGK_API const char *hsgk_last_error(void);
 #define HSGK_PROF_FINALIZE 2    /* M-step partial combine + normalise         */
 #define HSGK_PROF_ASSIGN 3      /* E-step (the roofline kernel)               */
 #define HSGK_PROF_RELABEL 4
-#define HSGK_PROF_FUSED 5       /* E-step + next M-step partial sums, one pass */
-#define HSGK_PROF_KINDS 6
+#define HSGK_PROF_KINDS 5
 HSGK_API void hsgk_profile_enable(int on);
 HSGK_API int hsgk_profile_collect(double *ms_sum, int64_t *count);
 

@@ -3,10 +3,6 @@ import sys
 
 import pytest
 
-# exercise the fused E+M Lloyd pass on the small parity shapes too (it is
-# normally reserved for batches of >= 256 chunks)
-os.environ.setdefault('HSGK_FUSED_MIN_CHUNKS', '1')
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
