@@ -6,15 +6,16 @@
 
 namespace hsgk {
 
+template <int NW>
 __device__ inline int owner_wave(int label) {
-  return (label ^ (label >> 2) ^ (label >> 4) ^ (label >> 6)) & 3;
+  return (label ^ (label >> 2) ^ (label >> 4) ^ (label >> 6)) & (NW - 1);
 }
 
 // Accumulates the rows of one chunk whose label lies in [lo, lo+cnt_lab) into
 // the zeroed LDS table sums[cnt_lab][DS].  Shared by the k-means M-step
 // (int32 working labels, window = cluster block) and segment_reduce (int64
 // labels, window = the chunk's own label range).
-template <int VEC, int UNROLL, typename LabT>
+template <int VEC, int UNROLL, typename LabT, int NW = 4>
 __device__ inline void chunk_accumulate(const float *__restrict__ xr, int d, int DS,
                                         const LabT *__restrict__ lab, int n, int64_t lo,
                                         int cnt_lab, float *sums, uint32_t *rlist,
@@ -28,7 +29,7 @@ __device__ inline void chunk_accumulate(const float *__restrict__ xr, int d, int
   for (int base = 0; base < n; base += 64) {
     int64_t l = -1;
     if (base + lane < n) l = (int64_t)lab[base + lane] - lo;
-    const bool mine = l >= 0 && l < cnt_lab && owner_wave((int)l) == w;
+    const bool mine = l >= 0 && l < cnt_lab && owner_wave<NW>((int)l) == w;
     cnt += __popcll(__ballot(mine));
   }
   if (lane == 0) wcount[w] = cnt;
@@ -40,7 +41,7 @@ __device__ inline void chunk_accumulate(const float *__restrict__ xr, int d, int
     for (int base = 0; base < n; base += 64) {
       int64_t l = -1;
       if (base + lane < n) l = (int64_t)lab[base + lane] - lo;
-      const bool mine = l >= 0 && l < cnt_lab && owner_wave((int)l) == w;
+      const bool mine = l >= 0 && l < cnt_lab && owner_wave<NW>((int)l) == w;
       const unsigned long long m = __ballot(mine);
       if (mine) rlist[pos + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)(base + lane) << 10) | (uint32_t)l;
       pos += __popcll(m);

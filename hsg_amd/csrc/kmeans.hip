@@ -31,27 +31,27 @@ namespace hsgk {
 //
 // LDS row stride DS = d rounded up to VEC floats so the per-lane VEC-wide
 // LDS accesses stay naturally aligned.
-template <int VEC, int UNROLL>
-__global__ __launch_bounds__(256) void accumulate_kernel(
+template <int VEC, int UNROLL, int NW>
+__global__ __launch_bounds__(NW * 64) void accumulate_kernel(
     const float *__restrict__ x, int d, const int32_t *__restrict__ klab,
     const int64_t *__restrict__ chunk_row0, const int32_t *__restrict__ chunk_rows,
     int K, int kb0, int kbn, float *__restrict__ partial,
     const hsgk_segkm_meta *__restrict__ meta) {
   extern __shared__ float sums[];   // [kbn][DS] then the row list
-  __shared__ int wcount[4];
+  __shared__ int wcount[8];
   const int c = blockIdx.x;
   if (c >= meta->n_chunks) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int DS = (d + VEC - 1) / VEC * VEC;
   const int tot = kbn * DS;
   uint32_t *rlist = reinterpret_cast<uint32_t *>(sums + tot);   // [HSGK_CHUNK] (row << 10 | label)
-  for (int i = tid; i < tot; i += 256) sums[i] = 0.0f;
+  for (int i = tid; i < tot; i += NW * 64) sums[i] = 0.0f;
   const int64_t row0 = chunk_row0[c];
-  chunk_accumulate<VEC, UNROLL, int32_t>(x + row0 * d, d, DS, klab + row0, chunk_rows[c], kb0,
-                                         kbn, sums, rlist, wcount);
+  chunk_accumulate<VEC, UNROLL, int32_t, NW>(x + row0 * d, d, DS, klab + row0, chunk_rows[c], kb0,
+                                             kbn, sums, rlist, wcount);
   __syncthreads();
   float *out = partial + ((int64_t)c * K + kb0) * d;
-  for (int k = w; k < kbn; k += 4)
+  for (int k = w; k < kbn; k += NW)
     for (int i = lane; i < d; i += 64) out[k * d + i] = sums[k * DS + i];
 }
 
@@ -73,14 +73,15 @@ int launch_accumulate(const float *x, int d, const int32_t *klab, const ChunkTab
   if (kbn > 1024) kbn = 1024;               // label field of the row list is 10 bits
   HSGK_REQUIRE(kbn >= 1, "row too long for the LDS segment table");
   // 16-byte global loads only need dword alignment on gfx950.
-  auto kern = wide ? accumulate_kernel<4, 8> : accumulate_kernel<1, 16>;
+  constexpr int NWA = 4;   // measured: 4 waves x 16 rows in flight 2.17 ms, 8 waves 2.32 ms, 24 rows 3.23 ms (cfg2)
+  auto kern = wide ? accumulate_kernel<4, 16, NWA> : accumulate_kernel<1, 16, NWA>;
   size_t lds = (size_t)kbn * DS * 4 + list_bytes;
   HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)(158 * 1024)));
   for (int kb0 = 0; kb0 < K; kb0 += kbn) {
     int cur = K - kb0 < kbn ? K - kb0 : kbn;
-    hipLaunchKernelGGL(kern, dim3(max_chunks), dim3(256), lds, s, x, d, klab,
+    hipLaunchKernelGGL(kern, dim3(max_chunks), dim3(NWA * 64), lds, s, x, d, klab,
                        t.chunk_row0, t.chunk_rows, K, kb0, cur, partial, meta);
     HSGK_LAUNCH_CHECK();
   }
