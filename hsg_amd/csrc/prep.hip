@@ -489,6 +489,157 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(
   }
 }
 
+// --------------------------------------------------------------------------
+// 32-pixel variant of the fast path: one workgroup handles HALF of a 64-pixel
+// compaction tile (blockIdx.x = 2 * tile + half).  33 KiB of LDS per workgroup
+// instead of 66 -> four workgroups per CU, so the serial norm chains of one
+// workgroup (wave 0 only) overlap the load / divide / store phases of three
+// others.  PMC on the 64-pixel kernel showed waves 69 % waiting (barriers +
+// memory) with only two workgroups per CU.  Same arithmetic, same outputs.
+__global__ __launch_bounds__(256) void prep_fast32_kernel(
+    const float *__restrict__ in, int C, int64_t HW, int ntiles,
+    const float *__restrict__ loc, int64_t loc_sb, const int64_t *__restrict__ labels,
+    int has_ignore, int64_t ignore, const int32_t *__restrict__ tile_off,
+    const int64_t *__restrict__ img_row0, const int32_t *__restrict__ seed_map,
+    float eps, float *__restrict__ emb, float *__restrict__ emb_loc,
+    int64_t *__restrict__ labels_out, int32_t *__restrict__ klab,
+    float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out) {
+  extern __shared__ float lds[];
+  float *tile = lds;                       // [32][C] swizzled
+  float *nrm1 = lds + 32 * C;              // [32]
+  float *nrm2 = nrm1 + 32;                 // [32]
+  float *locv = nrm2 + 32;                 // [32][2]
+  int64_t *rowi = reinterpret_cast<int64_t *>(locv + 64);   // [32]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int t = blockIdx.x >> 1, sh = blockIdx.x & 1, b = blockIdx.y;
+  const int64_t p0 = (int64_t)t * kTilePix;        // start of the 64-pixel compaction tile
+  const int64_t q0 = p0 + 32 * sh;                 // start of this half
+  const int D = C + 2;
+  const int NQ = C >> 2;
+
+  if (w == 0) {
+    const int64_t pix = p0 + lane;
+    bool keep = false;
+    int64_t lab = 0;
+    if (pix < HW) {
+      lab = labels ? labels[(int64_t)b * HW + pix] : 0;
+      keep = !(has_ignore && lab == ignore);
+    }
+    const unsigned long long m = __ballot(keep);
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    const int64_t base = img_row0[b] + (tile_off ? (int64_t)tile_off[(int64_t)b * ntiles + t] : p0);
+    const int64_t row = keep ? base + rank : -1;
+    if ((lane >> 5) == sh) {
+      const int jl = lane & 31;
+      rowi[jl] = row;
+      if (rowmap_out && pix < HW) rowmap_out[(int64_t)b * HW + pix] = row;
+      if (keep) {
+        labels_out[row] = lab;
+        klab[row] = seed_map[pix];
+        locv[2 * jl + 0] = loc[(int64_t)b * loc_sb + pix * 2 + 0];
+        locv[2 * jl + 1] = loc[(int64_t)b * loc_sb + pix * 2 + 1];
+      }
+    }
+    const unsigned long long mh = sh ? (m >> 32) : (m & 0xffffffffull);
+    if (lane == 0) nrm1[0] = mh ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+  if (nrm1[0] == 0.0f) return;
+  __syncthreads();
+
+  const int jl = lane & 31, sub = lane >> 5;
+  const int sw = jl & 15;
+  // phase 1: 4 channel planes -> one 16-byte LDS write per (pixel, quad)
+  {
+    const int64_t pix = q0 + jl;
+    const bool ok = pix < HW;
+    const float *src = in + (int64_t)b * C * HW + (ok ? pix : HW - 1);
+    for (int q = 2 * w + sub; q < NQ; q += 8) {
+      float4 v;
+      v.x = src[(int64_t)(4 * q + 0) * HW];
+      v.y = src[(int64_t)(4 * q + 1) * HW];
+      v.z = src[(int64_t)(4 * q + 2) * HW];
+      v.w = src[(int64_t)(4 * q + 3) * HW];
+      if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4 *>(tile + jl * C + ((q ^ sw) << 2)) = v;
+    }
+  }
+  __syncthreads();
+  // phase 2a: the C1 chain of pixel jl (wave 0, lanes 0..31)
+  if (w == 0 && sub == 0) {
+    const float *r = tile + jl * C;
+    float ss = 0.0f;
+    for (int q = 0; q < NQ; ++q) {
+      const float4 v = *reinterpret_cast<const float4 *>(r + ((q ^ sw) << 2));
+      ss = fmaf(v.x, v.x, ss);
+      ss = fmaf(v.y, v.y, ss);
+      ss = fmaf(v.z, v.z, ss);
+      ss = fmaf(v.w, v.w, ss);
+    }
+    float n1 = sqrtf(ss);
+    if (!(n1 >= eps)) n1 = eps;
+    nrm1[jl] = n1;
+  }
+  __syncthreads();
+  // phase 2b
+  {
+    const float n1 = nrm1[jl];
+    float *r = tile + jl * C;
+    for (int q = 2 * w + sub; q < NQ; q += 8) {
+      float4 *pv = reinterpret_cast<float4 *>(r + ((q ^ sw) << 2));
+      float4 v = *pv;
+      v.x = v.x / n1; v.y = v.y / n1; v.z = v.z / n1; v.w = v.w / n1;
+      *pv = v;
+    }
+  }
+  __syncthreads();
+  // phase 2c
+  if (w == 0 && sub == 0) {
+    const float *r = tile + jl * C;
+    float ss = 0.0f;
+    for (int q = 0; q < NQ; ++q) {
+      const float4 v = *reinterpret_cast<const float4 *>(r + ((q ^ sw) << 2));
+      ss = fmaf(v.x, v.x, ss);
+      ss = fmaf(v.y, v.y, ss);
+      ss = fmaf(v.z, v.z, ss);
+      ss = fmaf(v.w, v.w, ss);
+    }
+    const float ly = locv[2 * jl], lx = locv[2 * jl + 1];
+    ss = fmaf(ly, ly, ss);
+    ss = fmaf(lx, lx, ss);
+    float n2 = sqrtf(ss);
+    if (!(n2 >= eps)) n2 = eps;
+    nrm2[jl] = n2;
+  }
+  __syncthreads();
+  // phase 3
+  for (int j = w; j < 32; j += 4) {
+    const int64_t row = rowi[j];
+    if (row < 0) continue;
+    const float n2 = nrm2[j];
+    if (norms_out && lane == 0) { norms_out[2 * row] = nrm1[j]; norms_out[2 * row + 1] = n2; }
+    const float *r = tile + j * C;
+    float *eo = emb + row * C;
+    float *lo = emb_loc + row * D;
+    const int sj = j & 15;
+    for (int q = lane; q < NQ; q += 64) {
+      const float4 v = *reinterpret_cast<const float4 *>(r + ((q ^ sj) << 2));
+      *reinterpret_cast<float4 *>(eo + 4 * q) = v;
+      float2 a, c2;
+      a.x = v.x / n2; a.y = v.y / n2; c2.x = v.z / n2; c2.y = v.w / n2;
+      *reinterpret_cast<float2 *>(lo + 4 * q) = a;
+      *reinterpret_cast<float2 *>(lo + 4 * q + 2) = c2;
+    }
+    if (lane == 0) {
+      float2 lv;
+      lv.x = locv[2 * j] / n2;
+      lv.y = locv[2 * j + 1] / n2;
+      *reinterpret_cast<float2 *>(lo + C) = lv;
+    }
+  }
+}
+
 int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTable &t,
                 int32_t *klab, hipStream_t s) {
   const int64_t HW = (int64_t)a.H * a.W;
@@ -499,11 +650,20 @@ int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTa
   floats = (floats + 1) & ~(size_t)1;     // keep the int64 row table 8-byte aligned
   size_t lds = floats * 4 + 64 * 8;
   HSGK_REQUIRE(lds <= 160 * 1024, "embedding dimension too large for the prep tile");
+  static const int tile32 = [] {
+    const char *e = getenv("HSGK_PREP_TILE");        // "64" selects the 64-pixel fast kernel
+    return (e && e[0] == '6') ? 0 : 1;
+  }();
   auto kern = fast ? prep_fast_kernel : prep_kernel;
+  dim3 grid(ntiles, a.B);
+  if (fast && tile32) {
+    kern = prep_fast32_kernel;
+    lds = ((size_t)32 * a.C + 32 + 32 + 64) * 4 + 32 * 8;
+    grid.x = 2 * ntiles;
+  }
   HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));
-  dim3 grid(ntiles, a.B);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a.embeddings, a.C, HW, ntiles,
                      a.loc, a.loc_batch_stride, a.labels, a.has_ignore, a.ignore_index,
                      tile_off, t.img_row0, a.seed_map, HSGK_EPS, a.out_embeddings,
