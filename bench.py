@@ -9,9 +9,13 @@ clusters its own shard of the same per-GPU shape (weak scaling; images are
 independent, the only exchange is the prototype-table step).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline      assign (E-step) kernel: algorithmic bytes (4D+8 per pixel) over
-                its average launch time, measured with HIP events on the launch
-                stream inside the timed region (libhsgk's event profiler);
+  roofline      assign (E-step) launch group: algorithmic bytes (4D+8 per pixel)
+                over its average duration, measured with HIP events on the launch
+                stream inside the timed region (libhsgk's event profiler).
+                `traffic` is null: on gfx950 FETCH_SIZE counts between 0.5x and
+                ~0.94x of the bytes depending on the access pattern
+                (profiles/r01_pmc.txt, tools/probes/fetch_calib.hip), so no
+                defensible absolute exists for the 8-byte row-segment loads;
   cpu_baseline  oracle/torch_ref.py (same ATen op sequence as the reference's
                 CPU path) timed on the host cores, rank 0, N=1 only.
 """
@@ -130,7 +134,9 @@ def main():
     avg_s = a_ms / a_n * 1e-3
     bytes_per_launch = (4 * D + 8) * B * H * W           # 4D+8 B / pixel
     achieved = bytes_per_launch / avg_s / 1e9
-    roofline = {'bound': 'hbm', 'kernel': 'assign_kernel (E-step)',
+    roofline = {'bound': 'hbm',
+                'kernel': 'E-step launch group: assign_split_kernel (bf16x3 filter) + '
+                          'assign_requeue_rows_kernel (exact fp32 re-score)',
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
                 'avg_launch_ms': round(a_ms / a_n, 4), 'launches': int(a_n),
