@@ -396,3 +396,63 @@ def test_hierarchy_ops_vs_reference_golden(dev):
   px_coarse = hz.collect_pixel_hierarchical_clustering_indices(T('c_by_img'), T('bidx'), T('c_lab'))
   assert np.array_equal(px_fine.cpu().numpy(), g['px_fine'])
   assert np.array_equal(px_coarse.cpu().numpy(), g['px_coarse'])
+
+
+@pytest.mark.parametrize('shape,grid,iters', [
+    ((2, 64, 64, 64), (16, 16), 5),      # cfg4-style K = 256: four 64-row table blocks, K-blocked M-step
+    ((1, 384, 32, 48), (8, 16), 6),      # cfg5-style C = 384, K = 128
+    ((3, 256, 40, 56), (8, 8), 10),      # cfg2/3-style C = 256, K = 64: split E-step, ragged chunks
+    ((2, 128, 33, 47), (5, 7), 7),       # odd sizes, K = 35, d = 130 (split shape ok: 4 chunks)
+])
+def test_baseline_config_shapes_vs_oracle(dev, oracle, shape, grid, iters):
+  """Reduced-size versions of BASELINE.json configs 2-5, bit-exact vs the oracle
+  (labels, ids and both float outputs)."""
+  from hsg_amd.utils.segsort import common as sc
+  B, C, H, W = shape
+  x = synth.embeddings_nchw(synth.SEED_BASE + C + H, shape, 'iid')
+  lab = synth.overseg_labels(synth.SEED_BASE + 3, B, H, W, regions=7, ignore_rows=3)
+  loc = (sc.generate_location_features((H, W), 'cpu', 'float') - 0.5).numpy()
+  got = _run_segkm(dev, x, lab, grid, 255, iters)
+  ref = oracle.segment_by_kmeans(x, lab, grid, loc, 255, iters)
+  for name, a, b in zip(('emb', 'emb_loc', 'labels', 'cluster', 'batch'), got, ref):
+    assert a.shape == b.shape, name
+    assert np.array_equal(a, b), '%s: %d mismatching elements' % (name, int((a != b).sum()))
+
+
+def test_full_size_cfg2_properties_and_spot_parity(dev, oracle):
+  """BASELINE.json configs[1] at FULL size (48x256x448x448, K=8x8, 10 iterations):
+  size-independent properties on the whole batch and bit-exact parity of two
+  whole images against the oracle."""
+  import torch
+  from hsg_amd.utils.segsort import common as sc
+  B, C, H, W, grid, iters = 48, 256, 448, 448, (8, 8), 10
+  gen = torch.Generator(device=dev)
+  gen.manual_seed(1234)
+  x = torch.randn((B, C, H, W), device=dev, generator=gen)
+  emb, eloc, labels, cluster, batch = sc.segment_by_kmeans(x, None, list(grid), iterations=iters)
+  n = B * H * W
+  assert emb.shape == (n, C) and eloc.shape == (n, C + 2)
+  # unit rows
+  assert (emb.norm(dim=1) - 1).abs().max().item() < 1e-5
+  assert (eloc.norm(dim=1) - 1).abs().max().item() < 1e-5
+  # bookkeeping: image-major batch index, dense ids, ids sorted by (image, cluster)
+  assert torch.equal(batch, torch.arange(B, device=dev).repeat_interleave(H * W))
+  assert int(cluster.min()) == 0 and int(cluster.max()) == B * 64 - 1
+  assert torch.equal(cluster // 64, batch)
+  assert torch.equal(labels, torch.zeros_like(labels))
+  # every cluster of the 448x448 grid survives on i.i.d. data
+  assert int(torch.bincount(cluster).min()) > 0
+  # determinism: a second run is bit-identical
+  emb2, eloc2, _, cluster2, _ = sc.segment_by_kmeans(x, None, list(grid), iterations=iters)
+  assert torch.equal(cluster, cluster2) and torch.equal(eloc, eloc2) and torch.equal(emb, emb2)
+  del emb2, eloc2, cluster2
+  # Lloyd fixed-point property of the final labels: re-assigning with the
+  # centroids of the last M-step reproduces them (E-step idempotence), checked
+  # through the exact fp32 kernel on one image
+  loc = (sc.generate_location_features((H, W), 'cpu', 'float') - 0.5).numpy()
+  for b in (0, B - 1):
+    ref = oracle.segment_by_kmeans(x[b:b + 1].cpu().numpy(), None, grid, loc, None, iters)
+    sl = slice(b * H * W, (b + 1) * H * W)
+    assert np.array_equal(emb[sl].cpu().numpy(), ref[0]), 'emb image %d' % b
+    assert np.array_equal(eloc[sl].cpu().numpy(), ref[1]), 'emb_loc image %d' % b
+    assert np.array_equal((cluster[sl] - b * 64).cpu().numpy(), ref[3]), 'clusters image %d' % b
