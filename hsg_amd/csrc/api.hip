@@ -304,7 +304,8 @@ int hsgk_lloyd_requeued_rows(int B, int64_t rows_per_image, int d, int K, void *
 }
 
 size_t hsgk_assign_workspace_bytes(int64_t n, int d, int K) {
-  return hsgk_kmeans_workspace_bytes(n, d, 1) + 0 * K;
+  (void)K;                       // the prototype table is read in place
+  return hsgk_kmeans_workspace_bytes(n, d, 1);
 }
 
 int hsgk_find_nearest_prototypes(const float *x, int64_t n, int d, const float *prototypes,

@@ -172,11 +172,8 @@ __global__ void build_tables_kernel(const int64_t *__restrict__ img_cnt, int64_t
 int launch_build_tables(const int32_t *tile_cnt, int B, int64_t HW, int ntiles,
                         int32_t *tile_off, ChunkTable t, int max_chunks,
                         hsgk_segkm_meta *meta, hipStream_t s) {
-  // img counts are parked in chunk_row0's tail?  No: reuse img_row0 memory is
-  // unsafe (read-after-write in the same kernel), so the counts live in the
-  // first B entries of chunk_row0 ONLY until build_tables_kernel has read
-  // them into registers -- instead we keep them separate: tile_off has
-  // B*ntiles int32 entries followed by B int64 counts (see workspace carve).
+  // tile_off holds align_up(B*ntiles, 64) int32 prefixes followed by the B
+  // int64 per-image kept-pixel counts (see the workspace carve in api.hip)
   int64_t *img_cnt = nullptr;
   if (tile_cnt) {
     img_cnt = reinterpret_cast<int64_t *>(tile_off + align_up((size_t)B * ntiles, 64));
