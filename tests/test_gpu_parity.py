@@ -456,3 +456,33 @@ def test_full_size_cfg2_properties_and_spot_parity(dev, oracle):
     assert np.array_equal(emb[sl].cpu().numpy(), ref[0]), 'emb image %d' % b
     assert np.array_equal(eloc[sl].cpu().numpy(), ref[1]), 'emb_loc image %d' % b
     assert np.array_equal((cluster[sl] - b * 64).cpu().numpy(), ref[3]), 'clusters image %d' % b
+
+
+def test_train_step_slice_vs_reference(dev):
+  """k-means -> batch prototype table -> two SegSort losses ->
+  backward to the NCHW embeddings, against the reference running the same
+  calls on CPU (tests/golden/f9_train_step.npz)."""
+  import torch
+  from hsg_amd.utils.segsort import common as sc
+  from hsg_amd.utils.segsort.loss import SegSortLoss
+  from hsg_amd.models import utils as mu
+  g = util.load('f9_train_step')
+  shape = tuple(int(v) for v in g['shape'])
+  grid = [int(v) for v in g['grid']]
+  seed = int(g['seed'])
+  x = torch.from_numpy(synth.embeddings_nchw(seed, shape, 'mixture')).to(dev).requires_grad_(True)
+  lab = torch.from_numpy(synth.overseg_labels(int(g['label_seed']), shape[0], shape[2], shape[3],
+                                              regions=6, ignore_rows=2, ignore_index=255)).to(dev)
+  emb, emb_loc, labels, cidx, bidx = sc.segment_by_kmeans(x, lab, grid, ignore_index=255, iterations=6)
+  zeros = torch.zeros_like(labels)
+  protos, protos_loc, psem, pinst, pbatch, upd = mu.gather_clustering_and_update_prototypes(
+      [emb], [emb_loc], [cidx], [bidx], [labels], [zeros], dev)
+  assert protos[0].shape[0] == int(g['n_protos'])
+  assert np.array_equal(upd[0].cpu().numpy(), g['upd'].astype(np.int64))
+  loss_a = SegSortLoss(16, 'segsort+')(emb, labels, upd[0], protos[0], psem[0])
+  loss_b = SegSortLoss(10, 'segsort')(emb_loc, labels, upd[0], protos_loc[0], psem[0])
+  assert abs(loss_a.item() - float(g['loss_a'])) <= 1e-4
+  assert abs(loss_b.item() - float(g['loss_b'])) <= 1e-4
+  (loss_a + 0.5 * loss_b).backward()
+  got = x.grad.cpu().numpy().reshape(-1)[::11]
+  assert np.abs(got - g['grad']).max() <= 2e-5 * max(float(g['grad_absmax']), 1.0)

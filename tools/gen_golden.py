@@ -282,8 +282,37 @@ def f7():
        px_coarse=px_coarse.numpy())
 
 
+# ---- F9 one train-step slice: k-means -> prototype table -> loss -> backward ----
+def f9():
+  import torch.nn.parallel.scatter_gather as sg
+  import hsg.models.utils as ref_mu
+  sg_gather = sg.gather
+  sg.gather = lambda xs, dev=None, dim=0: torch.cat(list(xs), 0)
+  ref_mu.scatter_gather.gather = sg.gather
+  try:
+    seed = synth.SEED_BASE + 71
+    shape, grid = (3, 32, 24, 28), (3, 4)
+    x = torch.from_numpy(synth.embeddings_nchw(seed, shape, 'mixture')).requires_grad_(True)
+    lab = torch.from_numpy(synth.overseg_labels(seed + 7, shape[0], shape[2], shape[3], regions=6,
+                                                ignore_rows=2, ignore_index=255))
+    emb, emb_loc, labels, cidx, bidx = ref_segment_by_kmeans(x, lab, list(grid), ignore_index=255,
+                                                              iterations=6)
+    zeros = torch.zeros_like(labels)
+    protos, protos_loc, psem, pinst, pbatch, upd = ref_mu.gather_clustering_and_update_prototypes(
+        [emb], [emb_loc], [cidx], [bidx], [labels], [zeros], 'cpu')
+    loss_a = ref_loss.SegSortLoss(16, 'segsort+')(emb, labels, upd[0], protos[0], psem[0])
+    loss_b = ref_loss.SegSortLoss(10, 'segsort')(emb_loc, labels, upd[0], protos_loc[0], psem[0])
+    (loss_a + 0.5 * loss_b).backward()
+    save('f9_train_step', seed=seed, shape=np.array(shape), grid=np.array(grid), label_seed=seed + 7,
+         loss_a=np.float64(loss_a.item()), loss_b=np.float64(loss_b.item()),
+         grad=x.grad.numpy().reshape(-1)[::11].copy(), grad_absmax=np.float64(x.grad.abs().max().item()),
+         n_protos=protos[0].shape[0], upd=upd[0].numpy().astype(np.int32))
+  finally:
+    sg.gather = sg_gather
+
+
 if __name__ == '__main__':
   os.makedirs(OUT, exist_ok=True)
-  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8']
+  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9']
   for w in which:
     globals()[w]()
