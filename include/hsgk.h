@@ -216,6 +216,15 @@ HSGK_API int hsgk_group_mean(const float *protos, const int64_t *labels, const u
 HSGK_API int hsgk_gather_labels(const int64_t *table, int M, const int64_t *img,
                                 const int64_t *seg, int64_t n, int64_t *out, hsgk_stream_t stream);
 
+/* ---- hsg/utils/segsort/eval.py:9-52 top_k_ranking (retrieval contraction) ----
+ * queries [n,c], proto [P,c] -> out_idx [n,topk] (int64 prototype indices by
+ * descending <q,p>, lower index first on exact ties) and out_val [n,topk].
+ * 1 <= topk <= min(32, P).                                                      */
+HSGK_API size_t hsgk_topk_workspace_bytes(int64_t n, int c, int64_t P, int topk);
+HSGK_API int hsgk_topk_prototypes(const float *queries, int64_t n, int c, const float *proto,
+                                  int64_t P, int topk, int64_t *out_idx, float *out_val,
+                                  void *workspace, size_t workspace_bytes, hsgk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -486,3 +486,36 @@ def test_train_step_slice_vs_reference(dev):
   (loss_a + 0.5 * loss_b).backward()
   got = x.grad.cpu().numpy().reshape(-1)[::11]
   assert np.abs(got - g['grad']).max() <= 2e-5 * max(float(g['grad_absmax']), 1.0)
+
+
+@pytest.mark.parametrize('n,c,P,k', [(500, 48, 97, 3), (3000, 128, 700, 5), (2100, 256, 64, 20),
+                                     (70, 32, 40, 32)])
+def test_top_k_ranking_vs_torch(dev, oracle, n, c, P, k):
+  """eval.py:9-52: same accuracy and retrieved labels as the reference's
+  mm + argsort formulation (fp32 ATen on the GPU) on tie-free data."""
+  import torch
+  from hsg_amd.utils.segsort import eval as ev
+  e = torch.from_numpy(oracle.normalize_embedding(synth.gaussish(3 + n, n * c).reshape(n, c))).to(dev)
+  p = torch.from_numpy(oracle.normalize_embedding(synth.gaussish(5 + P, P * c).reshape(P, c))).to(dev)
+  plab = torch.from_numpy((synth.hash_u64(7 + P, P) % np.uint64(9)).astype(np.int64)).to(dev)
+  lab = torch.from_numpy((synth.hash_u64(9 + n, n) % np.uint64(9)).astype(np.int64)).to(dev)
+  acc, labs = ev.top_k_ranking(e, lab, p, plab, k)
+  aff = torch.mm(e, p.t())
+  idx = torch.argsort(aff, 1, descending=True)[:, :k]
+  ref_labs = plab[idx.reshape(-1)].view(-1, k)
+  ref_acc = torch.eq(lab.view(-1, 1), ref_labs).float().mean()
+  got_idx, got_val = ev.top_k_indices(e, p, k)
+  # scores agree to rounding and are sorted; indices agree wherever the gap to
+  # the next score exceeds the fp32 dot-product noise
+  ref_val = torch.gather(aff, 1, idx)
+  assert (got_val - ref_val).abs().max().item() <= 2e-6
+  gap_ok = torch.ones_like(idx, dtype=torch.bool)
+  srt = torch.sort(aff, 1, descending=True).values[:, :k + 1]
+  gap_ok &= (srt[:, :k] - srt[:, 1:k + 1]) > 1e-5 if srt.shape[1] > k else gap_ok
+  if k > 1:
+    gap_ok[:, 1:] &= (srt[:, :k - 1] - srt[:, 1:k]) > 1e-5
+  assert torch.equal(got_idx[gap_ok], idx[gap_ok])
+  assert abs(acc.item() - ref_acc.item()) <= 2e-3
+  assert (labs == ref_labs)[gap_ok].all()
+  maj = ev.majority_label_from_topk(labs, 9)
+  assert maj.shape == (n,)
