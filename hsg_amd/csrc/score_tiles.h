@@ -125,7 +125,7 @@ __device__ inline void score_tiles(const float *__restrict__ x, int d,
         v.x = src[0];
         v.y = src[1];                                 // q*KC + 2*lf2 + 1 < tcol0 <= d
       }
-      pre[i] = px < n ? v : make_float2(0.0f, 0.0f);
+      pre[i] = v;       // rows past the end re-read the last valid row and are never stored
     }
   };
   auto store_chunk = [&](int buf, const float2 (&pre)[LOADS]) {

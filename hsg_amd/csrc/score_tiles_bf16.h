@@ -125,8 +125,10 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
     for (int i = 0; i < LOADS; ++i) {
       const int px = lpx + 4 * i;
       const int pxc = max(min(px, n - 1), -(tile * TPX + w * 32));
-      const float2 v = *reinterpret_cast<const float2 *>(tb + pxc * d + 2 * lf2);
-      pre[i] = px < n ? v : make_float2(0.0f, 0.0f);
+      // rows past the end re-read the last valid row (clamped address) and are
+      // never written back: an unconditional load keeps the four prefetch sets
+      // on counted vmcnt waits (a select turned into a branch costs vmcnt(0))
+      pre[i] = *reinterpret_cast<const float2 *>(tb + pxc * d + 2 * lf2);
     }
   };
   auto store_chunk = [&](int buf, const float2 (&pre)[LOADS]) {
