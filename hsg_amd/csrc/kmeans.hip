@@ -298,27 +298,44 @@ __global__ __launch_bounds__(NW * 64) void assign_split_kernel(
   int *qnp = reinterpret_cast<int *>(tail - 16);            // [0] count, [1] global base
   uint32_t *qcand = reinterpret_cast<uint32_t *>(tail);     // [kSplitLdsList]
   uint16_t *qpx = reinterpret_cast<uint16_t *>(qcand + kSplitLdsList);
-  if (threadIdx.x == 0) qnp[0] = 0;
-  const int c = blockIdx.x / split;
-  if (c >= meta->n_chunks) return;
-  const int part = blockIdx.x - c * split;
-  const int tps = (HSGK_CHUNK / TPX + split - 1) / split;
-  const int nrows = min(chunk_rows[c] - part * tps * TPX, tps * TPX);
-  if (nrows <= 0) return;
-  const int64_t crow0 = chunk_row0[c] + (int64_t)part * tps * TPX;
-  const int b = chunk_img[c];
-  SplitEpi epi{K, nrows, b, crow0, klab, qpx, qcand, qnp, gqueue, gcount};
-  score_tiles_split<NW, 4>(x, d, cent + (int64_t)b * K * d, K, crow0, nrows, lds_raw, epi);
-  __syncthreads();
-  // publish the staged entries with ONE global atomic per workgroup; the exact
-  // pass then balances the queue over the whole chip
-  const int qn = min(qnp[0], kSplitLdsList);
-  if (qn > 0) {
-    if (threadIdx.x == 0) qnp[1] = atomicAdd(gcount, qn);
+  // PERSISTENT when split == 0: gridDim.x workgroups share the chunks in
+  // contiguous ranges (so the table is re-staged only when the image changes and
+  // there is no per-chunk launch / ramp-up cost); otherwise one workgroup per
+  // 1/split of a chunk (small batches).
+  int c_begin, c_end, part = 0, tps = HSGK_CHUNK / TPX;
+  if (split == 0) {
+    const int nc = (int)meta->n_chunks;
+    c_begin = (int)(((int64_t)blockIdx.x * nc) / gridDim.x);
+    c_end = (int)(((int64_t)(blockIdx.x + 1) * nc) / gridDim.x);
+  } else {
+    c_begin = blockIdx.x / split;
+    c_end = c_begin < meta->n_chunks ? c_begin + 1 : c_begin;
+    part = blockIdx.x - c_begin * split;
+    tps = (HSGK_CHUNK / TPX + split - 1) / split;
+  }
+  int staged_img = -1;
+  for (int c = c_begin; c < c_end; ++c) {
+    const int nrows = min(chunk_rows[c] - part * tps * TPX, tps * TPX);
+    if (nrows <= 0) continue;
+    const int64_t crow0 = chunk_row0[c] + (int64_t)part * tps * TPX;
+    const int b = chunk_img[c];
+    if (threadIdx.x == 0) qnp[0] = 0;       // ordered before any epilogue by the engine's barrier
+    SplitEpi epi{K, nrows, b, crow0, klab, qpx, qcand, qnp, gqueue, gcount};
+    score_tiles_split<NW, 4>(x, d, cent + (int64_t)b * K * d, K, crow0, nrows, lds_raw, epi,
+                             b != staged_img);
+    staged_img = b;
     __syncthreads();
-    const int base = qnp[1];
-    for (int i = threadIdx.x; i < qn; i += NW * 64)
-      gqueue[base + i] = SplitEntry{(int32_t)(crow0 + qpx[i]), qcand[i], b};
+    // publish the staged entries with ONE global atomic per chunk; the exact pass
+    // then balances the queue over the whole chip
+    const int qn = min(qnp[0], kSplitLdsList);
+    if (qn > 0) {
+      if (threadIdx.x == 0) qnp[1] = atomicAdd(gcount, qn);
+      __syncthreads();
+      const int base = qnp[1];
+      for (int i = threadIdx.x; i < qn; i += NW * 64)
+        gqueue[base + i] = SplitEntry{(int32_t)(crow0 + qpx[i]), qcand[i], b};
+    }
+    __syncthreads();                        // queue drained before the next chunk resets it
   }
 }
 
@@ -408,7 +425,21 @@ static int launch_assign_split(const float *x, int d, const float *cent, int K,
   constexpr int NW = 8, TPX = NW * 32, kTiles = HSGK_CHUNK / TPX;
   int split = 1;
   while (split < kTiles && (int64_t)max_chunks * split < 2048) split *= 2;
-  const int grid = max_chunks * split;
+  int grid = max_chunks * split;
+  static const int n_cu = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess)
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus > 0 ? cus : 256;
+  }();
+  static const bool persist = [] {
+    const char *e = getenv("HSGK_SPLIT_PERSIST");          // experiment switch, default on
+    return !(e && e[0] == '0');
+  }();
+  if (persist && split == 1 && max_chunks >= 4 * n_cu) {       // enough chunks: one persistent WG per CU
+    split = 0;
+    grid = n_cu;
+  }
   HSGK_CHECK_HIP(hipMemsetAsync(gcount, 0, sizeof(int32_t), s));
   {
     auto kern = assign_split_kernel<NW>;

@@ -64,7 +64,7 @@ template <int NW, int DEPTH, class Epi>
 __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, int d,
                                          const float *__restrict__ table, int kvalid,
                                          int64_t crow0, int nrows, unsigned char *lds_raw,
-                                         Epi &epi) {
+                                         Epi &epi, bool stage_table = true) {
   constexpr int NT = NW * 64;
   constexpr int TPX = NW * 32;
   constexpr int KC = 32;               // columns per staged chunk (2 k-blocks)
@@ -80,8 +80,10 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int j = lane & 31, g = lane >> 5;
 
-  // ---- table block -> bf16 hi / lo planes (zero padded)
-  {
+  // ---- table block -> bf16 hi / lo planes (zero padded); a persistent caller
+  //      skips this while consecutive chunks use the same table
+  if (stage_table) {
+    __syncthreads();                       // nobody still reads the previous table
     uint32_t *z = reinterpret_cast<uint32_t *>(chs);
     for (int i = tid; i < 64 * RS; i += NT) z[i] = 0u;            // 2 planes * 64*RS*2 B / 4
     __syncthreads();
@@ -117,18 +119,30 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
   uint16_t *xw = xs + w * (2 * 2 * 32 * XSB);
   const int lpx = lane >> 4, lf2 = lane & 15;
 
+  // Per-lane element offsets of the LOADS rows a lane touches are the same for
+  // every full tile and every chunk: hoisted out of the loop (the per-step address
+  // is then one wave-uniform base + a 32-bit lane offset).  Only a partial last
+  // tile needs the clamped slow path.
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  int roff[LOADS];
+#pragma unroll
+  for (int i = 0; i < LOADS; ++i) roff[i] = (lpx + 4 * i) * d + 2 * lf2;
+
   auto load_chunk = [&](int gidx, float2 (&pre)[LOADS]) {
     const int tile = gidx / nfull, q = gidx - tile * nfull;
-    const int n = nrows - tile * TPX - w * 32;
-    const float *tb = x + (crow0 + (int64_t)tile * TPX + w * 32) * d + q * KC;
+    const int n = nrows - tile * TPX - wu * 32;
+    const float *tb = x + (crow0 + (int64_t)tile * TPX + wu * 32) * d + q * KC;   // wave-uniform
+    if (n >= 32) {
 #pragma unroll
-    for (int i = 0; i < LOADS; ++i) {
-      const int px = lpx + 4 * i;
-      const int pxc = max(min(px, n - 1), -(tile * TPX + w * 32));
-      // rows past the end re-read the last valid row (clamped address) and are
-      // never written back: an unconditional load keeps the four prefetch sets
-      // on counted vmcnt waits (a select turned into a branch costs vmcnt(0))
-      pre[i] = *reinterpret_cast<const float2 *>(tb + pxc * d + 2 * lf2);
+      for (int i = 0; i < LOADS; ++i) pre[i] = *reinterpret_cast<const float2 *>(tb + roff[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < LOADS; ++i) {
+        // rows past the end re-read a valid row (clamped address) and are never
+        // written back; unconditional loads keep the prefetch sets branch-free
+        const int pxc = max(min(lpx + 4 * i, n - 1), -(tile * TPX + wu * 32));
+        pre[i] = *reinterpret_cast<const float2 *>(tb + pxc * d + 2 * lf2);
+      }
     }
   };
   auto store_chunk = [&](int buf, const float2 (&pre)[LOADS]) {

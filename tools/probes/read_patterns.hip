@@ -45,6 +45,13 @@ __global__ __launch_bounds__(512) void pat(const float *x, long rows, float *sin
   }
   if (s == 123.456f) *sink = s;
 }
+__global__ void fill_random(float *p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long z = (i + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+    p[i] = (float)(int)(z & 0xffff) * (1.0f / 65536.0f) - 0.5f;
+  }
+}
 __global__ void lin(const float4 *p, size_t n, float *sink) {
   float s = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -60,6 +67,7 @@ int main() {
   hipMalloc(&x, bytes);
   hipMalloc(&sink, 4);
   hipMemset(x, 0, bytes);
+  if (getenv("RANDOM_FILL")) { hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, x, bytes / 4); printf("random fill\n"); }
   hipEvent_t a, b;
   hipEventCreate(&a);
   hipEventCreate(&b);
