@@ -315,10 +315,16 @@ __global__ __launch_bounds__(NW * 64) void assign_split_kernel(
   }
   int staged_img = -1;
   for (int c = c_begin; c < c_end; ++c) {
-    const int nrows = min(chunk_rows[c] - part * tps * TPX, tps * TPX);
+    int nrows = min(chunk_rows[c] - part * tps * TPX, tps * TPX);
     if (nrows <= 0) continue;
     const int64_t crow0 = chunk_row0[c] + (int64_t)part * tps * TPX;
     const int b = chunk_img[c];
+    if (split == 0)          // merge the following chunks of the same image (adjacent rows) into
+      while (c + 1 < c_end && chunk_img[c + 1] == b && chunk_row0[c + 1] == crow0 + nrows &&
+             nrows + chunk_rows[c + 1] <= 0xFFFF) {            // one pass: queue offsets are u16
+        nrows += chunk_rows[c + 1];
+        ++c;
+      }
     if (threadIdx.x == 0) qnp[0] = 0;       // ordered before any epilogue by the engine's barrier
     SplitEpi epi{K, nrows, b, crow0, klab, qpx, qcand, qnp, gqueue, gcount};
     score_tiles_split<NW, 4>(x, d, cent + (int64_t)b * K * d, K, crow0, nrows, lds_raw, epi,
