@@ -50,6 +50,10 @@ struct KmeansScratch {
   float *cent;
   void *qrows;         // [max_chunks * HSGK_CHUNK] 12-byte entries: exact re-score queue (split E-step)
   int32_t *qcount;     // [1] queue length
+  _Float16 *xh;        // [rows][half_row_stride(d)] fp16 copy of the rows (first filter level), or null
+  int32_t *q1;         // [B][q1cap] rows the first level left undecided
+  int32_t *q1count;    // [B]
+  int64_t q1cap;
   int max_chunks;
 };
 
@@ -73,23 +77,49 @@ static void carve_kmeans(Carver &cv, int B, int64_t rows_per_img, int d, int K,
   k->cent = cv.take<float>((size_t)B * K * d + 1);
   k->qrows = cv.take<char>(mcs * HSGK_CHUNK * 12);
   k->qcount = cv.take<int32_t>(4);
+  k->xh = nullptr;
+  k->q1 = k->q1count = nullptr;
+  k->q1cap = rows_per_img;
+  if (assign_half_eligible(d, K)) {
+    k->xh = cv.take<_Float16>((size_t)B * rows_per_img * half_row_stride_host(d) + 8);
+    k->q1 = cv.take<int32_t>((size_t)B * rows_per_img + 1);
+    k->q1count = cv.take<int32_t>((size_t)B + 1);
+  }
 }
 
-// unit_rows: rows of x and centroids are L2-normalised (enables the bf16 split
-// filter of the E-step; results are identical either way)
+// HSGK_ASSIGN = "fp32": exact kernel only; "split": bf16x3 filter + exact; default: fp16 filter first
+static int assign_mode() {
+  static const int mode = [] {
+    const char *e = getenv("HSGK_ASSIGN");
+    return !e ? 2 : e[0] == 'f' ? 0 : e[0] == 's' ? 1 : 2;
+  }();
+  return mode;
+}
+
+// unit_rows: rows of x and centroids are L2-normalised (enables the filtered E-step:
+// fp16 copy -> bf16x3 -> exact; results are identical either way).
+// half_ready: the producer of x (the prep kernel) already wrote the fp16 copy k.xh;
+// otherwise a separate pass makes it when the iteration count pays for it.
 static int lloyd(const float *x, int d, int K, int B, int iterations,
                  const KmeansScratch &k, const hsgk_segkm_meta *meta, hipStream_t s,
-                 bool unit_rows = false) {
+                 bool unit_rows = false, bool half_ready = false) {
+  const bool half = unit_rows && assign_mode() == 2 && k.xh && (half_ready || iterations >= 3);
+  if (half && !half_ready) {
+    ProfScope p(HSGK_PROF_PREP, s);
+    if (int rc = launch_to_half_rows(x, k.t, k.max_chunks, d, k.xh, meta, s)) return rc;
+  }
   for (int it = 0; it < iterations; ++it) {
     { ProfScope p(HSGK_PROF_ACCUMULATE, s);
       if (int rc = launch_accumulate(x, d, k.klab, k.t, k.max_chunks, K, k.partial, meta, s)) return rc; }
     { ProfScope p(HSGK_PROF_FINALIZE, s);
       if (int rc = launch_finalize(k.partial, d, K, B, k.t, HSGK_EPS, k.cent, s)) return rc; }
     { ProfScope p(HSGK_PROF_ASSIGN, s);
-      if (int rc = unit_rows
-                       ? launch_assign_fast(x, d, k.cent, K, k.t, k.max_chunks, k.klab, k.best,
-                                            k.qrows, k.qcount, meta, s)
-                       : launch_assign(x, d, k.cent, K, k.t, k.max_chunks, k.klab, k.best, meta, s))
+      if (int rc = half ? launch_assign_half(x, k.xh, d, k.cent, K, B, k.t, k.max_chunks, k.klab, k.q1,
+                                             k.q1count, k.q1cap, k.qrows, k.qcount, meta, s)
+               : unit_rows && assign_mode() >= 1
+                   ? launch_assign_fast(x, d, k.cent, K, k.t, k.max_chunks, k.klab, k.best,
+                                        k.qrows, k.qcount, meta, s)
+                   : launch_assign(x, d, k.cent, K, k.t, k.max_chunks, k.klab, k.best, meta, s))
         return rc; }
   }
   return 0;
@@ -174,6 +204,8 @@ int hsgk_segment_by_kmeans(const hsgk_segkm_args *a, hsgk_stream_t stream) {
   int32_t *scan_tmp = cv.take<int32_t>((size_t)a->table_cap / 2048 + 2);
 
   const bool compact = a->labels != nullptr && a->has_ignore;
+  const bool want_half = assign_mode() == 2 && k.xh && a->iterations >= 1;
+  bool half_ready = false;
   (void)hipGetLastError();   // drop stale errors left by other users of the runtime
   {
     ProfScope p(HSGK_PROF_PREP, s);
@@ -181,10 +213,11 @@ int hsgk_segment_by_kmeans(const hsgk_segkm_args *a, hsgk_stream_t stream) {
                                     tile_cnt, a->meta, s)) return rc;
     if (int rc = launch_build_tables(compact ? tile_cnt : nullptr, a->B, HW, ntiles, tile_off,
                                      k.t, k.max_chunks, a->meta, s)) return rc;
-    if (int rc = launch_prep(*a, compact ? tile_off : nullptr, k.t, k.klab, s)) return rc;
+    if (int rc = launch_prep(*a, compact ? tile_off : nullptr, k.t, k.klab, s,
+                             want_half ? k.xh : nullptr, &half_ready)) return rc;
   }
   if (int rc = lloyd(a->out_embeddings_loc, D, a->K, a->B, a->iterations, k, a->meta, s,
-                     /*unit_rows=*/true)) return rc;
+                     /*unit_rows=*/true, half_ready)) return rc;
   {
     ProfScope p(HSGK_PROF_RELABEL, s);
     if (int rc = launch_relabel(*a, k.t, k.max_chunks, k.klab, table, scan_tmp, s)) return rc;
@@ -271,6 +304,11 @@ int hsgk_lloyd_estep(const float *x, int B, int64_t rows_per_image, int d, int K
   KmeansScratch k; hsgk_segkm_meta *meta;
   if (int rc = lloyd_setup(B, rows_per_image, d, K, workspace, workspace_bytes, &k, &meta, s)) return rc;
   ProfScope p(HSGK_PROF_ASSIGN, s);
+  if (unit_rows == 2 && k.xh) {              // fp16 filter first (the copy is made here)
+    if (int rc = launch_to_half_rows(x, k.t, k.max_chunks, d, k.xh, meta, s)) return rc;
+    return launch_assign_half(x, k.xh, d, centroids, K, B, k.t, k.max_chunks, labels_out, k.q1,
+                              k.q1count, k.q1cap, k.qrows, k.qcount, meta, s);
+  }
   if (unit_rows)
     return launch_assign_fast(x, d, centroids, K, k.t, k.max_chunks, labels_out, k.best, k.qrows,
                               k.qcount, meta, s);

@@ -14,6 +14,7 @@
 #include "accumulate.h"
 #include "score_tiles.h"
 #include "score_tiles_bf16.h"
+#include "score_tiles_f16.h"
 
 namespace hsgk {
 
@@ -216,6 +217,7 @@ struct SplitEpi {
   int *qn;               // LDS counter
   SplitEntry *gqueue;    // global queue (overflow path)
   int32_t *gcount;
+  const int32_t *rowlist;   // gathered pass (second level): row px of the pass is x[rowlist[px]]
   __device__ inline void chunk_begin() const {}
   __device__ inline void chunk_end() const {}
   __device__ inline void drain() const {}
@@ -248,7 +250,8 @@ struct SplitEpi {
     const int px = tile * TPX + w * 32 + j;
     const bool valid = px < nrows;
     const bool amb = valid && !(t1 - t2 > kSplitGap);       // ambiguous (or NaN)
-    if (h == 0 && valid) klab[crow0 + px] = ti;
+    const int64_t grow = !valid ? 0 : rowlist ? (int64_t)rowlist[px] : crow0 + px;
+    if (h == 0 && valid) klab[grow] = ti;
     if (!__any(amb)) return;
     // candidate list of this lane's half, then merged with the partner half
     const float thr = t1 - kSplitGap;
@@ -276,7 +279,7 @@ struct SplitEpi {
         qcand[pos] = cand;
       } else {                                               // staging full: straight to global
         const int g = atomicAdd(gcount, 1);
-        gqueue[g] = SplitEntry{(int32_t)(crow0 + px), cand, img};
+        gqueue[g] = SplitEntry{(int32_t)grow, cand, img};
       }
     }
   }
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(NW * 64) void assign_split_kernel(
         ++c;
       }
     if (threadIdx.x == 0) qnp[0] = 0;       // ordered before any epilogue by the engine's barrier
-    SplitEpi epi{K, nrows, b, crow0, klab, qpx, qcand, qnp, gqueue, gcount};
+    SplitEpi epi{K, nrows, b, crow0, klab, qpx, qcand, qnp, gqueue, gcount, nullptr};
     score_tiles_split<NW, 4>(x, d, cent + (int64_t)b * K * d, K, crow0, nrows, lds_raw, epi,
                              b != staged_img);
     staged_img = b;
@@ -467,6 +470,238 @@ static int launch_assign_split(const float *x, int d, const float *cent, int K,
 bool assign_split_eligible(int d, int K) {
   return K <= 64 && split_shape_ok(d) &&
          split_lds_bytes<8>(d) + (size_t)kSplitLdsList * 6 <= 160 * 1024;
+}
+
+// ===========================================================================
+// Three-level E-step (unit-norm rows, K <= 64):
+//   1. assign_half_kernel       fp16 filter over the fp16 copy of the rows (half the
+//                               HBM bytes); ambiguous rows -> per-image row queue
+//   2. assign_split_rows_kernel bf16x3 filter over the queued fp32 rows (gathered);
+//                               ambiguous rows + candidate sets -> exact queue
+//   3. assign_requeue_rows_kernel  exact fp32 chains of the candidates
+// Labels are identical to assign_kernel (each level only decides rows whose exact
+// argmax is strictly unique within its proven error bound).
+constexpr int kHalfLdsList = 4096;
+
+struct HalfEpi {
+  int K, nrows;
+  int64_t crow0;
+  int32_t *klab;
+  uint16_t *qpx;         // LDS [kHalfLdsList]
+  int *qn;               // LDS counter
+  int32_t *gq;           // this image's row queue (overflow path)
+  int32_t *gcnt;         // its length
+  __device__ inline void operator()(int tile, const f32x16 (&sacc)[2]) const {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int TPX = (int)(blockDim.x >> 1);
+    float b1 = -INFINITY, b2 = -INFINITY;
+    int bi = 0;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = k < K ? sacc[m][r] : -INFINITY;
+        b2 = fmaxf(b2, fminf(b1, v));
+        bi = v > b1 ? k : bi;
+        b1 = fmaxf(b1, v);
+      }
+    const float o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
+    const int oi = __shfl_xor(bi, 32);
+    float t1, t2;
+    int ti;
+    if (o1 > b1) { t1 = o1; ti = oi; t2 = fmaxf(b1, o2); }
+    else { t1 = b1; ti = bi; t2 = fmaxf(o1, b2); }
+    const int px = tile * TPX + w * 32 + j;
+    const bool valid = px < nrows;
+    const bool amb = h == 0 && valid && !(t1 - t2 > kHalfGap);       // ambiguous (or NaN)
+    if (h == 0 && valid) klab[crow0 + px] = ti;     // provisional for ambiguous rows
+    const unsigned long long m = __ballot(amb);
+    if (!m) return;
+    // one LDS atomic per wave-tile
+    int base = 0;
+    if (lane == __builtin_ctzll(m)) base = atomicAdd(qn, __popcll(m));
+    base = __shfl(base, __builtin_ctzll(m));
+    if (amb) {
+      const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (pos < kHalfLdsList) qpx[pos] = (uint16_t)px;
+      else gq[atomicAdd(gcnt, 1)] = (int32_t)(crow0 + px);           // staging full: straight to global
+    }
+  }
+};
+
+template <int NW, int DEPTH>
+__global__ __launch_bounds__(NW * 64) void assign_half_kernel(
+    const _Float16 *__restrict__ xh, int d, const float *__restrict__ cent, int K,
+    const int64_t *__restrict__ chunk_row0, const int32_t *__restrict__ chunk_rows,
+    const int32_t *__restrict__ chunk_img, int32_t *__restrict__ klab,
+    int32_t *__restrict__ q1, int32_t *__restrict__ q1count, int64_t q1cap, int split,
+    const hsgk_segkm_meta *__restrict__ meta) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int TPX = NW * 32;
+  uint16_t *qpx = reinterpret_cast<uint16_t *>(lds_raw + half_lds_bytes<NW>(d));
+  int *qnp = reinterpret_cast<int *>(qpx + kHalfLdsList);
+  // same work split as assign_split_kernel: persistent (split == 0) or 1/split of a chunk
+  int c_begin, c_end, part = 0, tps = HSGK_CHUNK / TPX;
+  if (split == 0) {
+    const int nc = (int)meta->n_chunks;
+    c_begin = (int)(((int64_t)blockIdx.x * nc) / gridDim.x);
+    c_end = (int)(((int64_t)(blockIdx.x + 1) * nc) / gridDim.x);
+  } else {
+    c_begin = blockIdx.x / split;
+    c_end = c_begin < meta->n_chunks ? c_begin + 1 : c_begin;
+    part = blockIdx.x - c_begin * split;
+    tps = (HSGK_CHUNK / TPX + split - 1) / split;
+  }
+  int staged_img = -1;
+  for (int c = c_begin; c < c_end; ++c) {
+    int nrows = min(chunk_rows[c] - part * tps * TPX, tps * TPX);
+    if (nrows <= 0) continue;
+    const int64_t crow0 = chunk_row0[c] + (int64_t)part * tps * TPX;
+    const int b = chunk_img[c];
+    if (split == 0)
+      while (c + 1 < c_end && chunk_img[c + 1] == b && chunk_row0[c + 1] == crow0 + nrows &&
+             nrows + chunk_rows[c + 1] <= 0xFFFF) {
+        nrows += chunk_rows[c + 1];
+        ++c;
+      }
+    if (threadIdx.x == 0) qnp[0] = 0;       // ordered before any epilogue by the engine's barrier
+    HalfEpi epi{K, nrows, crow0, klab, qpx, qnp, q1 + (int64_t)b * q1cap, q1count + b};
+    score_tiles_half<NW, DEPTH>(xh, d, cent + (int64_t)b * K * d, K, crow0, nrows, lds_raw, epi,
+                                b != staged_img);
+    staged_img = b;
+    __syncthreads();
+    const int qn = min(qnp[0], kHalfLdsList);
+    if (qn > 0) {
+      if (threadIdx.x == 0) qnp[1] = atomicAdd(q1count + b, qn);
+      __syncthreads();
+      int32_t *dst = q1 + (int64_t)b * q1cap + qnp[1];
+      for (int i = threadIdx.x; i < qn; i += NW * 64) dst[i] = (int32_t)(crow0 + qpx[i]);
+    }
+    __syncthreads();                        // queue drained before the next pass resets it
+  }
+}
+
+// Level 2: grid (T, B); workgroup (t, b) takes a contiguous slice of image b's queue.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void assign_split_rows_kernel(
+    const float *__restrict__ x, int d, const float *__restrict__ cent, int K,
+    const int32_t *__restrict__ q1, const int32_t *__restrict__ q1count, int64_t q1cap,
+    int32_t *__restrict__ klab, SplitEntry *__restrict__ gqueue, int32_t *__restrict__ gcount) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int TPX = NW * 32;
+  const int b = blockIdx.y;
+  const int n = q1count[b];
+  const int ntile = (n + TPX - 1) / TPX;
+  const int per = (ntile + (int)gridDim.x - 1) / (int)gridDim.x * TPX;
+  const int r0 = blockIdx.x * per;
+  const int nrows = min(per, n - r0);
+  if (nrows <= 0) return;
+  uint16_t *qpx = reinterpret_cast<uint16_t *>(lds_raw + split_lds_bytes<NW>(d));
+  uint32_t *qcand = reinterpret_cast<uint32_t *>(qpx + kSplitLdsList);
+  int *qnp = reinterpret_cast<int *>(qcand + kSplitLdsList);
+  const int32_t *list = q1 + (int64_t)b * q1cap + r0;
+  if (threadIdx.x == 0) qnp[0] = 0;
+  SplitEpi epi{K, nrows, b, 0, klab, qpx, qcand, qnp, gqueue, gcount, list};
+  score_tiles_split<NW, 4, SplitEpi, true>(x, d, cent + (int64_t)b * K * d, K, 0, nrows, lds_raw, epi,
+                                           true, list);
+  __syncthreads();
+  const int qn = min(qnp[0], kSplitLdsList);
+  if (qn > 0) {
+    if (threadIdx.x == 0) qnp[1] = atomicAdd(gcount, qn);
+    __syncthreads();
+    const int base = qnp[1];
+    for (int i = threadIdx.x; i < qn; i += NW * 64)
+      gqueue[base + i] = SplitEntry{list[qpx[i]], qcand[i], b};
+  }
+}
+
+// fp32 rows -> fp16 copy [rows][DH] (RNE, zero padded); workgroup per chunk, one
+// thread per 4 columns
+__global__ __launch_bounds__(256) void to_half_rows_kernel(
+    const float *__restrict__ x, const int64_t *__restrict__ chunk_row0,
+    const int32_t *__restrict__ chunk_rows, int d, _Float16 *__restrict__ xh,
+    const hsgk_segkm_meta *__restrict__ meta) {
+  const int c = blockIdx.x;
+  if (c >= meta->n_chunks) return;
+  const int DH = half_row_stride(d), G = DH / 4;
+  const int64_t row0 = chunk_row0[c];
+  const int total = chunk_rows[c] * G;
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int r = i / G, col = 4 * (i - r * G);
+    const float *src = x + (row0 + r) * d;
+    h4 v;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = col + t < d ? (_Float16)src[col + t] : (_Float16)0.0f;
+    *reinterpret_cast<h4 *>(xh + (row0 + r) * DH + col) = v;
+  }
+}
+
+int launch_to_half_rows(const float *x, const ChunkTable &t, int max_chunks, int d, _Float16 *xh,
+                        const hsgk_segkm_meta *meta, hipStream_t s) {
+  if (max_chunks <= 0) return 0;
+  hipLaunchKernelGGL(to_half_rows_kernel, dim3(max_chunks), dim3(256), 0, s, x, t.chunk_row0,
+                     t.chunk_rows, d, xh, meta);
+  HSGK_LAUNCH_CHECK();
+  return 0;
+}
+
+bool assign_half_eligible(int d, int K) {
+  return assign_split_eligible(d, K) && half_shape_ok(d) &&
+         half_lds_bytes<8>(d) + (size_t)kHalfLdsList * 2 + 16 <= 160 * 1024;
+}
+
+// x: fp32 rows, xh: their fp16 copy.  q1 [B][q1cap] / q1count [B]: per-image queues of
+// the rows the first level could not decide; qrows / qcount: exact queue.
+int launch_assign_half(const float *x, const _Float16 *xh, int d, const float *cent, int K, int B,
+                       const ChunkTable &t, int max_chunks, int32_t *klab, int32_t *q1,
+                       int32_t *q1count, int64_t q1cap, void *qrows, int32_t *qcount,
+                       const hsgk_segkm_meta *meta, hipStream_t s) {
+  if (max_chunks <= 0 || B <= 0) return 0;
+  constexpr int NW = 8, TPX = NW * 32, kTiles = HSGK_CHUNK / TPX;
+  int split = 1;
+  while (split < kTiles && (int64_t)max_chunks * split < 2048) split *= 2;
+  int grid = max_chunks * split;
+  static const int n_cu = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess)
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus > 0 ? cus : 256;
+  }();
+  if (split == 1 && max_chunks >= 4 * n_cu) {
+    split = 0;
+    grid = n_cu;
+  }
+  HSGK_CHECK_HIP(hipMemsetAsync(q1count, 0, sizeof(int32_t) * B, s));
+  HSGK_CHECK_HIP(hipMemsetAsync(qcount, 0, sizeof(int32_t), s));
+  {
+    const bool deep = ((half_row_stride(d) / 64) & 3) == 0;
+    auto kern = deep ? assign_half_kernel<NW, 4> : assign_half_kernel<NW, 2>;
+    const size_t lds = half_lds_bytes<NW>(d) + (size_t)kHalfLdsList * 2 + 16;
+    HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, xh, d, cent, K, t.chunk_row0,
+                       t.chunk_rows, t.chunk_img, klab, q1, q1count, q1cap, split, meta);
+    HSGK_LAUNCH_CHECK();
+  }
+  {
+    // slices of <= 65535 rows (u16 queue offsets): at least q1cap / 32768 workgroups per image
+    int T = 16;
+    while ((int64_t)T * 32768 < q1cap) T *= 2;
+    auto kern = assign_split_rows_kernel<NW>;
+    const size_t lds = split_lds_bytes<NW>(d) + (size_t)kSplitLdsList * 6;
+    HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(T, B), dim3(NW * 64), lds, s, x, d, cent, K, q1, q1count, q1cap,
+                       klab, reinterpret_cast<SplitEntry *>(qrows), qcount);
+    HSGK_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(assign_requeue_rows_kernel, dim3(2048), dim3(256), 0, s, x, d, cent, K, klab,
+                     reinterpret_cast<const SplitEntry *>(qrows), qcount);
+  HSGK_LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_assign_fast(const float *x, int d, const float *cent, int K, const ChunkTable &t,

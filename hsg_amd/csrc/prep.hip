@@ -240,7 +240,8 @@ __global__ __launch_bounds__(256) void prep_kernel(
     const int64_t *__restrict__ img_row0, const int32_t *__restrict__ seed_map,
     float eps, float *__restrict__ emb, float *__restrict__ emb_loc,
     int64_t *__restrict__ labels_out, int32_t *__restrict__ klab,
-    float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out) {
+    float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out,
+    _Float16 *__restrict__ xh) {
   extern __shared__ float lds[];
   const int S = C | 1;
   float *tile = lds;                       // [64][S]
@@ -355,7 +356,8 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(
     const int64_t *__restrict__ img_row0, const int32_t *__restrict__ seed_map,
     float eps, float *__restrict__ emb, float *__restrict__ emb_loc,
     int64_t *__restrict__ labels_out, int32_t *__restrict__ klab,
-    float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out) {
+    float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out,
+    _Float16 *__restrict__ xh) {
   extern __shared__ float lds[];
   float *tile = lds;                       // [64][C] swizzled
   float *nrm1 = lds + 64 * C;              // [64]
@@ -468,6 +470,11 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(
     const float *r = tile + j * C;
     float *eo = emb + row * C;
     float *lo = emb_loc + row * D;
+    // fp16 copy of the emb_loc row for the first E-step filter level: [C + 8] halfs
+    // (C % 64 == 0 here), zero padded
+    _Float16 *ho = xh ? xh + row * (C + 8) : nullptr;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     const int sj = j & 15;
     for (int q = lane; q < NQ; q += 64) {
       const float4 v = *reinterpret_cast<const float4 *>(r + ((q ^ sj) << 2));
@@ -476,12 +483,21 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(
       a.x = v.x / n2; a.y = v.y / n2; c2.x = v.z / n2; c2.y = v.w / n2;
       *reinterpret_cast<float2 *>(lo + 4 * q) = a;
       *reinterpret_cast<float2 *>(lo + 4 * q + 2) = c2;
+      if (ho) {
+        const h4 hv = {(_Float16)a.x, (_Float16)a.y, (_Float16)c2.x, (_Float16)c2.y};
+        *reinterpret_cast<h4 *>(ho + 4 * q) = hv;
+      }
     }
     if (lane == 0) {
       float2 lv;
       lv.x = locv[2 * j] / n2;
       lv.y = locv[2 * j + 1] / n2;
       *reinterpret_cast<float2 *>(lo + C) = lv;
+      if (ho) {
+        const _Float16 z = (_Float16)0.0f;
+        const h8 hv = {(_Float16)lv.x, (_Float16)lv.y, z, z, z, z, z, z};
+        *reinterpret_cast<h8 *>(ho + C) = hv;
+      }
     }
   }
 }
@@ -500,7 +516,8 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     const int64_t *__restrict__ img_row0, const int32_t *__restrict__ seed_map,
     float eps, float *__restrict__ emb, float *__restrict__ emb_loc,
     int64_t *__restrict__ labels_out, int32_t *__restrict__ klab,
-    float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out) {
+    float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out,
+    _Float16 *__restrict__ xh) {
   extern __shared__ float lds[];
   float *tile = lds;                       // [32][C] swizzled
   float *nrm1 = lds + 32 * C;              // [32]
@@ -619,6 +636,11 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     const float *r = tile + j * C;
     float *eo = emb + row * C;
     float *lo = emb_loc + row * D;
+    // fp16 copy of the emb_loc row for the first E-step filter level: [C + 8] halfs
+    // (C % 64 == 0 here), zero padded
+    _Float16 *ho = xh ? xh + row * (C + 8) : nullptr;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     const int sj = j & 15;
     for (int q = lane; q < NQ; q += 64) {
       const float4 v = *reinterpret_cast<const float4 *>(r + ((q ^ sj) << 2));
@@ -627,18 +649,30 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
       a.x = v.x / n2; a.y = v.y / n2; c2.x = v.z / n2; c2.y = v.w / n2;
       *reinterpret_cast<float2 *>(lo + 4 * q) = a;
       *reinterpret_cast<float2 *>(lo + 4 * q + 2) = c2;
+      if (ho) {
+        const h4 hv = {(_Float16)a.x, (_Float16)a.y, (_Float16)c2.x, (_Float16)c2.y};
+        *reinterpret_cast<h4 *>(ho + 4 * q) = hv;
+      }
     }
     if (lane == 0) {
       float2 lv;
       lv.x = locv[2 * j] / n2;
       lv.y = locv[2 * j + 1] / n2;
       *reinterpret_cast<float2 *>(lo + C) = lv;
+      if (ho) {
+        const _Float16 z = (_Float16)0.0f;
+        const h8 hv = {(_Float16)lv.x, (_Float16)lv.y, z, z, z, z, z, z};
+        *reinterpret_cast<h8 *>(ho + C) = hv;
+      }
     }
   }
 }
 
+// xh != nullptr asks for the fp16 copy of the emb_loc rows as well; *wrote_half tells
+// whether the selected kernel provides it (only the 32-pixel fast kernel does).
 int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTable &t,
-                int32_t *klab, hipStream_t s) {
+                int32_t *klab, hipStream_t s, _Float16 *xh, bool *wrote_half) {
+  if (wrote_half) *wrote_half = false;
   const int64_t HW = (int64_t)a.H * a.W;
   const int ntiles = (int)((HW + kTilePix - 1) / kTilePix);
   const bool fast = (a.C % 64) == 0;
@@ -657,6 +691,7 @@ int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTa
     kern = prep_fast32_kernel;
     lds = ((size_t)32 * a.C + 32 + 32 + 64) * 4 + 32 * 8;
     grid.x = 2 * ntiles;
+    if (wrote_half) *wrote_half = xh != nullptr;
   }
   HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -664,7 +699,7 @@ int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTa
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a.embeddings, a.C, HW, ntiles,
                      a.loc, a.loc_batch_stride, a.labels, a.has_ignore, a.ignore_index,
                      tile_off, t.img_row0, a.seed_map, HSGK_EPS, a.out_embeddings,
-                     a.out_embeddings_loc, a.out_labels, klab, a.out_norms, a.out_rowmap);
+                     a.out_embeddings_loc, a.out_labels, klab, a.out_norms, a.out_rowmap, xh);
   HSGK_LAUNCH_CHECK();
   return 0;
 }

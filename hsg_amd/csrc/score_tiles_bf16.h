@@ -60,11 +60,15 @@ __host__ __device__ constexpr size_t split_lds_bytes(int d) {
 
 // Epi(tile, acc): lane (j, h) holds acc[m][r] = approximate score of table row
 // m*32 + (r&3) + 8*(r>>2) + 4*h for x row tile*NW*32 + w*32 + j.
-template <int NW, int DEPTH, class Epi>
+//
+// ROWS: the pass covers the rows x[rowlist[0 .. nrows)] (a gathered subset: the
+// second filter level of the E-step) instead of x[crow0 .. crow0 + nrows).
+template <int NW, int DEPTH, class Epi, bool ROWS = false>
 __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, int d,
                                          const float *__restrict__ table, int kvalid,
                                          int64_t crow0, int nrows, unsigned char *lds_raw,
-                                         Epi &epi, bool stage_table = true) {
+                                         Epi &epi, bool stage_table = true,
+                                         const int32_t *__restrict__ rowlist = nullptr) {
   constexpr int NT = NW * 64;
   constexpr int TPX = NW * 32;
   constexpr int KC = 32;               // columns per staged chunk (2 k-blocks)
@@ -131,6 +135,14 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
   auto load_chunk = [&](int gidx, float2 (&pre)[LOADS]) {
     const int tile = gidx / nfull, q = gidx - tile * nfull;
     const int n = nrows - tile * TPX - wu * 32;
+    if constexpr (ROWS) {
+#pragma unroll
+      for (int i = 0; i < LOADS; ++i) {
+        const int li = min(tile * TPX + wu * 32 + lpx + 4 * i, nrows - 1);   // clamped: never written back
+        pre[i] = *reinterpret_cast<const float2 *>(x + (int64_t)rowlist[li] * d + q * KC + 2 * lf2);
+      }
+      return;
+    }
     const float *tb = x + (crow0 + (int64_t)tile * TPX + wu * 32) * d + q * KC;   // wave-uniform
     if (n >= 32) {
 #pragma unroll
@@ -190,6 +202,7 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
     const int n = nrows - tile * TPX - w * 32;
     const int jc = max(min(j, n - 1), -(tile * TPX + w * 32));
     const float *src = x + (crow0 + (int64_t)tile * TPX + w * 32 + jc) * d;
+    if constexpr (ROWS) src = x + (int64_t)rowlist[min(tile * TPX + w * 32 + j, nrows - 1)] * d;
     const int c0 = tcol0 + 16 * kb + 8 * g;
     uint32_t hw[4], lw[4];
 #pragma unroll

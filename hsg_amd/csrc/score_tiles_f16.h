@@ -1,0 +1,236 @@
+// score_tiles_f16.h -- first-level FILTER of the E-step: scores from an fp16 copy of
+// the rows (half the HBM bytes of the fp32 rows) against an fp16 hi/lo split of the
+// table, two v_mfma_f32_32x32x16_f16 per 16 columns:
+//
+//     acc += ch * xh + cl * xh          xh = fp16(x),  c = ch + cl + ec
+//
+// It decides every row whose two best approximate scores are far enough apart and
+// hands the rest (a few per cent) to the bf16x3 filter (score_tiles_bf16.h, on the
+// fp32 rows), which in turn hands its ambiguous rows to the exact fp32 chain -- the
+// labels stay bit-identical to the canonical arithmetic.
+//
+// Error of the approximate score against the canonical fp32 chain, for unit-norm
+// rows and centroids (|x_i|, |c_i| <= 1):
+//
+//     row rounding   sum |c_i| |x_i - xh_i| <= 2^-11 |x||c| + 2^-25 sum|c_i|  = 4.888e-4
+//        (fp16 RNE: relative 2^-11 in the normal range, absolute 2^-25 below 2^-14;
+//         subnormals are kept by v_cvt_f16_f32 and by the MFMA, tools/probes/mfma_f16_probe.hip)
+//     table residual sum |ec_i| |xh_i|      <= 2^-22 + 2^-25 sum|x_i|          = 7.2e-7
+//     fp16 MFMA accumulation, 2*17 instr.   <= 34 * 2^-21 * 1.01               = 1.64e-5
+//        (products of two fp16 are exact in fp32; measured |D - exact| <= 2^-22.4 sum|terms|
+//         per instruction on gfx950, same probe; 2^-21 used)
+//     fp32 chain of the oracle vs the real number  gamma_258                   = 1.54e-5
+//                                                              E1             <= 5.22e-4
+//
+// kHalfGap = 1.06e-3 > 2 E1: a row whose two best approximate scores differ by more
+// has a strictly unique exact argmax.  (d > 258 only changes gamma_d and the
+// instruction count; half_shape_ok() limits d so that the margin holds.)
+//
+// Layout: rows xh[n][DH] fp16, DH = d rounded up to 8 (16-byte rows, zero padded);
+// table block as two fp16 planes [64][RS] in LDS; every wave streams 32 rows x 64
+// columns (128 B per row) per chunk through a private double-buffered window
+// [32][72] -- no conversion, no barrier in the column loop, four chunks (16 KiB per
+// wave) in flight.
+#pragma once
+#include "common.h"
+#include "score_tiles.h"
+
+namespace hsgk {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr float kHalfGap = 1.06e-3f;
+
+__host__ __device__ constexpr int half_row_stride(int d) { return (d + 7) & ~7; }
+
+// (a, b) -> packed fp16 pair and the packed fp16 pair of the residuals (RNE; the
+// residual subtraction is exact)
+__device__ inline void f16_split2(float a, float b, uint32_t &hi, uint32_t &lo) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {a, b};
+  const f16x2 h = __builtin_convertvector(v, f16x2);
+  const f32x2 r = v - __builtin_convertvector(h, f32x2);
+  const f16x2 l = __builtin_convertvector(r, f16x2);
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+
+template <int NW>
+__host__ __device__ constexpr size_t half_lds_bytes(int d) {
+  return (size_t)2 * 64 * (((half_row_stride(d) + 15) / 16) * 16 + 8) * 2 + (size_t)NW * 2 * 32 * 72 * 2 + 16;
+}
+
+// shapes the fp16 engine accepts: an even number of 64-column chunks (prefetch depth
+// 2 or 4) and few enough columns for the error bound above (gamma_d, MFMA count)
+__host__ __device__ inline bool half_shape_ok(int d) {
+  const int nfull = half_row_stride(d) / 64;
+  return d >= 128 && d <= 320 && (nfull & 1) == 0;
+}
+
+// Epi(tile, acc): lane (j, h) holds acc[m][r] = approximate score of table row
+// m*32 + (r&3) + 8*(r>>2) + 4*h for row tile*NW*32 + w*32 + j of the pass.
+template <int NW, int DEPTH, class Epi>
+__device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xh, int d,
+                                                 const float *__restrict__ table, int kvalid,
+                                                 int64_t crow0, int nrows, unsigned char *lds_raw,
+                                                 Epi &epi, bool stage_table = true) {
+  constexpr int NT = NW * 64;
+  constexpr int TPX = NW * 32;
+  constexpr int KC = 64;               // columns per staged chunk (4 k-blocks)
+  constexpr int XSB = 72;              // fp16 elements per staged row (64 + 8 pad: conflict-free b128 reads)
+  constexpr int LOADS = 8;             // 8-byte loads per lane per chunk (4 rows x 128 B per instruction)
+  const int DH = half_row_stride(d);
+  const int dk16 = ((DH + 15) / 16) * 16;
+  const int RS = dk16 + 8;             // fp16 elements per table row
+
+  uint16_t *chs = reinterpret_cast<uint16_t *>(lds_raw);          // [64][RS]
+  uint16_t *cls = chs + 64 * RS;                                   // [64][RS]
+  uint16_t *xs = cls + 64 * RS;                                    // [NW][2 buf][32][XSB]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int j = lane & 31, g = lane >> 5;
+
+  // ---- table block -> fp16 hi / lo planes (zero padded); a persistent caller
+  //      skips this while consecutive passes use the same table
+  if (stage_table) {
+    __syncthreads();                       // nobody still reads the previous table
+    uint32_t *z = reinterpret_cast<uint32_t *>(chs);
+    for (int i = tid; i < 64 * RS; i += NT) z[i] = 0u;            // 2 planes * 64*RS*2 B / 4
+    __syncthreads();
+    const int total = kvalid * d;
+    for (int f0 = 0; f0 < total; f0 += NT * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = table[min(f0 + tid + NT * u, total - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int f = f0 + tid + NT * u;
+        if (f < total) {
+          const int k = f / d, col = f - k * d;
+          uint32_t hi, lo;
+          f16_split2(v[u], 0.0f, hi, lo);
+          chs[k * RS + col] = (uint16_t)hi;
+          cls[k * RS + col] = (uint16_t)lo;
+        }
+      }
+    }
+  }
+
+  const int nfull = DH / KC;
+  const int tcol0 = nfull * KC;
+  const int tblocks = (DH - tcol0 + 15) / 16;     // tail k-blocks fed from global (<= 4)
+  const int ntile = (nrows + TPX - 1) / TPX;
+  const int nsteps = ntile * nfull;
+
+  uint16_t *xw = xs + w * (2 * 32 * XSB);
+  const int lpx = lane >> 4, lf = lane & 15;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  int roff[LOADS];
+#pragma unroll
+  for (int i = 0; i < LOADS; ++i) roff[i] = (lpx + 4 * i) * DH + 4 * lf;
+
+  auto load_chunk = [&](int gidx, uint2 (&pre)[LOADS]) {
+    const int tile = gidx / nfull, q = gidx - tile * nfull;
+    const int n = nrows - tile * TPX - wu * 32;
+    const _Float16 *tb = xh + (crow0 + (int64_t)tile * TPX + wu * 32) * DH + q * KC;   // wave-uniform
+    if (n >= 32) {
+#pragma unroll
+      for (int i = 0; i < LOADS; ++i) pre[i] = *reinterpret_cast<const uint2 *>(tb + roff[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < LOADS; ++i) {
+        // rows past the end re-read a valid row (clamped address); their scores are
+        // never used.  Unconditional loads keep the prefetch sets branch-free.
+        const int pxc = max(min(lpx + 4 * i, n - 1), -(tile * TPX + wu * 32));
+        pre[i] = *reinterpret_cast<const uint2 *>(tb + pxc * DH + 4 * lf);
+      }
+    }
+  };
+  auto store_chunk = [&](int buf, const uint2 (&pre)[LOADS]) {
+    uint16_t *bp = xw + buf * (32 * XSB);
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i)
+      *reinterpret_cast<uint2 *>(bp + (lpx + 4 * i) * XSB + 4 * lf) = pre[i];
+  };
+
+  f32x16 acc[2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+  };
+  auto kblock = [&](const f16x8 &b, int col0) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const f16x8 ah = *reinterpret_cast<const f16x8 *>(chs + (m * 32 + j) * RS + col0 + 8 * g);
+      const f16x8 al = *reinterpret_cast<const f16x8 *>(cls + (m * 32 + j) * RS + col0 + 8 * g);
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b, acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b, acc[m], 0, 0, 0);
+    }
+  };
+  auto compute_chunk = [&](int buf, int q) {
+    const uint16_t *bp = xw + buf * (32 * XSB) + j * XSB + 8 * g;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const f16x8 b = *reinterpret_cast<const f16x8 *>(bp + kb * 16);
+      kblock(b, q * KC + kb * 16);
+    }
+  };
+  // tail k-block kb of a tile: columns tcol0 + 16 kb + 8 g + 0..7 of row j, one 16-byte
+  // global load (DH is a multiple of 8: the group is whole or absent)
+  auto finish_tile = [&](int tile) {
+    const int n = nrows - tile * TPX - w * 32;
+    const int jc = max(min(j, n - 1), -(tile * TPX + w * 32));
+    const _Float16 *src = xh + (crow0 + (int64_t)tile * TPX + w * 32 + jc) * DH;
+    for (int kb = 0; kb < tblocks; ++kb) {
+      const int c0 = tcol0 + 16 * kb + 8 * g;
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (c0 < DH) v = *reinterpret_cast<const u32x4 *>(src + c0);
+      kblock(__builtin_bit_cast(f16x8, v), tcol0 + 16 * kb);
+    }
+    epi(tile, acc);
+  };
+
+  __syncthreads();                         // table planes visible to all waves
+  zero_acc();
+  // DEPTH register sets rotate, each loaded DEPTH chunks (4 KiB per wave each) ahead
+  // of its use; nfull % DEPTH == 0 (half_shape_ok + the launcher's choice), so a tile
+  // always ends on the last set and there is ONE epilogue site.
+  static_assert(DEPTH == 2 || DEPTH == 4, "prefetch depth");
+  uint2 preA[LOADS], preB[LOADS], preC[DEPTH == 4 ? LOADS : 1], preD[DEPTH == 4 ? LOADS : 1];
+  if (nsteps > 0) load_chunk(0, preA);
+  if (nsteps > 1) load_chunk(1, preB);
+  if constexpr (DEPTH == 4) {
+    if (nsteps > 2) load_chunk(2, preC);
+    if (nsteps > 3) load_chunk(3, preD);
+  }
+  int gidx = 0;
+#define HSGK_HALF_STEP(BUF, PRE, STEP, QQ)                                    \
+  store_chunk(BUF, PRE);                                                      \
+  __builtin_amdgcn_sched_barrier(0);                                          \
+  if (gidx + (STEP) + DEPTH < nsteps) load_chunk(gidx + (STEP) + DEPTH, PRE); \
+  __builtin_amdgcn_sched_barrier(0);                                          \
+  compute_chunk(BUF, QQ);                                                     \
+  __builtin_amdgcn_sched_barrier(0);
+  for (int tile = 0; tile < ntile; ++tile) {
+    for (int q = 0; q < nfull; q += DEPTH, gidx += DEPTH) {
+      if constexpr (DEPTH == 4) {
+        HSGK_HALF_STEP(0, preA, 0, q)
+        HSGK_HALF_STEP(1, preB, 1, q + 1)
+        HSGK_HALF_STEP(0, preC, 2, q + 2)
+        HSGK_HALF_STEP(1, preD, 3, q + 3)
+      } else {
+        HSGK_HALF_STEP(0, preA, 0, q)
+        HSGK_HALF_STEP(1, preB, 1, q + 1)
+      }
+    }
+    finish_tile(tile);
+    zero_acc();
+  }
+#undef HSGK_HALF_STEP
+}
+
+}  // namespace hsgk

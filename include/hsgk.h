@@ -142,7 +142,9 @@ HSGK_API int hsgk_lloyd_mstep(const float *x, int B, int64_t rows_per_image, int
                               const int32_t *labels, float *centroids, void *workspace,
                               size_t workspace_bytes, hsgk_stream_t stream);
 /* unit_rows != 0 promises L2-normalised rows and centroids and enables the
- * bf16-split filter + exact re-score E-step (same labels, faster).            */
+ * filtered E-step (same labels, faster): 1 = bf16-split filter + exact re-score;
+ * 2 = fp16 copy of the rows first (made inside the call; the composite makes it
+ * once per segment_by_kmeans), then bf16-split on the undecided rows, then exact. */
 HSGK_API int hsgk_lloyd_estep(const float *x, int B, int64_t rows_per_image, int d, int K,
                               const float *centroids, int32_t *labels_out, int unit_rows,
                               void *workspace, size_t workspace_bytes, hsgk_stream_t stream);

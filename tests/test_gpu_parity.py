@@ -308,9 +308,10 @@ def test_exchange_list_api_on_gpu_vs_reference(dev):
 @pytest.mark.parametrize('B,HW,C,K', [(2, 4096, 32, 8), (1, 5000, 256, 64), (3, 2500, 128, 37),
                                       (1, 300, 64, 64)])
 def test_split_estep_matches_exact_labels(dev, oracle, B, HW, C, K):
-  """bf16-split filter + exact re-score == canonical fp32 argmax, including
-  exact ties (duplicate centroids), near ties (perturbed copies) and zero
-  centroids; also equals the pure fp32 kernel (unit_rows = 0)."""
+  """Filtered E-steps == canonical fp32 argmax: unit_rows = 2 (fp16 copy ->
+  bf16x3 on the undecided rows -> exact chains), 1 (bf16x3 -> exact) and 0 (pure
+  fp32 kernel), including exact ties (duplicate centroids), near ties at the
+  scale of each filter's gap (perturbed copies) and zero centroids."""
   import torch
   from hsg_amd import _lib
   D = C + 2
@@ -321,7 +322,9 @@ def test_split_estep_matches_exact_labels(dev, oracle, B, HW, C, K):
   if K >= 8:
     cent[:, 3] = cent[:, 1]                                   # exact tie -> first index
     near = cent[:, 2] + np.float32(3e-6) * cent[:, 5]
-    cent[:, 6] = oracle.normalize_embedding(near)             # gap ~1e-6: must be re-scored
+    cent[:, 6] = oracle.normalize_embedding(near)             # gap ~1e-6: must be re-scored exactly
+    mid = cent[:, 4] + np.float32(4e-4) * cent[:, 7]
+    cent[:, 0] = oracle.normalize_embedding(mid)              # gap ~1e-4: beyond the fp16 filter only
     cent[:, K - 1] = 0.0                                      # empty cluster
   L = _lib.lib()
   xt = torch.from_numpy(x).to(dev)
@@ -329,7 +332,7 @@ def test_split_estep_matches_exact_labels(dev, oracle, B, HW, C, K):
   wsb = L.hsgk_lloyd_workspace_bytes(B, HW, D, K)
   ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
   got = {}
-  for unit in (1, 0):
+  for unit in (2, 1, 0):
     out = torch.full((n,), -1, dtype=torch.int32, device=dev)
     _lib.check(L.hsgk_lloyd_estep(xt.data_ptr(), B, HW, D, K, ct.data_ptr(), out.data_ptr(), unit,
                                   ws.data_ptr(), wsb, _lib.stream_ptr()))
@@ -338,6 +341,7 @@ def test_split_estep_matches_exact_labels(dev, oracle, B, HW, C, K):
     ref = oracle.find_nearest_prototypes(x[b * HW:(b + 1) * HW], cent[b])
     assert np.array_equal(got[0][b * HW:(b + 1) * HW], ref), 'fp32 kernel'
     assert np.array_equal(got[1][b * HW:(b + 1) * HW], ref), 'split kernel'
+    assert np.array_equal(got[2][b * HW:(b + 1) * HW], ref), 'fp16 filter first'
 
 
 def test_hierarchy_ops_vs_reference_golden(dev):
