@@ -35,7 +35,7 @@ def test_workspace_queries_run_on_cpu():
   L = _lib.lib()
   a = L.hsgk_segment_by_kmeans_workspace_bytes(4, 32, 64, 64, 8, 32)
   b = L.hsgk_segment_by_kmeans_workspace_bytes(48, 256, 448, 448, 64, 48 * 64)
-  assert 0 < a < b < (1 << 31)
+  assert 0 < a < b < (1 << 33)        # cfg2: 5.6 GB, mostly the fp16 copy of the rows
   assert L.hsgk_kmeans_workspace_bytes(5000, 258, 64) > 0
   assert L.hsgk_lloyd_workspace_bytes(2, 4096, 34, 8) > 0
 
