@@ -66,8 +66,9 @@ __device__ inline void chunk_accumulate(const float *__restrict__ xr, int d, int
     for (int u = 0; u < UNROLL; ++u) {
       const int idx = min(b0 + u, cnt - 1);
       const int r = (int)(mylist[idx] >> 10);
-      if (npass > 0) v[u] = *reinterpret_cast<const gvec_t *>(xr + (int64_t)r * d + lane * VEC);
-      t[u] = on ? xr[(int64_t)r * d + tail0 + lane] : 0.0f;
+      // both loads unconditional (clamped columns; unused values are ignored by fold)
+      v[u] = *reinterpret_cast<const gvec_t *>(xr + (int64_t)r * d + min(lane * VEC, d - VEC));
+      t[u] = xr[(int64_t)r * d + min(tail0 + lane, d - 1)];
     }
   };
   auto fold = [&](int b0, const gvec_t (&v)[UNROLL], const float (&t)[UNROLL]) {
@@ -104,14 +105,16 @@ __device__ inline void chunk_accumulate(const float *__restrict__ xr, int d, int
     }
   };
   if (cnt > 0) {
+    // issue() clamps its row indices, so it runs UNCONDITIONALLY: with a conditional
+    // issue in the loop the compiler's s_waitcnt insertion (pessimistic at control-flow
+    // joins) waits for vmcnt(0) before every fold and the double buffering is lost.
     issue(0, va, ta);
     for (int b0 = 0; b0 < cnt; b0 += 2 * UNROLL) {
-      if (b0 + UNROLL < cnt) issue(b0 + UNROLL, vb, tb);
+      issue(b0 + UNROLL, vb, tb);
       __builtin_amdgcn_sched_barrier(0);
       fold(b0, va, ta);
       __builtin_amdgcn_sched_barrier(0);
-      if (b0 + UNROLL >= cnt) break;
-      if (b0 + 2 * UNROLL < cnt) issue(b0 + 2 * UNROLL, va, ta);
+      issue(b0 + 2 * UNROLL, va, ta);
       __builtin_amdgcn_sched_barrier(0);
       fold(b0 + UNROLL, vb, tb);
       __builtin_amdgcn_sched_barrier(0);

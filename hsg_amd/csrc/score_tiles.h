@@ -215,15 +215,17 @@ __device__ inline void score_tiles(const float *__restrict__ x, int d,
   // software pipeline over global chunk index g = tile * nfull + q: register
   // sets A / B alternate, each loaded two chunks ahead of its use.
   float2 preA[LOADS], preB[LOADS];
+  // (loads are unconditional with clamped indices: a conditional load in the loop makes
+  //  the compiler's s_waitcnt insertion drain the whole queue at the join)
   load_chunk(0, preA);
-  if (nsteps > 1) load_chunk(1, preB);
+  load_chunk(min(1, nsteps - 1), preB);
   preload_tail(0);
   int tile = 0, q = 0;
   for (int g = 0; g < nsteps; g += 2) {
     // ---- even step: set A, LDS buffer 0
     store_chunk(0, preA);
     __builtin_amdgcn_sched_barrier(0);
-    if (g + 2 < nsteps) load_chunk(g + 2, preA);
+    load_chunk(min(g + 2, nsteps - 1), preA);
     __builtin_amdgcn_sched_barrier(0);
     compute_chunk(0, q);
     if (++q == nfull) {
@@ -237,7 +239,7 @@ __device__ inline void score_tiles(const float *__restrict__ x, int d,
     // ---- odd step: set B, LDS buffer 1
     store_chunk(1, preB);
     __builtin_amdgcn_sched_barrier(0);
-    if (g + 3 < nsteps) load_chunk(g + 3, preB);
+    load_chunk(min(g + 3, nsteps - 1), preB);
     __builtin_amdgcn_sched_barrier(0);
     compute_chunk(1, q);
     if (++q == nfull) {

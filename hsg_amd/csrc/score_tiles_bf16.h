@@ -123,15 +123,12 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
   uint16_t *xw = xs + w * (2 * 2 * 32 * XSB);
   const int lpx = lane >> 4, lf2 = lane & 15;
 
-  // Per-lane element offsets of the LOADS rows a lane touches are the same for
-  // every full tile and every chunk: hoisted out of the loop (the per-step address
-  // is then one wave-uniform base + a 32-bit lane offset).  Only a partial last
-  // tile needs the clamped slow path.
   const int wu = __builtin_amdgcn_readfirstlane(w);
-  int roff[LOADS];
-#pragma unroll
-  for (int i = 0; i < LOADS; ++i) roff[i] = (lpx + 4 * i) * d + 2 * lf2;
 
+  // Every load is issued UNCONDITIONALLY with clamped indices: the compiler's s_waitcnt
+  // insertion merges the outstanding-load state pessimistically at control-flow joins,
+  // and one conditional load_chunk in the steady-state loop turns "wait for the oldest
+  // set" into vmcnt(0) -- a full drain of the prefetch queue once per tile.
   auto load_chunk = [&](int gidx, float2 (&pre)[LOADS]) {
     const int tile = gidx / nfull, q = gidx - tile * nfull;
     const int n = nrows - tile * TPX - wu * 32;
@@ -141,19 +138,13 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
         const int li = min(tile * TPX + wu * 32 + lpx + 4 * i, nrows - 1);   // clamped: never written back
         pre[i] = *reinterpret_cast<const float2 *>(x + (int64_t)rowlist[li] * d + q * KC + 2 * lf2);
       }
-      return;
-    }
-    const float *tb = x + (crow0 + (int64_t)tile * TPX + wu * 32) * d + q * KC;   // wave-uniform
-    if (n >= 32) {
-#pragma unroll
-      for (int i = 0; i < LOADS; ++i) pre[i] = *reinterpret_cast<const float2 *>(tb + roff[i]);
     } else {
+      const float *tb = x + (crow0 + (int64_t)tile * TPX + wu * 32) * d + q * KC + 2 * lf2;   // wave-uniform + lane column
 #pragma unroll
       for (int i = 0; i < LOADS; ++i) {
-        // rows past the end re-read a valid row (clamped address) and are never
-        // written back; unconditional loads keep the prefetch sets branch-free
+        // rows past the end re-read a valid row (clamped address) and are never written back
         const int pxc = max(min(lpx + 4 * i, n - 1), -(tile * TPX + wu * 32));
-        pre[i] = *reinterpret_cast<const float2 *>(tb + pxc * d + 2 * lf2);
+        pre[i] = *reinterpret_cast<const float2 *>(tb + pxc * d);
       }
     }
   };
@@ -235,11 +226,12 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
   // ONE epilogue site and the accumulators never move between code paths.
   static_assert(DEPTH == 2 || DEPTH == 4, "prefetch depth");
   float2 preA[LOADS], preB[LOADS], preC[DEPTH == 4 ? LOADS : 1], preD[DEPTH == 4 ? LOADS : 1];
+  if (nsteps <= 0) return;
   load_chunk(0, preA);
-  load_chunk(1, preB);
+  load_chunk(min(1, nsteps - 1), preB);
   if constexpr (DEPTH == 4) {
-    load_chunk(2, preC);
-    load_chunk(3, preD);
+    load_chunk(min(2, nsteps - 1), preC);
+    load_chunk(min(3, nsteps - 1), preD);
   }
   int gidx = 0;
   // epi.chunk_begin() / chunk_end() bracket every chunk's MFMA work: the fused
@@ -248,7 +240,7 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
 #define HSGK_SPLIT_STEP(BUF, PRE, STEP, QQ)                                   \
   store_chunk(BUF, PRE);                                                      \
   __builtin_amdgcn_sched_barrier(0);                                          \
-  if (gidx + (STEP) + DEPTH < nsteps) load_chunk(gidx + (STEP) + DEPTH, PRE); \
+  load_chunk(min(gidx + (STEP) + DEPTH, nsteps - 1), PRE);                    \
   epi.chunk_begin();                                                          \
   __builtin_amdgcn_sched_barrier(0);                                          \
   compute_chunk(BUF, QQ);                                                     \

@@ -22,9 +22,9 @@
 //     fp32 chain of the oracle vs the real number  gamma_258                   = 1.54e-5
 //                                                              E1             <= 5.22e-4
 //
-// kHalfGap = 1.06e-3 > 2 E1: a row whose two best approximate scores differ by more
-// has a strictly unique exact argmax.  (d > 258 only changes gamma_d and the
-// instruction count; half_shape_ok() limits d so that the margin holds.)
+// kHalfGap = 1.08e-3 > 2 E1: a row whose two best approximate scores differ by more
+// has a strictly unique exact argmax.  (Up to d = 320, the limit of half_shape_ok():
+// gamma_320 = 1.9e-5, 2*20 MFMAs = 1.93e-5, sum|c_i| <= 17.9 -> E1 <= 5.28e-4.)
 //
 // Layout: rows xh[n][DH] fp16, DH = d rounded up to 8 (16-byte rows, zero padded);
 // table block as two fp16 planes [64][RS] in LDS; every wave streams 32 rows x 64
@@ -39,7 +39,7 @@ namespace hsgk {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr float kHalfGap = 1.06e-3f;
+constexpr float kHalfGap = 1.08e-3f;
 
 __host__ __device__ constexpr int half_row_stride(int d) { return (d + 7) & ~7; }
 
@@ -62,10 +62,11 @@ __host__ __device__ constexpr size_t half_lds_bytes(int d) {
 }
 
 // shapes the fp16 engine accepts: an even number of 64-column chunks (prefetch depth
-// 2 or 4) and few enough columns for the error bound above (gamma_d, MFMA count)
+// 2 or 4), at most one tail k-block (C % 64 == 0 gives DH = C + 8), and few enough
+// columns for the error bound above (gamma_d, MFMA count)
 __host__ __device__ inline bool half_shape_ok(int d) {
-  const int nfull = half_row_stride(d) / 64;
-  return d >= 128 && d <= 320 && (nfull & 1) == 0;
+  const int DH = half_row_stride(d), nfull = DH / 64;
+  return d >= 128 && d <= 320 && (nfull & 1) == 0 && DH - nfull * 64 <= 16;
 }
 
 // Epi(tile, acc): lane (j, h) holds acc[m][r] = approximate score of table row
@@ -119,32 +120,29 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xh
 
   const int nfull = DH / KC;
   const int tcol0 = nfull * KC;
-  const int tblocks = (DH - tcol0 + 15) / 16;     // tail k-blocks fed from global (<= 4)
+  const bool has_tail = DH > tcol0;               // one tail k-block (half_shape_ok), fed from global
   const int ntile = (nrows + TPX - 1) / TPX;
   const int nsteps = ntile * nfull;
 
   uint16_t *xw = xs + w * (2 * 32 * XSB);
   const int lpx = lane >> 4, lf = lane & 15;
   const int wu = __builtin_amdgcn_readfirstlane(w);
-  int roff[LOADS];
-#pragma unroll
-  for (int i = 0; i < LOADS; ++i) roff[i] = (lpx + 4 * i) * DH + 4 * lf;
 
+  // NOTE on control flow: every load below is issued UNCONDITIONALLY (indices are
+  // clamped instead).  The compiler's s_waitcnt insertion merges the outstanding-load
+  // state pessimistically at control-flow joins: one conditional load_chunk in the
+  // steady-state loop turns every "wait for the oldest set" into vmcnt(0), i.e. a full
+  // drain of the prefetch queue once per tile (seen in the ISA, cost ~25 %).
   auto load_chunk = [&](int gidx, uint2 (&pre)[LOADS]) {
     const int tile = gidx / nfull, q = gidx - tile * nfull;
     const int n = nrows - tile * TPX - wu * 32;
-    const _Float16 *tb = xh + (crow0 + (int64_t)tile * TPX + wu * 32) * DH + q * KC;   // wave-uniform
-    if (n >= 32) {
+    const _Float16 *tb = xh + (crow0 + (int64_t)tile * TPX + wu * 32) * DH + q * KC + 4 * lf;   // wave-uniform + lane column
 #pragma unroll
-      for (int i = 0; i < LOADS; ++i) pre[i] = *reinterpret_cast<const uint2 *>(tb + roff[i]);
-    } else {
-#pragma unroll
-      for (int i = 0; i < LOADS; ++i) {
-        // rows past the end re-read a valid row (clamped address); their scores are
-        // never used.  Unconditional loads keep the prefetch sets branch-free.
-        const int pxc = max(min(lpx + 4 * i, n - 1), -(tile * TPX + wu * 32));
-        pre[i] = *reinterpret_cast<const uint2 *>(tb + pxc * DH + 4 * lf);
-      }
+    for (int i = 0; i < LOADS; ++i) {
+      // rows past the end re-read a valid row (clamped address); their scores are
+      // never used
+      const int pxc = max(min(lpx + 4 * i, n - 1), -(tile * TPX + wu * 32));
+      pre[i] = *reinterpret_cast<const uint2 *>(tb + pxc * DH);
     }
   };
   auto store_chunk = [&](int buf, const uint2 (&pre)[LOADS]) {
@@ -178,19 +176,22 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xh
       kblock(b, q * KC + kb * 16);
     }
   };
-  // tail k-block kb of a tile: columns tcol0 + 16 kb + 8 g + 0..7 of row j, one 16-byte
-  // global load (DH is a multiple of 8: the group is whole or absent)
-  auto finish_tile = [&](int tile) {
+  // tail k-block of a tile: columns tcol0 + 8 g + 0..7 of row j, one 16-byte global
+  // load (DH is a multiple of 8: the group is whole or absent).  It is issued a whole
+  // tile ahead, with the chunk loads, so the epilogue never waits on memory.
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  auto load_tail = [&](int tile, u32x4 &v) {
     const int n = nrows - tile * TPX - w * 32;
     const int jc = max(min(j, n - 1), -(tile * TPX + w * 32));
-    const _Float16 *src = xh + (crow0 + (int64_t)tile * TPX + w * 32 + jc) * DH;
-    for (int kb = 0; kb < tblocks; ++kb) {
-      const int c0 = tcol0 + 16 * kb + 8 * g;
-      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (c0 < DH) v = *reinterpret_cast<const u32x4 *>(src + c0);
-      kblock(__builtin_bit_cast(f16x8, v), tcol0 + 16 * kb);
-    }
+    const int c0 = tcol0 + 8 * g;
+    // unconditional (see the note above); the g = 1 half of a 8-column tail re-reads
+    // the g = 0 group and is zeroed afterwards
+    const int cc = c0 < DH ? c0 : tcol0;
+    v = *reinterpret_cast<const u32x4 *>(xh + (crow0 + (int64_t)tile * TPX + w * 32 + jc) * DH + cc);
+    if (c0 >= DH) v = u32x4{0u, 0u, 0u, 0u};
+  };
+  auto finish_tile = [&](int tile, const u32x4 &tv) {
+    if (has_tail) kblock(__builtin_bit_cast(f16x8, tv), tcol0);
     epi(tile, acc);
   };
 
@@ -201,21 +202,25 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xh
   // always ends on the last set and there is ONE epilogue site.
   static_assert(DEPTH == 2 || DEPTH == 4, "prefetch depth");
   uint2 preA[LOADS], preB[LOADS], preC[DEPTH == 4 ? LOADS : 1], preD[DEPTH == 4 ? LOADS : 1];
-  if (nsteps > 0) load_chunk(0, preA);
-  if (nsteps > 1) load_chunk(1, preB);
+  if (nsteps <= 0) return;              // (uniform; callers pass nrows > 0)
+  load_chunk(0, preA);
+  load_chunk(min(1, nsteps - 1), preB);
   if constexpr (DEPTH == 4) {
-    if (nsteps > 2) load_chunk(2, preC);
-    if (nsteps > 3) load_chunk(3, preD);
+    load_chunk(min(2, nsteps - 1), preC);
+    load_chunk(min(3, nsteps - 1), preD);
   }
+  u32x4 tail_cur = {0u, 0u, 0u, 0u}, tail_next = {0u, 0u, 0u, 0u};
+  if (has_tail) load_tail(0, tail_cur);
   int gidx = 0;
 #define HSGK_HALF_STEP(BUF, PRE, STEP, QQ)                                    \
   store_chunk(BUF, PRE);                                                      \
   __builtin_amdgcn_sched_barrier(0);                                          \
-  if (gidx + (STEP) + DEPTH < nsteps) load_chunk(gidx + (STEP) + DEPTH, PRE); \
+  load_chunk(min(gidx + (STEP) + DEPTH, nsteps - 1), PRE);                    \
   __builtin_amdgcn_sched_barrier(0);                                          \
   compute_chunk(BUF, QQ);                                                     \
   __builtin_amdgcn_sched_barrier(0);
   for (int tile = 0; tile < ntile; ++tile) {
+    if (has_tail) load_tail(min(tile + 1, ntile - 1), tail_next);
     for (int q = 0; q < nfull; q += DEPTH, gidx += DEPTH) {
       if constexpr (DEPTH == 4) {
         HSGK_HALF_STEP(0, preA, 0, q)
@@ -227,7 +232,8 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xh
         HSGK_HALF_STEP(1, preB, 1, q + 1)
       }
     }
-    finish_tile(tile);
+    finish_tile(tile, tail_cur);
+    tail_cur = tail_next;
     zero_acc();
   }
 #undef HSGK_HALF_STEP
