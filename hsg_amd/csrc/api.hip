@@ -50,7 +50,8 @@ struct KmeansScratch {
   float *cent;
   void *qrows;         // [max_chunks * HSGK_CHUNK] 12-byte entries: exact re-score queue (split E-step)
   int32_t *qcount;     // [1] queue length
-  _Float16 *xh;        // [rows][half_row_stride(d)] fp16 copy of the rows (first filter level), or null
+  _Float16 *xh;        // [rows][half_main_cols(d)] fp16 copy of the rows' main columns (first filter level), or null
+  uint32_t *xt;        // [rows] packed fp16 tail columns of the copy
   int32_t *q1;         // [B][q1cap] rows the first level left undecided
   int32_t *q1count;    // [B]
   int64_t q1cap;
@@ -78,10 +79,13 @@ static void carve_kmeans(Carver &cv, int B, int64_t rows_per_img, int d, int K,
   k->qrows = cv.take<char>(mcs * HSGK_CHUNK * 12);
   k->qcount = cv.take<int32_t>(4);
   k->xh = nullptr;
+  k->xt = nullptr;
   k->q1 = k->q1count = nullptr;
   k->q1cap = rows_per_img;
   if (assign_half_eligible(d, K)) {
-    k->xh = cv.take<_Float16>((size_t)B * rows_per_img * half_row_stride_host(d) + 8);
+    // + slack rows: the fp16 engine reads past the end of a pass instead of clamping
+    k->xh = cv.take<_Float16>(((size_t)B * rows_per_img + kHalfSlackRowsHost) * half_main_cols_host(d) + 8);
+    k->xt = cv.take<uint32_t>((size_t)B * rows_per_img + kHalfSlackRowsHost);
     k->q1 = cv.take<int32_t>((size_t)B * rows_per_img + 1);
     k->q1count = cv.take<int32_t>((size_t)B + 1);
   }
@@ -106,7 +110,7 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
   const bool half = unit_rows && assign_mode() == 2 && k.xh && (half_ready || iterations >= 3);
   if (half && !half_ready) {
     ProfScope p(HSGK_PROF_PREP, s);
-    if (int rc = launch_to_half_rows(x, k.t, k.max_chunks, d, k.xh, meta, s)) return rc;
+    if (int rc = launch_to_half_rows(x, k.t, k.max_chunks, d, k.xh, k.xt, meta, s)) return rc;
   }
   for (int it = 0; it < iterations; ++it) {
     { ProfScope p(HSGK_PROF_ACCUMULATE, s);
@@ -114,7 +118,7 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
     { ProfScope p(HSGK_PROF_FINALIZE, s);
       if (int rc = launch_finalize(k.partial, d, K, B, k.t, HSGK_EPS, k.cent, s)) return rc; }
     { ProfScope p(HSGK_PROF_ASSIGN, s);
-      if (int rc = half ? launch_assign_half(x, k.xh, d, k.cent, K, B, k.t, k.max_chunks, k.klab, k.q1,
+      if (int rc = half ? launch_assign_half(x, k.xh, k.xt, d, k.cent, K, B, k.t, k.max_chunks, k.klab, k.q1,
                                              k.q1count, k.q1cap, k.qrows, k.qcount, meta, s)
                : unit_rows && assign_mode() >= 1
                    ? launch_assign_fast(x, d, k.cent, K, k.t, k.max_chunks, k.klab, k.best,
@@ -214,7 +218,7 @@ int hsgk_segment_by_kmeans(const hsgk_segkm_args *a, hsgk_stream_t stream) {
     if (int rc = launch_build_tables(compact ? tile_cnt : nullptr, a->B, HW, ntiles, tile_off,
                                      k.t, k.max_chunks, a->meta, s)) return rc;
     if (int rc = launch_prep(*a, compact ? tile_off : nullptr, k.t, k.klab, s,
-                             want_half ? k.xh : nullptr, &half_ready)) return rc;
+                             want_half ? k.xh : nullptr, k.xt, &half_ready)) return rc;
   }
   if (int rc = lloyd(a->out_embeddings_loc, D, a->K, a->B, a->iterations, k, a->meta, s,
                      /*unit_rows=*/true, half_ready)) return rc;
@@ -305,8 +309,8 @@ int hsgk_lloyd_estep(const float *x, int B, int64_t rows_per_image, int d, int K
   if (int rc = lloyd_setup(B, rows_per_image, d, K, workspace, workspace_bytes, &k, &meta, s)) return rc;
   ProfScope p(HSGK_PROF_ASSIGN, s);
   if (unit_rows == 2 && k.xh) {              // fp16 filter first (the copy is made here)
-    if (int rc = launch_to_half_rows(x, k.t, k.max_chunks, d, k.xh, meta, s)) return rc;
-    return launch_assign_half(x, k.xh, d, centroids, K, B, k.t, k.max_chunks, labels_out, k.q1,
+    if (int rc = launch_to_half_rows(x, k.t, k.max_chunks, d, k.xh, k.xt, meta, s)) return rc;
+    return launch_assign_half(x, k.xh, k.xt, d, centroids, K, B, k.t, k.max_chunks, labels_out, k.q1,
                               k.q1count, k.q1cap, k.qrows, k.qcount, meta, s);
   }
   if (unit_rows)

@@ -76,8 +76,8 @@ int launch_build_tables(const int32_t *tile_cnt, int B, int64_t HW, int ntiles,
                         int32_t *tile_off, ChunkTable t, int max_chunks,
                         hsgk_segkm_meta *meta, hipStream_t s);
 int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off,
-                const ChunkTable &t, int32_t *klab, hipStream_t s, _Float16 *xh = nullptr,
-                bool *wrote_half = nullptr);
+                const ChunkTable &t, int32_t *klab, hipStream_t s, _Float16 *xm = nullptr,
+                uint32_t *xt = nullptr, bool *wrote_half = nullptr);
 int launch_prep_bwd(const float *g_emb, const float *g_emb_loc, const float *emb,
                     const float *emb_loc, const float *norms, const int64_t *rowmap, int B, int C,
                     int H, int W, float eps, float *gx, hipStream_t s);
@@ -100,12 +100,13 @@ int launch_assign_fast(const float *x, int d, const float *cent, int K, const Ch
                        int32_t *qcount, const hsgk_segkm_meta *meta, hipStream_t s);
 
 // three-level E-step (fp16 copy -> bf16x3 on the undecided rows -> exact chains)
-inline int half_row_stride_host(int d) { return (d + 7) & ~7; }
+inline int half_main_cols_host(int d) { return d & ~63; }
+constexpr int kHalfSlackRowsHost = 2 * 8 * 32 + 64;     // == kHalfSlackRows (score_tiles_f16.h)
 bool assign_split_eligible(int d, int K);
 bool assign_half_eligible(int d, int K);
-int launch_to_half_rows(const float *x, const ChunkTable &t, int max_chunks, int d, _Float16 *xh,
-                        const hsgk_segkm_meta *meta, hipStream_t s);
-int launch_assign_half(const float *x, const _Float16 *xh, int d, const float *cent, int K, int B,
+int launch_to_half_rows(const float *x, const ChunkTable &t, int max_chunks, int d, _Float16 *xm,
+                        uint32_t *xt, const hsgk_segkm_meta *meta, hipStream_t s);
+int launch_assign_half(const float *x, const _Float16 *xm, const uint32_t *xt, int d, const float *cent, int K, int B,
                        const ChunkTable &t, int max_chunks, int32_t *klab, int32_t *q1,
                        int32_t *q1count, int64_t q1cap, void *qrows, int32_t *qcount,
                        const hsgk_segkm_meta *meta, hipStream_t s);

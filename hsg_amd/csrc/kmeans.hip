@@ -16,6 +16,8 @@
 #include "score_tiles_bf16.h"
 #include "score_tiles_f16.h"
 
+static_assert(hsgk::kHalfSlackRows == hsgk::kHalfSlackRowsHost, "fp16 copy slack");
+
 namespace hsgk {
 
 
@@ -533,7 +535,8 @@ struct HalfEpi {
 
 template <int NW, int DEPTH>
 __global__ __launch_bounds__(NW * 64) void assign_half_kernel(
-    const _Float16 *__restrict__ xh, int d, const float *__restrict__ cent, int K,
+    const _Float16 *__restrict__ xm, const uint32_t *__restrict__ xt, int d,
+    const float *__restrict__ cent, int K,
     const int64_t *__restrict__ chunk_row0, const int32_t *__restrict__ chunk_rows,
     const int32_t *__restrict__ chunk_img, int32_t *__restrict__ klab,
     int32_t *__restrict__ q1, int32_t *__restrict__ q1count, int64_t q1cap, int split,
@@ -568,7 +571,7 @@ __global__ __launch_bounds__(NW * 64) void assign_half_kernel(
       }
     if (threadIdx.x == 0) qnp[0] = 0;       // ordered before any epilogue by the engine's barrier
     HalfEpi epi{K, nrows, crow0, klab, qpx, qnp, q1 + (int64_t)b * q1cap, q1count + b};
-    score_tiles_half<NW, DEPTH>(xh, d, cent + (int64_t)b * K * d, K, crow0, nrows, lds_raw, epi,
+    score_tiles_half<NW, DEPTH>(xm, xt, d, cent + (int64_t)b * K * d, K, crow0, nrows, lds_raw, epi,
                                 b != staged_img);
     staged_img = b;
     __syncthreads();
@@ -617,33 +620,37 @@ __global__ __launch_bounds__(NW * 64) void assign_split_rows_kernel(
   }
 }
 
-// fp32 rows -> fp16 copy [rows][DH] (RNE, zero padded); workgroup per chunk, one
-// thread per 4 columns
+// fp32 rows -> fp16 copy (RNE): main columns xm[rows][DM], packed tail word xt[rows]
+// (layout: score_tiles_f16.h); workgroup per chunk, one thread per 4 main columns
 __global__ __launch_bounds__(256) void to_half_rows_kernel(
     const float *__restrict__ x, const int64_t *__restrict__ chunk_row0,
-    const int32_t *__restrict__ chunk_rows, int d, _Float16 *__restrict__ xh,
-    const hsgk_segkm_meta *__restrict__ meta) {
+    const int32_t *__restrict__ chunk_rows, int d, _Float16 *__restrict__ xm,
+    uint32_t *__restrict__ xt, const hsgk_segkm_meta *__restrict__ meta) {
   const int c = blockIdx.x;
   if (c >= meta->n_chunks) return;
-  const int DH = half_row_stride(d), G = DH / 4;
+  const int DM = half_main_cols(d), G = DM / 4;
   const int64_t row0 = chunk_row0[c];
-  const int total = chunk_rows[c] * G;
+  const int nr = chunk_rows[c];
   typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-  for (int i = threadIdx.x; i < total; i += 256) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  for (int i = threadIdx.x; i < nr * G; i += 256) {
     const int r = i / G, col = 4 * (i - r * G);
-    const float *src = x + (row0 + r) * d;
-    h4 v;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) v[t] = col + t < d ? (_Float16)src[col + t] : (_Float16)0.0f;
-    *reinterpret_cast<h4 *>(xh + (row0 + r) * DH + col) = v;
+    const f4u v = *reinterpret_cast<const f4u *>(x + (row0 + r) * d + col);
+    *reinterpret_cast<h4 *>(xm + (row0 + r) * DM + col) = __builtin_convertvector(v, h4);
+  }
+  for (int r = threadIdx.x; r < nr; r += 256) {
+    const float *src = x + (row0 + r) * d + DM;
+    const h2 t = {d > DM ? (_Float16)src[0] : (_Float16)0.0f, d > DM + 1 ? (_Float16)src[1] : (_Float16)0.0f};
+    xt[row0 + r] = __builtin_bit_cast(uint32_t, t);
   }
 }
 
-int launch_to_half_rows(const float *x, const ChunkTable &t, int max_chunks, int d, _Float16 *xh,
-                        const hsgk_segkm_meta *meta, hipStream_t s) {
+int launch_to_half_rows(const float *x, const ChunkTable &t, int max_chunks, int d, _Float16 *xm,
+                        uint32_t *xt, const hsgk_segkm_meta *meta, hipStream_t s) {
   if (max_chunks <= 0) return 0;
   hipLaunchKernelGGL(to_half_rows_kernel, dim3(max_chunks), dim3(256), 0, s, x, t.chunk_row0,
-                     t.chunk_rows, d, xh, meta);
+                     t.chunk_rows, d, xm, xt, meta);
   HSGK_LAUNCH_CHECK();
   return 0;
 }
@@ -653,9 +660,9 @@ bool assign_half_eligible(int d, int K) {
          half_lds_bytes<8>(d) + (size_t)kHalfLdsList * 2 + 16 <= 160 * 1024;
 }
 
-// x: fp32 rows, xh: their fp16 copy.  q1 [B][q1cap] / q1count [B]: per-image queues of
-// the rows the first level could not decide; qrows / qcount: exact queue.
-int launch_assign_half(const float *x, const _Float16 *xh, int d, const float *cent, int K, int B,
+// x: fp32 rows, xm / xt: their fp16 copy.  q1 [B][q1cap] / q1count [B]: per-image queues
+// of the rows the first level could not decide; qrows / qcount: exact queue.
+int launch_assign_half(const float *x, const _Float16 *xm, const uint32_t *xt, int d, const float *cent, int K, int B,
                        const ChunkTable &t, int max_chunks, int32_t *klab, int32_t *q1,
                        int32_t *q1count, int64_t q1cap, void *qrows, int32_t *qcount,
                        const hsgk_segkm_meta *meta, hipStream_t s) {
@@ -677,12 +684,12 @@ int launch_assign_half(const float *x, const _Float16 *xh, int d, const float *c
   HSGK_CHECK_HIP(hipMemsetAsync(q1count, 0, sizeof(int32_t) * B, s));
   HSGK_CHECK_HIP(hipMemsetAsync(qcount, 0, sizeof(int32_t), s));
   {
-    const bool deep = ((half_row_stride(d) / 64) & 3) == 0;
+    const bool deep = ((d / 64) & 3) == 0;
     auto kern = deep ? assign_half_kernel<NW, 4> : assign_half_kernel<NW, 2>;
     const size_t lds = half_lds_bytes<NW>(d) + (size_t)kHalfLdsList * 2 + 16;
     HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, xh, d, cent, K, t.chunk_row0,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, xm, xt, d, cent, K, t.chunk_row0,
                        t.chunk_rows, t.chunk_img, klab, q1, q1count, q1cap, split, meta);
     HSGK_LAUNCH_CHECK();
   }

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void prep_kernel(
     float eps, float *__restrict__ emb, float *__restrict__ emb_loc,
     int64_t *__restrict__ labels_out, int32_t *__restrict__ klab,
     float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out,
-    _Float16 *__restrict__ xh) {
+    _Float16 *__restrict__ xh, uint32_t *__restrict__ xt) {
   extern __shared__ float lds[];
   const int S = C | 1;
   float *tile = lds;                       // [64][S]
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(
     float eps, float *__restrict__ emb, float *__restrict__ emb_loc,
     int64_t *__restrict__ labels_out, int32_t *__restrict__ klab,
     float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out,
-    _Float16 *__restrict__ xh) {
+    _Float16 *__restrict__ xh, uint32_t *__restrict__ xt) {
   extern __shared__ float lds[];
   float *tile = lds;                       // [64][C] swizzled
   float *nrm1 = lds + 64 * C;              // [64]
@@ -470,11 +470,12 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(
     const float *r = tile + j * C;
     float *eo = emb + row * C;
     float *lo = emb_loc + row * D;
-    // fp16 copy of the emb_loc row for the first E-step filter level: [C + 8] halfs
-    // (C % 64 == 0 here), zero padded
-    _Float16 *ho = xh ? xh + row * (C + 8) : nullptr;
+    // fp16 copy of the emb_loc row for the first E-step filter level: the C main
+    // columns (C % 64 == 0 here) in xh[row][C], the two location columns packed in
+    // xt[row] (layout: score_tiles_f16.h)
+    _Float16 *ho = xh ? xh + row * C : nullptr;
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const int sj = j & 15;
     for (int q = lane; q < NQ; q += 64) {
       const float4 v = *reinterpret_cast<const float4 *>(r + ((q ^ sj) << 2));
@@ -494,9 +495,8 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(
       lv.y = locv[2 * j + 1] / n2;
       *reinterpret_cast<float2 *>(lo + C) = lv;
       if (ho) {
-        const _Float16 z = (_Float16)0.0f;
-        const h8 hv = {(_Float16)lv.x, (_Float16)lv.y, z, z, z, z, z, z};
-        *reinterpret_cast<h8 *>(ho + C) = hv;
+        const h2 hv = {(_Float16)lv.x, (_Float16)lv.y};
+        xt[row] = __builtin_bit_cast(uint32_t, hv);
       }
     }
   }
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     float eps, float *__restrict__ emb, float *__restrict__ emb_loc,
     int64_t *__restrict__ labels_out, int32_t *__restrict__ klab,
     float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out,
-    _Float16 *__restrict__ xh) {
+    _Float16 *__restrict__ xh, uint32_t *__restrict__ xt) {
   extern __shared__ float lds[];
   float *tile = lds;                       // [32][C] swizzled
   float *nrm1 = lds + 32 * C;              // [32]
@@ -636,11 +636,12 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     const float *r = tile + j * C;
     float *eo = emb + row * C;
     float *lo = emb_loc + row * D;
-    // fp16 copy of the emb_loc row for the first E-step filter level: [C + 8] halfs
-    // (C % 64 == 0 here), zero padded
-    _Float16 *ho = xh ? xh + row * (C + 8) : nullptr;
+    // fp16 copy of the emb_loc row for the first E-step filter level: the C main
+    // columns (C % 64 == 0 here) in xh[row][C], the two location columns packed in
+    // xt[row] (layout: score_tiles_f16.h)
+    _Float16 *ho = xh ? xh + row * C : nullptr;
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const int sj = j & 15;
     for (int q = lane; q < NQ; q += 64) {
       const float4 v = *reinterpret_cast<const float4 *>(r + ((q ^ sj) << 2));
@@ -660,9 +661,8 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
       lv.y = locv[2 * j + 1] / n2;
       *reinterpret_cast<float2 *>(lo + C) = lv;
       if (ho) {
-        const _Float16 z = (_Float16)0.0f;
-        const h8 hv = {(_Float16)lv.x, (_Float16)lv.y, z, z, z, z, z, z};
-        *reinterpret_cast<h8 *>(ho + C) = hv;
+        const h2 hv = {(_Float16)lv.x, (_Float16)lv.y};
+        xt[row] = __builtin_bit_cast(uint32_t, hv);
       }
     }
   }
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
 // xh != nullptr asks for the fp16 copy of the emb_loc rows as well; *wrote_half tells
 // whether the selected kernel provides it (only the 32-pixel fast kernel does).
 int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTable &t,
-                int32_t *klab, hipStream_t s, _Float16 *xh, bool *wrote_half) {
+                int32_t *klab, hipStream_t s, _Float16 *xh, uint32_t *xt, bool *wrote_half) {
   if (wrote_half) *wrote_half = false;
   const int64_t HW = (int64_t)a.H * a.W;
   const int ntiles = (int)((HW + kTilePix - 1) / kTilePix);
@@ -699,7 +699,7 @@ int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTa
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a.embeddings, a.C, HW, ntiles,
                      a.loc, a.loc_batch_stride, a.labels, a.has_ignore, a.ignore_index,
                      tile_off, t.img_row0, a.seed_map, HSGK_EPS, a.out_embeddings,
-                     a.out_embeddings_loc, a.out_labels, klab, a.out_norms, a.out_rowmap, xh);
+                     a.out_embeddings_loc, a.out_labels, klab, a.out_norms, a.out_rowmap, xh, xt);
   HSGK_LAUNCH_CHECK();
   return 0;
 }

@@ -26,8 +26,12 @@
 // has a strictly unique exact argmax.  (Up to d = 320, the limit of half_shape_ok():
 // gamma_320 = 1.9e-5, 2*20 MFMAs = 1.93e-5, sum|c_i| <= 17.9 -> E1 <= 5.28e-4.)
 //
-// Layout: rows xh[n][DH] fp16, DH = d rounded up to 8 (16-byte rows, zero padded);
-// table block as two fp16 planes [64][RS] in LDS; every wave streams 32 rows x 64
+// Layout of the fp16 copy: the first DM = 64 * (d / 64) columns of every row in
+// xm[n][DM] -- rows are whole 128-byte lines, which streams 8 % faster than the
+// 1032 / 528-byte strides (tools/probes/read_patterns2.hip: 6.3 vs 5.8 TB/s) -- and
+// the remaining d - DM <= 2 columns (the location features of emb_loc) packed in
+// xt[n] (one 32-bit word per row: a 32-row tile reads ONE line instead of 32).
+// Table block as two fp16 planes [64][RS] in LDS; every wave streams 32 rows x 64
 // columns (128 B per row) per chunk through a private double-buffered window
 // [32][72] -- no conversion, no barrier in the column loop, four chunks (16 KiB per
 // wave) in flight.
@@ -41,7 +45,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr float kHalfGap = 1.08e-3f;
 
-__host__ __device__ constexpr int half_row_stride(int d) { return (d + 7) & ~7; }
+// rows the engine may read past the end of a pass (partial last tile + look-ahead):
+// the fp16 copy is allocated with this much slack
+constexpr int kHalfSlackRows = 2 * 8 * 32 + 64;
+
+// columns of a row kept in the main array / in the packed tail word
+__host__ __device__ constexpr int half_main_cols(int d) { return d & ~63; }
 
 // (a, b) -> packed fp16 pair and the packed fp16 pair of the residuals (RNE; the
 // residual subtraction is exact)
@@ -58,21 +67,22 @@ __device__ inline void f16_split2(float a, float b, uint32_t &hi, uint32_t &lo) 
 
 template <int NW>
 __host__ __device__ constexpr size_t half_lds_bytes(int d) {
-  return (size_t)2 * 64 * (((half_row_stride(d) + 15) / 16) * 16 + 8) * 2 + (size_t)NW * 2 * 32 * 72 * 2 + 16;
+  return (size_t)2 * 64 * (half_main_cols(d) + 16 + 8) * 2 + (size_t)NW * 2 * 32 * 72 * 2 + 16;
 }
 
 // shapes the fp16 engine accepts: an even number of 64-column chunks (prefetch depth
-// 2 or 4), at most one tail k-block (C % 64 == 0 gives DH = C + 8), and few enough
+// 2 or 4), at most two tail columns (d = C + 2 with C % 64 == 0), and few enough
 // columns for the error bound above (gamma_d, MFMA count)
 __host__ __device__ inline bool half_shape_ok(int d) {
-  const int DH = half_row_stride(d), nfull = DH / 64;
-  return d >= 128 && d <= 320 && (nfull & 1) == 0 && DH - nfull * 64 <= 16;
+  const int nfull = d / 64;
+  return d >= 128 && d <= 322 && (nfull & 1) == 0 && d - nfull * 64 <= 2;
 }
 
 // Epi(tile, acc): lane (j, h) holds acc[m][r] = approximate score of table row
 // m*32 + (r&3) + 8*(r>>2) + 4*h for row tile*NW*32 + w*32 + j of the pass.
 template <int NW, int DEPTH, class Epi>
-__device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xh, int d,
+__device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm,
+                                                 const uint32_t *__restrict__ xt, int d,
                                                  const float *__restrict__ table, int kvalid,
                                                  int64_t crow0, int nrows, unsigned char *lds_raw,
                                                  Epi &epi, bool stage_table = true) {
@@ -81,9 +91,8 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xh
   constexpr int KC = 64;               // columns per staged chunk (4 k-blocks)
   constexpr int XSB = 72;              // fp16 elements per staged row (64 + 8 pad: conflict-free b128 reads)
   constexpr int LOADS = 8;             // 8-byte loads per lane per chunk (4 rows x 128 B per instruction)
-  const int DH = half_row_stride(d);
-  const int dk16 = ((DH + 15) / 16) * 16;
-  const int RS = dk16 + 8;             // fp16 elements per table row
+  const int DM = half_main_cols(d);
+  const int RS = DM + 16 + 8;          // fp16 elements per table row (main + one tail k-block + pad)
 
   uint16_t *chs = reinterpret_cast<uint16_t *>(lds_raw);          // [64][RS]
   uint16_t *cls = chs + 64 * RS;                                   // [64][RS]
@@ -118,9 +127,9 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xh
     }
   }
 
-  const int nfull = DH / KC;
-  const int tcol0 = nfull * KC;
-  const bool has_tail = DH > tcol0;               // one tail k-block (half_shape_ok), fed from global
+  const int nfull = DM / KC;
+  const int tcol0 = DM;
+  const bool has_tail = d > DM;                   // <= 2 tail columns (half_shape_ok), fed from xt
   const int ntile = (nrows + TPX - 1) / TPX;
   const int nsteps = ntile * nfull;
 
@@ -128,22 +137,27 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xh
   const int lpx = lane >> 4, lf = lane & 15;
   const int wu = __builtin_amdgcn_readfirstlane(w);
 
-  // NOTE on control flow: every load below is issued UNCONDITIONALLY (indices are
-  // clamped instead).  The compiler's s_waitcnt insertion merges the outstanding-load
-  // state pessimistically at control-flow joins: one conditional load_chunk in the
-  // steady-state loop turns every "wait for the oldest set" into vmcnt(0), i.e. a full
-  // drain of the prefetch queue once per tile (seen in the ISA, cost ~25 %).
-  auto load_chunk = [&](int gidx, uint2 (&pre)[LOADS]) {
-    const int tile = gidx / nfull, q = gidx - tile * nfull;
-    const int n = nrows - tile * TPX - wu * 32;
-    const _Float16 *tb = xh + (crow0 + (int64_t)tile * TPX + wu * 32) * DH + q * KC + 4 * lf;   // wave-uniform + lane column
+  // NOTE on control flow: every load below is issued UNCONDITIONALLY.  The compiler's
+  // s_waitcnt insertion merges the outstanding-load state pessimistically at
+  // control-flow joins: one conditional load_chunk in the steady-state loop turns every
+  // "wait for the oldest set" into vmcnt(0), i.e. a full drain of the prefetch queue
+  // once per tile (seen in the ISA, cost ~25 %).
+  //
+  // No clamping either: the caller guarantees kHalfSlackRows readable rows past the
+  // last row of xm / xt (the library's own buffers), so a partial last tile and the
+  // DEPTH look-ahead chunks past the end simply read on; those rows' scores are never
+  // used (an x row only feeds its own accumulator column).  The chunk address is then
+  // one wave-uniform 64-bit base, advanced incrementally, plus constant lane offsets.
+  int roff[LOADS];
 #pragma unroll
-    for (int i = 0; i < LOADS; ++i) {
-      // rows past the end re-read a valid row (clamped address); their scores are
-      // never used
-      const int pxc = max(min(lpx + 4 * i, n - 1), -(tile * TPX + wu * 32));
-      pre[i] = *reinterpret_cast<const uint2 *>(tb + pxc * DH);
-    }
+  for (int i = 0; i < LOADS; ++i) roff[i] = (lpx + 4 * i) * DM + 4 * lf;
+  const _Float16 *wbase = xm + (crow0 + wu * 32) * DM;        // wave-uniform
+  int ld_tile = 0, ld_q = 0;                                    // next chunk to load (uniform)
+  auto load_next = [&](uint2 (&pre)[LOADS]) {
+    const _Float16 *tb = wbase + (int64_t)ld_tile * (TPX * DM) + ld_q * KC;
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) pre[i] = *reinterpret_cast<const uint2 *>(tb + roff[i]);
+    if (++ld_q == nfull) { ld_q = 0; ++ld_tile; }
   };
   auto store_chunk = [&](int buf, const uint2 (&pre)[LOADS]) {
     uint16_t *bp = xw + buf * (32 * XSB);
@@ -176,22 +190,18 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xh
       kblock(b, q * KC + kb * 16);
     }
   };
-  // tail k-block of a tile: columns tcol0 + 8 g + 0..7 of row j, one 16-byte global
-  // load (DH is a multiple of 8: the group is whole or absent).  It is issued a whole
-  // tile ahead, with the chunk loads, so the epilogue never waits on memory.
+  // tail k-block of a tile: the packed tail word of row j (k = 0, 1 of the block; the
+  // rest of the block and the g = 1 half are zero).  One line per wave tile, issued a
+  // whole tile ahead with the chunk loads, so the epilogue never waits on memory.
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  auto load_tail = [&](int tile, u32x4 &v) {
-    const int n = nrows - tile * TPX - w * 32;
-    const int jc = max(min(j, n - 1), -(tile * TPX + w * 32));
-    const int c0 = tcol0 + 8 * g;
-    // unconditional (see the note above); the g = 1 half of a 8-column tail re-reads
-    // the g = 0 group and is zeroed afterwards
-    const int cc = c0 < DH ? c0 : tcol0;
-    v = *reinterpret_cast<const u32x4 *>(xh + (crow0 + (int64_t)tile * TPX + w * 32 + jc) * DH + cc);
-    if (c0 >= DH) v = u32x4{0u, 0u, 0u, 0u};
+  auto load_tail = [&](int tile, uint32_t &v) {
+    v = xt[crow0 + (int64_t)tile * TPX + w * 32 + j];         // unconditional, unclamped (see above)
   };
-  auto finish_tile = [&](int tile, const u32x4 &tv) {
-    if (has_tail) kblock(__builtin_bit_cast(f16x8, tv), tcol0);
+  auto finish_tile = [&](int tile, uint32_t tw) {
+    if (has_tail) {
+      const u32x4 tv = {g == 0 ? tw : 0u, 0u, 0u, 0u};
+      kblock(__builtin_bit_cast(f16x8, tv), tcol0);
+    }
     epi(tile, acc);
   };
 
@@ -203,25 +213,24 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xh
   static_assert(DEPTH == 2 || DEPTH == 4, "prefetch depth");
   uint2 preA[LOADS], preB[LOADS], preC[DEPTH == 4 ? LOADS : 1], preD[DEPTH == 4 ? LOADS : 1];
   if (nsteps <= 0) return;              // (uniform; callers pass nrows > 0)
-  load_chunk(0, preA);
-  load_chunk(min(1, nsteps - 1), preB);
+  load_next(preA);
+  load_next(preB);
   if constexpr (DEPTH == 4) {
-    load_chunk(min(2, nsteps - 1), preC);
-    load_chunk(min(3, nsteps - 1), preD);
+    load_next(preC);
+    load_next(preD);
   }
-  u32x4 tail_cur = {0u, 0u, 0u, 0u}, tail_next = {0u, 0u, 0u, 0u};
+  uint32_t tail_cur = 0u, tail_next = 0u;
   if (has_tail) load_tail(0, tail_cur);
-  int gidx = 0;
 #define HSGK_HALF_STEP(BUF, PRE, STEP, QQ)                                    \
   store_chunk(BUF, PRE);                                                      \
   __builtin_amdgcn_sched_barrier(0);                                          \
-  load_chunk(min(gidx + (STEP) + DEPTH, nsteps - 1), PRE);                    \
+  load_next(PRE);                                                             \
   __builtin_amdgcn_sched_barrier(0);                                          \
   compute_chunk(BUF, QQ);                                                     \
   __builtin_amdgcn_sched_barrier(0);
   for (int tile = 0; tile < ntile; ++tile) {
-    if (has_tail) load_tail(min(tile + 1, ntile - 1), tail_next);
-    for (int q = 0; q < nfull; q += DEPTH, gidx += DEPTH) {
+    if (has_tail) load_tail(tile + 1, tail_next);
+    for (int q = 0; q < nfull; q += DEPTH) {
       if constexpr (DEPTH == 4) {
         HSGK_HALF_STEP(0, preA, 0, q)
         HSGK_HALF_STEP(1, preB, 1, q + 1)

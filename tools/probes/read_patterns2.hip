@@ -70,7 +70,7 @@ int main() {
     printf("%-58s RB %4d  %.3f ms  %.0f GB/s\n", name, RB, ms / 5, bytes / (ms / 5) / 1e6);
   };
 #define T(name, L, NW, GRID, RB) time(name, RB, [&] { hipLaunchKernelGGL((pat<L, NW>), dim3(GRID), dim3(NW * 64), 0, 0, x, rows, RB, sink); })
-  for (int RB : {1032, 528}) {
+  for (int RB : {1032, 1024, 528, 512}) {
     T("round-robin tiles, 8 waves, 256 WGs", 0, 8, 256, RB);
     T("round-robin tiles, 8 waves, 512 WGs", 0, 8, 512, RB);
     T("contiguous range per WG, 8 waves, 256 WGs", 1, 8, 256, RB);
