@@ -11,7 +11,7 @@ __device__ inline int owner_wave(int label) {
   return (label ^ (label >> 2) ^ (label >> 4) ^ (label >> 6)) & (NW - 1);
 }
 
-// Accumulates the rows of one chunk whose label lies in [lo, lo+cnt_lab) into
+// Accumulates the rows of one chunk (n <= HSGK_CHUNK) whose label lies in [lo, lo+cnt_lab) into
 // the zeroed LDS table sums[cnt_lab][DS].  Shared by the k-means M-step
 // (int32 working labels, window = cluster block) and segment_reduce (int64
 // labels, window = the chunk's own label range).
@@ -24,12 +24,22 @@ __device__ inline void chunk_accumulate(const float *__restrict__ xr, int d, int
   typedef float lvec_t __attribute__((ext_vector_type(VEC), aligned(4 * VEC))); // LDS: natural
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 
+  // ---- the chunk's labels, window-relative, 64 rows per register (n <= HSGK_CHUNK):
+  //      all loads are issued back to back (a load-use loop here costs one exposed
+  //      memory latency per 64 rows, twice)
+  constexpr int NL = HSGK_CHUNK / 64;
+  int lw[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int r = 64 * i + lane;
+    const int64_t l = (int64_t)lab[min(r, n - 1)] - lo;
+    lw[i] = (r < n && l >= 0 && l < cnt_lab) ? (int)l : -1;
+  }
   // ---- pass 1: every wave counts the rows it owns; pass 2: ordered row list
   int cnt = 0;
-  for (int base = 0; base < n; base += 64) {
-    int64_t l = -1;
-    if (base + lane < n) l = (int64_t)lab[base + lane] - lo;
-    const bool mine = l >= 0 && l < cnt_lab && owner_wave<NW>((int)l) == w;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const bool mine = lw[i] >= 0 && owner_wave<NW>(lw[i]) == w;
     cnt += __popcll(__ballot(mine));
   }
   if (lane == 0) wcount[w] = cnt;
@@ -38,12 +48,11 @@ __device__ inline void chunk_accumulate(const float *__restrict__ xr, int d, int
   for (int i = 0; i < w; ++i) lbeg += wcount[i];
   {
     int pos = lbeg;
-    for (int base = 0; base < n; base += 64) {
-      int64_t l = -1;
-      if (base + lane < n) l = (int64_t)lab[base + lane] - lo;
-      const bool mine = l >= 0 && l < cnt_lab && owner_wave<NW>((int)l) == w;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const bool mine = lw[i] >= 0 && owner_wave<NW>(lw[i]) == w;
       const unsigned long long m = __ballot(mine);
-      if (mine) rlist[pos + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)(base + lane) << 10) | (uint32_t)l;
+      if (mine) rlist[pos + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)(64 * i + lane) << 10) | (uint32_t)lw[i];
       pos += __popcll(m);
     }
   }
