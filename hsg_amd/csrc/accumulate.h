@@ -12,14 +12,15 @@ __device__ inline int owner_wave(int label) {
 }
 
 // Accumulates the rows of one chunk (n <= HSGK_CHUNK) whose label lies in [lo, lo+cnt_lab) into
-// the zeroed LDS table sums[cnt_lab][DS].  Shared by the k-means M-step
+// the zeroed LDS table sums[cnt_lab][DS]; present[l] (optional, LDS, zeroed by the
+// caller) is set for every label that owns at least one row.  Shared by the k-means M-step
 // (int32 working labels, window = cluster block) and segment_reduce (int64
 // labels, window = the chunk's own label range).
 template <int VEC, int UNROLL, typename LabT, int NW = 4>
 __device__ inline void chunk_accumulate(const float *__restrict__ xr, int d, int DS,
                                         const LabT *__restrict__ lab, int n, int64_t lo,
                                         int cnt_lab, float *sums, uint32_t *rlist,
-                                        int *wcount) {
+                                        int *wcount, unsigned char *present = nullptr) {
   typedef float gvec_t __attribute__((ext_vector_type(VEC), aligned(4)));       // global: dword aligned
   typedef float lvec_t __attribute__((ext_vector_type(VEC), aligned(4 * VEC))); // LDS: natural
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -52,7 +53,10 @@ __device__ inline void chunk_accumulate(const float *__restrict__ xr, int d, int
     for (int i = 0; i < NL; ++i) {
       const bool mine = lw[i] >= 0 && owner_wave<NW>(lw[i]) == w;
       const unsigned long long m = __ballot(mine);
-      if (mine) rlist[pos + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)(64 * i + lane) << 10) | (uint32_t)lw[i];
+      if (mine) {
+        rlist[pos + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)(64 * i + lane) << 10) | (uint32_t)lw[i];
+        if (present) present[lw[i]] = 1;          // (zeroed by the caller; benign same-value race)
+      }
       pos += __popcll(m);
     }
   }

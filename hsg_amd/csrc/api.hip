@@ -47,6 +47,7 @@ struct KmeansScratch {
   int32_t *klab;
   float *best;
   float *partial;
+  unsigned char *pmask;    // [max_chunks][K] which partial rows exist
   float *cent;
   void *qrows;         // [max_chunks * HSGK_CHUNK] 12-byte entries: exact re-score queue (split E-step)
   int32_t *qcount;     // [1] queue length
@@ -75,6 +76,7 @@ static void carve_kmeans(Carver &cv, int B, int64_t rows_per_img, int d, int K,
   k->klab = cv.take<int32_t>((size_t)B * rows_per_img + 1);
   k->best = cv.take<float>((size_t)B * rows_per_img + 1);
   k->partial = cv.take<float>(mcs * K * d);
+  k->pmask = cv.take<unsigned char>(mcs * K + 4);
   k->cent = cv.take<float>((size_t)B * K * d + 1);
   k->qrows = cv.take<char>(mcs * HSGK_CHUNK * 12);
   k->qcount = cv.take<int32_t>(4);
@@ -114,9 +116,9 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
   }
   for (int it = 0; it < iterations; ++it) {
     { ProfScope p(HSGK_PROF_ACCUMULATE, s);
-      if (int rc = launch_accumulate(x, d, k.klab, k.t, k.max_chunks, K, k.partial, meta, s)) return rc; }
+      if (int rc = launch_accumulate(x, d, k.klab, k.t, k.max_chunks, K, k.partial, k.pmask, meta, s)) return rc; }
     { ProfScope p(HSGK_PROF_FINALIZE, s);
-      if (int rc = launch_finalize(k.partial, d, K, B, k.t, HSGK_EPS, k.cent, s)) return rc; }
+      if (int rc = launch_finalize(k.partial, k.pmask, d, K, B, k.t, HSGK_EPS, k.cent, s)) return rc; }
     { ProfScope p(HSGK_PROF_ASSIGN, s);
       if (int rc = half ? launch_assign_half(x, k.xh, k.xt, d, k.cent, K, B, k.t, k.max_chunks, k.klab, k.q1,
                                              k.q1count, k.q1cap, k.qrows, k.qcount, meta, s)
@@ -296,9 +298,9 @@ int hsgk_lloyd_mstep(const float *x, int B, int64_t rows_per_image, int d, int K
   KmeansScratch k; hsgk_segkm_meta *meta;
   if (int rc = lloyd_setup(B, rows_per_image, d, K, workspace, workspace_bytes, &k, &meta, s)) return rc;
   { ProfScope p(HSGK_PROF_ACCUMULATE, s);
-    if (int rc = launch_accumulate(x, d, labels, k.t, k.max_chunks, K, k.partial, meta, s)) return rc; }
+    if (int rc = launch_accumulate(x, d, labels, k.t, k.max_chunks, K, k.partial, k.pmask, meta, s)) return rc; }
   ProfScope p(HSGK_PROF_FINALIZE, s);
-  return launch_finalize(k.partial, d, K, B, k.t, HSGK_EPS, centroids, s);
+  return launch_finalize(k.partial, k.pmask, d, K, B, k.t, HSGK_EPS, centroids, s);
 }
 
 int hsgk_lloyd_estep(const float *x, int B, int64_t rows_per_image, int d, int K,

@@ -84,11 +84,12 @@ int launch_prep_bwd(const float *g_emb, const float *g_emb_loc, const float *emb
 int launch_normalize_rows(const float *x, int64_t n, int d, float eps, float *out,
                           float *norms, hipStream_t s);
 
+// partial [chunks][K][d] holds only the rows flagged in pmask [chunks][K]
 int launch_accumulate(const float *x, int d, const int32_t *klab,
                       const ChunkTable &t, int max_chunks, int K, float *partial,
-                      const hsgk_segkm_meta *meta, hipStream_t s);
-int launch_finalize(const float *partial, int d, int K, int B, const ChunkTable &t,
-                    float eps, float *cent, hipStream_t s);
+                      unsigned char *pmask, const hsgk_segkm_meta *meta, hipStream_t s);
+int launch_finalize(const float *partial, const unsigned char *pmask, int d, int K, int B,
+                    const ChunkTable &t, float eps, float *cent, hipStream_t s);
 int launch_assign(const float *x, int d, const float *cent, int K,
                   const ChunkTable &t, int max_chunks, int32_t *klab, float *best,
                   const hsgk_segkm_meta *meta, hipStream_t s);

@@ -38,9 +38,9 @@ template <int VEC, int UNROLL, int NW>
 __global__ __launch_bounds__(NW * 64) void accumulate_kernel(
     const float *__restrict__ x, int d, const int32_t *__restrict__ klab,
     const int64_t *__restrict__ chunk_row0, const int32_t *__restrict__ chunk_rows,
-    int K, int kb0, int kbn, float *__restrict__ partial,
+    int K, int kb0, int kbn, float *__restrict__ partial, unsigned char *__restrict__ pmask,
     const hsgk_segkm_meta *__restrict__ meta) {
-  extern __shared__ float sums[];   // [kbn][DS] then the row list
+  extern __shared__ float sums[];   // [kbn][DS], the row list, the presence flags
   __shared__ int wcount[8];
   const int c = blockIdx.x;
   if (c >= meta->n_chunks) return;
@@ -48,25 +48,34 @@ __global__ __launch_bounds__(NW * 64) void accumulate_kernel(
   const int DS = (d + VEC - 1) / VEC * VEC;
   const int tot = kbn * DS;
   uint32_t *rlist = reinterpret_cast<uint32_t *>(sums + tot);   // [HSGK_CHUNK] (row << 10 | label)
+  unsigned char *present = reinterpret_cast<unsigned char *>(rlist + HSGK_CHUNK);   // [kbn rounded up to 4]
   for (int i = tid; i < tot; i += NW * 64) sums[i] = 0.0f;
+  for (int i = tid; i < (kbn + 3) / 4; i += NW * 64) reinterpret_cast<uint32_t *>(present)[i] = 0u;
+  // (chunk_accumulate's barrier orders the zeroing before the first fold / flag)
   const int64_t row0 = chunk_row0[c];
   chunk_accumulate<VEC, UNROLL, int32_t, NW>(x + row0 * d, d, DS, klab + row0, chunk_rows[c], kb0,
-                                             kbn, sums, rlist, wcount);
+                                             kbn, sums, rlist, wcount, present);
   __syncthreads();
+  // only the clusters that own rows of this chunk are written; pmask tells finalize
+  // which partial rows exist (a skipped row is an exact +0.0 sum: adding it is the identity)
   float *out = partial + ((int64_t)c * K + kb0) * d;
-  for (int k = w; k < kbn; k += NW)
-    for (int i = lane; i < d; i += 64) out[k * d + i] = sums[k * DS + i];
+  for (int k = w; k < kbn; k += NW) {
+    const bool has = present[k] != 0;
+    if (lane == 0) pmask[(int64_t)c * K + kb0 + k] = has ? 1 : 0;
+    if (has)
+      for (int i = lane; i < d; i += 64) out[k * d + i] = sums[k * DS + i];
+  }
 }
 
 int launch_accumulate(const float *x, int d, const int32_t *klab, const ChunkTable &t,
-                      int max_chunks, int K, float *partial,
+                      int max_chunks, int K, float *partial, unsigned char *pmask,
                       const hsgk_segkm_meta *meta, hipStream_t s) {
   if (max_chunks <= 0) return 0;
   const bool wide = d >= 256;
   const int DS = wide ? (d + 3) / 4 * 4 : d;
   // cluster rows per pass so that the table fits LDS (two workgroups per CU
   // when possible: <= 76 KiB each).
-  const size_t list_bytes = (size_t)HSGK_CHUNK * 4;
+  const size_t list_bytes = (size_t)HSGK_CHUNK * 4 + 1024;      // row list + presence flags
   const size_t budget2 = 78 * 1024 - list_bytes, budget1 = 156 * 1024 - list_bytes;
   int kbn = K;
   if ((size_t)kbn * DS * 4 > budget2) {
@@ -85,7 +94,7 @@ int launch_accumulate(const float *x, int d, const int32_t *klab, const ChunkTab
   for (int kb0 = 0; kb0 < K; kb0 += kbn) {
     int cur = K - kb0 < kbn ? K - kb0 : kbn;
     hipLaunchKernelGGL(kern, dim3(max_chunks), dim3(NWA * 64), lds, s, x, d, klab,
-                       t.chunk_row0, t.chunk_rows, K, kb0, cur, partial, meta);
+                       t.chunk_row0, t.chunk_rows, K, kb0, cur, partial, pmask, meta);
     HSGK_LAUNCH_CHECK();
   }
   return 0;
@@ -95,7 +104,7 @@ int launch_accumulate(const float *x, int d, const int32_t *klab, const ChunkTab
 // M-step, stage 2: sum the chunk partials of one (image, cluster) in chunk
 // order, normalise, write the centroid row.  grid = (K, B).
 __global__ __launch_bounds__(256) void finalize_kernel(
-    const float *__restrict__ partial, int d, int K,
+    const float *__restrict__ partial, const unsigned char *__restrict__ pmask, int d, int K,
     const int32_t *__restrict__ img_chunk0, float eps, float *__restrict__ cent) {
   extern __shared__ float row[];    // [d] + 1
   const int k = blockIdx.x, b = blockIdx.y;
@@ -103,7 +112,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(
   const int tid = threadIdx.x;
   for (int i = tid; i < d; i += 256) {
     float tsum = 0.0f;
-    for (int c = c0; c < c1; ++c) tsum = tsum + partial[((int64_t)c * K + k) * d + i];
+    for (int c = c0; c < c1; ++c)
+      if (pmask[(int64_t)c * K + k]) tsum = tsum + partial[((int64_t)c * K + k) * d + i];
     row[i] = tsum;
   }
   __syncthreads();
@@ -120,11 +130,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(
   for (int i = tid; i < d; i += 256) out[i] = row[i] / nrm;
 }
 
-int launch_finalize(const float *partial, int d, int K, int B, const ChunkTable &t,
-                    float eps, float *cent, hipStream_t s) {
+int launch_finalize(const float *partial, const unsigned char *pmask, int d, int K, int B,
+                    const ChunkTable &t, float eps, float *cent, hipStream_t s) {
   if (B <= 0 || K <= 0) return 0;
   hipLaunchKernelGGL(finalize_kernel, dim3(K, B), dim3(256), (size_t)(d + 1) * 4, s,
-                     partial, d, K, t.img_chunk0, eps, cent);
+                     partial, pmask, d, K, t.img_chunk0, eps, cent);
   HSGK_LAUNCH_CHECK();
   return 0;
 }
