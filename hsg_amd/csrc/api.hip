@@ -118,7 +118,7 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
     { ProfScope p(HSGK_PROF_ACCUMULATE, s);
       if (int rc = launch_accumulate(x, d, k.klab, k.t, k.max_chunks, K, k.partial, k.pmask, meta, s)) return rc; }
     { ProfScope p(HSGK_PROF_FINALIZE, s);
-      if (int rc = launch_finalize(k.partial, k.pmask, d, K, B, k.t, HSGK_EPS, k.cent, s)) return rc; }
+      if (int rc = launch_finalize(k.partial, k.pmask, d, K, B, k.t, k.max_chunks / B, HSGK_EPS, k.cent, s)) return rc; }
     { ProfScope p(HSGK_PROF_ASSIGN, s);
       if (int rc = half ? launch_assign_half(x, k.xh, k.xt, d, k.cent, K, B, k.t, k.max_chunks, k.klab, k.q1,
                                              k.q1count, k.q1cap, k.qrows, k.qcount, meta, s)
@@ -300,7 +300,7 @@ int hsgk_lloyd_mstep(const float *x, int B, int64_t rows_per_image, int d, int K
   { ProfScope p(HSGK_PROF_ACCUMULATE, s);
     if (int rc = launch_accumulate(x, d, labels, k.t, k.max_chunks, K, k.partial, k.pmask, meta, s)) return rc; }
   ProfScope p(HSGK_PROF_FINALIZE, s);
-  return launch_finalize(k.partial, k.pmask, d, K, B, k.t, HSGK_EPS, centroids, s);
+  return launch_finalize(k.partial, k.pmask, d, K, B, k.t, k.max_chunks / B, HSGK_EPS, centroids, s);
 }
 
 int hsgk_lloyd_estep(const float *x, int B, int64_t rows_per_image, int d, int K,

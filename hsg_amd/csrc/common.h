@@ -89,7 +89,8 @@ int launch_accumulate(const float *x, int d, const int32_t *klab,
                       const ChunkTable &t, int max_chunks, int K, float *partial,
                       unsigned char *pmask, const hsgk_segkm_meta *meta, hipStream_t s);
 int launch_finalize(const float *partial, const unsigned char *pmask, int d, int K, int B,
-                    const ChunkTable &t, float eps, float *cent, hipStream_t s);
+                    const ChunkTable &t, int max_chunks_per_image, float eps, float *cent,
+                    hipStream_t s);
 int launch_assign(const float *x, int d, const float *cent, int K,
                   const ChunkTable &t, int max_chunks, int32_t *klab, float *best,
                   const hsgk_segkm_meta *meta, hipStream_t s);

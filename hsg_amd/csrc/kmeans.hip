@@ -106,14 +106,39 @@ int launch_accumulate(const float *x, int d, const int32_t *klab, const ChunkTab
 __global__ __launch_bounds__(256) void finalize_kernel(
     const float *__restrict__ partial, const unsigned char *__restrict__ pmask, int d, int K,
     const int32_t *__restrict__ img_chunk0, float eps, float *__restrict__ cent) {
-  extern __shared__ float row[];    // [d] + 1
+  extern __shared__ float row[];    // [d] + 1, then the list of chunks that hold rows of this cluster
+  __shared__ int npresent;
   const int k = blockIdx.x, b = blockIdx.y;
   const int c0 = img_chunk0[b], c1 = img_chunk0[b + 1];
   const int tid = threadIdx.x;
+  int *plist = reinterpret_cast<int *>(row + d + 1);          // [c1 - c0], ascending
+  if (tid < 64) {                                              // wave 0: ordered compaction of the mask column
+    int n = 0;
+    for (int base = c0; base < c1; base += 64) {
+      const int c = base + tid;
+      const bool has = c < c1 && pmask[(int64_t)c * K + k] != 0;
+      const unsigned long long m = __ballot(has);
+      if (has) plist[n + __popcll(m & ((1ull << tid) - 1ull))] = c;
+      n += __popcll(m);
+    }
+    if (tid == 0) npresent = n;
+  }
+  __syncthreads();
+  const int np = npresent;
   for (int i = tid; i < d; i += 256) {
     float tsum = 0.0f;
-    for (int c = c0; c < c1; ++c)
-      if (pmask[(int64_t)c * K + k]) tsum = tsum + partial[((int64_t)c * K + k) * d + i];
+    int q = 0;
+    for (; q + 4 <= np; q += 4) {                              // loads of four partial rows in flight
+      const float p0 = partial[((int64_t)plist[q] * K + k) * d + i];
+      const float p1 = partial[((int64_t)plist[q + 1] * K + k) * d + i];
+      const float p2 = partial[((int64_t)plist[q + 2] * K + k) * d + i];
+      const float p3 = partial[((int64_t)plist[q + 3] * K + k) * d + i];
+      tsum = tsum + p0;
+      tsum = tsum + p1;
+      tsum = tsum + p2;
+      tsum = tsum + p3;
+    }
+    for (; q < np; ++q) tsum = tsum + partial[((int64_t)plist[q] * K + k) * d + i];
     row[i] = tsum;
   }
   __syncthreads();
@@ -131,9 +156,15 @@ __global__ __launch_bounds__(256) void finalize_kernel(
 }
 
 int launch_finalize(const float *partial, const unsigned char *pmask, int d, int K, int B,
-                    const ChunkTable &t, float eps, float *cent, hipStream_t s) {
+                    const ChunkTable &t, int max_chunks_per_image, float eps, float *cent,
+                    hipStream_t s) {
   if (B <= 0 || K <= 0) return 0;
-  hipLaunchKernelGGL(finalize_kernel, dim3(K, B), dim3(256), (size_t)(d + 1) * 4, s,
+  // LDS: the row + the present-chunk list (at most the image with the most chunks)
+  const size_t lds = ((size_t)(d + 1) + (size_t)(max_chunks_per_image > 0 ? max_chunks_per_image : 1)) * 4;
+  HSGK_REQUIRE(lds <= 160 * 1024, "too many chunks for the finalize list");
+  HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(finalize_kernel, dim3(K, B), dim3(256), lds, s,
                      partial, pmask, d, K, t.img_chunk0, eps, cent);
   HSGK_LAUNCH_CHECK();
   return 0;
