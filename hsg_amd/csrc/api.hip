@@ -341,9 +341,15 @@ int hsgk_lloyd_requeued_rows(int B, int64_t rows_per_image, int d, int K, void *
   cv.take<hsgk_segkm_meta>(1);
   KmeansScratch k;
   carve_kmeans(cv, B, rows_per_image, d, K, &k);
-  hipLaunchKernelGGL(sum_qcount_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     k.qcount, 1, out);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(sum_qcount_kernel, dim3(1), dim3(256), 0, s, k.qcount, 1, out);
   HSGK_LAUNCH_CHECK();
+  if (k.q1count) {                 // rows the fp16 level left to the bf16x3 level (unit_rows = 2)
+    hipLaunchKernelGGL(sum_qcount_kernel, dim3(1), dim3(256), 0, s, k.q1count, B, out + 1);
+    HSGK_LAUNCH_CHECK();
+  } else {
+    HSGK_CHECK_HIP(hipMemsetAsync(out + 1, 0, sizeof(int64_t), s));
+  }
   return 0;
 }
 

@@ -260,10 +260,7 @@ struct SplitEpi {
   int *qn;               // LDS counter
   SplitEntry *gqueue;    // global queue (overflow path)
   int32_t *gcount;
-  const int32_t *rowlist;   // gathered pass (second level): row px of the pass is x[rowlist[px]]
-  __device__ inline void chunk_begin() const {}
-  __device__ inline void chunk_end() const {}
-  __device__ inline void drain() const {}
+  const int32_t *rlw;    // gathered pass (second level): this wave's LDS row-id slots [2][32], else null
   __device__ inline void operator()(int tile, const f32x16 (&sacc)[2]) const {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -293,7 +290,7 @@ struct SplitEpi {
     const int px = tile * TPX + w * 32 + j;
     const bool valid = px < nrows;
     const bool amb = valid && !(t1 - t2 > kSplitGap);       // ambiguous (or NaN)
-    const int64_t grow = !valid ? 0 : rowlist ? (int64_t)rowlist[px] : crow0 + px;
+    const int64_t grow = rlw ? (int64_t)rlw[(tile & 1) * 32 + j] : crow0 + px;
     if (h == 0 && valid) klab[grow] = ti;
     if (!__any(amb)) return;
     // candidate list of this lane's half, then merged with the partner half
@@ -642,14 +639,16 @@ __global__ __launch_bounds__(NW * 64) void assign_split_rows_kernel(
   const int r0 = blockIdx.x * per;
   const int nrows = min(per, n - r0);
   if (nrows <= 0) return;
-  uint16_t *qpx = reinterpret_cast<uint16_t *>(lds_raw + split_lds_bytes<NW>(d));
-  uint32_t *qcand = reinterpret_cast<uint32_t *>(qpx + kSplitLdsList);
-  int *qnp = reinterpret_cast<int *>(qcand + kSplitLdsList);
+  unsigned char *tail = lds_raw + split_lds_bytes<NW>(d);   // same carve as assign_split_kernel ...
+  int *qnp = reinterpret_cast<int *>(tail - 16);
+  uint32_t *qcand = reinterpret_cast<uint32_t *>(tail);
+  uint16_t *qpx = reinterpret_cast<uint16_t *>(qcand + kSplitLdsList);
+  int32_t *rl = reinterpret_cast<int32_t *>(qpx + kSplitLdsList);   // ... + [NW][2][32] row-id slots
   const int32_t *list = q1 + (int64_t)b * q1cap + r0;
   if (threadIdx.x == 0) qnp[0] = 0;
-  SplitEpi epi{K, nrows, b, 0, klab, qpx, qcand, qnp, gqueue, gcount, list};
+  SplitEpi epi{K, nrows, b, 0, klab, qpx, qcand, qnp, gqueue, gcount, rl + (threadIdx.x >> 6) * 64};
   score_tiles_split<NW, 4, SplitEpi, true>(x, d, cent + (int64_t)b * K * d, K, 0, nrows, lds_raw, epi,
-                                           true, list);
+                                           true, list, rl);
   __syncthreads();
   const int qn = min(qnp[0], kSplitLdsList);
   if (qn > 0) {
@@ -698,7 +697,8 @@ int launch_to_half_rows(const float *x, const ChunkTable &t, int max_chunks, int
 
 bool assign_half_eligible(int d, int K) {
   return assign_split_eligible(d, K) && half_shape_ok(d) &&
-         half_lds_bytes<8>(d) + (size_t)kHalfLdsList * 2 + 16 <= 160 * 1024;
+         half_lds_bytes<8>(d) + (size_t)kHalfLdsList * 2 + 16 <= 160 * 1024 &&
+         split_lds_bytes<8>(d) + (size_t)kSplitLdsList * 6 + 8 * 64 * 4 <= 160 * 1024;
 }
 
 // x: fp32 rows, xm / xt: their fp16 copy.  q1 [B][q1cap] / q1count [B]: per-image queues
@@ -735,11 +735,12 @@ int launch_assign_half(const float *x, const _Float16 *xm, const uint32_t *xt, i
     HSGK_LAUNCH_CHECK();
   }
   {
-    // slices of <= 65535 rows (u16 queue offsets): at least q1cap / 32768 workgroups per image
-    int T = 16;
+    // about one workgroup per CU in total (the table is staged once per workgroup and the
+    // queues are short), in slices of <= 65535 rows (u16 queue offsets)
+    int T = n_cu / B > 1 ? n_cu / B : 1;
     while ((int64_t)T * 32768 < q1cap) T *= 2;
     auto kern = assign_split_rows_kernel<NW>;
-    const size_t lds = split_lds_bytes<NW>(d) + (size_t)kSplitLdsList * 6;
+    const size_t lds = split_lds_bytes<NW>(d) + (size_t)kSplitLdsList * 6 + (size_t)NW * 64 * 4;
     HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(T, B), dim3(NW * 64), lds, s, x, d, cent, K, q1, q1count, q1cap,

@@ -62,13 +62,18 @@ __host__ __device__ constexpr size_t split_lds_bytes(int d) {
 // m*32 + (r&3) + 8*(r>>2) + 4*h for x row tile*NW*32 + w*32 + j.
 //
 // ROWS: the pass covers the rows x[rowlist[0 .. nrows)] (a gathered subset: the
-// second filter level of the E-step) instead of x[crow0 .. crow0 + nrows).
+// second filter level of the E-step) instead of x[crow0 .. crow0 + nrows).  The row
+// ids of a wave's 32 rows are staged per tile in a wave-private LDS slot pair
+// rl_lds[NW][2][32] (tile parity), loaded two tiles ahead: an id fetched from global
+// right before its use would drain the whole prefetch queue (loads return in order).
+// Epi may read the ids of tile t from the slot t & 1 inside its call.
 template <int NW, int DEPTH, class Epi, bool ROWS = false>
 __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, int d,
                                          const float *__restrict__ table, int kvalid,
                                          int64_t crow0, int nrows, unsigned char *lds_raw,
                                          Epi &epi, bool stage_table = true,
-                                         const int32_t *__restrict__ rowlist = nullptr) {
+                                         const int32_t *__restrict__ rowlist = nullptr,
+                                         int32_t *rl_lds = nullptr) {
   constexpr int NT = NW * 64;
   constexpr int TPX = NW * 32;
   constexpr int KC = 32;               // columns per staged chunk (2 k-blocks)
@@ -124,6 +129,14 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
   const int lpx = lane >> 4, lf2 = lane & 15;
 
   const int wu = __builtin_amdgcn_readfirstlane(w);
+  int32_t *rlw = ROWS ? rl_lds + w * 64 : nullptr;            // [2][32] row ids of tiles t (slot t & 1)
+  auto row_id = [&](int tile) -> int32_t {                     // id of this lane's row j in `tile` (clamped)
+    return rowlist[max(min(tile * TPX + w * 32 + j, nrows - 1), 0)];
+  };
+  if constexpr (ROWS) {
+    rlw[j] = row_id(0);
+    rlw[32 + j] = row_id(1);
+  }
 
   // Every load is issued UNCONDITIONALLY with clamped indices: the compiler's s_waitcnt
   // insertion merges the outstanding-load state pessimistically at control-flow joins,
@@ -135,8 +148,8 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
     if constexpr (ROWS) {
 #pragma unroll
       for (int i = 0; i < LOADS; ++i) {
-        const int li = min(tile * TPX + wu * 32 + lpx + 4 * i, nrows - 1);   // clamped: never written back
-        pre[i] = *reinterpret_cast<const float2 *>(x + (int64_t)rowlist[li] * d + q * KC + 2 * lf2);
+        const int rid = rlw[(tile & 1) * 32 + lpx + 4 * i];      // (clamped ids: rows past the end re-read a valid row)
+        pre[i] = *reinterpret_cast<const float2 *>(x + (int64_t)rid * d + q * KC + 2 * lf2);
       }
     } else {
       const float *tb = x + (crow0 + (int64_t)tile * TPX + wu * 32) * d + q * KC + 2 * lf2;   // wave-uniform + lane column
@@ -189,11 +202,12 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
     }
   };
   // tail k-block kb of a tile: columns tcol0 + 16 kb + 8 g + 0..7 of row j, from global
+  // (generic path: loaded where it is used, which drains the prefetch queue once per tile)
   auto tail_operands = [&](int tile, int kb, bf16x8 &bh, bf16x8 &bl) {
     const int n = nrows - tile * TPX - w * 32;
     const int jc = max(min(j, n - 1), -(tile * TPX + w * 32));
     const float *src = x + (crow0 + (int64_t)tile * TPX + w * 32 + jc) * d;
-    if constexpr (ROWS) src = x + (int64_t)rowlist[min(tile * TPX + w * 32 + j, nrows - 1)] * d;
+    if constexpr (ROWS) src = x + (int64_t)rlw[(tile & 1) * 32 + j] * d;
     const int c0 = tcol0 + 16 * kb + 8 * g;
     uint32_t hw[4], lw[4];
 #pragma unroll
@@ -208,11 +222,29 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
     bh = __builtin_bit_cast(bf16x8, hv);
     bl = __builtin_bit_cast(bf16x8, lv);
   };
-  auto finish_tile = [&](int tile) {
-    for (int kb = 0; kb < tblocks; ++kb) {
-      bf16x8 bh, bl;
-      tail_operands(tile, kb, bh, bl);
-      kblock(bh, bl, tcol0 + 16 * kb);
+  // two tail columns (d = C + 2, the shape that matters): one float2 per row, loaded a
+  // whole tile ahead with the chunk loads -- the epilogue never waits on memory
+  const bool two_tail = d - tcol0 == 2;
+  auto load_tail2 = [&](int tile, float2 &v) {
+    const int n = nrows - tile * TPX - w * 32;
+    const int jc = max(min(j, n - 1), -(tile * TPX + w * 32));
+    const float *src = x + (crow0 + (int64_t)tile * TPX + w * 32 + jc) * d + tcol0;
+    if constexpr (ROWS) src = x + (int64_t)rlw[(tile & 1) * 32 + j] * d + tcol0;
+    v = *reinterpret_cast<const float2 *>(src);
+  };
+  auto finish_tile = [&](int tile, const float2 &tv) {
+    if (two_tail) {
+      uint32_t hi, lo;
+      bf16_split2(tv.x, tv.y, hi, lo);
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 hv = {g == 0 ? hi : 0u, 0u, 0u, 0u}, lv = {g == 0 ? lo : 0u, 0u, 0u, 0u};
+      kblock(__builtin_bit_cast(bf16x8, hv), __builtin_bit_cast(bf16x8, lv), tcol0);
+    } else {
+      for (int kb = 0; kb < tblocks; ++kb) {
+        bf16x8 bh, bl;
+        tail_operands(tile, kb, bh, bl);
+        kblock(bh, bl, tcol0 + 16 * kb);
+      }
     }
     epi(tile, acc);
   };
@@ -233,21 +265,20 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
     load_chunk(min(2, nsteps - 1), preC);
     load_chunk(min(3, nsteps - 1), preD);
   }
+  float2 tail_cur = {0.0f, 0.0f}, tail_next = {0.0f, 0.0f};
+  if (two_tail) load_tail2(0, tail_cur);
   int gidx = 0;
-  // epi.chunk_begin() / chunk_end() bracket every chunk's MFMA work: the fused
-  // Lloyd epilogue uses them to trickle the previous tile's M-step row loads
-  // through the pipeline (issue before, consume after the MFMAs).
 #define HSGK_SPLIT_STEP(BUF, PRE, STEP, QQ)                                   \
   store_chunk(BUF, PRE);                                                      \
   __builtin_amdgcn_sched_barrier(0);                                          \
   load_chunk(min(gidx + (STEP) + DEPTH, nsteps - 1), PRE);                    \
-  epi.chunk_begin();                                                          \
   __builtin_amdgcn_sched_barrier(0);                                          \
   compute_chunk(BUF, QQ);                                                     \
-  __builtin_amdgcn_sched_barrier(0);                                          \
-  epi.chunk_end();                                                            \
   __builtin_amdgcn_sched_barrier(0);
   for (int tile = 0; tile < ntile; ++tile) {
+    int32_t rid_next = 0;
+    if constexpr (ROWS) rid_next = row_id(tile + 2);           // into the slot this tile is about to free
+    if (two_tail) load_tail2(min(tile + 1, ntile - 1), tail_next);
     for (int q = 0; q < nfull; q += 4, gidx += 4) {
       if constexpr (DEPTH == 4) {
         HSGK_SPLIT_STEP(0, preA, 0, q)
@@ -261,11 +292,12 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
         HSGK_SPLIT_STEP(1, preB, 3, q + 3)
       }
     }
-    finish_tile(tile);
+    finish_tile(tile, tail_cur);
+    tail_cur = tail_next;
+    if constexpr (ROWS) rlw[(tile & 1) * 32 + j] = rid_next;
     zero_acc();
   }
 #undef HSGK_SPLIT_STEP
-  epi.drain();
 }
 
 // shapes the split engine accepts (number of 32-column chunks divisible by 4)

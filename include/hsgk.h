@@ -149,7 +149,9 @@ HSGK_API int hsgk_lloyd_estep(const float *x, int B, int64_t rows_per_image, int
                               const float *centroids, int32_t *labels_out, int unit_rows,
                               void *workspace, size_t workspace_bytes, hsgk_stream_t stream);
 
-/* diagnostics: rows the last unit_rows E-step on this workspace re-scored exactly */
+/* diagnostics of the last unit_rows E-step on this workspace: out[0] = rows re-scored
+ * exactly, out[1] = rows the fp16 level (unit_rows = 2) handed to the bf16-split level
+ * (only meaningful right after such a step).  out: int64[2] on the device.          */
 HSGK_API int hsgk_lloyd_requeued_rows(int B, int64_t rows_per_image, int d, int K,
                                       void *workspace, size_t workspace_bytes, int64_t *out,
                                       hsgk_stream_t stream);

@@ -74,9 +74,10 @@ def main():
   if 'assign' in res:
     res['assign']['TFLOP/s'] = round(2.0 * a.D * a.K * n / (res['assign']['ms'] * 1e-3) / 1e12, 1)
   if a.unit:
-    q = torch.zeros((1,), dtype=torch.int64, device=dev)
+    q = torch.zeros((2,), dtype=torch.int64, device=dev)
     _lib.check(L.hsgk_lloyd_requeued_rows(a.B, a.HW, a.D, a.K, ws.data_ptr(), wsb, q.data_ptr(), st))
-    res['requeued_fraction'] = round(q.item() / n, 5)
+    res['requeued_fraction'] = round(q[0].item() / n, 5)
+    res['fp16_undecided_fraction'] = round(q[1].item() / n, 5)
   print(json.dumps({'shape': vars(a), 'result': res}))
 
 
