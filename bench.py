@@ -9,13 +9,15 @@ clusters its own shard of the same per-GPU shape (weak scaling; images are
 independent, the only exchange is the prototype-table step).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline      assign (E-step) launch group: algorithmic bytes (4D+8 per pixel)
-                over its average duration, measured with HIP events on the launch
-                stream inside the timed region (libhsgk's event profiler).
+  roofline      the dominant kernel (M-step accumulate_kernel): algorithmic bytes
+                (4D per pixel) over its average duration, measured with HIP events
+                on the launch stream inside the timed region (libhsgk's event
+                profiler); roofline_assign / roofline_iteration: the same for the
+                E-step launch group (4D+8 per pixel) and for one whole iteration.
                 `traffic` is null: on gfx950 FETCH_SIZE counts between 0.5x and
                 ~0.94x of the bytes depending on the access pattern
                 (profiles/r01_pmc.txt, tools/probes/fetch_calib.hip), so no
-                defensible absolute exists for the 8-byte row-segment loads;
+                defensible absolute exists for these row-segment loads;
   cpu_baseline  oracle/torch_ref.py (same ATen op sequence as the reference's
                 CPU path) timed on the host cores, rank 0, N=1 only.
 """
@@ -128,19 +130,49 @@ def main():
   px_per_step = B * H * W * world
   value = px_per_step * args.steps / elapsed
 
+  # Rooflines (HBM-bound kernels; durations from libhsgk's HIP-event profiler, recorded on
+  # the launch stream inside the timed region).  `roofline` is the DOMINANT kernel by time
+  # (M-step accumulate_kernel); `roofline_assign` is the E-step launch group north_star's
+  # 50 % target names; `roofline_iteration` prices one whole Lloyd iteration (M + finalize
+  # + E) against SURVEY 8(d)'s fused-iteration figure of 4D+8 bytes per pixel.
+  npx = B * H * W
+  m_ms, m_n = prof['accumulate']
+  f_ms, f_n = prof['finalize']
   a_ms, a_n = prof['assign']
-  roofline = None
-  if a_n:
-    avg_s = a_ms / a_n * 1e-3
-    bytes_per_launch = (4 * D + 8) * B * H * W           # 4D+8 B / pixel
-    achieved = bytes_per_launch / avg_s / 1e9
-    roofline = {'bound': 'hbm',
-                'kernel': 'E-step launch group: assign_split_kernel (bf16x3 filter) + '
-                          'assign_requeue_rows_kernel (exact fp32 re-score)',
-                'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
-                'avg_launch_ms': round(a_ms / a_n, 4), 'launches': int(a_n),
-                'mfma_tflops': round(2.0 * D * (grid[0] * grid[1]) * B * H * W / avg_s / 1e12, 2)}
+
+  def rl(kernel, bytes_per_launch, ms, n, **extra):
+    if not n:
+      return None
+    avg_s = ms / n * 1e-3
+    ach = bytes_per_launch / avg_s / 1e9
+    out = {'bound': 'hbm', 'kernel': kernel, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
+           'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+           'avg_launch_ms': round(ms / n, 4), 'launches': int(n),
+           'algorithmic_bytes_per_launch': int(bytes_per_launch)}
+    out.update(extra)
+    return out
+
+  roofline = rl('M-step accumulate_kernel (ordered per-chunk segment sums; dominant kernel by time)',
+                4 * D * npx, m_ms, m_n)
+  half_ok = (D % 64 == 2 and 128 <= D <= 322 and (D // 64) % 2 == 0 and grid[0] * grid[1] <= 64)
+  roofline_assign = rl(
+      'E-step launch group: assign_half_kernel (fp16 filter over the fp16 row copy) + '
+      'assign_split_rows_kernel (bf16x3 on the undecided rows) + assign_requeue_rows_kernel '
+      '(exact fp32 chains)' if half_ok else 'E-step launch group',
+      (4 * D + 8) * npx, a_ms, a_n,
+      mfma_tflops=round(2.0 * D * (grid[0] * grid[1]) * npx / (a_ms / max(a_n, 1) * 1e-3) / 1e12, 2)
+      if a_n else None,
+      note=('algorithmic bytes are SURVEY 8(d)\'s 4D+8 per pixel; the filter streams the fp16 copy '
+            '(2(D-2)+4 B per pixel) plus the fp32 rows of the undecided few per cent, so the kernel '
+            'moves about half of them -- compare avg_launch_ms with that traffic at ~6 TB/s, not '
+            'frac with 1.0') if half_ok else None)
+  roofline_iteration = None
+  if m_n and a_n and f_n:
+    it_ms = m_ms / m_n + f_ms / f_n + a_ms / a_n
+    roofline_iteration = rl('one Lloyd iteration = accumulate + finalize + E-step group (reads the '
+                            'embeddings twice: fp32 for the sums, fp16 copy for the filter)',
+                            (4 * D + 8) * npx, it_ms, 1)
+    roofline_iteration['launches'] = int(m_n)
   phases = {k: round(v[0] / max(1, args.steps), 3) for k, v in prof.items()}
 
   cpu = None
@@ -177,7 +209,8 @@ def main():
                                                           grid[1], iters),
                    'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world,
                    'phase_ms_per_step': phases, 'prototype_exchange_untimed': exch},
-        'roofline': roofline, 'cpu_baseline': cpu}))
+        'roofline': roofline, 'roofline_assign': roofline_assign,
+        'roofline_iteration': roofline_iteration, 'cpu_baseline': cpu}))
   if dist is not None:
     dist.destroy_process_group()
 

@@ -173,22 +173,50 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
   };
+  // operands of one k-block (16 columns): the row operand and the table hi / lo operands
+  // of both 32-row table halves.  The LDS reads of block n+1 are issued before the MFMAs
+  // of block n (two register sets), so the per-wave chain is MFMA-bound, not a sequence
+  // of exposed LDS latencies.
+  struct Ops { f16x8 b, ah0, al0, ah1, al1; };
+  auto load_table_ops = [&](int col0, Ops &o) {
+    const uint16_t *hp = chs + j * RS + col0 + 8 * g;
+    const uint16_t *lp = cls + j * RS + col0 + 8 * g;
+    o.ah0 = *reinterpret_cast<const f16x8 *>(hp);
+    o.ah1 = *reinterpret_cast<const f16x8 *>(hp + 32 * RS);
+    o.al0 = *reinterpret_cast<const f16x8 *>(lp);
+    o.al1 = *reinterpret_cast<const f16x8 *>(lp + 32 * RS);
+  };
+  auto mfma_ops = [&](const Ops &o) {
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.ah0, o.b, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.ah1, o.b, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.al0, o.b, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.al1, o.b, acc[1], 0, 0, 0);
+  };
   auto kblock = [&](const f16x8 &b, int col0) {
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const f16x8 ah = *reinterpret_cast<const f16x8 *>(chs + (m * 32 + j) * RS + col0 + 8 * g);
-      const f16x8 al = *reinterpret_cast<const f16x8 *>(cls + (m * 32 + j) * RS + col0 + 8 * g);
-      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b, acc[m], 0, 0, 0);
-      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b, acc[m], 0, 0, 0);
-    }
+    Ops o;
+    o.b = b;
+    load_table_ops(col0, o);
+    mfma_ops(o);
   };
   auto compute_chunk = [&](int buf, int q) {
     const uint16_t *bp = xw + buf * (32 * XSB) + j * XSB + 8 * g;
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const f16x8 b = *reinterpret_cast<const f16x8 *>(bp + kb * 16);
-      kblock(b, q * KC + kb * 16);
-    }
+    Ops o0, o1;
+    o0.b = *reinterpret_cast<const f16x8 *>(bp);
+    load_table_ops(q * KC, o0);
+    __builtin_amdgcn_sched_barrier(0);
+    o1.b = *reinterpret_cast<const f16x8 *>(bp + 16);
+    load_table_ops(q * KC + 16, o1);
+    mfma_ops(o0);
+    __builtin_amdgcn_sched_barrier(0);
+    o0.b = *reinterpret_cast<const f16x8 *>(bp + 32);
+    load_table_ops(q * KC + 32, o0);
+    mfma_ops(o1);
+    __builtin_amdgcn_sched_barrier(0);
+    o1.b = *reinterpret_cast<const f16x8 *>(bp + 48);
+    load_table_ops(q * KC + 48, o1);
+    mfma_ops(o0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_ops(o1);
   };
   // tail k-block of a tile: the packed tail word of row j (k = 0, 1 of the block; the
   // rest of the block and the g = 1 half are zero).  One line per wave tile, issued a
