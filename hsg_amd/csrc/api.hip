@@ -52,7 +52,7 @@ struct KmeansScratch {
   void *qrows;         // [max_chunks * HSGK_CHUNK] 12-byte entries: exact re-score queue (split E-step)
   int32_t *qcount;     // [1] queue length
   _Float16 *xh;        // [rows][half_main_cols(d)] fp16 copy of the rows' main columns (first filter level), or null
-  uint32_t *xt;        // [rows] packed fp16 tail columns of the copy
+  uint2 *xt;           // [rows] {packed fp16 tail columns of the copy, measured rounding error of the row}
   int32_t *q1;         // [B][q1cap] rows the first level left undecided
   int32_t *q1count;    // [B]
   int64_t q1cap;
@@ -87,7 +87,7 @@ static void carve_kmeans(Carver &cv, int B, int64_t rows_per_img, int d, int K,
   if (assign_half_eligible(d, K)) {
     // + slack rows: the fp16 engine reads past the end of a pass instead of clamping
     k->xh = cv.take<_Float16>(((size_t)B * rows_per_img + kHalfSlackRowsHost) * half_main_cols_host(d) + 8);
-    k->xt = cv.take<uint32_t>((size_t)B * rows_per_img + kHalfSlackRowsHost);
+    k->xt = cv.take<uint2>((size_t)B * rows_per_img + kHalfSlackRowsHost);
     k->q1 = cv.take<int32_t>((size_t)B * rows_per_img + 1);
     k->q1count = cv.take<int32_t>((size_t)B + 1);
   }

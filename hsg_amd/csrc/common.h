@@ -77,7 +77,7 @@ int launch_build_tables(const int32_t *tile_cnt, int B, int64_t HW, int ntiles,
                         hsgk_segkm_meta *meta, hipStream_t s);
 int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off,
                 const ChunkTable &t, int32_t *klab, hipStream_t s, _Float16 *xm = nullptr,
-                uint32_t *xt = nullptr, bool *wrote_half = nullptr);
+                uint2 *xt = nullptr, bool *wrote_half = nullptr);
 int launch_prep_bwd(const float *g_emb, const float *g_emb_loc, const float *emb,
                     const float *emb_loc, const float *norms, const int64_t *rowmap, int B, int C,
                     int H, int W, float eps, float *gx, hipStream_t s);
@@ -107,8 +107,8 @@ constexpr int kHalfSlackRowsHost = 2 * 8 * 32 + 64;     // == kHalfSlackRows (sc
 bool assign_split_eligible(int d, int K);
 bool assign_half_eligible(int d, int K);
 int launch_to_half_rows(const float *x, const ChunkTable &t, int max_chunks, int d, _Float16 *xm,
-                        uint32_t *xt, const hsgk_segkm_meta *meta, hipStream_t s);
-int launch_assign_half(const float *x, const _Float16 *xm, const uint32_t *xt, int d, const float *cent, int K, int B,
+                        uint2 *xt, const hsgk_segkm_meta *meta, hipStream_t s);
+int launch_assign_half(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent, int K, int B,
                        const ChunkTable &t, int max_chunks, int32_t *klab, int32_t *q1,
                        int32_t *q1count, int64_t q1cap, void *qrows, int32_t *qcount,
                        const hsgk_segkm_meta *meta, hipStream_t s);

@@ -531,7 +531,7 @@ struct HalfEpi {
   int *qn;               // LDS counter
   int32_t *gq;           // this image's row queue (overflow path)
   int32_t *gcnt;         // its length
-  __device__ inline void operator()(int tile, const f32x16 (&sacc)[2]) const {
+  __device__ inline void operator()(int tile, const f32x16 (&sacc)[2], float err) const {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int TPX = (int)(blockDim.x >> 1);
@@ -555,7 +555,7 @@ struct HalfEpi {
     else { t1 = b1; ti = bi; t2 = fmaxf(o1, b2); }
     const int px = tile * TPX + w * 32 + j;
     const bool valid = px < nrows;
-    const bool amb = h == 0 && valid && !(t1 - t2 > kHalfGap);       // ambiguous (or NaN)
+    const bool amb = h == 0 && valid && !(t1 - t2 > half_gap(err));  // ambiguous (or NaN)
     if (h == 0 && valid) klab[crow0 + px] = ti;     // provisional for ambiguous rows
     const unsigned long long m = __ballot(amb);
     if (!m) return;
@@ -573,7 +573,7 @@ struct HalfEpi {
 
 template <int NW, int DEPTH>
 __global__ __launch_bounds__(NW * 64) void assign_half_kernel(
-    const _Float16 *__restrict__ xm, const uint32_t *__restrict__ xt, int d,
+    const _Float16 *__restrict__ xm, const uint2 *__restrict__ xt, int d,
     const float *__restrict__ cent, int K,
     const int64_t *__restrict__ chunk_row0, const int32_t *__restrict__ chunk_rows,
     const int32_t *__restrict__ chunk_img, int32_t *__restrict__ klab,
@@ -660,34 +660,45 @@ __global__ __launch_bounds__(NW * 64) void assign_split_rows_kernel(
   }
 }
 
-// fp32 rows -> fp16 copy (RNE): main columns xm[rows][DM], packed tail word xt[rows]
-// (layout: score_tiles_f16.h); workgroup per chunk, one thread per 4 main columns
+// fp32 rows -> fp16 copy (RNE): main columns xm[rows][DM], xt[rows] = {packed tail
+// columns, measured rounding error of the row} (layout and bound: score_tiles_f16.h);
+// workgroup per chunk, wave per row
 __global__ __launch_bounds__(256) void to_half_rows_kernel(
     const float *__restrict__ x, const int64_t *__restrict__ chunk_row0,
     const int32_t *__restrict__ chunk_rows, int d, _Float16 *__restrict__ xm,
-    uint32_t *__restrict__ xt, const hsgk_segkm_meta *__restrict__ meta) {
+    uint2 *__restrict__ xt, const hsgk_segkm_meta *__restrict__ meta) {
   const int c = blockIdx.x;
   if (c >= meta->n_chunks) return;
   const int DM = half_main_cols(d), G = DM / 4;
   const int64_t row0 = chunk_row0[c];
   const int nr = chunk_rows[c];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   typedef _Float16 h4 __attribute__((ext_vector_type(4)));
   typedef _Float16 h2 __attribute__((ext_vector_type(2)));
   typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-  for (int i = threadIdx.x; i < nr * G; i += 256) {
-    const int r = i / G, col = 4 * (i - r * G);
-    const f4u v = *reinterpret_cast<const f4u *>(x + (row0 + r) * d + col);
-    *reinterpret_cast<h4 *>(xm + (row0 + r) * DM + col) = __builtin_convertvector(v, h4);
-  }
-  for (int r = threadIdx.x; r < nr; r += 256) {
-    const float *src = x + (row0 + r) * d + DM;
-    const h2 t = {d > DM ? (_Float16)src[0] : (_Float16)0.0f, d > DM + 1 ? (_Float16)src[1] : (_Float16)0.0f};
-    xt[row0 + r] = __builtin_bit_cast(uint32_t, t);
+  for (int r = w; r < nr; r += 4) {
+    const float *src = x + (row0 + r) * d;
+    float e2 = 0.0f;
+    for (int q = lane; q < G; q += 64) {
+      const f4u v = *reinterpret_cast<const f4u *>(src + 4 * q);
+      const h4 hv = __builtin_convertvector(v, h4);
+      *reinterpret_cast<h4 *>(xm + (row0 + r) * DM + 4 * q) = hv;
+      const f4u e = v - __builtin_convertvector(hv, f4u);        // exact residuals
+      e2 = fmaf(e.x, e.x, e2); e2 = fmaf(e.y, e.y, e2); e2 = fmaf(e.z, e.z, e2); e2 = fmaf(e.w, e.w, e2);
+    }
+    for (int off = 32; off > 0; off >>= 1) e2 += __shfl_xor(e2, off);
+    if (lane == 0) {
+      const float t0 = d > DM ? src[DM] : 0.0f, t1 = d > DM + 1 ? src[DM + 1] : 0.0f;
+      const h2 t = {(_Float16)t0, (_Float16)t1};
+      const float e0 = t0 - (float)t[0], e1 = t1 - (float)t[1];
+      e2 = fmaf(e0, e0, e2); e2 = fmaf(e1, e1, e2);
+      xt[row0 + r] = make_uint2(__builtin_bit_cast(uint32_t, t), __float_as_uint(sqrtf(e2) * 1.0001f));
+    }
   }
 }
 
 int launch_to_half_rows(const float *x, const ChunkTable &t, int max_chunks, int d, _Float16 *xm,
-                        uint32_t *xt, const hsgk_segkm_meta *meta, hipStream_t s) {
+                        uint2 *xt, const hsgk_segkm_meta *meta, hipStream_t s) {
   if (max_chunks <= 0) return 0;
   hipLaunchKernelGGL(to_half_rows_kernel, dim3(max_chunks), dim3(256), 0, s, x, t.chunk_row0,
                      t.chunk_rows, d, xm, xt, meta);
@@ -703,7 +714,7 @@ bool assign_half_eligible(int d, int K) {
 
 // x: fp32 rows, xm / xt: their fp16 copy.  q1 [B][q1cap] / q1count [B]: per-image queues
 // of the rows the first level could not decide; qrows / qcount: exact queue.
-int launch_assign_half(const float *x, const _Float16 *xm, const uint32_t *xt, int d, const float *cent, int K, int B,
+int launch_assign_half(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent, int K, int B,
                        const ChunkTable &t, int max_chunks, int32_t *klab, int32_t *q1,
                        int32_t *q1count, int64_t q1cap, void *qrows, int32_t *qcount,
                        const hsgk_segkm_meta *meta, hipStream_t s) {

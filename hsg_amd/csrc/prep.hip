@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void prep_kernel(
     float eps, float *__restrict__ emb, float *__restrict__ emb_loc,
     int64_t *__restrict__ labels_out, int32_t *__restrict__ klab,
     float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out,
-    _Float16 *__restrict__ xh, uint32_t *__restrict__ xt) {
+    _Float16 *__restrict__ xh, uint2 *__restrict__ xt) {
   extern __shared__ float lds[];
   const int S = C | 1;
   float *tile = lds;                       // [64][S]
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(
     float eps, float *__restrict__ emb, float *__restrict__ emb_loc,
     int64_t *__restrict__ labels_out, int32_t *__restrict__ klab,
     float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out,
-    _Float16 *__restrict__ xh, uint32_t *__restrict__ xt) {
+    _Float16 *__restrict__ xh, uint2 *__restrict__ xt) {
   extern __shared__ float lds[];
   float *tile = lds;                       // [64][C] swizzled
   float *nrm1 = lds + 64 * C;              // [64]
@@ -477,6 +477,7 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const int sj = j & 15;
+    float e2 = 0.0f;                         // |row - fp16(row)|^2, this lane's columns
     for (int q = lane; q < NQ; q += 64) {
       const float4 v = *reinterpret_cast<const float4 *>(r + ((q ^ sj) << 2));
       *reinterpret_cast<float4 *>(eo + 4 * q) = v;
@@ -487,8 +488,13 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(
       if (ho) {
         const h4 hv = {(_Float16)a.x, (_Float16)a.y, (_Float16)c2.x, (_Float16)c2.y};
         *reinterpret_cast<h4 *>(ho + 4 * q) = hv;
+        const float e0 = a.x - (float)hv[0], e1 = a.y - (float)hv[1];       // exact residuals
+        const float e2b = c2.x - (float)hv[2], e3 = c2.y - (float)hv[3];
+        e2 = fmaf(e0, e0, e2); e2 = fmaf(e1, e1, e2); e2 = fmaf(e2b, e2b, e2); e2 = fmaf(e3, e3, e2);
       }
     }
+    if (ho)
+      for (int off = 32; off > 0; off >>= 1) e2 += __shfl_xor(e2, off);
     if (lane == 0) {
       float2 lv;
       lv.x = locv[2 * j] / n2;
@@ -496,7 +502,11 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(
       *reinterpret_cast<float2 *>(lo + C) = lv;
       if (ho) {
         const h2 hv = {(_Float16)lv.x, (_Float16)lv.y};
-        xt[row] = __builtin_bit_cast(uint32_t, hv);
+        const float e0 = lv.x - (float)hv[0], e1 = lv.y - (float)hv[1];
+        e2 = fmaf(e0, e0, e2); e2 = fmaf(e1, e1, e2);
+        // measured rounding error of the copy of this row, inflated against the rounding
+        // of this very sum (bound: score_tiles_f16.h)
+        xt[row] = make_uint2(__builtin_bit_cast(uint32_t, hv), __float_as_uint(sqrtf(e2) * 1.0001f));
       }
     }
   }
@@ -517,7 +527,7 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     float eps, float *__restrict__ emb, float *__restrict__ emb_loc,
     int64_t *__restrict__ labels_out, int32_t *__restrict__ klab,
     float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out,
-    _Float16 *__restrict__ xh, uint32_t *__restrict__ xt) {
+    _Float16 *__restrict__ xh, uint2 *__restrict__ xt) {
   extern __shared__ float lds[];
   float *tile = lds;                       // [32][C] swizzled
   float *nrm1 = lds + 32 * C;              // [32]
@@ -643,6 +653,7 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const int sj = j & 15;
+    float e2 = 0.0f;                         // |row - fp16(row)|^2, this lane's columns
     for (int q = lane; q < NQ; q += 64) {
       const float4 v = *reinterpret_cast<const float4 *>(r + ((q ^ sj) << 2));
       *reinterpret_cast<float4 *>(eo + 4 * q) = v;
@@ -653,8 +664,13 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
       if (ho) {
         const h4 hv = {(_Float16)a.x, (_Float16)a.y, (_Float16)c2.x, (_Float16)c2.y};
         *reinterpret_cast<h4 *>(ho + 4 * q) = hv;
+        const float e0 = a.x - (float)hv[0], e1 = a.y - (float)hv[1];       // exact residuals
+        const float e2b = c2.x - (float)hv[2], e3 = c2.y - (float)hv[3];
+        e2 = fmaf(e0, e0, e2); e2 = fmaf(e1, e1, e2); e2 = fmaf(e2b, e2b, e2); e2 = fmaf(e3, e3, e2);
       }
     }
+    if (ho)
+      for (int off = 32; off > 0; off >>= 1) e2 += __shfl_xor(e2, off);
     if (lane == 0) {
       float2 lv;
       lv.x = locv[2 * j] / n2;
@@ -662,7 +678,11 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
       *reinterpret_cast<float2 *>(lo + C) = lv;
       if (ho) {
         const h2 hv = {(_Float16)lv.x, (_Float16)lv.y};
-        xt[row] = __builtin_bit_cast(uint32_t, hv);
+        const float e0 = lv.x - (float)hv[0], e1 = lv.y - (float)hv[1];
+        e2 = fmaf(e0, e0, e2); e2 = fmaf(e1, e1, e2);
+        // measured rounding error of the copy of this row, inflated against the rounding
+        // of this very sum (bound: score_tiles_f16.h)
+        xt[row] = make_uint2(__builtin_bit_cast(uint32_t, hv), __float_as_uint(sqrtf(e2) * 1.0001f));
       }
     }
   }
@@ -671,7 +691,7 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
 // xh != nullptr asks for the fp16 copy of the emb_loc rows as well; *wrote_half tells
 // whether the selected kernel provides it (only the 32-pixel fast kernel does).
 int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTable &t,
-                int32_t *klab, hipStream_t s, _Float16 *xh, uint32_t *xt, bool *wrote_half) {
+                int32_t *klab, hipStream_t s, _Float16 *xh, uint2 *xt, bool *wrote_half) {
   if (wrote_half) *wrote_half = false;
   const int64_t HW = (int64_t)a.H * a.W;
   const int ntiles = (int)((HW + kTilePix - 1) / kTilePix);
@@ -691,8 +711,8 @@ int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTa
     kern = prep_fast32_kernel;
     lds = ((size_t)32 * a.C + 32 + 32 + 64) * 4 + 32 * 8;
     grid.x = 2 * ntiles;
-    if (wrote_half) *wrote_half = xh != nullptr;
   }
+  if (fast && wrote_half) *wrote_half = xh != nullptr;      // both fast kernels write the fp16 copy
   HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));

@@ -10,27 +10,31 @@
 // labels stay bit-identical to the canonical arithmetic.
 //
 // Error of the approximate score against the canonical fp32 chain, for unit-norm
-// rows and centroids (|x_i|, |c_i| <= 1):
+// rows and centroids (|x_i|, |c_i| <= 1, |c| <= 1 + 1.6e-5):
 //
-//     row rounding   sum |c_i| |x_i - xh_i| <= 2^-11 |x||c| + 2^-25 sum|c_i|  = 4.888e-4
-//        (fp16 RNE: relative 2^-11 in the normal range, absolute 2^-25 below 2^-14;
-//         subnormals are kept by v_cvt_f16_f32 and by the MFMA, tools/probes/mfma_f16_probe.hip)
+//     row rounding   |sum c_i (x_i - xh_i)| <= |c| |x - xh|  =  |c| * err(row)
+//        err(row) = |x - xh|_2 is MEASURED when the copy is made (fp32 sum of the exact
+//        per-element residuals, inflated by 1.0001 against its own rounding) and stored
+//        per row; fp16 RNE gives about 2^-12.3 |x| = 2.0e-4, 2.4x below the worst case
+//        2^-11 |x| = 4.88e-4 (subnormal residuals are part of the measurement;
+//        v_cvt_f16_f32 and the MFMA keep fp16 subnormals, tools/probes/mfma_f16_probe.hip)
 //     table residual sum |ec_i| |xh_i|      <= 2^-22 + 2^-25 sum|x_i|          = 7.2e-7
-//     fp16 MFMA accumulation, 2*17 instr.   <= 34 * 2^-21 * 1.01               = 1.64e-5
+//     fp16 MFMA accumulation, 2*21 instr.   <= 42 * 2^-21 * 1.01               = 2.02e-5
 //        (products of two fp16 are exact in fp32; measured |D - exact| <= 2^-22.4 sum|terms|
-//         per instruction on gfx950, same probe; 2^-21 used)
-//     fp32 chain of the oracle vs the real number  gamma_258                   = 1.54e-5
-//                                                              E1             <= 5.22e-4
+//         per instruction on gfx950, same probe; 2^-21 used; d <= 322)
+//     fp32 chain of the oracle vs the real number  gamma_322                   = 1.92e-5
+//                                           E1(row) <= 1.00002 err(row) + 4.02e-5
 //
-// kHalfGap = 1.08e-3 > 2 E1: a row whose two best approximate scores differ by more
-// has a strictly unique exact argmax.  (Up to d = 320, the limit of half_shape_ok():
-// gamma_320 = 1.9e-5, 2*20 MFMAs = 1.93e-5, sum|c_i| <= 17.9 -> E1 <= 5.28e-4.)
+// half_gap(err) = 2.0002 err + 8.1e-5 > 2 E1(row): a row whose two best approximate
+// scores differ by more has a strictly unique exact argmax (typically gap = 4.8e-4; with
+// the worst-case constant it would be 1.06e-3 and twice as many rows would be undecided).
 //
 // Layout of the fp16 copy: the first DM = 64 * (d / 64) columns of every row in
 // xm[n][DM] -- rows are whole 128-byte lines, which streams 8 % faster than the
 // 1032 / 528-byte strides (tools/probes/read_patterns2.hip: 6.3 vs 5.8 TB/s) -- and
 // the remaining d - DM <= 2 columns (the location features of emb_loc) packed in
-// xt[n] (one 32-bit word per row: a 32-row tile reads ONE line instead of 32).
+// xt[n] = {two fp16 tail columns, err(row) as fp32 bits} (8 bytes per row: a 32-row
+// tile reads two lines instead of 32).
 // Table block as two fp16 planes [64][RS] in LDS; every wave streams 32 rows x 64
 // columns (128 B per row) per chunk through a private double-buffered window
 // [32][72] -- no conversion, no barrier in the column loop, four chunks (16 KiB per
@@ -43,7 +47,10 @@ namespace hsgk {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr float kHalfGap = 1.08e-3f;
+// decision threshold of a row whose copy has rounding error err = |x - xh|_2
+__device__ inline float half_gap(float err) { return fmaf(2.0002f, err, 8.1e-5f); }
+// err of a row whose residual was not measured: 2^-11 |x| + the subnormal floor
+constexpr float kHalfWorstErr = 4.89e-4f;
 
 // rows the engine may read past the end of a pass (partial last tile + look-ahead):
 // the fp16 copy is allocated with this much slack
@@ -78,11 +85,12 @@ __host__ __device__ inline bool half_shape_ok(int d) {
   return d >= 128 && d <= 322 && (nfull & 1) == 0 && d - nfull * 64 <= 2;
 }
 
-// Epi(tile, acc): lane (j, h) holds acc[m][r] = approximate score of table row
-// m*32 + (r&3) + 8*(r>>2) + 4*h for row tile*NW*32 + w*32 + j of the pass.
+// Epi(tile, acc, err): lane (j, h) holds acc[m][r] = approximate score of table row
+// m*32 + (r&3) + 8*(r>>2) + 4*h for row tile*NW*32 + w*32 + j of the pass, and err =
+// the measured rounding error of that row's copy.
 template <int NW, int DEPTH, class Epi>
 __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm,
-                                                 const uint32_t *__restrict__ xt, int d,
+                                                 const uint2 *__restrict__ xt, int d,
                                                  const float *__restrict__ table, int kvalid,
                                                  int64_t crow0, int nrows, unsigned char *lds_raw,
                                                  Epi &epi, bool stage_table = true) {
@@ -219,18 +227,19 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
     mfma_ops(o1);
   };
   // tail k-block of a tile: the packed tail word of row j (k = 0, 1 of the block; the
-  // rest of the block and the g = 1 half are zero).  One line per wave tile, issued a
-  // whole tile ahead with the chunk loads, so the epilogue never waits on memory.
+  // rest of the block and the g = 1 half are zero), together with the row's err.  Two
+  // lines per wave tile, issued a whole tile ahead with the chunk loads, so the epilogue
+  // never waits on memory.
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  auto load_tail = [&](int tile, uint32_t &v) {
+  auto load_tail = [&](int tile, uint2 &v) {
     v = xt[crow0 + (int64_t)tile * TPX + w * 32 + j];         // unconditional, unclamped (see above)
   };
-  auto finish_tile = [&](int tile, uint32_t tw) {
+  auto finish_tile = [&](int tile, const uint2 &tw) {
     if (has_tail) {
-      const u32x4 tv = {g == 0 ? tw : 0u, 0u, 0u, 0u};
+      const u32x4 tv = {g == 0 ? tw.x : 0u, 0u, 0u, 0u};
       kblock(__builtin_bit_cast(f16x8, tv), tcol0);
     }
-    epi(tile, acc);
+    epi(tile, acc, __uint_as_float(tw.y));
   };
 
   __syncthreads();                         // table planes visible to all waves
@@ -247,8 +256,8 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
     load_next(preC);
     load_next(preD);
   }
-  uint32_t tail_cur = 0u, tail_next = 0u;
-  if (has_tail) load_tail(0, tail_cur);
+  uint2 tail_cur = {0u, 0u}, tail_next = {0u, 0u};
+  load_tail(0, tail_cur);
 #define HSGK_HALF_STEP(BUF, PRE, STEP, QQ)                                    \
   store_chunk(BUF, PRE);                                                      \
   __builtin_amdgcn_sched_barrier(0);                                          \
@@ -257,7 +266,7 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
   compute_chunk(BUF, QQ);                                                     \
   __builtin_amdgcn_sched_barrier(0);
   for (int tile = 0; tile < ntile; ++tile) {
-    if (has_tail) load_tail(tile + 1, tail_next);
+    load_tail(tile + 1, tail_next);
     for (int q = 0; q < nfull; q += DEPTH) {
       if constexpr (DEPTH == 4) {
         HSGK_HALF_STEP(0, preA, 0, q)
