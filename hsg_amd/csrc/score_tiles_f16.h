@@ -145,28 +145,43 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
   const int lpx = lane >> 4, lf = lane & 15;
   const int wu = __builtin_amdgcn_readfirstlane(w);
 
-  // NOTE on control flow: every load below is issued UNCONDITIONALLY.  The compiler's
-  // s_waitcnt insertion merges the outstanding-load state pessimistically at
-  // control-flow joins: one conditional load_chunk in the steady-state loop turns every
-  // "wait for the oldest set" into vmcnt(0), i.e. a full drain of the prefetch queue
-  // once per tile (seen in the ISA, cost ~25 %).
-  //
-  // No clamping either: the caller guarantees kHalfSlackRows readable rows past the
-  // last row of xm / xt (the library's own buffers), so a partial last tile and the
-  // DEPTH look-ahead chunks past the end simply read on; those rows' scores are never
-  // used (an x row only feeds its own accumulator column).  The chunk address is then
-  // one wave-uniform 64-bit base, advanced incrementally, plus constant lane offsets.
-  int roff[LOADS];
-#pragma unroll
-  for (int i = 0; i < LOADS; ++i) roff[i] = (lpx + 4 * i) * DM + 4 * lf;
-  const _Float16 *wbase = xm + (crow0 + wu * 32) * DM;        // wave-uniform
+  // ---- the row stream: explicit loads, explicit counted waits -----------------
+  // Loads return in order, so "wait for the oldest of DEPTH sets" is s_waitcnt
+  // vmcnt(8 * (DEPTH - 1)).  The compiler's own s_waitcnt insertion cannot be relied on
+  // for that: it merges the outstanding-load state pessimistically at every control-flow
+  // join (the tile loop, the epilogue's branches), and whether the steady-state loop ends
+  // up with counted waits or with a full drain of the prefetch queue once per tile
+  // (vmcnt(0): ~25 % slower) changed with unrelated edits.  So the chunk and tail loads
+  // are inline asm (invisible to that pass) and the waits are written out by hand.
+  //   * only asm loads are counted; compiler-visible VM ops in between (the epilogue's
+  //     label store, the rare queue-overflow atomic) can only make a wait longer.
+  //   * every wait names the registers it protects as "+v" operands, so their first use
+  //     is ordered after it; a final vmcnt(0) keeps look-ahead loads from landing in
+  //     registers the compiler has already handed to someone else.
+  //   * every load is unconditional and unclamped: the caller guarantees kHalfSlackRows
+  //     readable rows past the last row of xm / xt (the library's own buffers), so a
+  //     partial last tile and the look-ahead chunks past the end simply read on; those
+  //     rows' scores are never used (an x row only feeds its own accumulator column).
+  // Address = wave-uniform 64-bit base (SGPR pair, advanced incrementally) + one constant
+  // 32-bit lane offset.
+  const uint32_t voff = (uint32_t)(lpx * DM + 4 * lf) * 2u;                   // bytes
+  const char *wbase = reinterpret_cast<const char *>(xm + (crow0 + wu * 32) * DM);   // wave-uniform
+  const int64_t tile_bytes = (int64_t)TPX * DM * 2, grp_bytes = (int64_t)4 * DM * 2;
   int ld_tile = 0, ld_q = 0;                                    // next chunk to load (uniform)
   auto load_next = [&](uint2 (&pre)[LOADS]) {
-    const _Float16 *tb = wbase + (int64_t)ld_tile * (TPX * DM) + ld_q * KC;
+    const char *tb = wbase + ld_tile * tile_bytes + ld_q * (KC * 2);
 #pragma unroll
-    for (int i = 0; i < LOADS; ++i) pre[i] = *reinterpret_cast<const uint2 *>(tb + roff[i]);
-    if (++ld_q == nfull) { ld_q = 0; ++ld_tile; }
+    for (int i = 0; i < LOADS; ++i)
+      asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(pre[i]) : "v"(voff), "s"(tb + i * grp_bytes));
+    const bool wrap = ld_q + 1 == nfull;
+    ld_q = wrap ? 0 : ld_q + 1;
+    ld_tile += wrap ? 1 : 0;
   };
+#define HSGK_VMWAIT8(N, P)                                                              \
+  asm volatile("s_waitcnt vmcnt(%8)"                                                    \
+               : "+v"(P[0]), "+v"(P[1]), "+v"(P[2]), "+v"(P[3]), "+v"(P[4]), "+v"(P[5]), \
+                 "+v"(P[6]), "+v"(P[7])                                                 \
+               : "n"(N))
   auto store_chunk = [&](int buf, const uint2 (&pre)[LOADS]) {
     uint16_t *bp = xw + buf * (32 * XSB);
 #pragma unroll
@@ -228,11 +243,13 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
   };
   // tail k-block of a tile: the packed tail word of row j (k = 0, 1 of the block; the
   // rest of the block and the g = 1 half are zero), together with the row's err.  Two
-  // lines per wave tile, issued a whole tile ahead with the chunk loads, so the epilogue
-  // never waits on memory.
+  // lines per wave tile, issued at the top of the tile (nfull >= DEPTH chunk sets are
+  // issued after it), so the epilogue never waits on memory.
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  auto load_tail = [&](int tile, uint2 &v) {
-    v = xt[crow0 + (int64_t)tile * TPX + w * 32 + j];         // unconditional, unclamped (see above)
+  const uint32_t toff = (uint32_t)(w * 32 + j) * 8u;
+  auto load_tail = [&](int tile, uint2 &v) {                  // unconditional, unclamped (see above)
+    const char *tb = reinterpret_cast<const char *>(xt + crow0 + (int64_t)tile * TPX);
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(toff), "s"(tb));
   };
   auto finish_tile = [&](int tile, const uint2 &tw) {
     if (has_tail) {
@@ -242,6 +259,11 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
     epi(tile, acc, __uint_as_float(tw.y));
   };
 
+  // A visible full wait: the staging loads above are consumed under per-lane conditions,
+  // so on paths where a consumer block is skipped the compiler's model keeps them
+  // "pending" -- and would protect their registers (reused for the accumulators) with
+  // vmcnt(0) waits inside the streaming loop, draining the prefetch queue.
+  __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();                         // table planes visible to all waves
   zero_acc();
   // DEPTH register sets rotate, each loaded DEPTH chunks (4 KiB per wave each) ahead
@@ -256,9 +278,9 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
     load_next(preC);
     load_next(preD);
   }
-  uint2 tail_cur = {0u, 0u}, tail_next = {0u, 0u};
-  load_tail(0, tail_cur);
-#define HSGK_HALF_STEP(BUF, PRE, STEP, QQ)                                    \
+  uint2 tailv = {0u, 0u};
+#define HSGK_HALF_STEP(BUF, PRE, QQ)                                          \
+  HSGK_VMWAIT8(8 * (DEPTH - 1), PRE);                                         \
   store_chunk(BUF, PRE);                                                      \
   __builtin_amdgcn_sched_barrier(0);                                          \
   load_next(PRE);                                                             \
@@ -266,23 +288,32 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
   compute_chunk(BUF, QQ);                                                     \
   __builtin_amdgcn_sched_barrier(0);
   for (int tile = 0; tile < ntile; ++tile) {
-    load_tail(tile + 1, tail_next);
+    load_tail(tile, tailv);
     for (int q = 0; q < nfull; q += DEPTH) {
       if constexpr (DEPTH == 4) {
-        HSGK_HALF_STEP(0, preA, 0, q)
-        HSGK_HALF_STEP(1, preB, 1, q + 1)
-        HSGK_HALF_STEP(0, preC, 2, q + 2)
-        HSGK_HALF_STEP(1, preD, 3, q + 3)
+        HSGK_HALF_STEP(0, preA, q)
+        HSGK_HALF_STEP(1, preB, q + 1)
+        HSGK_HALF_STEP(0, preC, q + 2)
+        HSGK_HALF_STEP(1, preD, q + 3)
       } else {
-        HSGK_HALF_STEP(0, preA, 0, q)
-        HSGK_HALF_STEP(1, preB, 1, q + 1)
+        HSGK_HALF_STEP(0, preA, q)
+        HSGK_HALF_STEP(1, preB, q + 1)
       }
     }
-    finish_tile(tile, tail_cur);
-    tail_cur = tail_next;
+    // the tail was issued before this tile's nfull >= DEPTH chunk sets
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(tailv) : "n"(8 * DEPTH));
+    finish_tile(tile, tailv);
     zero_acc();
   }
+  // drain the look-ahead sets; naming them keeps their registers reserved until here
+  HSGK_VMWAIT8(0, preA);
+  HSGK_VMWAIT8(0, preB);
+  if constexpr (DEPTH == 4) {
+    HSGK_VMWAIT8(0, preC);
+    HSGK_VMWAIT8(0, preD);
+  }
 #undef HSGK_HALF_STEP
+#undef HSGK_VMWAIT8
 }
 
 }  // namespace hsgk
