@@ -194,6 +194,10 @@ __device__ inline void score_tiles(const float *__restrict__ x, int d,
     epi(tile, acc);
   };
 
+  // visible full wait: staging loads consumed under per-lane conditions stay "pending" in
+  // the compiler's s_waitcnt model on the skipped paths, and it would then guard their
+  // registers with vmcnt(0) inside the streaming loop (see score_tiles_f16.h)
+  __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();                         // table block visible to all waves
   zero_acc();
 

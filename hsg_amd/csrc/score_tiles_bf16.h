@@ -249,6 +249,10 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
     epi(tile, acc);
   };
 
+  // visible full wait: staging loads consumed under per-lane conditions stay "pending" in
+  // the compiler's s_waitcnt model on the skipped paths, and it would then guard their
+  // registers with vmcnt(0) inside the streaming loop (see score_tiles_f16.h)
+  __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();                         // table planes visible to all waves
   zero_acc();
   // The caller guarantees nfull % 4 == 0 (split_shape_ok): four register sets
