@@ -579,14 +579,26 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     const int64_t pix = q0 + jl;
     const bool ok = pix < HW;
     const float *src = in + (int64_t)b * C * HW + (ok ? pix : HW - 1);
-    for (int q = 2 * w + sub; q < NQ; q += 8) {
-      float4 v;
-      v.x = src[(int64_t)(4 * q + 0) * HW];
-      v.y = src[(int64_t)(4 * q + 1) * HW];
-      v.z = src[(int64_t)(4 * q + 2) * HW];
-      v.w = src[(int64_t)(4 * q + 3) * HW];
-      if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4 *>(tile + jl * C + ((q ^ sw) << 2)) = v;
+    // batches of 8 quads per thread: all 32 loads of a batch are issued before the
+    // first LDS write (a load-use loop here exposes one memory latency per quad);
+    // indices are clamped, not branched on, so the loads stay unconditional
+    for (int q0b = 2 * w + sub; q0b < NQ; q0b += 64) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = min(q0b + 8 * u, NQ - 1);
+        v[u].x = src[(int64_t)(4 * q + 0) * HW];
+        v[u].y = src[(int64_t)(4 * q + 1) * HW];
+        v[u].z = src[(int64_t)(4 * q + 2) * HW];
+        v[u].w = src[(int64_t)(4 * q + 3) * HW];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = q0b + 8 * u;
+        if (q < NQ)
+          *reinterpret_cast<float4 *>(tile + jl * C + ((q ^ sw) << 2)) =
+              ok ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   }
   __syncthreads();
