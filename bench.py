@@ -162,10 +162,15 @@ def main():
       (4 * D + 8) * npx, a_ms, a_n,
       mfma_tflops=round(2.0 * D * (grid[0] * grid[1]) * npx / (a_ms / max(a_n, 1) * 1e-3) / 1e12, 2)
       if a_n else None,
-      note=('algorithmic bytes are SURVEY 8(d)\'s 4D+8 per pixel; the filter streams the fp16 copy '
-            '(2(D-2)+4 B per pixel) plus the fp32 rows of the undecided few per cent, so the kernel '
-            'moves about half of them -- compare avg_launch_ms with that traffic at ~6 TB/s, not '
-            'frac with 1.0') if half_ok else None)
+      note=('achieved / frac follow the contract: SURVEY 8(d)\'s algorithmic 4D+8 B per pixel over the '
+            'group\'s duration.  By design the group STREAMS less than that -- the fp16 copy '
+            '(2(D-2)+8 B per pixel), 4 B of labels and the fp32 rows of the ~1.5 % undecided pixels '
+            '-- which is how frac can exceed 1; streamed_* price that traffic instead') if half_ok else None)
+  if roofline_assign and half_ok:
+    streamed = (2 * (D - 2) + 8 + 4 + 0.015 * 4 * D) * npx
+    sg = streamed / (a_ms / a_n * 1e-3) / 1e9
+    roofline_assign.update({'streamed_bytes_per_launch': int(streamed), 'streamed_GBps': round(sg, 1),
+                            'streamed_frac': round(sg / HBM_PEAK_GBS, 4)})
   roofline_iteration = None
   if m_n and a_n and f_n:
     it_ms = m_ms / m_n + f_ms / f_n + a_ms / a_n
