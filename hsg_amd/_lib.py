@@ -73,6 +73,7 @@ SIGNATURES = {
     'hsgk_hier_assign': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'hsgk_group_mean': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     'hsgk_gather_labels': (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _vp]),
+    'hsgk_cluster_topk': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     'hsgk_topk_workspace_bytes': (_sz, [_i64, _i32, _i64, _i32]),
     'hsgk_topk_prototypes': (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),
     'hsgk_assign_workspace_bytes': (_sz, [_i64, _i32, _i32]),

@@ -115,6 +115,77 @@ __global__ void gather_labels_kernel(const int64_t *__restrict__ table, int M,
     out[i] = table[img[i] * M + seg[i]];
 }
 
+// ---------------------------------------------------------------------------
+// TransformerClustering.forward tail (hsg/models/embeddings/transformer_clusters.py:99-114):
+//   logits[b,i,j] = (sum_c cent[b,c,i] * feat[b,c,j]) / sqrt(C)          (C1 chain over c)
+//   order[b,:]    = the k rows i with the largest max_j logits[b,i,j], descending,
+//                   lower i first on exact ties (NaN maxima first, like torch.topk)
+//   outputs       = logits / cent / cfeat gathered in that order
+// Two launches: (1) logits_all [B,tl,sl], one thread per output, lanes along j
+// (coalesced node features, broadcast centroid element); (2) one workgroup per image:
+// row maxima, rank by counting, gathers.  tl, sl are a few hundred at most: the op is
+// launch bound in the reference (three einsum / max / topk / gather dispatches).
+__global__ __launch_bounds__(256) void cluster_logits_kernel(
+    const float *__restrict__ cent, const float *__restrict__ feat, int C, int tl, int sl,
+    float divisor, float *__restrict__ logits_all) {
+  const int b = blockIdx.z, i = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= sl) return;
+  const float *cb = cent + (int64_t)b * C * tl + i;
+  const float *fb = feat + (int64_t)b * C * sl + j;
+  float acc = 0.0f;
+  for (int c = 0; c < C; ++c) acc = fmaf(cb[(int64_t)c * tl], fb[(int64_t)c * sl], acc);
+  logits_all[((int64_t)b * tl + i) * sl + j] = acc / divisor;      // divisor = (float)sqrt((double)C), a true division like ATen on CPU
+}
+
+__global__ __launch_bounds__(256) void cluster_topk_kernel(
+    const float *__restrict__ cent, const float *__restrict__ cfeat,
+    const float *__restrict__ logits_all, int C, int tl, int sl, int k,
+    int64_t *__restrict__ order, float *__restrict__ logits_sel, float *__restrict__ cent_sel,
+    float *__restrict__ cfeat_sel) {
+  extern __shared__ float smax[];              // [tl] row maxima, then int sel[k]
+  int *sel = reinterpret_cast<int *>(smax + tl);
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float *lg = logits_all + (int64_t)b * tl * sl;
+  for (int i = w; i < tl; i += 4) {            // wave per row: max over j (NaN propagates, like torch.max)
+    float m = -INFINITY;
+    bool nan = false;
+    for (int j = lane; j < sl; j += 64) {
+      const float v = lg[(int64_t)i * sl + j];
+      nan |= v != v;
+      m = fmaxf(m, v);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      m = fmaxf(m, __shfl_xor(m, off));
+      nan |= __shfl_xor((int)nan, off) != 0;
+    }
+    if (lane == 0) smax[i] = nan ? NAN : m;
+  }
+  __syncthreads();
+  for (int i = tid; i < tl; i += 256) {        // rank = number of rows that sort before row i
+    const float v = smax[i];
+    const bool vn = v != v;
+    int rank = 0;
+    for (int o = 0; o < tl; ++o) {
+      const float u = smax[o];
+      const bool un = u != u;
+      const bool before = un ? (!vn || o < i) : (!vn && (u > v || (u == v && o < i)));
+      rank += before ? 1 : 0;
+    }
+    if (rank < k) { sel[rank] = i; order[(int64_t)b * k + rank] = i; }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < k * sl; idx += 256) {
+    const int r = idx / sl, j = idx - r * sl;
+    logits_sel[((int64_t)b * k + r) * sl + j] = lg[(int64_t)sel[r] * sl + j];
+  }
+  for (int idx = tid; idx < C * k; idx += 256) {
+    const int c = idx / k, r = idx - c * k;
+    cent_sel[((int64_t)b * C + c) * k + r] = cent[((int64_t)b * C + c) * tl + sel[r]];
+    cfeat_sel[((int64_t)b * C + c) * k + r] = cfeat[((int64_t)b * C + c) * tl + sel[r]];
+  }
+}
+
 }  // namespace hsgk
 
 using namespace hsgk;
@@ -160,6 +231,27 @@ int hsgk_gather_labels(const int64_t *table, int M, const int64_t *img, const in
   int64_t g = (n + 255) / 256;
   hipLaunchKernelGGL(gather_labels_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), table, M, img, seg, n, out);
+  HSGK_LAUNCH_CHECK();
+  return 0;
+}
+
+int hsgk_cluster_topk(const float *centroids, const float *centroid_feats, const float *node_features,
+                      int B, int C, int tl, int sl, int k, float *logits_all, int64_t *order,
+                      float *logits_sel, float *centroids_sel, float *centroid_feats_sel,
+                      hsgk_stream_t stream) {
+  HSGK_REQUIRE(B >= 0 && C >= 1 && tl >= 1 && sl >= 1 && k >= 1 && k <= tl, "bad shape");
+  HSGK_REQUIRE(centroids && centroid_feats && node_features && logits_all && order && logits_sel &&
+                   centroids_sel && centroid_feats_sel, "null argument");
+  HSGK_REQUIRE(tl <= 65535 && (size_t)(tl + k) * 4 <= 64 * 1024, "too many queries");
+  if (B == 0) return 0;
+  (void)hipGetLastError();
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(cluster_logits_kernel, dim3((sl + 255) / 256, tl, B), dim3(256), 0, s, centroids,
+                     node_features, C, tl, sl, (float)sqrt((double)C), logits_all);
+  HSGK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(cluster_topk_kernel, dim3(B), dim3(256), (size_t)(tl + k) * 4, s, centroids,
+                     centroid_feats, logits_all, C, tl, sl, k, order, logits_sel, centroids_sel,
+                     centroid_feats_sel);
   HSGK_LAUNCH_CHECK();
   return 0;
 }

@@ -16,6 +16,8 @@ kernels and the backward pass re-derives the tiny local graph with ATen ops.
 """
 import ctypes
 
+import math
+
 import torch
 import torch.nn.functional as F
 
@@ -207,3 +209,60 @@ def collect_pixel_hierarchical_clustering_indices(cluster_indices_by_batch,
                                              seg.data_ptr(), seg.shape[0], out.data_ptr(),
                                              _lib.stream_ptr()))
   return out
+
+
+class _ClusterTopk(torch.autograd.Function):
+  """transformer_clusters.py:99-114 on the C ABI (hsgk_cluster_topk); backward = the
+  two batched GEMMs of the einsum plus the scatter of the gathered rows."""
+
+  @staticmethod
+  def forward(ctx, centroids, centroid_feats, node_features, k):
+    B, C, tl = centroids.shape
+    sl = node_features.shape[-1]
+    cen = centroids.detach().contiguous().float()
+    cfe = centroid_feats.detach().contiguous().float()
+    nod = node_features.detach().contiguous().float()
+    dev = cen.device
+    logits_all = torch.empty((B, tl, sl), dtype=torch.float32, device=dev)
+    order = torch.empty((B, k), dtype=torch.int64, device=dev)
+    logits = torch.empty((B, k, sl), dtype=torch.float32, device=dev)
+    cen_sel = torch.empty((B, C, k), dtype=torch.float32, device=dev)
+    cfe_sel = torch.empty((B, C, k), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+      _lib.check(_lib.lib().hsgk_cluster_topk(
+          cen.data_ptr(), cfe.data_ptr(), nod.data_ptr(), B, C, tl, sl, k, logits_all.data_ptr(),
+          order.data_ptr(), logits.data_ptr(), cen_sel.data_ptr(), cfe_sel.data_ptr(),
+          _lib.stream_ptr()))
+    ctx.save_for_backward(cen, nod, order)
+    ctx.mark_non_differentiable(order)
+    return cen_sel, cfe_sel, logits, order
+
+  @staticmethod
+  def backward(ctx, g_cen_sel, g_cfe_sel, g_logits, _g_order):
+    cen, nod, order = ctx.saved_tensors
+    B, C, tl = cen.shape
+    sl = nod.shape[-1]
+    k = order.shape[1]
+    scale = 1.0 / math.sqrt(C)
+    g_full = torch.zeros((B, tl, sl), dtype=torch.float32, device=cen.device)
+    g_full.scatter_(1, order.unsqueeze(2).expand(B, k, sl), g_logits.contiguous().float())
+    g_cen = torch.bmm(nod, g_full.transpose(1, 2)) * scale                     # [B,C,tl]
+    g_nod = torch.bmm(cen, g_full) * scale                                     # [B,C,sl]
+    idx = order.unsqueeze(1).expand(B, C, k)
+    g_cen = g_cen.scatter_add(2, idx, g_cen_sel.contiguous().float())
+    g_cfe = torch.zeros((B, C, tl), dtype=torch.float32, device=cen.device).scatter_add(
+        2, idx, g_cfe_sel.contiguous().float())
+    return g_cen, g_cfe, g_nod, None
+
+
+def transformer_clustering_tail(centroids, centroid_feats, node_features, num_clusters):
+  """The tail of `TransformerClustering.forward` after the two FC+BN heads
+  (hsg/models/embeddings/transformer_clusters.py:99-114): logits =
+  centroids^T node_features / sqrt(C), the `num_clusters` queries with the largest
+  maximum activation (descending), and centroids / centroid_feats / logits gathered in
+  that order.  Shapes as in the reference: centroids, centroid_feats [B,C,tl],
+  node_features [B,C,sl] -> (centroids [B,C,k], centroid_feats [B,C,k], logits [B,k,sl]);
+  also returns the selected query indices [B,k]."""
+  if not centroids.is_cuda:
+    raise _lib.HsgkError('transformer_clustering_tail: tensors must be on a ROCm device')
+  return _ClusterTopk.apply(centroids, centroid_feats, node_features, int(num_clusters))

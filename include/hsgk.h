@@ -220,6 +220,18 @@ HSGK_API int hsgk_group_mean(const float *protos, const int64_t *labels, const u
 HSGK_API int hsgk_gather_labels(const int64_t *table, int M, const int64_t *img,
                                 const int64_t *seg, int64_t n, int64_t *out, hsgk_stream_t stream);
 
+/* ---- hsg/models/embeddings/transformer_clusters.py:99-114 TransformerClustering tail
+ * centroids / centroid_feats [B,C,tl], node_features [B,C,sl] (the reference's
+ * channel-major layouts).  logits_all [B,tl,sl] = cent^T feat / sqrt(C); order [B,k] =
+ * the k query rows with the largest row maximum, descending (lower index first on
+ * ties); logits_sel [B,k,sl], centroids_sel / centroid_feats_sel [B,C,k] gathered in
+ * that order.  1 <= k <= tl.                                                       */
+HSGK_API int hsgk_cluster_topk(const float *centroids, const float *centroid_feats,
+                               const float *node_features, int B, int C, int tl, int sl, int k,
+                               float *logits_all, int64_t *order, float *logits_sel,
+                               float *centroids_sel, float *centroid_feats_sel,
+                               hsgk_stream_t stream);
+
 /* ---- hsg/utils/segsort/eval.py:9-52 top_k_ranking (retrieval contraction) ----
  * queries [n,c], proto [P,c] -> out_idx [n,topk] (int64 prototype indices by
  * descending <q,p>, lower index first on exact ties) and out_val [n,topk].

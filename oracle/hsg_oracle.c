@@ -260,3 +260,20 @@ ORC_API void orc_segsort_nll(const float *emb, int64_t n, int c,
   free(s);
   free(w);
 }
+
+
+/* hsg/models/embeddings/transformer_clusters.py:99-102 logits of the TransformerClustering
+ * tail: logits[b,i,j] = (sum_c cent[b,c,i] * feat[b,c,j]) / (float)sqrt(C), the sum as
+ * one fmaf chain over ascending c from +0.0f (C1), then a correctly rounded division.  */
+ORC_API void orc_cluster_logits(const float *cent, const float *feat, int B, int C, int tl,
+                                int sl, float *out) {
+  const float div = (float)sqrt((double)C);
+  for (int b = 0; b < B; ++b)
+    for (int i = 0; i < tl; ++i)
+      for (int j = 0; j < sl; ++j) {
+        float acc = 0.0f;
+        for (int c = 0; c < C; ++c)
+          acc = fmaf(cent[((size_t)b * C + c) * tl + i], feat[((size_t)b * C + c) * sl + j], acc);
+        out[((size_t)b * tl + i) * sl + j] = acc / div;
+      }
+}

@@ -328,3 +328,20 @@ def calculate_kmeans_prototypes(emb, cluster_indices, cluster_batch_indices, pos
   pos = np.stack(outs[1]).transpose(0, 2, 1) if outs[1] else None
   return (protos, pos, np.stack(outs[2]), np.stack(outs[3]), np.stack(outs[4]),
           np.concatenate(outs[5]))
+
+
+def transformer_clustering_tail(centroids, centroid_feats, node_features, k):
+  """hsg/models/embeddings/transformer_clusters.py:99-114: logits = cent^T feat / sqrt(C)
+  (C1 chain over channels), the k rows with the largest row maximum (descending, lower
+  index first on ties), gathers."""
+  cen, cfe, nod = _f32(centroids), _f32(centroid_feats), _f32(node_features)
+  B, C, tl = cen.shape
+  sl = nod.shape[-1]
+  logits_all = np.empty((B, tl, sl), np.float32)
+  lib().orc_cluster_logits(_p(cen, _f32p), _p(nod, _f32p), B, C, tl, sl, _p(logits_all, _f32p))
+  mx = logits_all.max(axis=2)
+  order = np.stack([np.lexsort((np.arange(tl), -mx[b]))[:k] for b in range(B)]).astype(np.int64)
+  logits = np.stack([logits_all[b, order[b]] for b in range(B)])
+  cen_sel = np.stack([cen[b][:, order[b]] for b in range(B)])
+  cfe_sel = np.stack([cfe[b][:, order[b]] for b in range(B)])
+  return cen_sel, cfe_sel, logits, order

@@ -523,3 +523,56 @@ def test_top_k_ranking_vs_torch(dev, oracle, n, c, P, k):
   assert (labs == ref_labs)[gap_ok].all()
   maj = ev.majority_label_from_topk(labs, 9)
   assert maj.shape == (n,)
+
+
+def test_transformer_clustering_tail_vs_reference_golden(dev, oracle):
+  """a11: hsgk_cluster_topk through the Python mirror against the reference's own
+  TransformerClustering.forward tail (tests/golden/f10_cluster_tail.npz) -- selection
+  identical, logits bit-exact vs the oracle and <= 1e-5 vs the reference, gradients of
+  all three inputs vs the reference's autograd."""
+  import torch
+  from hsg_amd.models.embeddings import hierarchy as hz
+  g = util.load('f10_cluster_tail')
+  seed = int(g['seed'])
+  B, C, tl, sl, k = (int(v) for v in g['shape'])
+  cen_np = synth.gaussish(seed, B * C * tl).reshape(B, C, tl).copy()
+  nod_np = synth.gaussish(seed + 1, B * C * sl).reshape(B, C, sl).copy()
+  cen = torch.from_numpy(cen_np).to(dev).requires_grad_(True)
+  nod = torch.from_numpy(nod_np).to(dev).requires_grad_(True)
+  cfe = cen * 0.5 + 1.0
+  c_sel, cf_sel, logits, order = hz.transformer_clustering_tail(cen, cfe, nod, k)
+  assert np.array_equal(c_sel.detach().cpu().numpy(), g['c_sel'])
+  assert np.array_equal(cf_sel.detach().cpu().numpy(), g['cf_sel'])
+  assert np.abs(logits.detach().cpu().numpy() - g['logits']).max() <= 1e-5
+  o_c, o_cf, o_l, o_ord = oracle.transformer_clustering_tail(cen_np, cen_np * np.float32(0.5) + np.float32(1.0),
+                                                             nod_np, k)
+  assert np.array_equal(order.cpu().numpy(), o_ord)
+  assert np.array_equal(logits.detach().cpu().numpy(), o_l)          # same C1 chain: bit-exact
+  T = lambda s_, shape: torch.from_numpy(synth.gaussish(s_, int(np.prod(shape))).reshape(shape).copy()).to(dev)
+  ((c_sel * T(seed + 2, (B, C, k))).sum() + (cf_sel * T(seed + 3, (B, C, k))).sum()
+   + (logits * T(seed + 4, (B, k, sl))).sum()).backward()
+  assert np.abs(cen.grad.cpu().numpy() - g['g_cen']).max() <= 1e-4
+  assert np.abs(nod.grad.cpu().numpy() - g['g_nod']).max() <= 1e-4
+
+
+def test_transformer_clustering_tail_ties_and_full_permutation(dev, oracle):
+  """k == tl (the reference's configuration: the top-k is a permutation sorted by maximum
+  activation), duplicated queries (exact ties -> lower index first) at a larger shape."""
+  import torch
+  from hsg_amd.models.embeddings import hierarchy as hz
+  B, C, tl, sl = 4, 256, 64, 256
+  cen = synth.gaussish(991, B * C * tl).reshape(B, C, tl).copy()
+  cen[:, :, 7] = cen[:, :, 3]                                         # exact tie
+  cen[:, :, 40] = cen[:, :, 3]
+  nod = synth.gaussish(992, B * C * sl).reshape(B, C, sl).copy()
+  cfe = synth.gaussish(993, B * C * tl).reshape(B, C, tl).copy()
+  got = hz.transformer_clustering_tail(torch.from_numpy(cen).to(dev), torch.from_numpy(cfe).to(dev),
+                                       torch.from_numpy(nod).to(dev), tl)
+  ref = oracle.transformer_clustering_tail(cen, cfe, nod, tl)
+  for a, b in zip(got, ref):
+    assert np.array_equal(a.cpu().numpy(), b)
+  o = got[3].cpu().numpy()
+  for b in range(B):
+    assert sorted(o[b].tolist()) == list(range(tl))
+    p3, p7, p40 = (int(np.where(o[b] == q)[0][0]) for q in (3, 7, 40))
+    assert p3 < p7 < p40 and p7 == p3 + 1 and p40 == p7 + 1

@@ -141,3 +141,23 @@ def test_f7_hierarchy(oracle):
                 - g['fine_pos_n']).max() <= 2e-6
   assert np.array_equal(oracle.collect_pixel_hierarchical_clustering_indices(
       g['c_by_img'], g['bidx'], g['f_lab']), g['px_fine'])
+
+
+def _f10_inputs(g):
+  seed = int(g['seed'])
+  B, C, tl, sl, k = (int(v) for v in g['shape'])
+  cen = synth.gaussish(seed, B * C * tl).reshape(B, C, tl)
+  nod = synth.gaussish(seed + 1, B * C * sl).reshape(B, C, sl)
+  cfe = cen * np.float32(0.5) + np.float32(1.0)        # the generator's stand-in for centroid_feat_fc
+  return cen, cfe, nod, k
+
+
+def test_f10_transformer_clustering_tail(oracle):
+  """a11: the tail of the reference's TransformerClustering.forward (logits, max, topk,
+  gathers) on the golden inputs: the selection is identical, floats within 1e-5."""
+  g = util.load('f10_cluster_tail')
+  cen, cfe, nod, k = _f10_inputs(g)
+  c_sel, cf_sel, logits, order = oracle.transformer_clustering_tail(cen, cfe, nod, k)
+  assert np.array_equal(c_sel, g['c_sel'])             # pure gathers: bit-exact <=> same selection
+  assert np.array_equal(cf_sel, g['cf_sel'])
+  assert np.abs(logits - g['logits']).max() <= 1e-5

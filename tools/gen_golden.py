@@ -282,6 +282,31 @@ def f7():
        px_coarse=px_coarse.numpy())
 
 
+# ---- F10 TransformerClustering tail (transformer_clusters.py:99-114) -------------
+def f10():
+  """The reference's own `TransformerClustering.forward`, with the transformer and the two
+  FC+BN heads stubbed out (identity), so that exactly the tail -- logits, max, topk, the
+  three gathers -- runs on known inputs; plus its autograd gradients."""
+  import types
+  import torch.nn as nn
+  import hsg.models.embeddings.transformer_clusters as ref_tc
+  seed = synth.SEED_BASE + 81
+  B, C, tl, sl, k = 3, 32, 12, 40, 5
+  cen = torch.from_numpy(synth.gaussish(seed, B * C * tl).reshape(B, C, tl).copy()).requires_grad_(True)
+  nod = torch.from_numpy(synth.gaussish(seed + 1, B * C * sl).reshape(B, C, sl).copy()).requires_grad_(True)
+  stub = types.SimpleNamespace(
+      _transformer=lambda src, mask, query_embed, pos_embed: (cen, nod),
+      centroid_fc=nn.Identity(), centroid_feat_fc=lambda t: t * 0.5 + 1.0, _num_clusters=k)
+  c_sel, cf_sel, logits, node = ref_tc.TransformerClustering.forward(stub, nod, None, None, None)
+  w1 = torch.from_numpy(synth.gaussish(seed + 2, B * C * k).reshape(B, C, k).copy())
+  w2 = torch.from_numpy(synth.gaussish(seed + 3, B * C * k).reshape(B, C, k).copy())
+  w3 = torch.from_numpy(synth.gaussish(seed + 4, B * k * sl).reshape(B, k, sl).copy())
+  ((c_sel * w1).sum() + (cf_sel * w2).sum() + (logits * w3).sum()).backward()
+  save('f10_cluster_tail', seed=seed, shape=np.array([B, C, tl, sl, k]),
+       c_sel=c_sel.detach().numpy(), cf_sel=cf_sel.detach().numpy(), logits=logits.detach().numpy(),
+       g_cen=cen.grad.numpy(), g_nod=nod.grad.numpy())
+
+
 # ---- F9 one train-step slice: k-means -> prototype table -> loss -> backward ----
 def f9():
   import torch.nn.parallel.scatter_gather as sg
@@ -313,6 +338,6 @@ def f9():
 
 if __name__ == '__main__':
   os.makedirs(OUT, exist_ok=True)
-  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9']
+  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10']
   for w in which:
     globals()[w]()
