@@ -481,11 +481,7 @@ static int launch_assign_split(const float *x, int d, const float *cent, int K,
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     return cus > 0 ? cus : 256;
   }();
-  static const bool persist = [] {
-    const char *e = getenv("HSGK_SPLIT_PERSIST");          // experiment switch, default on
-    return !(e && e[0] == '0');
-  }();
-  if (persist && split == 1 && max_chunks >= 4 * n_cu) {       // enough chunks: one persistent WG per CU
+  if (split == 1 && max_chunks >= 4 * n_cu) {       // enough chunks: one persistent WG per CU
     split = 0;
     grid = n_cu;
   }
