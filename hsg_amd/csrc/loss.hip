@@ -19,12 +19,20 @@
 
 namespace hsgk {
 
+// "same semantic label": equal labels (SegSortLoss), or -- set mode, SetSegSortLoss --
+// a non-zero label affinity: sem / psem then carry one bit per class and the affinity
+// sum_c sem[i,c] * psem[p,c] of non-negative multi-hot labels is > 0 iff the masks meet
+__device__ inline bool same_semantic(int64_t a, int64_t b, int set_mode) {
+  return set_mode ? (a & b) != 0 : a == b;
+}
+
 struct LossFwdEpi {
   int kb0, nrows, pb;
   int64_t P, N, crow0;
   float kappa;
   const int64_t *sem, *inst, *psem;
   float *part;                                   // [npb][N][3]
+  int set_mode;
   template <int MB>
   __device__ inline void operator()(int tile, const f32x16 (&acc)[MB]) const {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -43,7 +51,7 @@ struct LossFwdEpi {
         if (p < P) {
           const float s = expf(acc[m][r] * kappa);
           if (p == ij) own += s;
-          if (psem[p] == sj) same += s; else diff += s;
+          if (same_semantic(psem[p], sj, set_mode)) same += s; else diff += s;
         }
       }
     own += __shfl_xor(own, 32);
@@ -64,6 +72,7 @@ struct LossBwdEpi {
   const float *num, *den, *gscale;
   const int32_t *use_same;
   float *wt;                                     // [P][N]
+  int set_mode;
   template <int MB>
   __device__ inline void operator()(int tile, const f32x16 (&acc)[MB]) const {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -83,11 +92,13 @@ struct LossBwdEpi {
         const int64_t p = kb0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (p < P && valid) {
           const float s = expf(acc[m][r] * kappa);
-          const bool in_diff = psem[p] != sj;
-          const bool in_num = (group_plus && us) ? (!in_diff && p != ij) : (p == ij);
-          float g = 0.0f;
-          if (in_num) g = inv_den - inv_num;
-          else if (in_diff) g = inv_den;
+          // nll = -log(num / den), den = diff + num; with a = d num / d s_p, b = d diff / d s_p:
+          // d nll / d s_p = a (1/den - 1/num) + b / den.  num = sum_same - own ('segsort+',
+          // positive) else own; the own prototype can also sit in the "different" sum
+          // (labels without affinity), loss.py:71-78 / 118-127
+          const bool same = same_semantic(psem[p], sj, set_mode);
+          const float a = (group_plus && us) ? (float)((int)same - (int)(p == ij)) : (p == ij ? 1.0f : 0.0f);
+          const float g = a * (inv_den - inv_num) + (same ? 0.0f : inv_den);
           wt[p * N + row] = g * s * gs;
         }
       }
@@ -193,11 +204,11 @@ int hsgk_segsort_loss_fwd(const float *emb, int64_t n, int c, const int64_t *sem
   hipStream_t s = static_cast<hipStream_t>(stream);
   (void)hipGetLastError();
   float *part = static_cast<float *>(workspace);
-  LossFwdEpi epi{0, 0, 0, P, n, 0, kappa, sem, inst, psem, part};
+  LossFwdEpi epi{0, 0, 0, P, n, 0, kappa, sem, inst, psem, part, (group_plus >> 1) & 1};
   if (int rc = launch_loss_tiles(emb, n, c, proto, P, epi, s)) return rc;
   const int npb = (int)((P + 63) / 64);
   hipLaunchKernelGGL(loss_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, npb,
-                     n, group_plus, nll, num, den, use_same);
+                     n, group_plus & 1, nll, num, den, use_same);
   HSGK_LAUNCH_CHECK();
   return 0;
 }
@@ -211,7 +222,8 @@ int hsgk_segsort_loss_bwd_weights(const float *emb, int64_t n, int c, const int6
   if (n == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   (void)hipGetLastError();
-  LossBwdEpi epi{0, 0, group_plus, P, n, 0, kappa, sem, inst, psem, num, den, gscale, use_same, wt};
+  LossBwdEpi epi{0, 0, group_plus & 1, P, n, 0, kappa, sem, inst, psem, num, den, gscale, use_same, wt,
+                 (group_plus >> 1) & 1};
   return launch_loss_tiles(emb, n, c, proto, P, epi, s);
 }
 

@@ -184,8 +184,11 @@ HSGK_API int hsgk_segment_reduce_bwd(const float *gout, const float *out, const 
 
 /* ---- hsg/utils/segsort/loss.py:15-82,149-190 SegSortLoss --------------------
  * emb [n,c] f32, sem/inst int64 [n] (inst indexes the prototype table),
- * proto [P,c] f32, psem int64 [P], kappa = concentration, group_plus = 1 for
- * 'segsort+', 0 for 'segsort'.  fwd writes the per-pixel negative log
+ * proto [P,c] f32, psem int64 [P], kappa = concentration, group_plus bit 0 = 1 for
+ * 'segsort+', 0 for 'segsort'; bit 1 = set mode (SetSegSortLoss, loss.py:85-130,
+ * 193-251): sem / psem carry one bit per class of the multi-hot labels (<= 64 classes)
+ * and "same semantic label" means a non-zero label affinity, i.e. the masks meet.
+ * fwd writes the per-pixel negative log
  * likelihood nll[n] and the backward state num[n], den[n], use_same[n].
  * bwd_weights writes W^T [P,n] with W^T[p][i] = gscale[i] * dnll_i/d(e_i.p_p);
  * the caller finishes with two plain GEMMs: g_emb = W proto, g_proto = W^T emb. */

@@ -208,7 +208,17 @@ ORC_API void orc_segment_mean(const float *x, int64_t n, int d,
  * argument the kernels use.  group_plus = 1 for 'segsort+', 0 for 'segsort'.
  * Also returns d(mean loss)/d(emb) and d(mean loss)/d(proto) when non-NULL
  * (scaled by `gscale`, i.e. 1/N for reduction='mean').                      */
-ORC_API void orc_segsort_nll(const float *emb, int64_t n, int c,
+/* label affinity of pixel i and prototype j: nc == 0 -> scalar labels, 1 if equal else 0
+ * (loss.py:42-44); nc > 0 -> multi-hot rows, sum_c sem[i,c] * psem[j,c] clamped to its sign
+ * (loss.py:108-110: "> 0" same, "== 0" different).                                    */
+static int orc_affinity(const int64_t *sem, const int64_t *psem, int64_t i, int64_t j, int nc) {
+  if (nc == 0) return psem[j] == sem[i] ? 1 : 0;
+  int64_t a = 0;
+  for (int t = 0; t < nc; ++t) a += sem[i * nc + t] * psem[j * nc + t];
+  return a > 0 ? 1 : (a < 0 ? -1 : 0);
+}
+
+static void orc_segsort_nll_impl(const float *emb, int64_t n, int c, int nc,
                              const int64_t *sem, const int64_t *inst,
                              const float *proto, int64_t P,
                              const int64_t *psem, float kappa, int group_plus,
@@ -227,7 +237,8 @@ ORC_API void orc_segsort_nll(const float *emb, int64_t n, int c,
       float acc = 0.0f;
       for (int t = 0; t < c; ++t) acc = fmaf(e[t], p[t], acc);
       s[j] = exp((double)(acc * kappa));
-      if (psem[j] == sem[i]) same += s[j]; else diff += s[j];
+      const int aff = orc_affinity(sem, psem, i, j, nc);
+      if (aff > 0) same += s[j]; else if (aff == 0) diff += s[j];
     }
     double own = s[inst[i]];
     double same_wo = same - own;
@@ -236,16 +247,17 @@ ORC_API void orc_segsort_nll(const float *emb, int64_t n, int c,
     double den = diff + num;
     nll[i] = -log(num / den);
     if (!gemb && !gproto) continue;
-    /* d nll / d s_j = -[j in num]/num + [j in num or diff]/den */
+    /* nll = -log(num / den), den = diff + num.  With a_j = d num / d s_j and
+     * b_j = d diff / d s_j:  d nll / d s_j = a_j (1/den - 1/num) + b_j / den.
+     * num = sum_{aff>0} s_j - s_own ('segsort+' with a positive result), else s_own; so
+     * a_j = [aff_j > 0] - [j == own] resp. [j == own]; b_j = [aff_j == 0].  The pixel's
+     * own prototype can have b = 1 (no affinity with its pixel): it is then in both sums. */
     for (int64_t j = 0; j < P; ++j) {
-      int in_diff = psem[j] != sem[i];
-      int in_num;
-      if (!group_plus) in_num = (j == inst[i]);
-      else if (use_same) in_num = (!in_diff) && (j != inst[i]);
-      else in_num = (j == inst[i]);
-      double g = 0.0;
-      if (in_num) g += -1.0 / num + 1.0 / den;
-      else if (in_diff) g += 1.0 / den;
+      const int aff = orc_affinity(sem, psem, i, j, nc);
+      const int own_j = (j == inst[i]);
+      const double a = (group_plus && use_same) ? (double)((aff > 0) - own_j) : (double)own_j;
+      const double b = aff == 0 ? 1.0 : 0.0;
+      const double g = a * (1.0 / den - 1.0 / num) + b / den;
       w[j] = g * s[j] * (double)kappa * gscale;   /* d/d(dot_ij) */
     }
     for (int64_t j = 0; j < P; ++j) {
@@ -259,6 +271,28 @@ ORC_API void orc_segsort_nll(const float *emb, int64_t n, int c,
   }
   free(s);
   free(w);
+}
+
+ORC_API void orc_segsort_nll(const float *emb, int64_t n, int c,
+                             const int64_t *sem, const int64_t *inst,
+                             const float *proto, int64_t P,
+                             const int64_t *psem, float kappa, int group_plus,
+                             double *nll /* [n] */, double gscale,
+                             double *gemb /* [n,c] or NULL */,
+                             double *gproto /* [P,c] or NULL */) {
+  orc_segsort_nll_impl(emb, n, c, 0, sem, inst, proto, P, psem, kappa, group_plus, nll, gscale, gemb,
+                       gproto);
+}
+
+/* hsg/utils/segsort/loss.py:85-130 _one_hot_calculate_log_likelihood (SetSegSortLoss):
+ * sem [n,nc], psem [P,nc] multi-hot labels, same / different by the label affinity.   */
+ORC_API void orc_set_segsort_nll(const float *emb, int64_t n, int c, int nc,
+                                 const int64_t *sem, const int64_t *inst,
+                                 const float *proto, int64_t P,
+                                 const int64_t *psem, float kappa, int group_plus,
+                                 double *nll, double gscale, double *gemb, double *gproto) {
+  orc_segsort_nll_impl(emb, n, c, nc, sem, inst, proto, P, psem, kappa, group_plus, nll, gscale, gemb,
+                       gproto);
 }
 
 

@@ -233,6 +233,32 @@ def segsort_nll(embeddings, semantic_labels, instance_labels, prototypes,
   return (nll, ge, gp) if want_grads else nll
 
 
+def set_segsort_nll(embeddings, semantic_labels, instance_labels, prototypes,
+                    prototype_semantic_labels, concentration, group_mode='segsort+',
+                    want_grads=False, gscale=None):
+  """hsg/utils/segsort/loss.py:85-130 (SetSegSortLoss): multi-hot labels [n,nc] / [P,nc],
+  same / different by the label affinity sem @ psem.T (f64)."""
+  e = _f32(embeddings).reshape(-1, embeddings.shape[-1])
+  p = _f32(prototypes).reshape(-1, prototypes.shape[-1])
+  sem = _i64(semantic_labels)
+  psem = _i64(prototype_semantic_labels)
+  nc = sem.shape[-1]
+  sem, psem = sem.reshape(-1, nc), psem.reshape(-1, nc)
+  inst = _i64(instance_labels).reshape(-1)
+  n, c = e.shape
+  nll = np.empty(n, np.float64)
+  ge = np.zeros((n, c), np.float64) if want_grads else None
+  gp = np.zeros((p.shape[0], c), np.float64) if want_grads else None
+  if gscale is None:
+    gscale = 1.0 / max(n, 1)
+  lib().orc_set_segsort_nll(_p(e, _f32p), ctypes.c_int64(n), c, nc, _p(sem, _i64p),
+                            _p(inst, _i64p), _p(p, _f32p), ctypes.c_int64(p.shape[0]),
+                            _p(psem, _i64p), ctypes.c_float(concentration),
+                            int(group_mode == 'segsort+'), _p(nll, _f64p),
+                            ctypes.c_double(gscale), _p(ge, _f64p), _p(gp, _f64p))
+  return (nll, ge, gp) if want_grads else nll
+
+
 def segsort_loss(*args, reduction='mean', **kw):
   """hsg/utils/segsort/loss.py:149-190 SegSortLoss.forward."""
   nll = segsort_nll(*args, **kw)

@@ -161,3 +161,26 @@ def test_f10_transformer_clustering_tail(oracle):
   assert np.array_equal(c_sel, g['c_sel'])             # pure gathers: bit-exact <=> same selection
   assert np.array_equal(cf_sel, g['cf_sel'])
   assert np.abs(logits - g['logits']).max() <= 1e-5
+
+
+def test_f11_set_segsort_loss(oracle):
+  """n3: SetSegSortLoss (multi-hot labels, same / different by the label affinity) on the
+  golden inputs, incl. pixels that have no affinity with their own prototype."""
+  g = util.load('f11_set_segsort_loss')
+  n, c, P, nc = (int(v) for v in g['shape'])
+  e_np, inst, sem, psem = util.set_loss_inputs(int(g['seed']), n, c, P, nc)
+  e = oracle.normalize_embedding(e_np)
+  proto = oracle.calculate_prototypes_from_labels(e, inst, P)
+  own_aff = (sem * psem[inst]).sum(1)
+  assert (own_aff == 0).any() and (own_aff > 0).any()
+  for kappa in (10, 16):
+    for mode, tag in (('segsort+', 'plus'), ('segsort', 'plain')):
+      key = 'k%d_%s' % (kappa, tag)
+      nll, ge, gp = oracle.set_segsort_nll(e, sem, inst, proto, psem, float(kappa), mode,
+                                           want_grads=True)
+      assert abs(nll.mean() - float(g[key + '_loss'])) <= 1e-4
+      # per pixel: 'segsort+' takes same - own in fp32 in the reference; where that nearly
+      # cancels (3 pixels at kappa 16, nll ~ 10.7) its own rounding noise is 4e-4
+      assert np.abs(nll - g[key + '_nll']).max() <= 1e-3
+      assert np.abs(ge[::7] - g[key + '_gemb']).max() <= 1e-6
+      assert np.abs(gp - g[key + '_gproto']).max() <= 1e-5

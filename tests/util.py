@@ -67,3 +67,26 @@ def exchange_inputs(seed, n_gpus=2, imgs_per_gpu=3, C=16, K=6):
   return out
 
 
+
+
+def set_loss_inputs(seed, n, c, P, nc):
+  """Multi-hot labels: every prototype carries 1-3 classes; a pixel carries the classes
+  of its own prototype, except every 5th pixel which gets two pseudo-random classes (so
+  that some pixels have NO affinity with their own prototype: it then counts as
+  'different', loss.py:123-125)."""
+  e = synth.gaussish(seed, n * c).reshape(n, c).copy()
+  inst = (synth.hash_u64(seed + 1, n) % np.uint64(P)).astype(np.int64)
+  h = synth.hash_u64(seed + 2, P * 3).reshape(P, 3)
+  psem = np.zeros((P, nc), np.int64)
+  for j in range(P):
+    for t in range(1 + int(h[j, 0] % np.uint64(3))):
+      psem[j, int(h[j, t] % np.uint64(nc))] = 1
+  sem = psem[inst].copy()
+  hp = synth.hash_u64(seed + 3, n * 2).reshape(n, 2)
+  for i in range(0, n, 5):
+    sem[i] = 0
+    sem[i, int(hp[i, 0] % np.uint64(nc))] = 1
+    sem[i, int(hp[i, 1] % np.uint64(nc))] = 1
+  return e, inst, sem, psem
+
+

@@ -212,6 +212,32 @@ def f6():
   save('f6_segsort_loss', **rec)
 
 
+# ---- F11 SetSegSortLoss (loss.py:85-130, 193-251): multi-hot semantic labels ----
+def f11():
+  seed = synth.SEED_BASE + 91
+  n, c, P, nc = 2000, 40, 61, 21
+  from tests import util as tutil
+  e_np, inst_np, sem_np, psem_np = tutil.set_loss_inputs(seed, n, c, P, nc)
+  e = ref_general.normalize_embedding(torch.from_numpy(e_np))
+  inst, sem, psem = (torch.from_numpy(a) for a in (inst_np, sem_np, psem_np))
+  rec = dict(seed=seed, shape=np.array([n, c, P, nc]))
+  for kappa in (10.0, 16.0):
+    for mode in ('segsort+', 'segsort'):
+      ee = e.clone().requires_grad_(True)
+      proto = ref_common.calculate_prototypes_from_labels(ee, inst, P)
+      pp = proto.detach().clone().requires_grad_(True)
+      loss = ref_loss.SetSegSortLoss(kappa, mode)(ee, sem, inst, pp, psem)
+      loss.backward()
+      nll = ref_loss.SetSegSortLoss(kappa, mode, reduction='none')(
+          e, sem, inst, proto.detach(), psem).view(-1)
+      tag = 'k%d_%s' % (int(kappa), 'plus' if mode == 'segsort+' else 'plain')
+      rec[tag + '_loss'] = np.float64(loss.item())
+      rec[tag + '_nll'] = nll.numpy()
+      rec[tag + '_gemb'] = ee.grad.numpy()[::7].copy()
+      rec[tag + '_gproto'] = pp.grad.numpy()
+  save('f11_set_segsort_loss', **rec)
+
+
 # ---- F8 cross-GPU glue (hsg/models/utils.py) with 2 simulated GPUs ------------
 def f8():
   import torch.nn.parallel.scatter_gather as sg
@@ -338,6 +364,6 @@ def f9():
 
 if __name__ == '__main__':
   os.makedirs(OUT, exist_ok=True)
-  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10']
+  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11']
   for w in which:
     globals()[w]()
