@@ -268,3 +268,30 @@ def prepare_prototype_labels(semantic_labels, instance_labels, offset=256):
   panoptic = semantic_labels + instance_labels * offset
   proto_panoptic, unique_instance = torch.unique(panoptic, return_inverse=True)
   return proto_panoptic % offset, unique_instance
+
+
+def find_majority_label_index(semantic_labels, cluster_labels):
+  """Reference common.py:221-268: the majority semantic label of every cluster (first
+  maximal class, like `torch.argmax` on CPU) and the indices `[M, 1]` of the pixels that
+  carry their cluster's majority label.  One histogram + argmax + select pass in
+  libhsgk (`hsgk_majority_labels`) instead of the [N, num_classes] one-hot scatter."""
+  ops.require_gpu(semantic_labels, 'semantic_labels')
+  sem = semantic_labels.reshape(-1).to(torch.int64).contiguous()
+  clu = cluster_labels.reshape(-1).to(torch.int64).contiguous()
+  n = sem.numel()
+  if n == 0:
+    raise ValueError('find_majority_label_index: empty input')      # the reference's .max() raises too
+  lo = torch.stack([sem.min(), clu.min()])
+  hi = torch.stack([sem.max(), clu.max()]).cpu()                    # the reference syncs on both maxima too
+  if int(lo.min().item()) < 0:
+    raise ValueError('find_majority_label_index: negative label')
+  num_classes, num_clusters = int(hi[0].item()) + 1, int(hi[1].item()) + 1
+  dev = sem.device
+  with torch.cuda.device(dev):
+    hist = torch.empty((num_clusters * num_classes,), dtype=torch.int32, device=dev)
+    majority = torch.empty((num_clusters,), dtype=torch.int64, device=dev)
+    select = torch.empty((n,), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib().hsgk_majority_labels(
+        sem.data_ptr(), clu.data_ptr(), n, num_clusters, num_classes, hist.data_ptr(),
+        majority.data_ptr(), select.data_ptr(), _lib.stream_ptr()))
+  return select.nonzero(), majority

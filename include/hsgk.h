@@ -244,6 +244,24 @@ HSGK_API int hsgk_topk_prototypes(const float *queries, int64_t n, int c, const 
                                   int64_t P, int topk, int64_t *out_idx, float *out_val,
                                   void *workspace, size_t workspace_bytes, hsgk_stream_t stream);
 
+/* ---- full-resolution inference around k-means ---------------------------------
+ * pyscripts/inference/prototype.py:141-177 (inference.py:165-196): crop [C,h,w] (NCHW
+ * plane of one crop) is L2-normalised per pixel (general/common.py:101-120, eps 1e-12)
+ * and added into canvas [C,H,W] at (sh, sw); counts [H,W] += 1.  finish: canvas /=
+ * counts.  Crops are accumulated in call order (same float sums as the reference).    */
+HSGK_API int hsgk_overlap_accumulate(const float *crop, int C, int h, int w, float *canvas,
+                                     float *counts, int H, int W, int sh, int sw, float eps,
+                                     hsgk_stream_t stream);
+HSGK_API int hsgk_overlap_finish(float *canvas, const float *counts, int C, int H, int W,
+                                 hsgk_stream_t stream);
+/* ---- hsg/utils/segsort/common.py:221-268 find_majority_label_index -------------
+ * hist [num_clusters,num_classes] int32 (workspace, overwritten), majority [num_clusters]
+ * = first maximal class per cluster, select [n] = 1 where the pixel's class is its
+ * cluster's majority class.  Labels must lie in [0,num_classes) / [0,num_clusters).  */
+HSGK_API int hsgk_majority_labels(const int64_t *semantic, const int64_t *cluster, int64_t n,
+                                  int64_t num_clusters, int num_classes, int32_t *hist,
+                                  int64_t *majority, uint8_t *select, hsgk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

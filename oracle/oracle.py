@@ -371,3 +371,29 @@ def transformer_clustering_tail(centroids, centroid_feats, node_features, k):
   cen_sel = np.stack([cen[b][:, order[b]] for b in range(B)])
   cfe_sel = np.stack([cfe[b][:, order[b]] for b in range(B)])
   return cen_sel, cfe_sel, logits, order
+
+
+def find_majority_label_index(semantic_labels, cluster_labels):
+  """hsg/utils/segsort/common.py:221-268."""
+  sem = _i64(semantic_labels).reshape(-1)
+  clu = _i64(cluster_labels).reshape(-1)
+  nk, nc = int(clu.max()) + 1, int(sem.max()) + 1
+  hist = np.zeros((nk, nc), np.int64)
+  np.add.at(hist, (clu, sem), 1)
+  majority = hist.argmax(axis=1).astype(np.int64)              # first maximum
+  select = np.nonzero(majority[clu] == sem)[0].reshape(-1, 1).astype(np.int64)
+  return select, majority
+
+
+def overlap_average(crops, corners, channels, height, width, eps=EPS):
+  """pyscripts/inference/prototype.py:141-177: canvas += normalize(crop) per crop (in the
+  given order), counts += 1, canvas /= counts.  crops: list of [C,h,w] float32."""
+  canvas = np.zeros((channels, height, width), np.float32)
+  counts = np.zeros((height, width), np.float32)
+  for crop, (sh, sw) in zip(crops, corners):
+    c = _f32(crop)
+    C, h, w = c.shape
+    rows = normalize_embedding(np.ascontiguousarray(c.reshape(C, h * w).T), eps)   # [h*w, C], C1 chain
+    canvas[:, sh:sh + h, sw:sw + w] = canvas[:, sh:sh + h, sw:sw + w] + rows.T.reshape(C, h, w)
+    counts[sh:sh + h, sw:sw + w] += np.float32(1)
+  return canvas / counts[None]

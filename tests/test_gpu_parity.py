@@ -610,3 +610,69 @@ def test_set_segsort_loss_vs_golden_and_oracle(dev, oracle):
       assert abs(loss.item() - ref.mean()) <= 1e-4
   with pytest.raises(ValueError):
     SetSegSortLoss()(e.detach(), -sem, inst, proto.detach(), psem)
+
+
+def test_inference_pieces_vs_reference_golden(dev, oracle):
+  """n2: find_majority_label_index (histogram / argmax / select kernels) and the
+  overlap-averaged patch accumulation (normalise + accumulate + divide kernels) against
+  the reference (tests/golden/f12_inference.npz) and bit-exact against the oracle."""
+  import torch
+  from hsg_amd.utils.segsort import common as sc
+  from hsg_amd.utils.segsort import inference as inf
+  g = util.load('f12_inference')
+  sem, clu, crops, corners, (C, H, W), _, _ = util.inference_inputs(g)
+  sel, maj = sc.find_majority_label_index(torch.from_numpy(sem).to(dev), torch.from_numpy(clu).to(dev))
+  assert sel.dtype == torch.int64 and sel.dim() == 2 and sel.shape[1] == 1
+  assert np.array_equal(maj.cpu().numpy(), g['maj'])
+  assert np.array_equal(sel.cpu().numpy(), g['sel'].astype(np.int64))
+  crop_h, crop_w, stride_h, stride_w = (int(v) for v in g['ov_shape'][3:7])
+  assert np.array_equal(inf.patch_end_indices(H, crop_h, stride_h), g['patch_ind_h'])
+  assert np.array_equal(inf.patch_end_indices(W, crop_w, stride_w), g['patch_ind_w'])
+  avg = inf.OverlapAverager(C, H, W, dev)
+  for crop, (sh, sw) in zip(crops, corners):
+    avg.add(torch.from_numpy(crop).to(dev).unsqueeze(0), sh, sw)
+  from hsg_amd import _lib
+  with pytest.raises(_lib.HsgkError):
+    avg.add(torch.from_numpy(crops[0]).to(dev), H, 0)                              # outside the canvas
+  canvas = avg.result()
+  assert canvas.shape == (1, C, H, W)
+  got = canvas[0].cpu().numpy()
+  assert np.abs(got - g['canvas']).max() <= FTOL
+  assert np.array_equal(got, oracle.overlap_average(crops, corners, C, H, W))     # same C1 chain and order
+
+
+def test_inference_pipeline_end_to_end_vs_oracle(dev, oracle, tmp_path):
+  """prototype.py:141-208 as a whole on a small image: overlap-averaged embeddings ->
+  full-resolution segment_by_kmeans (ignore band from the padding) -> prototypes ->
+  majority labels -> .npy memory bank -> reload; every stage against the oracle."""
+  import torch
+  from hsg_amd.utils.segsort import common as sc
+  from hsg_amd.utils.segsort import inference as inf
+  from hsg_amd.utils.segsort import others
+  g = util.load('f12_inference')
+  _, _, crops, corners, (C, H, W), _, _ = util.inference_inputs(g)
+  avg = inf.OverlapAverager(C, H, W, dev)
+  for crop, (sh, sw) in zip(crops, corners):
+    avg.add(torch.from_numpy(crop).to(dev), sh, sw)
+  emb_full = avg.result()
+  fake = np.zeros((1, H, W), np.int64)
+  fake[:, H - 6:, :] = 255                                   # padded rows are ignored by the clustering
+  true_sem = (synth.hash_u64(777, H * W) % np.uint64(4)).astype(np.int64).reshape(1, H, W)
+  loc = sc.generate_location_features((H, W), dev, 'float') - 0.5     # torch's linspace bits are input data
+  out = sc.segment_by_kmeans(emb_full, torch.from_numpy(fake).to(dev), [3, 4], local_features=loc,
+                             ignore_index=255, iterations=5)
+  ref = oracle.segment_by_kmeans(emb_full.cpu().numpy(), fake, (3, 4), local_features=loc.cpu().numpy(),
+                                 ignore_index=255, iterations=5)
+  for a, b in zip(out, ref):
+    assert np.array_equal(a.cpu().numpy(), b)
+  emb, _, _, cidx, _ = out
+  protos = sc.calculate_prototypes_from_labels(emb, cidx)
+  assert np.array_equal(protos.cpu().numpy(), oracle.calculate_prototypes_from_labels(ref[0], ref[3]))
+  keep = torch.from_numpy(fake.reshape(-1) != 255).to(dev)
+  sem_kept = torch.from_numpy(true_sem.reshape(-1)).to(dev)[keep]
+  sel, maj = sc.find_majority_label_index(sem_kept, cidx)
+  o_sel, o_maj = oracle.find_majority_label_index(sem_kept.cpu().numpy(), ref[3])
+  assert np.array_equal(maj.cpu().numpy(), o_maj) and np.array_equal(sel.cpu().numpy(), o_sel)
+  others.save_prototypes(str(tmp_path / 'img0.npy'), protos, maj)
+  bank_p, bank_l = others.load_memory_banks(str(tmp_path))
+  assert np.array_equal(bank_p.numpy(), protos.cpu().numpy()) and np.array_equal(bank_l.numpy(), o_maj)

@@ -184,3 +184,31 @@ def test_f11_set_segsort_loss(oracle):
       assert np.abs(nll - g[key + '_nll']).max() <= 1e-3
       assert np.abs(ge[::7] - g[key + '_gemb']).max() <= 1e-6
       assert np.abs(gp - g[key + '_gproto']).max() <= 1e-5
+
+
+def test_f12_inference_pieces(oracle):
+  """n2: find_majority_label_index and the overlap-averaged patch accumulation against
+  the reference (function / script statements) on the golden inputs."""
+  g = util.load('f12_inference')
+  sem, clu, crops, corners, (C, H, W), _, _ = util.inference_inputs(g)
+  sel, maj = oracle.find_majority_label_index(sem, clu)
+  assert np.array_equal(maj, g['maj'])
+  assert np.array_equal(sel, g['sel'].astype(np.int64))
+  canvas = oracle.overlap_average(crops, corners, C, H, W)
+  assert np.abs(canvas - g['canvas']).max() <= FTOL
+
+
+def test_f12_memory_bank_format(tmp_path):
+  """The .npy prototype files (prototype.py:204-208 -> others.py:11-41): what
+  save_prototypes writes is what the reference's reader returned for the same data."""
+  import torch
+  from hsg_amd.utils.segsort import others
+  g = util.load('f12_inference')
+  _, _, _, _, _, protos, labs = util.inference_inputs(g)
+  others.save_prototypes(str(tmp_path / 'b_second.npy'), torch.from_numpy(protos[6:]), torch.from_numpy(labs[6:]))
+  others.save_prototypes(str(tmp_path / 'a_first.npy'), protos[:6], labs[:6])
+  p, l = others.load_memory_banks(str(tmp_path))
+  assert p.dtype == torch.float32 and l.dtype == torch.int64
+  assert np.array_equal(p.numpy(), g['bank_p']) and np.array_equal(l.numpy(), g['bank_l'])
+  raw = np.load(str(tmp_path / 'a_first.npy'), allow_pickle=True).item()
+  assert sorted(raw) == ['prototype', 'prototype_label']

@@ -90,3 +90,25 @@ def set_loss_inputs(seed, n, c, P, nc):
   return e, inst, sem, psem
 
 
+
+
+def inference_inputs(g):
+  """Inputs of tests/golden/f12_inference.npz (tools/gen_golden.py f12)."""
+  seed = int(g['seed'])
+  n, nk, nc = (int(v) for v in g['maj_shape'])
+  sem = (synth.hash_u64(seed, n) % np.uint64(nc)).astype(np.int64)
+  clu = (synth.hash_u64(seed + 1, n) % np.uint64(nk)).astype(np.int64)
+  clu[clu == 5] = 6
+  C, pad_h, pad_w, crop_h, crop_w = (int(v) for v in g['ov_shape'][:5])
+  crops, corners, k = [], [], 0
+  for ind_h in g['patch_ind_h']:
+    for ind_w in g['patch_ind_w']:
+      crop = synth.gaussish(seed + 10 + k, C * crop_h * crop_w).reshape(C, crop_h, crop_w).copy()
+      if k == 1:
+        crop[:, 3, 4] = 0.0
+      k += 1
+      crops.append(crop)
+      corners.append((int(ind_h) - crop_h, int(ind_w) - crop_w))
+  protos = synth.gaussish(seed + 3, 11 * 8).reshape(11, 8).copy()
+  labs = (synth.hash_u64(seed + 4, 11) % np.uint64(5)).astype(np.int64)
+  return sem, clu, crops, corners, (C, pad_h, pad_w), protos, labs

@@ -238,6 +238,60 @@ def f11():
   save('f11_set_segsort_loss', **rec)
 
 
+# ---- F12 full-resolution inference pieces -------------------------------------
+def f12():
+  """(i) the reference's find_majority_label_index; (ii) the overlap-averaged patch
+  accumulation of pyscripts/inference/prototype.py:131-177 -- the script's own statements
+  (patch grid, normalize_embedding on the permuted crop, slice +=, counts, division) run
+  on synthetic crop embeddings; (iii) a memory-bank file written the way
+  prototype.py:204-208 does and read back by the reference's load_memory_banks."""
+  import math
+  import tempfile
+  import hsg.utils.segsort.others as ref_others
+  seed = synth.SEED_BASE + 101
+  n, nk, nc = 5000, 37, 9
+  sem = (synth.hash_u64(seed, n) % np.uint64(nc)).astype(np.int64)
+  clu = (synth.hash_u64(seed + 1, n) % np.uint64(nk)).astype(np.int64)
+  clu[clu == 5] = 6                                   # an empty cluster (all-zero histogram row)
+  sel, maj = ref_common.find_majority_label_index(torch.from_numpy(sem), torch.from_numpy(clu))
+  # overlap averaging
+  C, pad_h, pad_w, crop_h, crop_w, stride_h, stride_w = 24, 70, 90, 32, 40, 20, 28
+  npatches_h = math.ceil(1.0 * (pad_h - crop_h) / stride_h) + 1
+  npatches_w = math.ceil(1.0 * (pad_w - crop_w) / stride_w) + 1
+  patch_ind_h = np.linspace(crop_h, pad_h, npatches_h, dtype=np.int32)
+  patch_ind_w = np.linspace(crop_w, pad_w, npatches_w, dtype=np.int32)
+  emb = None
+  counts = torch.zeros(1, 1, pad_h, pad_w)
+  k = 0
+  for ind_h in patch_ind_h:
+    for ind_w in patch_ind_w:
+      sh, eh = ind_h - crop_h, ind_h
+      sw, ew = ind_w - crop_w, ind_w
+      crop = torch.from_numpy(synth.gaussish(seed + 10 + k, C * crop_h * crop_w)
+                              .reshape(1, C, crop_h, crop_w).copy())
+      if k == 1:
+        crop[:, :, 3, 4] = 0.0                        # a zero pixel: the eps branch
+      k += 1
+      crop_emb = ref_general.normalize_embedding(crop.permute(0, 2, 3, 1).contiguous())
+      crop_emb = crop_emb.permute(0, 3, 1, 2)
+      if emb is None:
+        emb = torch.zeros(1, C, pad_h, pad_w)
+      emb[:, :, sh:eh, sw:ew] += crop_emb
+      counts[:, :, sh:eh, sw:ew] += 1
+  emb /= counts
+  # memory bank round trip through the reference reader
+  with tempfile.TemporaryDirectory() as d:
+    protos = synth.gaussish(seed + 3, 11 * 8).reshape(11, 8).copy()
+    labs = (synth.hash_u64(seed + 4, 11) % np.uint64(5)).astype(np.int64)
+    np.save(os.path.join(d, 'b_second.npy'), {'prototype': protos[6:], 'prototype_label': labs[6:]})
+    np.save(os.path.join(d, 'a_first.npy'), {'prototype': protos[:6], 'prototype_label': labs[:6]})
+    bank_p, bank_l = ref_others.load_memory_banks(d)
+  save('f12_inference', seed=seed, maj_shape=np.array([n, nk, nc]), sel=sel.numpy().astype(np.int32),
+       maj=maj.numpy(), ov_shape=np.array([C, pad_h, pad_w, crop_h, crop_w, stride_h, stride_w]),
+       patch_ind_h=patch_ind_h, patch_ind_w=patch_ind_w, canvas=emb.numpy()[0],
+       bank_p=bank_p.numpy(), bank_l=bank_l.numpy())
+
+
 # ---- F8 cross-GPU glue (hsg/models/utils.py) with 2 simulated GPUs ------------
 def f8():
   import torch.nn.parallel.scatter_gather as sg
@@ -364,6 +418,6 @@ def f9():
 
 if __name__ == '__main__':
   os.makedirs(OUT, exist_ok=True)
-  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11']
+  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12']
   for w in which:
     globals()[w]()
