@@ -77,6 +77,7 @@ SIGNATURES = {
     'hsgk_overlap_accumulate': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     'hsgk_overlap_finish': (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     'hsgk_majority_labels': (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
+    'hsgk_knn_affinity': (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     'hsgk_topk_workspace_bytes': (_sz, [_i64, _i32, _i64, _i32]),
     'hsgk_topk_prototypes': (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),
     'hsgk_assign_workspace_bytes': (_sz, [_i64, _i32, _i32]),

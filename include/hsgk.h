@@ -262,6 +262,20 @@ HSGK_API int hsgk_majority_labels(const int64_t *semantic, const int64_t *cluste
                                   int64_t num_clusters, int num_classes, int32_t *hist,
                                   int64_t *majority, uint8_t *select, hsgk_stream_t stream);
 
+/* ---- hsg/utils/graph/common.py:39-125 affinity_matrix_as_attention -------------
+ * x [B,C,N]: A = exp(concentration * x^T x) (common.py:23-36) is computed into
+ * affinity_tmp [B,N,N] unless affinity_in [B,N,N] is given (a caller-evaluated kernel
+ * function).  Then, per image: entries of padded nodes (padding_mask [B,N], nullable)
+ * -> 0; the diagonal -> 0 when remove_self_loop and the image has more than one valid
+ * node; knn > 0: within every segment (segment_labels [B,N], nullable = one segment)
+ * each row keeps the entries that are not below its k-th largest one of that segment,
+ * k = min(valid nodes of the segment, knn); binarize: out = (A > 0).  out [B,N,N].    */
+HSGK_API int hsgk_knn_affinity(const float *x, const float *affinity_in, int B, int C, int N,
+                               float concentration, const uint8_t *padding_mask,
+                               const int64_t *segment_labels, int knn, int remove_self_loop,
+                               int binarize, float *affinity_tmp, float *out,
+                               hsgk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

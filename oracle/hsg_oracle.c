@@ -311,3 +311,17 @@ ORC_API void orc_cluster_logits(const float *cent, const float *feat, int B, int
         out[((size_t)b * tl + i) * sl + j] = acc / div;
       }
 }
+
+
+/* hsg/utils/graph/common.py:23-36 exp_inner_product_kernel: A[b,i,j] = exp(conc * dot),
+ * the dot product as one fmaf chain over ascending c (C1), x [B,C,N].  expf in float.   */
+ORC_API void orc_exp_affinity(const float *x, int B, int C, int N, float conc, float *out) {
+  for (int b = 0; b < B; ++b)
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < N; ++j) {
+        float acc = 0.0f;
+        for (int c = 0; c < C; ++c)
+          acc = fmaf(x[((size_t)b * C + c) * N + i], x[((size_t)b * C + c) * N + j], acc);
+        out[((size_t)b * N + i) * N + j] = expf(acc * conc);
+      }
+}

@@ -397,3 +397,39 @@ def overlap_average(crops, corners, channels, height, width, eps=EPS):
     canvas[:, sh:sh + h, sw:sw + w] = canvas[:, sh:sh + h, sw:sw + w] + rows.T.reshape(C, h, w)
     counts[sh:sh + h, sw:sw + w] += np.float32(1)
   return canvas / counts[None]
+
+
+def affinity_matrix_as_attention(x, x_padding_mask=None, x_segment_labels=None, knn=None,
+                                 remove_self_loop=True, binarize=True, concentration=5.0,
+                                 affinity=None):
+  """hsg/utils/graph/common.py:39-125, statement by statement (the per-image /
+  per-segment loop with the k-th largest value taken from a sorted copy)."""
+  x = _f32(x)
+  B, C, N = x.shape
+  if affinity is None:
+    A = np.empty((B, N, N), np.float32)
+    lib().orc_exp_affinity(_p(x, _f32p), B, C, N, ctypes.c_float(concentration), _p(A, _f32p))
+  else:
+    A = _f32(affinity).copy()
+  pad = np.zeros((B, N), bool) if x_padding_mask is None else np.asarray(x_padding_mask, bool)
+  seg = np.zeros((B, N), np.int64) if x_segment_labels is None else _i64(x_segment_labels)
+  A[pad[:, :, None] | pad[:, None, :]] = 0                                   # :81-82
+  if remove_self_loop:                                                        # :85-93
+    for b in range(B):
+      if (~pad[b]).sum() > 1:
+        A[b][np.eye(N, dtype=bool)] = 0
+  if knn is not None:                                                         # :96-118
+    for b in range(B):
+      cur = A[b]
+      for lab in np.unique(seg[b]):
+        m = (~pad[b]) & (seg[b] == lab)
+        if not m.any():
+          continue
+        k = min(int(m.sum()), knn)
+        adj = cur[:, m]
+        kth = -np.sort(-adj, axis=1)[:, k - 1]
+        cut = m[None, :] & (cur < kth[:, None])
+        cur[cut] = 0
+  if binarize:                                                                # :121-122
+    A = np.where(A > 0, np.float32(1), np.float32(0)).astype(np.float32)
+  return A

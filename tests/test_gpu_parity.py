@@ -676,3 +676,53 @@ def test_inference_pipeline_end_to_end_vs_oracle(dev, oracle, tmp_path):
   others.save_prototypes(str(tmp_path / 'img0.npy'), protos, maj)
   bank_p, bank_l = others.load_memory_banks(str(tmp_path))
   assert np.array_equal(bank_p.numpy(), protos.cpu().numpy()) and np.array_equal(bank_l.numpy(), o_maj)
+
+
+def test_dmon_affinity_graph_and_loss_vs_reference_golden(dev, oracle):
+  """n4: hsgk_knn_affinity through the graph mirror against the reference's
+  affinity_matrix_as_attention (tests/golden/f13_dmon_graph.npz) and the oracle; DMonLoss
+  value and logit gradients against the reference's autograd."""
+  import torch
+  from hsg_amd.utils.graph import common as gc
+  from hsg_amd.utils.graph import loss as gl
+  g = util.load('f13_dmon_graph')
+  B, C, N, K, knn = (int(v) for v in g['shape'])
+  x, pad, seg, logits = util.graph_inputs(int(g['seed']), B, C, N, K)
+  xt, padt, segt = (torch.from_numpy(a).to(dev) for a in (x, pad, seg))
+  a_knn = gc.affinity_matrix_as_attention(xt, padt, segt, knn, True, True, concentration=5)
+  assert a_knn.shape == (B, N, N) and a_knn.dtype == torch.float32
+  assert np.array_equal(a_knn.cpu().numpy().astype(np.uint8), g['adj_knn'])
+  a_all = gc.affinity_matrix_as_attention(xt, padt)
+  assert np.array_equal(a_all.cpu().numpy().astype(np.uint8), g['adj_all'])
+  a_val = gc.affinity_matrix_as_attention(xt, padt, segt, 3, False, False)
+  ref_val = oracle.affinity_matrix_as_attention(x, pad, seg, 3, remove_self_loop=False, binarize=False)
+  assert np.array_equal(a_val.cpu().numpy() > 0, g['adj_val'] > 0)
+  assert np.abs(a_val.cpu().numpy() - ref_val).max() <= 1e-5 * ref_val.max()      # expf ulps only
+  # a caller-evaluated kernel function: same graph through the affinity_in path
+  a_fn = gc.affinity_matrix_as_attention(xt, padt, segt, knn, True, True,
+                                         kernel_fn=lambda t: gc.exp_inner_product_kernel(t, 5))
+  assert np.array_equal(a_fn.cpu().numpy().astype(np.uint8), g['adj_knn'])
+  keep = [0, 1, 3, 4]
+  lg = torch.from_numpy(logits).to(dev).requires_grad_(True)
+  d, c = gl.DMonLoss(adj_knn=knn)(torch.softmax(lg[keep], 1), xt[keep], padt[keep], segt[keep])
+  (d + 0.5 * c).backward()
+  assert abs(d.item() - float(g['dmon'])) <= 1e-5 and abs(c.item() - float(g['collapse'])) <= 1e-5
+  assert np.abs(lg.grad.cpu().numpy() - g['g_logits']).max() <= 1e-6
+
+
+def test_dmon_affinity_graph_larger_vs_oracle(dev, oracle):
+  """256 nodes, 3 segments, knn 10, ties from duplicated nodes."""
+  import torch
+  from hsg_amd.utils.graph import common as gc
+  B, C, N = 3, 64, 256
+  x = synth.gaussish(4242, B * C * N).reshape(B, C, N).copy()
+  x /= np.sqrt((x * x).sum(1, keepdims=True))
+  x[:, :, 17] = x[:, :, 3]                                   # duplicate node: tied affinities
+  pad = np.zeros((B, N), bool)
+  pad[1, 200:] = True
+  seg = (synth.hash_u64(4243, B * N) % np.uint64(3)).astype(np.int64).reshape(B, N)
+  seg[:, 17] = seg[:, 3]
+  got = gc.affinity_matrix_as_attention(torch.from_numpy(x.astype(np.float32)).to(dev),
+                                        torch.from_numpy(pad).to(dev), torch.from_numpy(seg).to(dev), 10)
+  ref = oracle.affinity_matrix_as_attention(x.astype(np.float32), pad, seg, 10)
+  assert np.array_equal(got.cpu().numpy(), ref)

@@ -212,3 +212,16 @@ def test_f12_memory_bank_format(tmp_path):
   assert np.array_equal(p.numpy(), g['bank_p']) and np.array_equal(l.numpy(), g['bank_l'])
   raw = np.load(str(tmp_path / 'a_first.npy'), allow_pickle=True).item()
   assert sorted(raw) == ['prototype', 'prototype_label']
+
+
+def test_f13_dmon_affinity_graph(oracle):
+  """n4: the reference's affinity_matrix_as_attention (padding, self loops, per-segment
+  k-NN cut, binarisation) on the golden inputs: binary graphs identical, raw values close."""
+  g = util.load('f13_dmon_graph')
+  B, C, N, K, knn = (int(v) for v in g['shape'])
+  x, pad, seg, _ = util.graph_inputs(int(g['seed']), B, C, N, K)
+  assert np.array_equal(oracle.affinity_matrix_as_attention(x, pad, seg, knn).astype(np.uint8), g['adj_knn'])
+  assert np.array_equal(oracle.affinity_matrix_as_attention(x, pad, None, None).astype(np.uint8), g['adj_all'])
+  val = oracle.affinity_matrix_as_attention(x, pad, seg, 3, remove_self_loop=False, binarize=False)
+  assert np.array_equal(val > 0, g['adj_val'] > 0)
+  assert np.abs(val - g['adj_val']).max() <= 1e-4 * g['adj_val'].max()

@@ -112,3 +112,20 @@ def inference_inputs(g):
   protos = synth.gaussish(seed + 3, 11 * 8).reshape(11, 8).copy()
   labs = (synth.hash_u64(seed + 4, 11) % np.uint64(5)).astype(np.int64)
   return sem, clu, crops, corners, (C, pad_h, pad_w), protos, labs
+
+
+def graph_inputs(seed, B, C, N, K):
+  """Inputs of tests/golden/f13_dmon_graph.npz (tools/gen_golden.py f13)."""
+  x = synth.gaussish(seed, B * C * N).reshape(B, C, N).copy()
+  x /= np.sqrt((x * x).sum(1, keepdims=True))                 # unit columns, like the normalised prototypes
+  pad = np.zeros((B, N), bool)
+  pad[0, N - 7:] = True
+  pad[1, 5] = True
+  pad[2, :] = True                                             # an image without valid nodes
+  pad[3, 1:] = True                                            # a single valid node: its self loop stays
+  seg = (synth.hash_u64(seed + 1, B * N) % np.uint64(2)).astype(np.int64).reshape(B, N)
+  seg[1] = 3                                                   # one segment only
+  logits = synth.gaussish(seed + 2, B * K * N).reshape(B, K, N).copy()
+  return x.astype(np.float32), pad, seg, logits
+
+

@@ -292,6 +292,29 @@ def f12():
        bank_p=bank_p.numpy(), bank_l=bank_l.numpy())
 
 
+# ---- F13 DMon affinity graph and losses (graph/common.py:39-125, graph/loss.py) ----
+def f13():
+  import hsg.utils.graph.common as ref_gc
+  import hsg.utils.graph.loss as ref_gl
+  from tests import util as tutil
+  seed = synth.SEED_BASE + 111
+  B, C, N, K, knn = 5, 24, 48, 6, 7
+  x, pad, seg, logits = tutil.graph_inputs(seed, B, C, N, K)
+  xt, padt, segt = torch.from_numpy(x), torch.from_numpy(pad), torch.from_numpy(seg)
+  kfn = lambda t: ref_gc.exp_inner_product_kernel(t, 5)
+  adj_knn = ref_gc.affinity_matrix_as_attention(xt, padt, segt, knn, True, True, kfn)
+  adj_all = ref_gc.affinity_matrix_as_attention(xt, padt, None, None, True, True, kfn)
+  adj_val = ref_gc.affinity_matrix_as_attention(xt, padt, segt, 3, False, False, kfn)
+  lg = torch.from_numpy(logits).requires_grad_(True)
+  # image 2 has no valid node: its 0/0 terms are NaN in the reference too -> keep it out of the loss fixture
+  keep = [0, 1, 3, 4]
+  d, c = ref_gl.DMonLoss(adj_knn=knn)(torch.softmax(lg[keep], 1), xt[keep], padt[keep], segt[keep])
+  (d + 0.5 * c).backward()
+  save('f13_dmon_graph', seed=seed, shape=np.array([B, C, N, K, knn]), adj_knn=adj_knn.numpy().astype(np.uint8),
+       adj_all=adj_all.numpy().astype(np.uint8), adj_val=adj_val.numpy(),
+       dmon=np.float64(d.item()), collapse=np.float64(c.item()), g_logits=lg.grad.numpy())
+
+
 # ---- F8 cross-GPU glue (hsg/models/utils.py) with 2 simulated GPUs ------------
 def f8():
   import torch.nn.parallel.scatter_gather as sg
@@ -418,6 +441,6 @@ def f9():
 
 if __name__ == '__main__':
   os.makedirs(OUT, exist_ok=True)
-  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12']
+  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13']
   for w in which:
     globals()[w]()
