@@ -16,7 +16,12 @@ __device__ inline int owner_wave(int label) {
 // caller) is set for every label that owns at least one row.  Shared by the k-means M-step
 // (int32 working labels, window = cluster block) and segment_reduce (int64
 // labels, window = the chunk's own label range).
-template <int VEC, int UNROLL, typename LabT, int NW = 4>
+//
+// TAILV = 1 (VEC = 4, rows of 256 + 65..255 columns, e.g. d = 386): the columns after the
+// first 256 are prefetched too -- one more x4 per lane for the whole quads, one float per
+// lane for the last d mod 4 columns -- instead of being loaded where they are folded (a
+// load consumed right after its issue drains the in-order prefetch queue).
+template <int VEC, int UNROLL, typename LabT, int NW = 4, int TAILV = 0>
 __device__ inline void chunk_accumulate(const float *__restrict__ xr, int d, int DS,
                                         const LabT *__restrict__ lab, int n, int64_t lo,
                                         int cnt_lab, float *sums, uint32_t *rlist,
@@ -72,19 +77,25 @@ __device__ inline void chunk_accumulate(const float *__restrict__ xr, int d, int
   // folded into LDS (only the first column pass is double buffered: npass == 1
   // for d < 2*64*VEC, the shapes this kernel is tuned for).
   gvec_t va[UNROLL], vb[UNROLL];
+  gvec_t wa[TAILV ? UNROLL : 1], wb[TAILV ? UNROLL : 1];      // second prefetched vector (TAILV)
   float ta[UNROLL], tb[UNROLL];
-  const bool on = lane < tail;
-  auto issue = [&](int b0, gvec_t (&v)[UNROLL], float (&t)[UNROLL]) {
+  const int nv2 = TAILV ? tail / VEC : 0;                      // lanes with a whole tail quad
+  const int tcol = tail0 + nv2 * VEC;                          // first column of the scalar tail
+  const bool on = lane < d - tcol;
+  auto issue = [&](int b0, gvec_t (&v)[UNROLL], gvec_t (&v2)[TAILV ? UNROLL : 1], float (&t)[UNROLL]) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int idx = min(b0 + u, cnt - 1);
       const int r = (int)(mylist[idx] >> 10);
-      // both loads unconditional (clamped columns; unused values are ignored by fold)
+      // all loads unconditional (clamped columns; unused values are ignored by fold)
       v[u] = *reinterpret_cast<const gvec_t *>(xr + (int64_t)r * d + min(lane * VEC, d - VEC));
-      t[u] = xr[(int64_t)r * d + min(tail0 + lane, d - 1)];
+      if constexpr (TAILV != 0)
+        v2[u] = *reinterpret_cast<const gvec_t *>(xr + (int64_t)r * d + min(tail0 + lane * VEC, d - VEC));
+      t[u] = xr[(int64_t)r * d + min(tcol + lane, d - 1)];
     }
   };
-  auto fold = [&](int b0, const gvec_t (&v)[UNROLL], const float (&t)[UNROLL]) {
+  auto fold = [&](int b0, const gvec_t (&v)[UNROLL], const gvec_t (&v2)[TAILV ? UNROLL : 1],
+                  const float (&t)[UNROLL]) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       if (b0 + u < cnt) {
@@ -105,15 +116,25 @@ __device__ inline void chunk_accumulate(const float *__restrict__ xr, int d, int
           for (int i = 0; i < VEC; ++i) acc[i] = acc[i] + vv[i];
           *dst = acc;
         }
+        if constexpr (TAILV != 0) {
+          if (lane < nv2) {
+            lvec_t *dst = reinterpret_cast<lvec_t *>(sums + l * DS + tail0 + lane * VEC);
+            lvec_t acc = *dst;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = acc[i] + v2[u][i];
+            *dst = acc;
+          }
+        }
         if (on) {
-          float *dst = sums + l * DS + tail0 + lane;
+          float *dst = sums + l * DS + tcol + lane;
           *dst = *dst + t[u];
         }
-        for (int t0 = 64; t0 < tail; t0 += 64)                // wider tails (VEC > 1 only)
-          if (t0 + lane < tail) {
-            float *dst = sums + l * DS + tail0 + t0 + lane;
-            *dst = *dst + xr[(int64_t)r * d + tail0 + t0 + lane];
-          }
+        if constexpr (TAILV == 0)
+          for (int t0 = 64; t0 < tail; t0 += 64)              // wider tails, loaded in place (slow path)
+            if (t0 + lane < tail) {
+              float *dst = sums + l * DS + tail0 + t0 + lane;
+              *dst = *dst + xr[(int64_t)r * d + tail0 + t0 + lane];
+            }
       }
     }
   };
@@ -121,15 +142,15 @@ __device__ inline void chunk_accumulate(const float *__restrict__ xr, int d, int
     // issue() clamps its row indices, so it runs UNCONDITIONALLY: with a conditional
     // issue in the loop the compiler's s_waitcnt insertion (pessimistic at control-flow
     // joins) waits for vmcnt(0) before every fold and the double buffering is lost.
-    issue(0, va, ta);
+    issue(0, va, wa, ta);
     for (int b0 = 0; b0 < cnt; b0 += 2 * UNROLL) {
-      issue(b0 + UNROLL, vb, tb);
+      issue(b0 + UNROLL, vb, wb, tb);
       __builtin_amdgcn_sched_barrier(0);
-      fold(b0, va, ta);
+      fold(b0, va, wa, ta);
       __builtin_amdgcn_sched_barrier(0);
-      issue(b0 + 2 * UNROLL, va, ta);
+      issue(b0 + 2 * UNROLL, va, wa, ta);
       __builtin_amdgcn_sched_barrier(0);
-      fold(b0 + UNROLL, vb, tb);
+      fold(b0 + UNROLL, vb, wb, tb);
       __builtin_amdgcn_sched_barrier(0);
     }
   }

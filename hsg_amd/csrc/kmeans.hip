@@ -34,7 +34,7 @@ namespace hsgk {
 //
 // LDS row stride DS = d rounded up to VEC floats so the per-lane VEC-wide
 // LDS accesses stay naturally aligned.
-template <int VEC, int UNROLL, int NW>
+template <int VEC, int UNROLL, int NW, int TAILV>
 __global__ __launch_bounds__(NW * 64) void accumulate_kernel(
     const float *__restrict__ x, int d, const int32_t *__restrict__ klab,
     const int64_t *__restrict__ chunk_row0, const int32_t *__restrict__ chunk_rows,
@@ -53,8 +53,8 @@ __global__ __launch_bounds__(NW * 64) void accumulate_kernel(
   for (int i = tid; i < (kbn + 3) / 4; i += NW * 64) reinterpret_cast<uint32_t *>(present)[i] = 0u;
   // (chunk_accumulate's barrier orders the zeroing before the first fold / flag)
   const int64_t row0 = chunk_row0[c];
-  chunk_accumulate<VEC, UNROLL, int32_t, NW>(x + row0 * d, d, DS, klab + row0, chunk_rows[c], kb0,
-                                             kbn, sums, rlist, wcount, present);
+  chunk_accumulate<VEC, UNROLL, int32_t, NW, TAILV>(x + row0 * d, d, DS, klab + row0, chunk_rows[c],
+                                                    kb0, kbn, sums, rlist, wcount, present);
   __syncthreads();
   // only the clusters that own rows of this chunk are written; pmask tells finalize
   // which partial rows exist (a skipped row is an exact +0.0 sum: adding it is the identity)
@@ -86,7 +86,10 @@ int launch_accumulate(const float *x, int d, const int32_t *klab, const ChunkTab
   HSGK_REQUIRE(kbn >= 1, "row too long for the LDS segment table");
   // 16-byte global loads only need dword alignment on gfx950.
   constexpr int NWA = 4;   // measured: 4 waves x 16 rows in flight 2.17 ms, 8 waves 2.32 ms, 24 rows 3.23 ms (cfg2)
-  auto kern = wide ? accumulate_kernel<4, 16, NWA> : accumulate_kernel<1, 16, NWA>;
+  // rows of 256 + (65..255) columns (C = 384: d = 386) prefetch their second vector too
+  const bool tailv = wide && d < 512 && d - 256 > 64;
+  auto kern = tailv ? accumulate_kernel<4, 8, NWA, 1>
+              : wide ? accumulate_kernel<4, 16, NWA, 0> : accumulate_kernel<1, 16, NWA, 0>;
   size_t lds = (size_t)kbn * DS * 4 + list_bytes;
   HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize,
