@@ -51,11 +51,14 @@ struct KmeansScratch {
   float *cent;
   void *qrows;         // [max_chunks * HSGK_CHUNK] 12-byte entries: exact re-score queue (split E-step)
   int32_t *qcount;     // [1] queue length
+  int32_t *klab_prev;  // [rows] labels the exact sums currently hold (-1 = row not added yet), or null
+  long long *sumq;     // [B][K][d] exact fixed-point segment sums (sums_fx.hip)
   _Float16 *xh;        // [rows][half_main_cols(d)] fp16 copy of the rows' main columns (first filter level), or null
   uint2 *xt;           // [rows] {packed fp16 tail columns of the copy, measured rounding error of the row}
   int32_t *q1;         // [B][q1cap] rows the first level left undecided
   int32_t *q1count;    // [B]
   int64_t q1cap;
+  size_t rows_cap;     // B * rows_per_image
   int max_chunks;
 };
 
@@ -68,6 +71,7 @@ static void carve_kmeans(Carver &cv, int B, int64_t rows_per_img, int d, int K,
   const int mc = max_chunks_for(B, rows_per_img);
   const size_t mcs = mc > 0 ? mc : 1;
   k->max_chunks = mc;
+  k->rows_cap = (size_t)B * rows_per_img;
   k->t.img_row0 = cv.take<int64_t>(B + 1);
   k->t.img_chunk0 = cv.take<int32_t>(B + 1);
   k->t.chunk_row0 = cv.take<int64_t>(mcs);
@@ -80,6 +84,12 @@ static void carve_kmeans(Carver &cv, int B, int64_t rows_per_img, int d, int K,
   k->cent = cv.take<float>((size_t)B * K * d + 1);
   k->qrows = cv.take<char>(mcs * HSGK_CHUNK * 12);
   k->qcount = cv.take<int32_t>(4);
+  k->klab_prev = nullptr;
+  k->sumq = nullptr;
+  if (sums_fx_eligible(d)) {
+    k->klab_prev = cv.take<int32_t>((size_t)B * rows_per_img + 1);
+    k->sumq = cv.take<long long>((size_t)B * K * d + 1);
+  }
   k->xh = nullptr;
   k->xt = nullptr;
   k->q1 = k->q1count = nullptr;
@@ -114,11 +124,32 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
     ProfScope p(HSGK_PROF_PREP, s);
     if (int rc = launch_to_half_rows(x, k.t, k.max_chunks, d, k.xh, k.xt, meta, s)) return rc;
   }
+  // exact (fixed-point) segment sums, updated from the rows whose label changed: unit rows
+  // only (|x| <= 1 bounds the integer sums); HSGK_MSTEP=stream keeps the streaming C2 M-step
+  static const bool fx_on = [] {
+    const char *e = getenv("HSGK_MSTEP");
+    return !(e && e[0] == 's');
+  }();
+  const bool fx = unit_rows && fx_on && k.sumq != nullptr && k.max_chunks > 0;
+  if (fx) {
+    HSGK_CHECK_HIP(hipMemsetAsync(k.klab_prev, 0xFF, sizeof(int32_t) * k.rows_cap, s));
+    HSGK_CHECK_HIP(hipMemsetAsync(k.sumq, 0, sizeof(long long) * (size_t)B * K * d, s));
+  }
   for (int it = 0; it < iterations; ++it) {
-    { ProfScope p(HSGK_PROF_ACCUMULATE, s);
-      if (int rc = launch_accumulate(x, d, k.klab, k.t, k.max_chunks, K, k.partial, k.pmask, meta, s)) return rc; }
-    { ProfScope p(HSGK_PROF_FINALIZE, s);
-      if (int rc = launch_finalize(k.partial, k.pmask, d, K, B, k.t, k.max_chunks / B, HSGK_EPS, k.cent, s)) return rc; }
+    if (fx) {
+      { ProfScope p(HSGK_PROF_ACCUMULATE, s);
+        if (int rc = launch_update_sums(x, d, k.klab_prev, k.klab, k.t, k.max_chunks, K, k.sumq, meta, s))
+          return rc;
+        HSGK_CHECK_HIP(hipMemcpyAsync(k.klab_prev, k.klab, sizeof(int32_t) * k.rows_cap,
+                                      hipMemcpyDeviceToDevice, s)); }
+      { ProfScope p(HSGK_PROF_FINALIZE, s);
+        if (int rc = launch_finalize_fx(k.sumq, d, K, B, HSGK_EPS, k.cent, s)) return rc; }
+    } else {
+      { ProfScope p(HSGK_PROF_ACCUMULATE, s);
+        if (int rc = launch_accumulate(x, d, k.klab, k.t, k.max_chunks, K, k.partial, k.pmask, meta, s)) return rc; }
+      { ProfScope p(HSGK_PROF_FINALIZE, s);
+        if (int rc = launch_finalize(k.partial, k.pmask, d, K, B, k.t, k.max_chunks / B, HSGK_EPS, k.cent, s)) return rc; }
+    }
     { ProfScope p(HSGK_PROF_ASSIGN, s);
       if (int rc = half ? launch_assign_half(x, k.xh, k.xt, d, k.cent, K, B, k.t, k.max_chunks, k.klab, k.q1,
                                              k.q1count, k.q1cap, k.qrows, k.qcount, meta, s)

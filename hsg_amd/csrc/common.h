@@ -101,6 +101,15 @@ int launch_assign_fast(const float *x, int d, const float *cent, int K, const Ch
                        int max_chunks, int32_t *klab, float *best, void *qrows,
                        int32_t *qcount, const hsgk_segkm_meta *meta, hipStream_t s);
 
+// M-step with exact (fixed-point) segment sums, updated from the rows whose label changed
+// (sums_fx.hip): prev / cur int32 labels [rows], sumq [B][K][d] int64
+bool sums_fx_eligible(int d);
+int launch_update_sums(const float *x, int d, const int32_t *prev, const int32_t *cur,
+                       const ChunkTable &t, int max_chunks, int K, long long *sumq,
+                       const hsgk_segkm_meta *meta, hipStream_t s);
+int launch_finalize_fx(const long long *sumq, int d, int K, int B, float eps, float *cent,
+                       hipStream_t s);
+
 // three-level E-step (fp16 copy -> bf16x3 on the undecided rows -> exact chains)
 inline int half_main_cols_host(int d) { return d & ~63; }
 constexpr int kHalfSlackRowsHost = 2 * 8 * 32 + 64;     // == kHalfSlackRows (score_tiles_f16.h)

@@ -118,6 +118,38 @@ ORC_API void orc_segment_sums(const float *x, int64_t n, int d,
   free(part);
 }
 
+/* Canonical order C2x (the Lloyd loop of segment_by_kmeans, unit-norm rows): EXACT segment
+ * sums.  Every element is converted to the fixed-point integer q = rint(x * 2^40) (exact for
+ * |x| >= 2^-16), the q are summed as 64-bit integers (any order: integer addition is
+ * associative), and the sum is converted to fp32 with one rounding.  Closer to the real sum
+ * than any fp32 summation order, and independent of it -- which is what lets the GPU M-step
+ * update the sums from the rows whose label changed (csrc/sums_fx.hip).                    */
+static void orc_segment_sums_fx(const float *x, int64_t n, int d, const int64_t *labels, int64_t P,
+                                float *sums) {
+  size_t tot = (size_t)P * (size_t)d;
+  int64_t *acc = (int64_t *)calloc(tot, sizeof(int64_t));
+  for (int64_t r = 0; r < n; ++r) {
+    int64_t l = labels[r];
+    if (l < 0 || l >= P) continue;
+    for (int i = 0; i < d; ++i) {
+      const float v = x[r * (int64_t)d + i] * 65536.0f;            /* exact */
+      const float hi = rintf(v);
+      const float lo = rintf((v - hi) * 16777216.0f);               /* exact remainder, exact scaling */
+      acc[(size_t)l * d + i] += (int64_t)(int32_t)hi * 16777216 + (int64_t)(int32_t)lo;
+    }
+  }
+  for (size_t i = 0; i < tot; ++i) sums[i] = (float)acc[i] * 9.094947017729282e-13f;   /* 2^-40 */
+  free(acc);
+}
+
+static void orc_normalize_table(float *out, int64_t P, int d, float eps) {
+  for (int64_t k = 0; k < P; ++k) {
+    float *row = out + k * (int64_t)d;
+    float nrm = orc_row_norm(row, d, eps);
+    for (int i = 0; i < d; ++i) row[i] = row[i] / nrm;
+  }
+}
+
 ORC_API void orc_prototypes(const float *x, int64_t n, int d,
                             const int64_t *labels, int64_t P, int chunk,
                             float eps, float *out /* [P,d] */) {
@@ -170,15 +202,31 @@ ORC_API void orc_assign(const float *x, int64_t n, int d, const float *cent,
 /* hsg/utils/segsort/common.py:67-97 kmeans_with_initial_labels:
  * `iters` x ( M-step :92 -> E-step :95 ), starting from the given labels.
  * cent_out (nullable) receives the centroids of the last M-step.           */
+/* exact_sums != 0: M-step in order C2x (exact fixed-point sums; needs |x| <= 1), else C2. */
+ORC_API void orc_kmeans_ex(const float *x, int64_t n, int d, const int32_t *init,
+                           int K, int iters, int chunk, float eps, int exact_sums,
+                           int32_t *labels_out, float *cent_out);
+
 ORC_API void orc_kmeans(const float *x, int64_t n, int d, const int32_t *init,
                         int K, int iters, int chunk, float eps,
                         int32_t *labels_out, float *cent_out) {
+  orc_kmeans_ex(x, n, d, init, K, iters, chunk, eps, 0, labels_out, cent_out);
+}
+
+ORC_API void orc_kmeans_ex(const float *x, int64_t n, int d, const int32_t *init,
+                           int K, int iters, int chunk, float eps, int exact_sums,
+                           int32_t *labels_out, float *cent_out) {
   int64_t *lab64 = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
   float *cent = (float *)malloc(sizeof(float) * (size_t)K * d);
   for (int64_t r = 0; r < n; ++r) labels_out[r] = init[r];
   for (int it = 0; it < iters; ++it) {
     for (int64_t r = 0; r < n; ++r) lab64[r] = labels_out[r];
-    orc_prototypes(x, n, d, lab64, K, chunk, eps, cent);
+    if (exact_sums) {
+      orc_segment_sums_fx(x, n, d, lab64, K, cent);
+      orc_normalize_table(cent, K, d, eps);
+    } else {
+      orc_prototypes(x, n, d, lab64, K, chunk, eps, cent);
+    }
     orc_assign(x, n, d, cent, K, labels_out, NULL);
   }
   if (cent_out) memcpy(cent_out, cent, sizeof(float) * (size_t)K * d);

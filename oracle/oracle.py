@@ -138,16 +138,19 @@ def find_nearest_prototypes(embeddings, prototypes, return_best=False):
 
 
 def kmeans_with_initial_labels(embeddings, initial_labels, max_label=None,
-                               iterations=10, chunk=CHUNK, return_centroids=False):
-  """hsg/utils/segsort/common.py:67-97."""
+                               iterations=10, chunk=CHUNK, return_centroids=False,
+                               exact_sums=False):
+  """hsg/utils/segsort/common.py:67-97.  exact_sums: M-step with exact fixed-point segment
+  sums (canonical order C2x, unit-norm rows -- what segment_by_kmeans uses), else the
+  chunked fp32 order C2."""
   x = _f32(embeddings)
   init = np.ascontiguousarray(initial_labels, dtype=np.int32)
   K = int(init.max()) + 1 if max_label is None else int(max_label)
   out = np.empty(x.shape[0], np.int32)
   cent = np.empty((K, x.shape[1]), np.float32)
-  lib().orc_kmeans(_p(x, _f32p), ctypes.c_int64(x.shape[0]), x.shape[1],
-                   _p(init, _i32p), K, int(iterations), chunk,
-                   ctypes.c_float(EPS), _p(out, _i32p), _p(cent, _f32p))
+  lib().orc_kmeans_ex(_p(x, _f32p), ctypes.c_int64(x.shape[0]), x.shape[1],
+                      _p(init, _i32p), K, int(iterations), chunk,
+                      ctypes.c_float(EPS), int(bool(exact_sums)), _p(out, _i32p), _p(cent, _f32p))
   out = out.astype(np.int64)
   return (out, cent) if return_centroids else out
 
@@ -198,7 +201,7 @@ def segment_by_kmeans(embeddings, labels=None, num_clusters=(5, 5),
       init = seeds
     if cnt > 0:                                             # common.py:368
       cluster[off:off + cnt] = kmeans_with_initial_labels(
-          emb_loc[off:off + cnt], init, K, iterations, chunk)
+          emb_loc[off:off + cnt], init, K, iterations, chunk, exact_sums=True)
     batch[off:off + cnt] = b + B * gpu_id                  # common.py:375-381
     off += cnt
 
