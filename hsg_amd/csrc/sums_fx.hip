@@ -13,12 +13,17 @@
 // every row once (prev label = -1).  Range: |x| <= 1 and <= 2^22 rows per segment keep
 // every sum below 2^63 (segment_by_kmeans: unit rows, one image per table).
 //
-// update_sums_kernel: one workgroup (8 waves) per 2048-row chunk; the chunk's changed
-// rows are compacted into an LDS list, each is loaded once (16-byte row loads, 8 rows per
-// wave in flight, double buffered), converted, and added to / subtracted from a
-// [kbn][d] int64 LDS table with ds_add_u64 (measured 2.5x faster than a plain 64-bit
-// LDS read-add-write and 20x faster than ds_add_f32, tools/probes/lds_atomics.hip); the
-// touched table rows are flushed to the per-image table with global 64-bit atomics.
+// update_sums_kernel: one workgroup (4 waves) per 512 rows (a quarter of a chunk: any
+// partition is valid, the sums do not depend on it).  The changed rows are compacted into
+// an LDS list; the clusters they touch (old or new label; a 512-row strip of an image meets
+// one row of grid cells) get one of S slots of an int64 [S][d] LDS table (28 KiB for S = 12,
+// d = 258: five workgroups per CU hide each other's latencies; a big [K][d] table would
+// allow one); each changed row is loaded once (16-byte row loads, 4 rows per wave in
+// flight, double buffered), converted, and added to / subtracted from its slots with
+// ds_add_u64 (measured 2.5x faster than a plain 64-bit LDS read-add-write and 20x faster
+// than ds_add_f32, tools/probes/lds_atomics.hip); the slots are flushed to the image's
+// table with global 64-bit atomics.  More than S touched clusters: further rounds over the
+// same list (the rows are re-read).
 #include "common.h"
 
 namespace hsgk {
@@ -30,49 +35,42 @@ __device__ inline long long to_fixed(float x) {
   return (long long)(int)hi * 16777216ll + (long long)(int)lo;
 }
 
-template <int NW, int UNROLL>
+constexpr int kFxRows = 512;                         // rows per workgroup
+
+template <int NW, int UNROLL, int S>
 __global__ __launch_bounds__(NW * 64) void update_sums_kernel(
     const float *__restrict__ x, int d, const int32_t *__restrict__ prev,
     const int32_t *__restrict__ cur, const int64_t *__restrict__ chunk_row0,
-    const int32_t *__restrict__ chunk_rows, const int32_t *__restrict__ chunk_img, int K, int kb0,
-    int kbn, unsigned long long *__restrict__ sumq, const hsgk_segkm_meta *__restrict__ meta) {
+    const int32_t *__restrict__ chunk_rows, const int32_t *__restrict__ chunk_img, int K,
+    unsigned long long *__restrict__ sumq, const hsgk_segkm_meta *__restrict__ meta) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  unsigned long long *tab = reinterpret_cast<unsigned long long *>(lds_raw);          // [kbn][d]
-  uint32_t *list = reinterpret_cast<uint32_t *>(tab + (size_t)kbn * d);               // [HSGK_CHUNK]
-  int *wcount = reinterpret_cast<int *>(list + HSGK_CHUNK);                           // [NW + 1]
-  unsigned char *touched = reinterpret_cast<unsigned char *>(wcount + NW + 1);        // [kbn]
-  const int c = blockIdx.x;
+  unsigned long long *tab = reinterpret_cast<unsigned long long *>(lds_raw);          // [S][d]
+  uint32_t *list = reinterpret_cast<uint32_t *>(tab + (size_t)S * d);                 // [kFxRows] + 2 (zeroing tail)
+  int *wcount = reinterpret_cast<int *>(list + kFxRows + 2);                          // [NW], [NW] = touched clusters
+  uint16_t *slot = reinterpret_cast<uint16_t *>(wcount + NW + 1);                     // [K] rank among the touched clusters (0xFFFF = untouched)
+  constexpr int PARTS = HSGK_CHUNK / kFxRows;
+  const int c = blockIdx.x / PARTS, part = blockIdx.x - c * PARTS;
   if (c >= meta->n_chunks) return;
+  const int n = min(chunk_rows[c] - part * kFxRows, kFxRows);
+  if (n <= 0) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int64_t row0 = chunk_row0[c];
-  const int n = chunk_rows[c];
-  // ---- changed rows of this chunk that touch the cluster window [kb0, kb0 + kbn)
-  constexpr int PER = HSGK_CHUNK / (NW * 64);
+  const int64_t row0 = chunk_row0[c] + (int64_t)part * kFxRows;
+  // ---- changed rows of this strip
+  constexpr int PER = kFxRows / (NW * 64);
   int pl[PER], cl[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    const int r = (w * PER + i) * 64 + lane;                   // wave-contiguous rows: ascending list
+    const int r = (w * PER + i) * 64 + lane;                   // wave-contiguous rows
     const int rr = min(r, n - 1);
     pl[i] = prev[row0 + rr];
     cl[i] = cur[row0 + rr];
     if (r >= n) pl[i] = cl[i];                                 // past the end: unchanged
   }
+  for (int i = tid; i < K; i += NW * 64) slot[i] = 0xFFFF;
   int cnt = 0;
-  auto in_win = [&](int l) { return l >= kb0 && l < kb0 + kbn; };
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const bool ch = pl[i] != cl[i] && (in_win(pl[i]) || in_win(cl[i]));
-    cnt += __popcll(__ballot(ch));
-  }
+  for (int i = 0; i < PER; ++i) cnt += __popcll(__ballot(pl[i] != cl[i]));
   if (lane == 0) wcount[w] = cnt;
-  // zero the table while the counts settle
-  {
-    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    const int tot2 = (kbn * d + 1) / 2;                          // (the list behind absorbs an odd tail)
-    u64x2 *t2 = reinterpret_cast<u64x2 *>(tab);
-    for (int i = tid; i < tot2; i += NW * 64) t2[i] = u64x2{0ull, 0ull};
-    for (int i = tid; i < kbn; i += NW * 64) touched[i] = 0;
-  }
   __syncthreads();
   int lbeg = 0, total = 0;
   for (int i = 0; i < NW; ++i) {
@@ -84,90 +82,264 @@ __global__ __launch_bounds__(NW * 64) void update_sums_kernel(
     int pos = lbeg;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const bool ch = pl[i] != cl[i] && (in_win(pl[i]) || in_win(cl[i]));
+      const bool ch = pl[i] != cl[i];
       const unsigned long long m = __ballot(ch);
       if (ch) {
-        // row (11 bits) | new label + 1 in the window, 0 = outside (10+1 bits) | old label + 1 (10+1 bits)
-        const uint32_t nw = in_win(cl[i]) ? (uint32_t)(cl[i] - kb0 + 1) : 0u;
-        const uint32_t od = in_win(pl[i]) ? (uint32_t)(pl[i] - kb0 + 1) : 0u;
+        // row (9 bits) | new label + 1 (11 bits) | old label + 1 (11 bits, 0 = not added yet)
         list[pos + __popcll(m & ((1ull << lane) - 1ull))] =
-            ((uint32_t)((w * PER + i) * 64 + lane) << 21) | (nw << 10) | od;
-        if (nw) touched[nw - 1] = 1;
-        if (od) touched[od - 1] = 1;
+            ((uint32_t)((w * PER + i) * 64 + lane) << 22) | ((uint32_t)(cl[i] + 1) << 11) | (uint32_t)(pl[i] + 1);
+        slot[cl[i]] = 1;                                         // (benign same-value races)
+        if (pl[i] >= 0) slot[pl[i]] = 1;
       }
       pos += __popcll(m);
     }
   }
   __syncthreads();
-  // ---- every wave takes entries w, w + NW, ...: load the row once, add / subtract
+  // rank the touched clusters (ascending cluster id); thread per cluster
+  {
+    int my[(1024 + NW * 64 - 1) / (NW * 64)];
+    int q = 0;
+    for (int k = tid; k < K; k += NW * 64, ++q) {
+      int rank = -1;
+      if (slot[k] != 0xFFFF) {
+        rank = 0;
+        for (int o = 0; o < k; ++o) rank += slot[o] != 0xFFFF ? 1 : 0;
+      }
+      my[q] = rank;
+    }
+    int nt = 0;
+    if (tid == 0)
+      for (int o = 0; o < K; ++o) nt += slot[o] != 0xFFFF ? 1 : 0;
+    __syncthreads();
+    q = 0;
+    for (int k = tid; k < K; k += NW * 64, ++q) slot[k] = my[q] < 0 ? 0xFFFF : (uint16_t)my[q];
+    if (tid == 0) wcount[NW] = nt;
+  }
+  __syncthreads();
+  const int ntouched = wcount[NW];
   typedef float gvec_t __attribute__((ext_vector_type(4), aligned(4)));
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
   const float *xr = x + row0 * d;
   const int nq = d / 4, tail0 = nq * 4;                         // quads, then d mod 4 scalar columns
   const int nmine = (total - w + NW - 1) / NW;
   auto entry = [&](int i) { return list[min(w + i * NW, total - 1)]; };
-  auto issue = [&](int i0, gvec_t (&v)[UNROLL][2], float (&t)[UNROLL]) {
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const int r = (int)(entry(i0 + u) >> 21);
-      const float *src = xr + (int64_t)r * d;
-      v[u][0] = *reinterpret_cast<const gvec_t *>(src + 4 * min(lane, nq - 1));
-      v[u][1] = *reinterpret_cast<const gvec_t *>(src + 4 * min(lane + 64, nq - 1));
-      t[u] = src[min(tail0 + lane, d - 1)];
+  unsigned long long *gq = sumq + (int64_t)chunk_img[c] * K * d;
+  for (int base = 0; base < ntouched; base += S) {               // (one round unless > S clusters are touched)
+    // ---- zero the slots of this round
+    {
+      const int tot2 = (min(S, ntouched - base) * d + 1) / 2;      // (the list's 2 spare words absorb an odd tail)
+      u64x2 *t2 = reinterpret_cast<u64x2 *>(tab);
+      for (int i = tid; i < tot2; i += NW * 64) t2[i] = u64x2{0ull, 0ull};
     }
-  };
-  auto fold = [&](int i0, const gvec_t (&v)[UNROLL][2], const float (&t)[UNROLL]) {
+    __syncthreads();
+    // ---- every wave takes entries w, w + NW, ...: load the row once, add / subtract
+    auto issue = [&](int i0, gvec_t (&v)[UNROLL][2], float (&t)[UNROLL]) {
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      if (i0 + u < nmine) {
-        const uint32_t e = entry(i0 + u);
-        const int nw = (int)((e >> 10) & 2047u), od = (int)(e & 1023u);
-        long long q[2][4];
+      for (int u = 0; u < UNROLL; ++u) {
+        const int r = (int)(entry(i0 + u) >> 22);
+        const float *src = xr + (int64_t)r * d;
+        v[u][0] = *reinterpret_cast<const gvec_t *>(src + 4 * min(lane, nq - 1));
+        v[u][1] = *reinterpret_cast<const gvec_t *>(src + 4 * min(lane + 64, nq - 1));
+        t[u] = src[min(tail0 + lane, d - 1)];
+      }
+    };
+    auto fold = [&](int i0, const gvec_t (&v)[UNROLL][2], const float (&t)[UNROLL]) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+      for (int u = 0; u < UNROLL; ++u) {
+        if (i0 + u < nmine) {
+          const uint32_t e = entry(i0 + u);
+          const int labs[2] = {(int)((e >> 11) & 2047u) - 1, (int)(e & 2047u) - 1};
+          int sl[2];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) q[h][j] = to_fixed(v[u][h][j]);
-        const long long qt = to_fixed(t[u]);
-#pragma unroll
-        for (int side = 0; side < 2; ++side) {
-          const int lab = side == 0 ? nw : od;
-          if (lab == 0) continue;
-          unsigned long long *rowp = tab + (size_t)(lab - 1) * d;
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int q4 = lane + 64 * h;
-            if (q4 < nq) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-                atomicAdd(rowp + 4 * q4 + j, (unsigned long long)(side ? -q[h][j] : q[h][j]));
-            }
+          for (int side = 0; side < 2; ++side) {
+            const int s0 = labs[side] >= 0 ? (int)slot[labs[side]] - base : -1;      // (listed labels are touched)
+            sl[side] = (s0 >= 0 && s0 < S) ? s0 : -1;
           }
-          if (tail0 + lane < d) atomicAdd(rowp + tail0 + lane, (unsigned long long)(side ? -qt : qt));
+          if (sl[0] < 0 && sl[1] < 0) continue;                  // (uniform per entry)
+          long long q[2][4];
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q[h][j] = to_fixed(v[u][h][j]);
+          const long long qt = to_fixed(t[u]);
+#pragma unroll
+          for (int side = 0; side < 2; ++side) {
+            if (sl[side] < 0) continue;
+            unsigned long long *rowp = tab + (size_t)sl[side] * d;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int q4 = lane + 64 * h;
+              if (q4 < nq) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                  atomicAdd(rowp + 4 * q4 + j, (unsigned long long)(side ? -q[h][j] : q[h][j]));
+              }
+            }
+            if (tail0 + lane < d) atomicAdd(rowp + tail0 + lane, (unsigned long long)(side ? -qt : qt));
+          }
         }
       }
+    };
+    gvec_t va[UNROLL][2], vb[UNROLL][2];
+    float ta[UNROLL], tb[UNROLL];
+    issue(0, va, ta);
+    for (int i0 = 0; i0 < nmine; i0 += 2 * UNROLL) {
+      issue(i0 + UNROLL, vb, tb);
+      __builtin_amdgcn_sched_barrier(0);
+      fold(i0, va, ta);
+      __builtin_amdgcn_sched_barrier(0);
+      issue(i0 + 2 * UNROLL, va, ta);
+      __builtin_amdgcn_sched_barrier(0);
+      fold(i0 + UNROLL, vb, tb);
+      __builtin_amdgcn_sched_barrier(0);
     }
-  };
-  gvec_t va[UNROLL][2], vb[UNROLL][2];
-  float ta[UNROLL], tb[UNROLL];
-  issue(0, va, ta);
-  for (int i0 = 0; i0 < nmine; i0 += 2 * UNROLL) {
-    issue(i0 + UNROLL, vb, tb);
-    __builtin_amdgcn_sched_barrier(0);
-    fold(i0, va, ta);
-    __builtin_amdgcn_sched_barrier(0);
-    issue(i0 + 2 * UNROLL, va, ta);
-    __builtin_amdgcn_sched_barrier(0);
-    fold(i0 + UNROLL, vb, tb);
-    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    // ---- flush the slots of this round into the image's table
+    for (int k = w; k < K; k += NW) {
+      const int s0 = slot[k] == 0xFFFF ? -1 : (int)slot[k] - base;
+      if (s0 >= 0 && s0 < S)
+        for (int i = lane; i < d; i += 64) {
+          const unsigned long long v = tab[(size_t)s0 * d + i];
+          if (v) atomicAdd(gq + (size_t)k * d + i, v);
+        }
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  // ---- flush the touched table rows into the image's table
-  unsigned long long *gq = sumq + ((int64_t)chunk_img[c] * K + kb0) * d;
-  for (int k = w; k < kbn; k += NW)
-    if (touched[k])
-      for (int i = lane; i < d; i += 64) {
-        const unsigned long long v = tab[(size_t)k * d + i];
-        if (v) atomicAdd(gq + (size_t)k * d + i, v);
+}
+
+// ---------------------------------------------------------------------------
+// Persistent variant for K * d * 8 <= ~132 KiB (K = 64, d = 258): the whole [K][d] int64
+// table of ONE image lives in LDS, one workgroup (8 waves) per CU owns a contiguous range
+// of chunks (mostly one image), and every WAVE works through its own 256-row strips with
+// no workgroup barrier: labels of the strip -> wave-private list of changed rows -> rows
+// loaded (8 in flight, double buffered), converted, ds_add_u64 into the shared table.  The
+// table is flushed with global atomics only when the workgroup's image changes -- about 5 M
+// global atomics per launch instead of one flush per chunk (17 M), which is what bounded the
+// late iterations where only a few per cent of the rows move.
+template <int NW, int UNROLL>
+__global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
+    const float *__restrict__ x, int d, const int32_t *__restrict__ prev,
+    const int32_t *__restrict__ cur, const int64_t *__restrict__ chunk_row0,
+    const int32_t *__restrict__ chunk_rows, const int32_t *__restrict__ chunk_img, int K,
+    unsigned long long *__restrict__ sumq, const hsgk_segkm_meta *__restrict__ meta) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  unsigned long long *tab = reinterpret_cast<unsigned long long *>(lds_raw);          // [K][d]
+  uint32_t *lists = reinterpret_cast<uint32_t *>(tab + (size_t)K * d + 2);            // [NW][256]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  uint32_t *list = lists + w * 256;
+  const int nc = (int)meta->n_chunks;
+  const int c_begin = (int)(((int64_t)blockIdx.x * nc) / gridDim.x);
+  const int c_end = (int)(((int64_t)(blockIdx.x + 1) * nc) / gridDim.x);
+  typedef float gvec_t __attribute__((ext_vector_type(4), aligned(4)));
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  const int nq = d / 4, tail0 = nq * 4;
+  constexpr int STRIP = 256, SPC = HSGK_CHUNK / STRIP;          // strips per chunk
+  int c = c_begin;
+  while (c < c_end) {
+    // ---- the run of chunks [c, ce) of one image
+    const int b = chunk_img[c];
+    int ce = c + 1;
+    while (ce < c_end && chunk_img[ce] == b) ++ce;
+    {
+      const int tot2 = (K * d + 1) / 2;
+      u64x2 *t2 = reinterpret_cast<u64x2 *>(tab);
+      for (int i = tid; i < tot2; i += NW * 64) t2[i] = u64x2{0ull, 0ull};
+    }
+    __syncthreads();
+    // ---- strips of the run, dealt to the waves round robin; no barrier inside
+    const int nstrips = (ce - c) * SPC;
+    for (int st = w; st < nstrips; st += NW) {
+      const int cc = c + st / SPC, part = st - (st / SPC) * SPC;
+      const int n = min(chunk_rows[cc] - part * STRIP, STRIP);
+      if (n <= 0) continue;
+      const int64_t row0 = chunk_row0[cc] + (int64_t)part * STRIP;
+      int pl[4], cl[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 64 * i + lane;
+        const int rr = min(r, n - 1);
+        pl[i] = prev[row0 + rr];
+        cl[i] = cur[row0 + rr];
+        if (r >= n) pl[i] = cl[i];
       }
+      int total = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool ch = pl[i] != cl[i];
+        const unsigned long long m = __ballot(ch);
+        if (ch)   // row (8 bits) | new label + 1 (11 bits) | old label + 1 (11 bits, 0 = not added yet)
+          list[total + __popcll(m & ((1ull << lane) - 1ull))] =
+              ((uint32_t)(64 * i + lane) << 22) | ((uint32_t)(cl[i] + 1) << 11) | (uint32_t)(pl[i] + 1);
+        total += __popcll(m);
+      }
+      if (total == 0) continue;
+      // (wave-private list: own LDS writes are visible to own reads in order)
+      const float *xr = x + row0 * d;
+      auto entry = [&](int i) { return list[min(i, total - 1)]; };
+      auto issue = [&](int i0, gvec_t (&v)[UNROLL][2], float (&t)[UNROLL]) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+          const int r = (int)(entry(i0 + u) >> 22);
+          const float *src = xr + (int64_t)r * d;
+          v[u][0] = *reinterpret_cast<const gvec_t *>(src + 4 * min(lane, nq - 1));
+          v[u][1] = *reinterpret_cast<const gvec_t *>(src + 4 * min(lane + 64, nq - 1));
+          t[u] = src[min(tail0 + lane, d - 1)];
+        }
+      };
+      auto fold = [&](int i0, const gvec_t (&v)[UNROLL][2], const float (&t)[UNROLL]) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+          if (i0 + u < total) {
+            const uint32_t e = entry(i0 + u);
+            const int labs[2] = {(int)((e >> 11) & 2047u) - 1, (int)(e & 2047u) - 1};
+            long long q[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) q[h][j] = to_fixed(v[u][h][j]);
+            const long long qt = to_fixed(t[u]);
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+              if (labs[side] < 0) continue;
+              unsigned long long *rowp = tab + (size_t)labs[side] * d;
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                const int q4 = lane + 64 * h;
+                if (q4 < nq) {
+#pragma unroll
+                  for (int j = 0; j < 4; ++j)
+                    atomicAdd(rowp + 4 * q4 + j, (unsigned long long)(side ? -q[h][j] : q[h][j]));
+                }
+              }
+              if (tail0 + lane < d) atomicAdd(rowp + tail0 + lane, (unsigned long long)(side ? -qt : qt));
+            }
+          }
+        }
+      };
+      gvec_t va[UNROLL][2], vb[UNROLL][2];
+      float ta[UNROLL], tb[UNROLL];
+      issue(0, va, ta);
+      for (int i0 = 0; i0 < total; i0 += 2 * UNROLL) {
+        issue(i0 + UNROLL, vb, tb);
+        __builtin_amdgcn_sched_barrier(0);
+        fold(i0, va, ta);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(i0 + 2 * UNROLL, va, ta);
+        __builtin_amdgcn_sched_barrier(0);
+        fold(i0 + UNROLL, vb, tb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+    // ---- flush the image's table
+    unsigned long long *gq = sumq + (int64_t)b * K * d;
+    for (int i = tid; i < K * d; i += NW * 64) {
+      const unsigned long long v = tab[i];
+      if (v) atomicAdd(gq + i, v);
+    }
+    __syncthreads();
+    c = ce;
+  }
 }
 
 // centroid row = normalise((float)sum * 2^-40): one rounding per element, then the C1 norm chain
@@ -191,36 +363,45 @@ __global__ __launch_bounds__(256) void finalize_fx_kernel(const long long *__res
   for (int i = tid; i < d; i += 256) out[i] = row[i] / nrm;
 }
 
-// rows of d <= 512 columns (two 16-byte loads per lane + one scalar tail) and a cluster
-// window that fits the LDS table
+// rows of d <= 515 columns (two 16-byte loads per lane + the d mod 4 scalar columns)
 bool sums_fx_eligible(int d) { return d >= 8 && d <= 515; }
-
-int sums_fx_window(int d, int K) {
-  const size_t budget = 150 * 1024 - (size_t)HSGK_CHUNK * 4 - 64 - 1024;
-  int kbn = (int)(budget / ((size_t)d * 8));
-  if (kbn > K) kbn = K;
-  if (kbn > 1023) kbn = 1023;               // 10-bit label fields of the list
-  return kbn;
-}
 
 int launch_update_sums(const float *x, int d, const int32_t *prev, const int32_t *cur,
                        const ChunkTable &t, int max_chunks, int K, long long *sumq,
                        const hsgk_segkm_meta *meta, hipStream_t s) {
   if (max_chunks <= 0) return 0;
-  const int kbn = sums_fx_window(d, K);
-  HSGK_REQUIRE(kbn >= 1, "row too long for the exact-sum table");
-  constexpr int NW = 8;
-  auto kern = update_sums_kernel<NW, 8>;
-  const size_t lds = (size_t)kbn * d * 8 + (size_t)HSGK_CHUNK * 4 + (NW + 1) * 4 + 1024 + 32;
-  HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(158 * 1024)));
-  for (int kb0 = 0; kb0 < K; kb0 += kbn) {
-    const int curk = K - kb0 < kbn ? K - kb0 : kbn;
-    hipLaunchKernelGGL(kern, dim3(max_chunks), dim3(NW * 64), lds, s, x, d, prev, cur, t.chunk_row0,
-                       t.chunk_rows, t.chunk_img, K, kb0, curk,
-                       reinterpret_cast<unsigned long long *>(sumq), meta);
-    HSGK_LAUNCH_CHECK();
+  HSGK_REQUIRE(K <= 1023, "too many clusters for the exact-sum update (11-bit label fields)");
+  {
+    // persistent big-table variant when one image's table fits LDS
+    constexpr int NWP = 8;
+    const size_t ldsp = (size_t)K * d * 8 + 16 + (size_t)NWP * 256 * 4 + 32;
+    if (ldsp <= 150 * 1024) {
+      static const int n_cu = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess)
+          (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return cus > 0 ? cus : 256;
+      }();
+      auto kp = update_sums_persistent_kernel<NWP, 8>;
+      HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kp),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
+      const int grid = max_chunks < n_cu ? max_chunks : n_cu;
+      hipLaunchKernelGGL(kp, dim3(grid), dim3(NWP * 64), ldsp, s, x, d, prev, cur, t.chunk_row0,
+                         t.chunk_rows, t.chunk_img, K, reinterpret_cast<unsigned long long *>(sumq), meta);
+      HSGK_LAUNCH_CHECK();
+      return 0;
+    }
   }
+  constexpr int NW = 4, S = 12;
+  auto kern = update_sums_kernel<NW, 4, S>;
+  const size_t lds = (size_t)S * d * 8 + (size_t)(kFxRows + 2) * 4 + (NW + 1) * 4 + (size_t)K * 2 + 32;
+  HSGK_REQUIRE(lds <= 150 * 1024, "row too long for the exact-sum table");
+  HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(max_chunks * (HSGK_CHUNK / kFxRows)), dim3(NW * 64), lds, s, x, d, prev,
+                     cur, t.chunk_row0, t.chunk_rows, t.chunk_img, K,
+                     reinterpret_cast<unsigned long long *>(sumq), meta);
+  HSGK_LAUNCH_CHECK();
   return 0;
 }
 
