@@ -9,11 +9,11 @@ clusters its own shard of the same per-GPU shape (weak scaling; images are
 independent, the only exchange is the prototype-table step).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline      the dominant kernel (M-step accumulate_kernel): algorithmic bytes
-                (4D per pixel) over its average duration, measured with HIP events
-                on the launch stream inside the timed region (libhsgk's event
-                profiler); roofline_assign / roofline_iteration: the same for the
-                E-step launch group (4D+8 per pixel) and for one whole iteration.
+  roofline      the dominant launch group (the E-step): algorithmic bytes (4D+8 per
+                pixel) over its average duration, measured with HIP events on the
+                launch stream inside the timed region (libhsgk's event profiler);
+                roofline_mstep / roofline_prep / roofline_iteration: the same for
+                the M-step update, the prep kernel and one whole Lloyd iteration.
                 `traffic` is null: on gfx950 FETCH_SIZE counts between 0.5x and
                 ~0.94x of the bytes depending on the access pattern
                 (profiles/r01_pmc.txt, tools/probes/fetch_calib.hip), so no
@@ -138,11 +138,13 @@ def main():
   value = px_per_step * args.steps / elapsed
 
   # Rooflines (HBM-bound kernels; durations from libhsgk's HIP-event profiler, recorded on
-  # the launch stream inside the timed region).  `roofline` is the DOMINANT kernel by time
-  # (M-step accumulate_kernel); `roofline_assign` is the E-step launch group north_star's
-  # 50 % target names; `roofline_iteration` prices one whole Lloyd iteration (M + finalize
-  # + E) against SURVEY 8(d)'s fused-iteration figure of 4D+8 bytes per pixel.
+  # the launch stream inside the timed region).  `roofline` is the DOMINANT launch group by
+  # time, the E-step (also the one north_star's 50 % target names); `roofline_mstep` is the
+  # exact-sum M-step update, `roofline_prep` the prep kernel, `roofline_iteration` one whole
+  # Lloyd iteration (M + finalize + E) against SURVEY 8(d)'s fused-iteration figure of
+  # 4D+8 bytes per pixel.
   npx = B * H * W
+  p_ms, p_n = prof['prep']
   m_ms, m_n = prof['accumulate']
   f_ms, f_n = prof['finalize']
   a_ms, a_n = prof['assign']
@@ -159,13 +161,11 @@ def main():
     out.update(extra)
     return out
 
-  roofline = rl('M-step accumulate_kernel (ordered per-chunk segment sums; dominant kernel by time)',
-                4 * D * npx, m_ms, m_n)
   half_ok = (D % 64 == 2 and 128 <= D <= 322 and (D // 64) % 2 == 0 and grid[0] * grid[1] <= 64)
-  roofline_assign = rl(
-      'E-step launch group: assign_half_kernel (fp16 filter over the fp16 row copy) + '
-      'assign_split_rows_kernel (bf16x3 on the undecided rows) + assign_requeue_rows_kernel '
-      '(exact fp32 chains)' if half_ok else 'E-step launch group',
+  roofline = rl(
+      'E-step launch group (dominant by time): assign_half_kernel (fp16 filter over the fp16 row '
+      'copy) + assign_split_rows_kernel (bf16x3 on the undecided rows) + assign_requeue_rows_kernel '
+      '(exact fp32 chains)' if half_ok else 'E-step launch group (dominant by time)',
       (4 * D + 8) * npx, a_ms, a_n,
       mfma_tflops=round(2.0 * D * (grid[0] * grid[1]) * npx / (a_ms / max(a_n, 1) * 1e-3) / 1e12, 2)
       if a_n else None,
@@ -173,18 +173,25 @@ def main():
             'group\'s duration.  By design the group STREAMS less than that -- the fp16 copy '
             '(2(D-2)+8 B per pixel), 4 B of labels and the fp32 rows of the ~1.5 % undecided pixels '
             '-- which is how frac can exceed 1; streamed_* price that traffic instead') if half_ok else None)
-  if roofline_assign and half_ok:
+  if roofline and half_ok:
     streamed = (2 * (D - 2) + 8 + 4 + 0.015 * 4 * D) * npx
     sg = streamed / (a_ms / a_n * 1e-3) / 1e9
-    roofline_assign.update({'streamed_bytes_per_launch': int(streamed), 'streamed_GBps': round(sg, 1),
-                            'streamed_frac': round(sg / HBM_PEAK_GBS, 4)})
+    roofline.update({'streamed_bytes_per_launch': int(streamed), 'streamed_GBps': round(sg, 1),
+                     'streamed_frac': round(sg / HBM_PEAK_GBS, 4)})
+  roofline_mstep = rl(
+      'M-step: update_sums kernel (exact fixed-point segment sums, updated from the rows whose '
+      'label changed; the first launches of a call touch every row, the later ones a few per cent)',
+      4 * D * npx, m_ms, m_n,
+      note='algorithmic bytes = one read of every fp32 row (4D B per pixel) per launch; the update only '
+           'reads the changed rows, so the average launch beats that stream')
+  roofline_prep = rl('prep kernel (NCHW -> normalised rows, both float outputs, labels, fp16 copy)',
+                     (8 * C + 4 * D + 24) * npx, p_ms, p_n)
   roofline_iteration = None
   if m_n and a_n and f_n:
     it_ms = m_ms / m_n + f_ms / f_n + a_ms / a_n
-    roofline_iteration = rl('one Lloyd iteration = accumulate + finalize + E-step group (reads the '
-                            'embeddings twice: fp32 for the sums, fp16 copy for the filter)',
-                            (4 * D + 8) * npx, it_ms, 1)
-    roofline_iteration['launches'] = int(m_n)
+    roofline_iteration = rl('one Lloyd iteration = sums update + finalize + E-step group, against one '
+                            'read of the fp32 rows + the label write', (4 * D + 8) * npx, it_ms, 1)
+    roofline_iteration['launches'] = int(a_n)
   phases = {k: round(v[0] / max(1, args.steps), 3) for k, v in prof.items()}
 
   cpu = None
@@ -221,7 +228,7 @@ def main():
                                                           grid[1], iters),
                    'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world,
                    'phase_ms_per_step': phases, 'prototype_exchange_untimed': exch},
-        'roofline': roofline, 'roofline_assign': roofline_assign,
+        'roofline': roofline, 'roofline_mstep': roofline_mstep, 'roofline_prep': roofline_prep,
         'roofline_iteration': roofline_iteration, 'cpu_baseline': cpu}))
   if dist is not None:
     dist.destroy_process_group()
