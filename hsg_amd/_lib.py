@@ -60,6 +60,7 @@ SIGNATURES = {
     'hsgk_profile_collect': (_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     'hsgk_lloyd_workspace_bytes': (_sz, [_i32, _i64, _i32, _i32]),
     'hsgk_lloyd_mstep': (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    'hsgk_lloyd_mstep_exact': (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'hsgk_lloyd_estep': (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _sz, _vp]),
     'hsgk_segment_reduce_workspace_bytes': (_sz, [_i64, _i32, _i64]),
     'hsgk_segment_reduce': (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),

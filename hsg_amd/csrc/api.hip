@@ -137,6 +137,12 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
   }
   for (int it = 0; it < iterations; ++it) {
     if (fx) {
+      if (it == 1) {
+        // the first E-step replaces the seed grid by real assignments: nearly every row moves,
+        // so rebuilding (one add per row) is cheaper than subtract + add.  Exact either way.
+        HSGK_CHECK_HIP(hipMemsetAsync(k.klab_prev, 0xFF, sizeof(int32_t) * k.rows_cap, s));
+        HSGK_CHECK_HIP(hipMemsetAsync(k.sumq, 0, sizeof(long long) * (size_t)B * K * d, s));
+      }
       { ProfScope p(HSGK_PROF_ACCUMULATE, s);
         if (int rc = launch_update_sums(x, d, k.klab_prev, k.klab, k.t, k.max_chunks, K, k.sumq, meta, s))
           return rc;
@@ -332,6 +338,28 @@ int hsgk_lloyd_mstep(const float *x, int B, int64_t rows_per_image, int d, int K
     if (int rc = launch_accumulate(x, d, labels, k.t, k.max_chunks, K, k.partial, k.pmask, meta, s)) return rc; }
   ProfScope p(HSGK_PROF_FINALIZE, s);
   return launch_finalize(k.partial, k.pmask, d, K, B, k.t, k.max_chunks / B, HSGK_EPS, centroids, s);
+}
+
+int hsgk_lloyd_mstep_exact(const float *x, int B, int64_t rows_per_image, int d, int K,
+                           const int32_t *labels_prev, const int32_t *labels, int64_t *sums,
+                           float *centroids, void *workspace, size_t workspace_bytes,
+                           hsgk_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HSGK_REQUIRE(x && labels && sums && centroids, "null argument");
+  HSGK_REQUIRE(sums_fx_eligible(d), "row length not supported by the exact-sum M-step");
+  KmeansScratch k; hsgk_segkm_meta *meta;
+  if (int rc = lloyd_setup(B, rows_per_image, d, K, workspace, workspace_bytes, &k, &meta, s)) return rc;
+  const int32_t *prev = labels_prev;
+  if (!prev) {                                  // from scratch: nothing added yet
+    HSGK_CHECK_HIP(hipMemsetAsync(k.klab_prev, 0xFF, sizeof(int32_t) * k.rows_cap, s));
+    HSGK_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(int64_t) * (size_t)B * K * d, s));
+    prev = k.klab_prev;
+  }
+  { ProfScope p(HSGK_PROF_ACCUMULATE, s);
+    if (int rc = launch_update_sums(x, d, prev, labels, k.t, k.max_chunks, K,
+                                    reinterpret_cast<long long *>(sums), meta, s)) return rc; }
+  ProfScope p(HSGK_PROF_FINALIZE, s);
+  return launch_finalize_fx(reinterpret_cast<const long long *>(sums), d, K, B, HSGK_EPS, centroids, s);
 }
 
 int hsgk_lloyd_estep(const float *x, int B, int64_t rows_per_image, int d, int K,

@@ -141,6 +141,16 @@ HSGK_API size_t hsgk_lloyd_workspace_bytes(int B, int64_t rows_per_image, int d,
 HSGK_API int hsgk_lloyd_mstep(const float *x, int B, int64_t rows_per_image, int d, int K,
                               const int32_t *labels, float *centroids, void *workspace,
                               size_t workspace_bytes, hsgk_stream_t stream);
+/* M-step with EXACT segment sums (canonical order C2x: fixed point, quantum 2^-40, 64-bit
+ * integer sums, one rounding to fp32; rows must be bounded, |x| <= 1 for unit rows), the
+ * arithmetic of the Lloyd loop inside hsgk_segment_by_kmeans.  sums [B,K,d] int64 is the
+ * caller-owned state: labels_prev == NULL computes it from scratch for `labels`; otherwise
+ * sums must hold the exact sums of labels_prev and is UPDATED from the rows whose label
+ * differs (identical to a from-scratch pass over `labels`).  centroids [B,K,d].          */
+HSGK_API int hsgk_lloyd_mstep_exact(const float *x, int B, int64_t rows_per_image, int d, int K,
+                                    const int32_t *labels_prev, const int32_t *labels,
+                                    int64_t *sums, float *centroids, void *workspace,
+                                    size_t workspace_bytes, hsgk_stream_t stream);
 /* unit_rows != 0 promises L2-normalised rows and centroids and enables the
  * filtered E-step (same labels, faster): 1 = bf16-split filter + exact re-score;
  * 2 = fp16 copy of the rows first (made inside the call; the composite makes it

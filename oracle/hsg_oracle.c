@@ -142,12 +142,22 @@ static void orc_segment_sums_fx(const float *x, int64_t n, int d, const int64_t 
   free(acc);
 }
 
+/* prototypes with exact sums (C2x): the M-step of the Lloyd loop of segment_by_kmeans */
+ORC_API void orc_prototypes_exact(const float *x, int64_t n, int d, const int64_t *labels, int64_t P,
+                                  float eps, float *out);
+
 static void orc_normalize_table(float *out, int64_t P, int d, float eps) {
   for (int64_t k = 0; k < P; ++k) {
     float *row = out + k * (int64_t)d;
     float nrm = orc_row_norm(row, d, eps);
     for (int i = 0; i < d; ++i) row[i] = row[i] / nrm;
   }
+}
+
+ORC_API void orc_prototypes_exact(const float *x, int64_t n, int d, const int64_t *labels, int64_t P,
+                                  float eps, float *out) {
+  orc_segment_sums_fx(x, n, d, labels, P, out);
+  orc_normalize_table(out, P, d, eps);
 }
 
 ORC_API void orc_prototypes(const float *x, int64_t n, int d,

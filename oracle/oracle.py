@@ -102,12 +102,17 @@ def prepare_prototype_labels(semantic_labels, instance_labels, offset=256):
 
 
 def calculate_prototypes_from_labels(embeddings, labels, max_label=None,
-                                     chunk=CHUNK):
-  """hsg/utils/segsort/common.py:11-41 with summation order C2."""
+                                     chunk=CHUNK, exact_sums=False):
+  """hsg/utils/segsort/common.py:11-41 with summation order C2 (exact_sums: C2x, the
+  M-step arithmetic of the Lloyd loop in segment_by_kmeans)."""
   x = _f32(embeddings).reshape(-1, embeddings.shape[-1])
   lab = _i64(labels).reshape(-1)
   P = int(lab.max()) + 1 if max_label is None else int(max_label)
   out = np.empty((P, x.shape[1]), np.float32)
+  if exact_sums:
+    lib().orc_prototypes_exact(_p(x, _f32p), ctypes.c_int64(x.shape[0]), x.shape[1],
+                               _p(lab, _i64p), ctypes.c_int64(P), ctypes.c_float(EPS), _p(out, _f32p))
+    return out
   lib().orc_prototypes(_p(x, _f32p), ctypes.c_int64(x.shape[0]), x.shape[1],
                        _p(lab, _i64p), ctypes.c_int64(P), chunk,
                        ctypes.c_float(EPS), _p(out, _f32p))

@@ -726,3 +726,49 @@ def test_dmon_affinity_graph_larger_vs_oracle(dev, oracle):
                                         torch.from_numpy(pad).to(dev), torch.from_numpy(seg).to(dev), 10)
   ref = oracle.affinity_matrix_as_attention(x.astype(np.float32), pad, seg, 10)
   assert np.array_equal(got.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize('B,HW,C,K', [(2, 5000, 256, 64), (3, 3000, 384, 128), (1, 700, 30, 5)])
+def test_exact_sum_mstep_full_and_incremental(dev, oracle, B, HW, C, K):
+  """C2x M-step (hsgk_lloyd_mstep_exact): from scratch == oracle exact sums (centroids
+  bit-exact) with adversarial labels (every strip touches every cluster; K * d beyond the
+  LDS table at C=384/K=128 -> strip kernel with several slot rounds); then two
+  incremental updates (30 % / 1 % of the rows relabelled, some clusters emptied) give the
+  SAME int64 sums and centroids as from-scratch passes."""
+  import torch
+  from hsg_amd import _lib
+  D = C + 2
+  n = B * HW
+  x = oracle.normalize_embedding(synth.gaussish(500 + C, n * D).reshape(n, D))
+  lab0 = (synth.hash_u64(501 + K, n) % np.uint64(K)).astype(np.int32)
+  lab1 = lab0.copy()
+  m = (synth.hash_u64(502, n) % np.uint64(10)) < 3
+  lab1[m] = (synth.hash_u64(503, n)[m] % np.uint64(K)).astype(np.int32)
+  lab1[lab1 == K - 1] = 0                                          # empty the last cluster
+  lab2 = lab1.copy()
+  m2 = (synth.hash_u64(504, n) % np.uint64(100)) == 0
+  lab2[m2] = K - 1
+  L = _lib.lib()
+  xt = torch.from_numpy(x).to(dev)
+  wsb = L.hsgk_lloyd_workspace_bytes(B, HW, D, K)
+  ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+
+  def mstep(prev, cur, sums):
+    cent = torch.empty((B, K, D), dtype=torch.float32, device=dev)
+    _lib.check(L.hsgk_lloyd_mstep_exact(xt.data_ptr(), B, HW, D, K, prev.data_ptr() if prev is not None else None,
+                                        cur.data_ptr(), sums.data_ptr(), cent.data_ptr(), ws.data_ptr(), wsb,
+                                        _lib.stream_ptr()))
+    return cent
+  t = lambda a: torch.from_numpy(a).to(dev)
+  sums = torch.empty((B, K, D), dtype=torch.int64, device=dev)
+  l0, l1, l2 = t(lab0), t(lab1), t(lab2)
+  for step, (prev, cur, lab_np) in enumerate(((None, l0, lab0), (l0, l1, lab1), (l1, l2, lab2))):
+    cent = mstep(prev, cur, sums)
+    fresh = torch.empty_like(sums)
+    cent_fresh = mstep(None, cur, fresh)
+    assert torch.equal(sums, fresh), 'incremental sums differ from a from-scratch pass (step %d)' % step
+    assert torch.equal(cent, cent_fresh)
+    for b in range(B):
+      ref = oracle.calculate_prototypes_from_labels(x[b * HW:(b + 1) * HW], lab_np[b * HW:(b + 1) * HW].astype(np.int64),
+                                                    K, exact_sums=True)
+      assert np.array_equal(cent[b].cpu().numpy(), ref), 'centroids vs oracle (step %d, image %d)' % (step, b)
