@@ -137,12 +137,6 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
   }
   for (int it = 0; it < iterations; ++it) {
     if (fx) {
-      if (it == 1) {
-        // the first E-step replaces the seed grid by real assignments: nearly every row moves,
-        // so rebuilding (one add per row) is cheaper than subtract + add.  Exact either way.
-        HSGK_CHECK_HIP(hipMemsetAsync(k.klab_prev, 0xFF, sizeof(int32_t) * k.rows_cap, s));
-        HSGK_CHECK_HIP(hipMemsetAsync(k.sumq, 0, sizeof(long long) * (size_t)B * K * d, s));
-      }
       { ProfScope p(HSGK_PROF_ACCUMULATE, s);
         if (int rc = launch_update_sums(x, d, k.klab_prev, k.klab, k.t, k.max_chunks, K, k.sumq, meta, s))
           return rc;
