@@ -570,42 +570,33 @@ struct HalfEpi {
   }
 };
 
+// Persistent: gridDim.x workgroups share the rows [0, N) of the batch in equal contiguous
+// ranges (a multiple of the 256-row tile; no dependence on the chunk table, so small batches
+// balance as well as large ones), cut at image boundaries into passes; the table is re-staged
+// only when the image changes.
 template <int NW, int DEPTH>
 __global__ __launch_bounds__(NW * 64) void assign_half_kernel(
     const _Float16 *__restrict__ xm, const uint2 *__restrict__ xt, int d,
-    const float *__restrict__ cent, int K,
-    const int64_t *__restrict__ chunk_row0, const int32_t *__restrict__ chunk_rows,
-    const int32_t *__restrict__ chunk_img, int32_t *__restrict__ klab,
-    int32_t *__restrict__ q1, int32_t *__restrict__ q1count, int64_t q1cap, int split,
-    const hsgk_segkm_meta *__restrict__ meta) {
+    const float *__restrict__ cent, int K, const int64_t *__restrict__ img_row0, int B,
+    int32_t *__restrict__ klab, int32_t *__restrict__ q1, int32_t *__restrict__ q1count,
+    int64_t q1cap, const hsgk_segkm_meta *__restrict__ meta) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int TPX = NW * 32;
   uint16_t *qpx = reinterpret_cast<uint16_t *>(lds_raw + half_lds_bytes<NW>(d));
   int *qnp = reinterpret_cast<int *>(qpx + kHalfLdsList);
-  // same work split as assign_split_kernel: persistent (split == 0) or 1/split of a chunk
-  int c_begin, c_end, part = 0, tps = HSGK_CHUNK / TPX;
-  if (split == 0) {
-    const int nc = (int)meta->n_chunks;
-    c_begin = (int)(((int64_t)blockIdx.x * nc) / gridDim.x);
-    c_end = (int)(((int64_t)(blockIdx.x + 1) * nc) / gridDim.x);
-  } else {
-    c_begin = blockIdx.x / split;
-    c_end = c_begin < meta->n_chunks ? c_begin + 1 : c_begin;
-    part = blockIdx.x - c_begin * split;
-    tps = (HSGK_CHUNK / TPX + split - 1) / split;
-  }
+  const int64_t N = meta->n_rows;
+  const int64_t per = (N + (int64_t)gridDim.x * TPX - 1) / ((int64_t)gridDim.x * TPX) * TPX;
+  int64_t r = (int64_t)blockIdx.x * per;
+  const int64_t r_end = min(N, r + per);
+  if (r >= r_end) return;
+  int b = 0;
+  while (b + 1 < B && img_row0[b + 1] <= r) ++b;                 // image of the first row
   int staged_img = -1;
-  for (int c = c_begin; c < c_end; ++c) {
-    int nrows = min(chunk_rows[c] - part * tps * TPX, tps * TPX);
-    if (nrows <= 0) continue;
-    const int64_t crow0 = chunk_row0[c] + (int64_t)part * tps * TPX;
-    const int b = chunk_img[c];
-    if (split == 0)
-      while (c + 1 < c_end && chunk_img[c + 1] == b && chunk_row0[c + 1] == crow0 + nrows &&
-             nrows + chunk_rows[c + 1] <= 0xFFFF) {
-        nrows += chunk_rows[c + 1];
-        ++c;
-      }
+  while (r < r_end) {
+    while (img_row0[b + 1] <= r) ++b;                            // (empty images are skipped)
+    const int64_t seg_end = min(r_end, img_row0[b + 1]);
+    const int nrows = (int)min(seg_end - r, (int64_t)(0xFFFF / TPX) * TPX);   // queue offsets are u16
+    const int64_t crow0 = r;
     if (threadIdx.x == 0) qnp[0] = 0;       // ordered before any epilogue by the engine's barrier
     HalfEpi epi{K, nrows, crow0, klab, qpx, qnp, q1 + (int64_t)b * q1cap, q1count + b};
     score_tiles_half<NW, DEPTH>(xm, xt, d, cent + (int64_t)b * K * d, K, crow0, nrows, lds_raw, epi,
@@ -620,6 +611,7 @@ __global__ __launch_bounds__(NW * 64) void assign_half_kernel(
       for (int i = threadIdx.x; i < qn; i += NW * 64) dst[i] = (int32_t)(crow0 + qpx[i]);
     }
     __syncthreads();                        // queue drained before the next pass resets it
+    r += nrows;
   }
 }
 
@@ -718,20 +710,16 @@ int launch_assign_half(const float *x, const _Float16 *xm, const uint2 *xt, int 
                        int32_t *q1count, int64_t q1cap, void *qrows, int32_t *qcount,
                        const hsgk_segkm_meta *meta, hipStream_t s) {
   if (max_chunks <= 0 || B <= 0) return 0;
-  constexpr int NW = 8, TPX = NW * 32, kTiles = HSGK_CHUNK / TPX;
-  int split = 1;
-  while (split < kTiles && (int64_t)max_chunks * split < 2048) split *= 2;
-  int grid = max_chunks * split;
+  constexpr int NW = 8, TPX = NW * 32;
   static const int n_cu = [] {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess)
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     return cus > 0 ? cus : 256;
   }();
-  if (split == 1 && max_chunks >= 4 * n_cu) {
-    split = 0;
-    grid = n_cu;
-  }
+  // one persistent workgroup per CU, fewer when the batch has fewer tiles
+  const int64_t max_tiles = ((int64_t)max_chunks * HSGK_CHUNK + TPX - 1) / TPX;
+  const int grid = (int)(max_tiles < n_cu ? max_tiles : n_cu);
   HSGK_CHECK_HIP(hipMemsetAsync(q1count, 0, sizeof(int32_t) * B, s));
   HSGK_CHECK_HIP(hipMemsetAsync(qcount, 0, sizeof(int32_t), s));
   {
@@ -740,8 +728,8 @@ int launch_assign_half(const float *x, const _Float16 *xm, const uint2 *xt, int 
     const size_t lds = half_lds_bytes<NW>(d) + (size_t)kHalfLdsList * 2 + 16;
     HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, xm, xt, d, cent, K, t.chunk_row0,
-                       t.chunk_rows, t.chunk_img, klab, q1, q1count, q1cap, split, meta);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, xm, xt, d, cent, K, t.img_row0, B,
+                       klab, q1, q1count, q1cap, meta);
     HSGK_LAUNCH_CHECK();
   }
   {
