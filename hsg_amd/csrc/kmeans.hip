@@ -3,10 +3,12 @@
 // (:11-41), E-step = find_nearest_prototypes (:44-64).
 //
 // Canonical arithmetic:
-//   M  per chunk (<= 2048 consecutive rows of one image) every (cluster,
-//      column) is summed sequentially in row order from +0.0f; chunk partials
-//      are summed sequentially in chunk order from +0.0f; the centroid is the
-//      sum divided by its norm (fmaf chain over columns, sqrtf, '/').
+//   M  order C2 (this file: the batch M-step of the C ABI, kmeans_with_initial_labels):
+//      per chunk (<= 2048 consecutive rows of one image) every (cluster, column) is
+//      summed sequentially in row order from +0.0f; chunk partials are summed
+//      sequentially in chunk order from +0.0f.  The Lloyd loop of segment_by_kmeans
+//      uses the exact sums of order C2x instead (sums_fx.hip).  Either way the
+//      centroid is the sum divided by its norm (fmaf chain over columns, sqrtf, '/').
 //   E  <x, c_k> is one fmaf chain over ascending column index from +0.0f --
 //      exactly what v_mfma_f32_32x32x2_f32 computes (k-ordered fmaf chain) --
 //      argmax takes the first maximal index.

@@ -18,9 +18,10 @@
  *     thread-local message.  Errors detected on the device (label range too
  *     large for the relabel table, negative labels) are reported through the
  *     `meta` block, see hsgk_segkm_meta.
- *   - floating-point summation orders are fixed ("canonical order", DESIGN.md
- *     section 4) so results are run-to-run deterministic and bit-identical to
- *     oracle/hsg_oracle.c.
+ *   - floating-point summation orders are fixed ("canonical orders" C1, C2, C2x,
+ *     DESIGN.md section 4; C2x = exact fixed-point segment sums in the Lloyd loop of
+ *     hsgk_segment_by_kmeans) so results are run-to-run deterministic and
+ *     bit-identical to oracle/hsg_oracle.c.
  */
 #ifndef HSGK_H_
 #define HSGK_H_
@@ -52,8 +53,8 @@ HSGK_API const char *hsgk_last_error(void);
  * stream; hsgk_profile_collect waits for them, returns summed milliseconds and
  * launch counts per kind, and clears the log.                                 */
 #define HSGK_PROF_PREP 0        /* count + tables + prep kernels              */
-#define HSGK_PROF_ACCUMULATE 1  /* M-step chunk partial sums                  */
-#define HSGK_PROF_FINALIZE 2    /* M-step partial combine + normalise         */
+#define HSGK_PROF_ACCUMULATE 1  /* M-step sums (exact update or streaming pass)  */
+#define HSGK_PROF_FINALIZE 2    /* M-step: sums -> normalised centroids         */
 #define HSGK_PROF_ASSIGN 3      /* E-step (the roofline kernel)               */
 #define HSGK_PROF_RELABEL 4
 #define HSGK_PROF_KINDS 5
