@@ -117,6 +117,10 @@ bool assign_split_eligible(int d, int K);
 bool assign_half_eligible(int d, int K);
 int launch_to_half_rows(const float *x, const ChunkTable &t, int max_chunks, int d, _Float16 *xm,
                         uint2 *xt, const hsgk_segkm_meta *meta, hipStream_t s);
+bool assign_half_wide_eligible(int d, int K);          // 64 < K <= 128: hi-plane fp16 filter -> exact chains
+int launch_assign_half_wide(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent,
+                            float *errc, int K, int B, const ChunkTable &t, int max_chunks, int32_t *klab,
+                            void *qrows, int32_t *qcount, const hsgk_segkm_meta *meta, hipStream_t s);
 int launch_assign_half(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent, int K, int B,
                        const ChunkTable &t, int max_chunks, int32_t *klab, int32_t *q1,
                        int32_t *q1count, int64_t q1cap, void *qrows, int32_t *qcount,

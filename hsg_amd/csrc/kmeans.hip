@@ -458,10 +458,15 @@ __global__ __launch_bounds__(256) void assign_requeue_rows_kernel(
       hard &= hard - 1;
       const int row = __builtin_amdgcn_readlane(ent.row, src);
       const int img = __builtin_amdgcn_readlane(ent.img, src);
-      float a = -INFINITY;
-      if (lane < K) a = exact_chain(cent + ((int64_t)img * K + lane) * d, x + (int64_t)row * d, d);
-      float hv = (lane < K && a == a) ? a : -INFINITY;
-      int hi = lane;
+      float hv = -INFINITY;
+      int hi = 0x7fffffff;
+      for (int k0 = 0; k0 < K; k0 += 64) {                    // lane = centroid k0 + lane, first maximum wins
+        const int k = k0 + lane;
+        float a = -INFINITY;
+        if (k < K) a = exact_chain(cent + ((int64_t)img * K + k) * d, x + (int64_t)row * d, d);
+        if (k < K && a == a && a > hv) { hv = a; hi = k; }
+      }
+      if (hi == 0x7fffffff) hi = lane;                         // (all NaN: lowest lane index, as before)
       for (int off = 32; off > 0; off >>= 1) {
         const float ov = __shfl_xor(hv, off);
         const int oi = __shfl_xor(hi, off);
@@ -615,6 +620,195 @@ __global__ __launch_bounds__(NW * 64) void assign_half_kernel(
     __syncthreads();                        // queue drained before the next pass resets it
     r += nrows;
   }
+}
+
+// ===========================================================================
+// 64 < K <= 128: ONE pass with the hi plane of the table only (the hi + lo planes of 128
+// centroids do not fit LDS), four accumulator sets.  The table's own fp16 rounding error
+// errc(k) = |c_k - fp16(c_k)|_2 is measured (centroid_half_err_kernel) and enters the bound
+// next to the row's: |s~ - s| <= |c| err(row) + |xh| errc(k) + 4.2e-5 (d <= 450: 29 MFMA
+// column blocks, gamma_450), so a row is decided when its two best approximate scores differ
+// by more than 2.0002 err(row) + 2.003 max_k errc(k) + 8.5e-5; every other row goes straight
+// to the exact chains with its candidate set (no bf16x3 level: its planes do not fit either).
+__global__ __launch_bounds__(256) void centroid_half_err_kernel(const float *__restrict__ cent, int d,
+                                                                int64_t rows, float *__restrict__ errc) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  float e2 = 0.0f;
+  for (int i = lane; i < d; i += 64) {
+    const float v = cent[r * d + i];
+    const float e = v - (float)(_Float16)v;                  // exact residual
+    e2 = fmaf(e, e, e2);
+  }
+  for (int off = 32; off > 0; off >>= 1) e2 += __shfl_xor(e2, off);
+  if (lane == 0) errc[r] = sqrtf(e2) * 1.0001f;
+}
+
+__device__ inline float half_wide_gap(float err, float errc_max) {
+  return fmaf(2.0002f, err, fmaf(2.003f, errc_max, 8.5e-5f));
+}
+
+template <int MB>
+struct HalfWideEpi {
+  int K, nrows, img;
+  int64_t crow0;
+  float errc_max;
+  int32_t *klab;
+  uint16_t *qpx;         // LDS [kSplitLdsList]
+  uint32_t *qcand;       // LDS [kSplitLdsList]
+  int *qn;               // LDS counter
+  SplitEntry *gqueue;    // global exact queue (overflow path)
+  int32_t *gcount;
+  __device__ inline void operator()(int tile, const f32x16 (&sacc)[MB], float err) const {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int TPX = (int)(blockDim.x >> 1);
+    float b1 = -INFINITY, b2 = -INFINITY;
+    int bi = 0;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = k < K ? sacc[m][r] : -INFINITY;
+        b2 = fmaxf(b2, fminf(b1, v));
+        bi = v > b1 ? k : bi;
+        b1 = fmaxf(b1, v);
+      }
+    const float o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
+    const int oi = __shfl_xor(bi, 32);
+    float t1, t2;
+    int ti;
+    if (o1 > b1 || (o1 == b1 && oi < bi)) { t1 = o1; ti = oi; t2 = fmaxf(b1, o2); }
+    else { t1 = b1; ti = bi; t2 = fmaxf(o1, b2); }
+    const int px = tile * TPX + w * 32 + j;
+    const bool valid = px < nrows;
+    const float gap = half_wide_gap(err, errc_max);
+    const bool amb = valid && !(t1 - t2 > gap);               // ambiguous (or NaN)
+    if (h == 0 && valid) klab[crow0 + px] = ti;               // provisional for ambiguous rows
+    if (!__any(amb)) return;
+    // candidates of this lane's half, merged with the partner half (<= 3, else "all")
+    const float thr = t1 - gap;
+    uint32_t list = 0;
+    int cnt = 0;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool hit = k < (uint32_t)K && sacc[m][r] >= thr;  // NaN scores never hit
+        list = hit ? ((list << 8) | k) : list;
+        cnt += hit ? 1 : 0;
+      }
+    const uint32_t olist = __shfl_xor(list, 32);
+    const int ocnt = __shfl_xor(cnt, 32);
+    const int tot = cnt + ocnt;
+    uint32_t cand = 255u << 24;
+    if (tot <= 3 && tot >= 1 && t1 == t1)
+      cand = (list & ((1u << (8 * cnt)) - 1u)) | (olist << (8 * cnt)) | ((uint32_t)tot << 24);
+    if (h == 0 && amb) {
+      const int pos = atomicAdd(qn, 1);
+      if (pos < kSplitLdsList) {
+        qpx[pos] = (uint16_t)px;
+        qcand[pos] = cand;
+      } else {
+        const int g = atomicAdd(gcount, 1);
+        gqueue[g] = SplitEntry{(int32_t)(crow0 + px), cand, img};
+      }
+    }
+  }
+};
+
+template <int NW, int DEPTH, int MB>
+__global__ __launch_bounds__(NW * 64) void assign_half_wide_kernel(
+    const _Float16 *__restrict__ xm, const uint2 *__restrict__ xt, int d,
+    const float *__restrict__ cent, const float *__restrict__ errc, int K,
+    const int64_t *__restrict__ img_row0, int B, int32_t *__restrict__ klab,
+    SplitEntry *__restrict__ gqueue, int32_t *__restrict__ gcount,
+    const hsgk_segkm_meta *__restrict__ meta) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int TPX = NW * 32;
+  unsigned char *tail = lds_raw + half_lds_bytes<NW, MB, 1, 1>(d);
+  int *qnp = reinterpret_cast<int *>(tail - 16);            // [0] count, [1] global base, [2] errc max bits
+  uint32_t *qcand = reinterpret_cast<uint32_t *>(tail);     // [kSplitLdsList]
+  uint16_t *qpx = reinterpret_cast<uint16_t *>(qcand + kSplitLdsList);
+  const int64_t N = meta->n_rows;
+  const int64_t per = (N + (int64_t)gridDim.x * TPX - 1) / ((int64_t)gridDim.x * TPX) * TPX;
+  int64_t r = (int64_t)blockIdx.x * per;
+  const int64_t r_end = min(N, r + per);
+  if (r >= r_end) return;
+  int b = 0;
+  while (b + 1 < B && img_row0[b + 1] <= r) ++b;
+  int staged_img = -1;
+  float errc_max = 0.0f;
+  while (r < r_end) {
+    while (img_row0[b + 1] <= r) ++b;
+    const int64_t seg_end = min(r_end, img_row0[b + 1]);
+    const int nrows = (int)min(seg_end - r, (int64_t)(0xFFFF / TPX) * TPX);
+    const int64_t crow0 = r;
+    if (b != staged_img) {                                     // largest table rounding error of this image
+      float m = 0.0f;
+      for (int k = threadIdx.x & 63; k < K; k += 64) m = fmaxf(m, errc[(int64_t)b * K + k]);
+      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+      errc_max = m;
+    }
+    if (threadIdx.x == 0) qnp[0] = 0;
+    HalfWideEpi<MB> epi{K, nrows, b, crow0, errc_max, klab, qpx, qcand, qnp, gqueue, gcount};
+    score_tiles_half<NW, DEPTH, HalfWideEpi<MB>, MB, 1, 1>(xm, xt, d, cent + (int64_t)b * K * d, K, crow0,
+                                                           nrows, lds_raw, epi, b != staged_img);
+    staged_img = b;
+    __syncthreads();
+    const int qn = min(qnp[0], kSplitLdsList);
+    if (qn > 0) {
+      if (threadIdx.x == 0) qnp[1] = atomicAdd(gcount, qn);
+      __syncthreads();
+      const int base = qnp[1];
+      for (int i = threadIdx.x; i < qn; i += NW * 64)
+        gqueue[base + i] = SplitEntry{(int32_t)(crow0 + qpx[i]), qcand[i], b};
+    }
+    __syncthreads();
+    r += nrows;
+  }
+}
+
+bool assign_half_wide_eligible(int d, int K) {
+  return K > 64 && K <= 128 && half_wide_shape_ok(d) &&
+         half_lds_bytes<8, 4, 1, 1>(d) + (size_t)kSplitLdsList * 6 <= 160 * 1024;
+}
+
+// errc: [B][K] scratch for the measured table rounding errors
+int launch_assign_half_wide(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent,
+                            float *errc, int K, int B, const ChunkTable &t, int max_chunks, int32_t *klab,
+                            void *qrows, int32_t *qcount, const hsgk_segkm_meta *meta, hipStream_t s) {
+  if (max_chunks <= 0 || B <= 0) return 0;
+  constexpr int NW = 8, TPX = NW * 32, MB = 4;
+  static const int n_cu = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess)
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus > 0 ? cus : 256;
+  }();
+  const int64_t max_tiles = ((int64_t)max_chunks * HSGK_CHUNK + TPX - 1) / TPX;
+  const int grid = (int)(max_tiles < n_cu ? max_tiles : n_cu);
+  HSGK_CHECK_HIP(hipMemsetAsync(qcount, 0, sizeof(int32_t), s));
+  hipLaunchKernelGGL(centroid_half_err_kernel, dim3((unsigned)(((int64_t)B * K + 3) / 4)), dim3(256), 0, s,
+                     cent, d, (int64_t)B * K, errc);
+  HSGK_LAUNCH_CHECK();
+  {
+    const bool deep = ((d / 64) & 3) == 0;
+    auto kern = deep ? assign_half_wide_kernel<NW, 4, MB> : assign_half_wide_kernel<NW, 2, MB>;
+    const size_t lds = half_lds_bytes<NW, MB, 1, 1>(d) + (size_t)kSplitLdsList * 6;
+    HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, xm, xt, d, cent, errc, K, t.img_row0, B,
+                       klab, reinterpret_cast<SplitEntry *>(qrows), qcount, meta);
+    HSGK_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(assign_requeue_rows_kernel, dim3(2048), dim3(256), 0, s, x, d, cent, K, klab,
+                     reinterpret_cast<const SplitEntry *>(qrows), qcount);
+  HSGK_LAUNCH_CHECK();
+  return 0;
 }
 
 // Level 2: grid (T, B); workgroup (t, b) takes a contiguous slice of image b's queue.

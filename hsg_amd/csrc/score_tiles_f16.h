@@ -72,9 +72,10 @@ __device__ inline void f16_split2(float a, float b, uint32_t &hi, uint32_t &lo) 
   lo = __builtin_bit_cast(uint32_t, l);
 }
 
-template <int NW>
+// LDS of the engine: PLANES table planes of MB*32 rows, NW windows of NBUF buffers
+template <int NW, int MB = 2, int PLANES = 2, int NBUF = 2>
 __host__ __device__ constexpr size_t half_lds_bytes(int d) {
-  return (size_t)2 * 64 * (half_main_cols(d) + 16 + 8) * 2 + (size_t)NW * 2 * 32 * 72 * 2 + 16;
+  return (size_t)PLANES * 32 * MB * (half_main_cols(d) + 16 + 8) * 2 + (size_t)NW * NBUF * 32 * 72 * 2 + 16;
 }
 
 // shapes the fp16 engine accepts: an even number of 64-column chunks (prefetch depth
@@ -84,11 +85,21 @@ __host__ __device__ inline bool half_shape_ok(int d) {
   const int nfull = d / 64;
   return d >= 128 && d <= 322 && (nfull & 1) == 0 && d - nfull * 64 <= 2;
 }
+// the hi-plane-only variant (64 < K <= 128, see HalfWide in kmeans.hip) has half the MFMA
+// instructions per column block and its own constant: d up to 450
+__host__ __device__ inline bool half_wide_shape_ok(int d) {
+  const int nfull = d / 64;
+  return d >= 128 && d <= 450 && (nfull & 1) == 0 && d - nfull * 64 <= 2;
+}
 
 // Epi(tile, acc, err): lane (j, h) holds acc[m][r] = approximate score of table row
 // m*32 + (r&3) + 8*(r>>2) + 4*h for row tile*NW*32 + w*32 + j of the pass, and err =
 // the measured rounding error of that row's copy.
-template <int NW, int DEPTH, class Epi>
+// MB: table blocks of 32 rows (2 or 4); PLANES: 2 = hi + lo planes of the table, 1 = hi
+// plane only (the caller's bound then carries the table's rounding error); NBUF: window
+// buffers per wave (1 is enough for correctness -- a wave's LDS operations execute in
+// order -- and saves LDS for the wide variants).
+template <int NW, int DEPTH, class Epi, int MB = 2, int PLANES = 2, int NBUF = 2>
 __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm,
                                                  const uint2 *__restrict__ xt, int d,
                                                  const float *__restrict__ table, int kvalid,
@@ -102,9 +113,10 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
   const int DM = half_main_cols(d);
   const int RS = DM + 16 + 8;          // fp16 elements per table row (main + one tail k-block + pad)
 
-  uint16_t *chs = reinterpret_cast<uint16_t *>(lds_raw);          // [64][RS]
-  uint16_t *cls = chs + 64 * RS;                                   // [64][RS]
-  uint16_t *xs = cls + 64 * RS;                                    // [NW][2 buf][32][XSB]
+  constexpr int TR = 32 * MB;          // table rows
+  uint16_t *chs = reinterpret_cast<uint16_t *>(lds_raw);          // [TR][RS]
+  uint16_t *cls = chs + (PLANES == 2 ? TR * RS : 0);               // [TR][RS] (PLANES == 2)
+  uint16_t *xs = chs + PLANES * TR * RS;                           // [NW][NBUF][32][XSB]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int j = lane & 31, g = lane >> 5;
@@ -114,7 +126,7 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
   if (stage_table) {
     __syncthreads();                       // nobody still reads the previous table
     uint32_t *z = reinterpret_cast<uint32_t *>(chs);
-    for (int i = tid; i < 64 * RS; i += NT) z[i] = 0u;            // 2 planes * 64*RS*2 B / 4
+    for (int i = tid; i < PLANES * TR * RS / 2; i += NT) z[i] = 0u;
     __syncthreads();
     const int total = kvalid * d;
     for (int f0 = 0; f0 < total; f0 += NT * 8) {
@@ -129,7 +141,7 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
           uint32_t hi, lo;
           f16_split2(v[u], 0.0f, hi, lo);
           chs[k * RS + col] = (uint16_t)hi;
-          cls[k * RS + col] = (uint16_t)lo;
+          if constexpr (PLANES == 2) cls[k * RS + col] = (uint16_t)lo;
         }
       }
     }
@@ -141,7 +153,7 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
   const int ntile = (nrows + TPX - 1) / TPX;
   const int nsteps = ntile * nfull;
 
-  uint16_t *xw = xs + w * (2 * 32 * XSB);
+  uint16_t *xw = xs + w * (NBUF * 32 * XSB);
   const int lpx = lane >> 4, lf = lane & 15;
   const int wu = __builtin_amdgcn_readfirstlane(w);
 
@@ -183,37 +195,43 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
                  "+v"(P[6]), "+v"(P[7])                                                 \
                : "n"(N))
   auto store_chunk = [&](int buf, const uint2 (&pre)[LOADS]) {
-    uint16_t *bp = xw + buf * (32 * XSB);
+    uint16_t *bp = xw + (buf % NBUF) * (32 * XSB);
 #pragma unroll
     for (int i = 0; i < LOADS; ++i)
       *reinterpret_cast<uint2 *>(bp + (lpx + 4 * i) * XSB + 4 * lf) = pre[i];
   };
 
-  f32x16 acc[2];
+  f32x16 acc[MB];
   auto zero_acc = [&]() {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
   };
-  // operands of one k-block (16 columns): the row operand and the table hi / lo operands
-  // of both 32-row table halves.  The LDS reads of block n+1 are issued before the MFMAs
-  // of block n (two register sets), so the per-wave chain is MFMA-bound, not a sequence
-  // of exposed LDS latencies.
-  struct Ops { f16x8 b, ah0, al0, ah1, al1; };
+  // operands of one k-block (16 columns): the row operand and the table operands of the
+  // MB table blocks (hi, and lo when PLANES == 2).  The LDS reads of block n+1 are issued
+  // before the MFMAs of block n (two register sets), so the per-wave chain is MFMA-bound,
+  // not a sequence of exposed LDS latencies.
+  struct Ops { f16x8 b; f16x8 ah[MB]; f16x8 al[PLANES == 2 ? MB : 1]; };
   auto load_table_ops = [&](int col0, Ops &o) {
     const uint16_t *hp = chs + j * RS + col0 + 8 * g;
-    const uint16_t *lp = cls + j * RS + col0 + 8 * g;
-    o.ah0 = *reinterpret_cast<const f16x8 *>(hp);
-    o.ah1 = *reinterpret_cast<const f16x8 *>(hp + 32 * RS);
-    o.al0 = *reinterpret_cast<const f16x8 *>(lp);
-    o.al1 = *reinterpret_cast<const f16x8 *>(lp + 32 * RS);
+#pragma unroll
+    for (int m = 0; m < MB; ++m) o.ah[m] = *reinterpret_cast<const f16x8 *>(hp + m * 32 * RS);
+    if constexpr (PLANES == 2) {
+      const uint16_t *lp = cls + j * RS + col0 + 8 * g;
+#pragma unroll
+      for (int m = 0; m < MB; ++m) o.al[m] = *reinterpret_cast<const f16x8 *>(lp + m * 32 * RS);
+    }
   };
   auto mfma_ops = [&](const Ops &o) {
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.ah0, o.b, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.ah1, o.b, acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.al0, o.b, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.al1, o.b, acc[1], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.ah[m], o.b, acc[m], 0, 0, 0);
+    if constexpr (PLANES == 2) {
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.al[m], o.b, acc[m], 0, 0, 0);
+    }
   };
   auto kblock = [&](const f16x8 &b, int col0) {
     Ops o;
@@ -222,7 +240,7 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
     mfma_ops(o);
   };
   auto compute_chunk = [&](int buf, int q) {
-    const uint16_t *bp = xw + buf * (32 * XSB) + j * XSB + 8 * g;
+    const uint16_t *bp = xw + (buf % NBUF) * (32 * XSB) + j * XSB + 8 * g;
     Ops o0, o1;
     o0.b = *reinterpret_cast<const f16x8 *>(bp);
     load_table_ops(q * KC, o0);
