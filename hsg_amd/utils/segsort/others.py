@@ -25,13 +25,10 @@ def save_prototypes(path, prototypes, prototype_labels):
 def load_memory_banks(memory_dir):
   """Reference others.py:11-41: `[num_prototypes, C]` float tensor and `[num_prototypes]`
   long tensor over all `*.npy` files of the directory, in sorted file-name order."""
-  memory_paths = sorted(glob.glob(os.path.join(memory_dir, '*.npy')))
-  assert len(memory_paths) > 0, 'No memory stored in the directory'
-  prototypes, prototype_labels = [], []
-  for memory_path in memory_paths:
-    datas = np.load(memory_path, allow_pickle=True).item()
-    prototypes.append(datas['prototype'])
-    prototype_labels.append(datas['prototype_label'])
-  prototypes = np.concatenate(prototypes, 0)
-  prototype_labels = np.concatenate(prototype_labels, 0)
-  return torch.FloatTensor(prototypes), torch.LongTensor(prototype_labels)
+  paths = sorted(glob.glob(os.path.join(memory_dir, '*.npy')))
+  if not paths:
+    raise AssertionError('No memory stored in the directory')        # the reference asserts
+  banks = [np.load(path, allow_pickle=True).item() for path in paths]
+  protos = np.concatenate([bank['prototype'] for bank in banks], axis=0)
+  labels = np.concatenate([bank['prototype_label'] for bank in banks], axis=0)
+  return torch.from_numpy(protos).float(), torch.from_numpy(labels).long()
