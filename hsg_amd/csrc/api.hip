@@ -54,6 +54,7 @@ struct KmeansScratch {
   int32_t *klab_prev;  // [rows] labels the exact sums currently hold (-1 = row not added yet), or null
   long long *sumq;     // [B][K][d] exact fixed-point segment sums (sums_fx.hip)
   _Float16 *xh;        // [rows][half_main_cols(d)] fp16 copy of the rows' main columns (first filter level), or null
+  void *state;         // [rows] 16-byte records of the two-half filter (128 < K <= 256)
   float *errc;         // [B][K] measured fp16 rounding error of the centroid rows (wide filter)
   uint2 *xt;           // [rows] {packed fp16 tail columns of the copy, measured rounding error of the row}
   int32_t *q1;         // [B][q1cap] rows the first level left undecided
@@ -96,7 +97,9 @@ static void carve_kmeans(Carver &cv, int B, int64_t rows_per_img, int d, int K,
   k->q1 = k->q1count = nullptr;
   k->q1cap = rows_per_img;
   k->errc = nullptr;
-  if (assign_half_eligible(d, K) || assign_half_wide_eligible(d, K)) {
+  k->state = nullptr;
+  if (assign_half_wide2_eligible(d, K)) k->state = cv.take<char>(((size_t)B * rows_per_img + kHalfSlackRowsHost) * 16);
+  if (assign_half_eligible(d, K) || assign_half_wide_eligible(d, K) || assign_half_wide2_eligible(d, K)) {
     k->errc = cv.take<float>((size_t)B * K + 1);
     // + slack rows: the fp16 engine reads past the end of a pass instead of clamping
     k->xh = cv.take<_Float16>(((size_t)B * rows_per_img + kHalfSlackRowsHost) * half_main_cols_host(d) + 8);
@@ -125,7 +128,8 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
   const bool half_any = unit_rows && assign_mode() == 2 && k.xh && (half_ready || iterations >= 3);
   const bool half = half_any && assign_half_eligible(d, K);
   const bool wide = half_any && !half && assign_half_wide_eligible(d, K);
-  if ((half || wide) && !half_ready) {
+  const bool wide2 = half_any && !half && !wide && assign_half_wide2_eligible(d, K);
+  if ((half || wide || wide2) && !half_ready) {
     ProfScope p(HSGK_PROF_PREP, s);
     if (int rc = launch_to_half_rows(x, k.t, k.max_chunks, d, k.xh, k.xt, meta, s)) return rc;
   }
@@ -160,6 +164,8 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
                                              k.q1count, k.q1cap, k.qrows, k.qcount, meta, s)
                : wide ? launch_assign_half_wide(x, k.xh, k.xt, d, k.cent, k.errc, K, B, k.t, k.max_chunks, k.klab,
                                                 k.qrows, k.qcount, meta, s)
+               : wide2 ? launch_assign_half_wide2(x, k.xh, k.xt, d, k.cent, k.errc, K, B, k.t, k.max_chunks,
+                                                  k.klab, k.state, k.qrows, k.qcount, meta, s)
                : unit_rows && assign_mode() >= 1
                    ? launch_assign_fast(x, d, k.cent, K, k.t, k.max_chunks, k.klab, k.best,
                                         k.qrows, k.qcount, meta, s)
@@ -375,8 +381,11 @@ int hsgk_lloyd_estep(const float *x, int B, int64_t rows_per_image, int d, int K
     if (assign_half_eligible(d, K))
       return launch_assign_half(x, k.xh, k.xt, d, centroids, K, B, k.t, k.max_chunks, labels_out, k.q1,
                                 k.q1count, k.q1cap, k.qrows, k.qcount, meta, s);
-    return launch_assign_half_wide(x, k.xh, k.xt, d, centroids, k.errc, K, B, k.t, k.max_chunks, labels_out,
-                                   k.qrows, k.qcount, meta, s);
+    if (assign_half_wide_eligible(d, K))
+      return launch_assign_half_wide(x, k.xh, k.xt, d, centroids, k.errc, K, B, k.t, k.max_chunks, labels_out,
+                                     k.qrows, k.qcount, meta, s);
+    return launch_assign_half_wide2(x, k.xh, k.xt, d, centroids, k.errc, K, B, k.t, k.max_chunks, labels_out,
+                                    k.state, k.qrows, k.qcount, meta, s);
   }
   if (unit_rows)
     return launch_assign_fast(x, d, centroids, K, k.t, k.max_chunks, labels_out, k.best, k.qrows,

@@ -121,6 +121,11 @@ bool assign_half_wide_eligible(int d, int K);          // 64 < K <= 128: hi-plan
 int launch_assign_half_wide(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent,
                             float *errc, int K, int B, const ChunkTable &t, int max_chunks, int32_t *klab,
                             void *qrows, int32_t *qcount, const hsgk_segkm_meta *meta, hipStream_t s);
+bool assign_half_wide2_eligible(int d, int K);         // 128 < K <= 256: two table halves per pass
+int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent,
+                             float *errc, int K, int B, const ChunkTable &t, int max_chunks, int32_t *klab,
+                             void *state, void *qrows, int32_t *qcount, const hsgk_segkm_meta *meta,
+                             hipStream_t s);
 int launch_assign_half(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent, int K, int B,
                        const ChunkTable &t, int max_chunks, int32_t *klab, int32_t *q1,
                        int32_t *q1count, int64_t q1cap, void *qrows, int32_t *qcount,

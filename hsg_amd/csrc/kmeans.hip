@@ -811,6 +811,242 @@ int launch_assign_half_wide(const float *x, const _Float16 *xm, const uint2 *xt,
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// 128 < K <= 256: the same hi-plane filter in TWO table halves per pass.  The first half
+// leaves (best, second best, index) of every row in a 16-byte state record; the second
+// half's epilogue gets that record prefetched with the row tail, merges, and decides.
+// The first half leaves its best THREE values (and the indices of two): the candidate set of
+// an undecided row is then known exactly unless three first-half scores lie within the gap
+// (such rows are re-scored against all K centroids by the whole-wave path).
+// running top-3 of a lane's scores (values) with the indices of the two best; branch-free
+struct Top3 {
+  float b1 = -INFINITY, b2 = -INFINITY, b3 = -INFINITY;
+  int i1 = 0, i2 = 0;
+  __device__ inline void push(float v, int k) {
+    const float n3 = fmaxf(b3, fminf(b2, v)), n2 = fmaxf(b2, fminf(b1, v));
+    i2 = v > b1 ? i1 : (v > b2 ? k : i2);
+    i1 = v > b1 ? k : i1;
+    b1 = fmaxf(b1, v);
+    b2 = n2;
+    b3 = n3;
+  }
+  // merge with the partner half-lane's (sorted) triple; lower index first on ties of the maxima
+  __device__ inline void merge(float o1, float o2, float o3, int oi1, int oi2) {
+    const bool mine = b1 > o1 || (b1 == o1 && i1 <= oi1);
+    const float w1 = mine ? b1 : o1, w2 = mine ? b2 : o2, w3 = mine ? b3 : o3;      // winner's triple
+    const float l1 = mine ? o1 : b1, l2 = mine ? o2 : b2;                              // loser's two best
+    const int wi1 = mine ? i1 : oi1, wi2 = mine ? i2 : oi2, li1 = mine ? oi1 : i1;
+    const bool second_w = w2 >= l1;                                // second overall: winner's 2nd or loser's 1st
+    b1 = w1; i1 = wi1;
+    b2 = second_w ? w2 : l1;
+    i2 = second_w ? wi2 : li1;
+    b3 = second_w ? fmaxf(w3, l1) : fmaxf(w2, l2);
+  }
+};
+
+template <int MB>
+struct HalfStateEpi {
+  int K, nrows;
+  int64_t crow0;
+  uint4 *state;                // {best, second, third value, index of best | index of second << 16}
+  __device__ inline void operator()(int tile, const f32x16 (&sacc)[MB], float) const {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int TPX = (int)(blockDim.x >> 1);
+    Top3 t;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        t.push(k < K ? sacc[m][r] : -INFINITY, k);
+      }
+    t.merge(__shfl_xor(t.b1, 32), __shfl_xor(t.b2, 32), __shfl_xor(t.b3, 32), __shfl_xor(t.i1, 32),
+            __shfl_xor(t.i2, 32));
+    const int px = tile * TPX + w * 32 + j;
+    if (h == 0 && px < nrows)
+      state[crow0 + px] = make_uint4(__float_as_uint(t.b1), __float_as_uint(t.b2), __float_as_uint(t.b3),
+                                     (uint32_t)t.i1 | ((uint32_t)t.i2 << 16));
+  }
+};
+
+template <int MB>
+struct HalfMergeEpi {
+  int K2, nrows, img;          // K2 = centroids in the second half
+  int64_t crow0;
+  float errc_max;
+  int32_t *klab;
+  uint16_t *qpx;               // LDS [kSplitLdsList]
+  uint32_t *qcand;             // LDS [kSplitLdsList]
+  int *qn;
+  SplitEntry *gqueue;
+  int32_t *gcount;
+  __device__ inline void operator()(int tile, const f32x16 (&sacc)[MB], float err, const u32x4 &st) const {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int TPX = (int)(blockDim.x >> 1);
+    constexpr int KH = 32 * MB;
+    float b1 = -INFINITY, b2 = -INFINITY;
+    int bi = 0;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = k < K2 ? sacc[m][r] : -INFINITY;
+        b2 = fmaxf(b2, fminf(b1, v));
+        bi = v > b1 ? k : bi;
+        b1 = fmaxf(b1, v);
+      }
+    const float o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
+    const int oi = __shfl_xor(bi, 32);
+    float u1, u2;
+    int ui;
+    if (o1 > b1 || (o1 == b1 && oi < bi)) { u1 = o1; ui = oi; u2 = fmaxf(b1, o2); }
+    else { u1 = b1; ui = bi; u2 = fmaxf(o1, b2); }
+    // merge with the first half (lower indices win ties)
+    const float a1 = __uint_as_float(st[0]), a2 = __uint_as_float(st[1]), a3 = __uint_as_float(st[2]);
+    const int ai1 = (int)(st[3] & 0xFFFFu), ai2 = (int)(st[3] >> 16);
+    float t1, t2;
+    int ti;
+    if (u1 > a1) { t1 = u1; ti = ui + KH; t2 = fmaxf(a1, u2); }
+    else { t1 = a1; ti = ai1; t2 = fmaxf(u1, a2); }
+    const int px = tile * TPX + w * 32 + j;
+    const bool valid = px < nrows;
+    const float gap = half_wide_gap(err, errc_max);
+    const bool amb = valid && !(t1 - t2 > gap);                    // ambiguous (or NaN)
+    if (h == 0 && valid) klab[crow0 + px] = ti;                    // provisional for ambiguous rows
+    if (!__any(amb)) return;
+    // candidate set {k : score >= best - gap}: second-half members from the registers, first-half
+    // members from the stored top three (a third one within the gap: re-score all K)
+    const float thr = t1 - gap;
+    uint32_t list = 0;
+    int cnt = 0;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool hit = k < (uint32_t)K2 && sacc[m][r] >= thr;     // NaN scores never hit
+        list = hit ? ((list << 8) | (k + KH)) : list;
+        cnt += hit ? 1 : 0;
+      }
+    uint32_t olist = __shfl_xor(list, 32);
+    int ocnt = __shfl_xor(cnt, 32);
+    if (cnt + ocnt <= 3) {                                          // fold the partner half in
+      list = (list & ((1u << (8 * cnt)) - 1u)) | (olist << (8 * cnt));
+    }
+    int tot = cnt + ocnt;
+    const bool over = a3 >= thr || tot > 3;
+    if (!over) {
+      if (a1 >= thr) { list = (list << 8) | (uint32_t)ai1; ++tot; }
+      if (a2 >= thr) { list = (list << 8) | (uint32_t)ai2; ++tot; }
+    }
+    uint32_t cand = 255u << 24;
+    if (!over && tot >= 1 && tot <= 3 && t1 == t1) cand = (list & 0xFFFFFFu) | ((uint32_t)tot << 24);
+    if (h == 0 && amb) {
+      const int pos = atomicAdd(qn, 1);
+      if (pos < kSplitLdsList) {
+        qpx[pos] = (uint16_t)px;
+        qcand[pos] = cand;
+      } else {
+        gqueue[atomicAdd(gcount, 1)] = SplitEntry{(int32_t)(crow0 + px), cand, img};
+      }
+    }
+  }
+};
+
+template <int NW, int DEPTH, int MB>
+__global__ __launch_bounds__(NW * 64) void assign_half_wide2_kernel(
+    const _Float16 *__restrict__ xm, const uint2 *__restrict__ xt, int d,
+    const float *__restrict__ cent, const float *__restrict__ errc, int K,
+    const int64_t *__restrict__ img_row0, int B, int32_t *__restrict__ klab, uint4 *__restrict__ state,
+    SplitEntry *__restrict__ gqueue, int32_t *__restrict__ gcount,
+    const hsgk_segkm_meta *__restrict__ meta) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int TPX = NW * 32, KH = 32 * MB;
+  unsigned char *tail = lds_raw + half_lds_bytes<NW, MB, 1, 1>(d);
+  int *qnp = reinterpret_cast<int *>(tail - 16);
+  uint32_t *qcand = reinterpret_cast<uint32_t *>(tail);     // [kSplitLdsList]
+  uint16_t *qpx = reinterpret_cast<uint16_t *>(qcand + kSplitLdsList);
+  const int64_t N = meta->n_rows;
+  const int64_t per = (N + (int64_t)gridDim.x * TPX - 1) / ((int64_t)gridDim.x * TPX) * TPX;
+  int64_t r = (int64_t)blockIdx.x * per;
+  const int64_t r_end = min(N, r + per);
+  if (r >= r_end) return;
+  int b = 0;
+  while (b + 1 < B && img_row0[b + 1] <= r) ++b;
+  while (r < r_end) {
+    while (img_row0[b + 1] <= r) ++b;
+    const int64_t seg_end = min(r_end, img_row0[b + 1]);
+    const int nrows = (int)min(seg_end - r, (int64_t)(0xFFFF / TPX) * TPX);
+    const int64_t crow0 = r;
+    float em = 0.0f;
+    for (int k = threadIdx.x & 63; k < K; k += 64) em = fmaxf(em, errc[(int64_t)b * K + k]);
+    for (int off = 32; off > 0; off >>= 1) em = fmaxf(em, __shfl_xor(em, off));
+    const float *tb = cent + (int64_t)b * K * d;
+    HalfStateEpi<MB> e0{KH, nrows, crow0, state};
+    score_tiles_half<NW, DEPTH, HalfStateEpi<MB>, MB, 1, 1>(xm, xt, d, tb, KH, crow0, nrows, lds_raw, e0, true);
+    __syncthreads();
+    if (threadIdx.x == 0) qnp[0] = 0;
+    HalfMergeEpi<MB> e1{K - KH, nrows, b, crow0, em, klab, qpx, qcand, qnp, gqueue, gcount};
+    score_tiles_half<NW, DEPTH, HalfMergeEpi<MB>, MB, 1, 1, true>(xm, xt, d, tb + (int64_t)KH * d, K - KH, crow0,
+                                                                   nrows, lds_raw, e1, true, state);
+    __syncthreads();
+    const int qn = min(qnp[0], kSplitLdsList);
+    if (qn > 0) {
+      if (threadIdx.x == 0) qnp[1] = atomicAdd(gcount, qn);
+      __syncthreads();
+      const int base = qnp[1];
+      for (int i = threadIdx.x; i < qn; i += NW * 64)
+        gqueue[base + i] = SplitEntry{(int32_t)(crow0 + qpx[i]), qcand[i], b};
+    }
+    __syncthreads();
+    r += nrows;
+  }
+}
+
+bool assign_half_wide2_eligible(int d, int K) {
+  return K > 128 && K <= 256 && half_wide_shape_ok(d) &&
+         half_lds_bytes<8, 4, 1, 1>(d) + (size_t)kSplitLdsList * 6 <= 160 * 1024;
+}
+
+// state: [rows] 16-byte scratch records
+int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent,
+                             float *errc, int K, int B, const ChunkTable &t, int max_chunks, int32_t *klab,
+                             void *state, void *qrows, int32_t *qcount, const hsgk_segkm_meta *meta,
+                             hipStream_t s) {
+  if (max_chunks <= 0 || B <= 0) return 0;
+  constexpr int NW = 8, TPX = NW * 32, MB = 4;
+  static const int n_cu = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess)
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus > 0 ? cus : 256;
+  }();
+  const int64_t max_tiles = ((int64_t)max_chunks * HSGK_CHUNK + TPX - 1) / TPX;
+  const int grid = (int)(max_tiles < n_cu ? max_tiles : n_cu);
+  HSGK_CHECK_HIP(hipMemsetAsync(qcount, 0, sizeof(int32_t), s));
+  hipLaunchKernelGGL(centroid_half_err_kernel, dim3((unsigned)(((int64_t)B * K + 3) / 4)), dim3(256), 0, s,
+                     cent, d, (int64_t)B * K, errc);
+  HSGK_LAUNCH_CHECK();
+  {
+    const bool deep = ((d / 64) & 3) == 0;
+    auto kern = deep ? assign_half_wide2_kernel<NW, 4, MB> : assign_half_wide2_kernel<NW, 2, MB>;
+    const size_t lds = half_lds_bytes<NW, MB, 1, 1>(d) + (size_t)kSplitLdsList * 6;
+    HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, xm, xt, d, cent, errc, K, t.img_row0, B,
+                       klab, reinterpret_cast<uint4 *>(state), reinterpret_cast<SplitEntry *>(qrows), qcount,
+                       meta);
+    HSGK_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(assign_requeue_rows_kernel, dim3(2048), dim3(256), 0, s, x, d, cent, K, klab,
+                     reinterpret_cast<const SplitEntry *>(qrows), qcount);
+  HSGK_LAUNCH_CHECK();
+  return 0;
+}
+
 // Level 2: grid (T, B); workgroup (t, b) takes a contiguous slice of image b's queue.
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void assign_split_rows_kernel(

@@ -46,6 +46,7 @@
 namespace hsgk {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // decision threshold of a row whose copy has rounding error err = |x - xh|_2
 __device__ inline float half_gap(float err) { return fmaf(2.0002f, err, 8.1e-5f); }
@@ -99,12 +100,15 @@ __host__ __device__ inline bool half_wide_shape_ok(int d) {
 // plane only (the caller's bound then carries the table's rounding error); NBUF: window
 // buffers per wave (1 is enough for correctness -- a wave's LDS operations execute in
 // order -- and saves LDS for the wide variants).
-template <int NW, int DEPTH, class Epi, int MB = 2, int PLANES = 2, int NBUF = 2>
+// AUX: a 16-byte per-row record aux[row] (state left by an earlier pass over the same rows)
+// is prefetched with the tail and handed to Epi(tile, acc, err, aux).
+template <int NW, int DEPTH, class Epi, int MB = 2, int PLANES = 2, int NBUF = 2, bool AUX = false>
 __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm,
                                                  const uint2 *__restrict__ xt, int d,
                                                  const float *__restrict__ table, int kvalid,
                                                  int64_t crow0, int nrows, unsigned char *lds_raw,
-                                                 Epi &epi, bool stage_table = true) {
+                                                 Epi &epi, bool stage_table = true,
+                                                 const uint4 *__restrict__ aux = nullptr) {
   constexpr int NT = NW * 64;
   constexpr int TPX = NW * 32;
   constexpr int KC = 64;               // columns per staged chunk (4 k-blocks)
@@ -263,18 +267,23 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
   // rest of the block and the g = 1 half are zero), together with the row's err.  Two
   // lines per wave tile, issued at the top of the tile (nfull >= DEPTH chunk sets are
   // issued after it), so the epilogue never waits on memory.
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   const uint32_t toff = (uint32_t)(w * 32 + j) * 8u;
   auto load_tail = [&](int tile, uint2 &v) {                  // unconditional, unclamped (see above)
     const char *tb = reinterpret_cast<const char *>(xt + crow0 + (int64_t)tile * TPX);
     asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(toff), "s"(tb));
   };
-  auto finish_tile = [&](int tile, const uint2 &tw) {
+  const uint32_t aoff = (uint32_t)(w * 32 + j) * 16u;
+  auto load_aux = [&](int tile, u32x4 &v) {
+    const char *tb = reinterpret_cast<const char *>(aux + crow0 + (int64_t)tile * TPX);
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(aoff), "s"(tb));
+  };
+  auto finish_tile = [&](int tile, const uint2 &tw, const u32x4 &av) {
     if (has_tail) {
       const u32x4 tv = {g == 0 ? tw.x : 0u, 0u, 0u, 0u};
       kblock(__builtin_bit_cast(f16x8, tv), tcol0);
     }
-    epi(tile, acc, __uint_as_float(tw.y));
+    if constexpr (AUX) epi(tile, acc, __uint_as_float(tw.y), av);
+    else epi(tile, acc, __uint_as_float(tw.y));
   };
 
   // A visible full wait: the staging loads above are consumed under per-lane conditions,
@@ -297,6 +306,7 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
     load_next(preD);
   }
   uint2 tailv = {0u, 0u};
+  u32x4 auxv = {0u, 0u, 0u, 0u};
 #define HSGK_HALF_STEP(BUF, PRE, QQ)                                          \
   HSGK_VMWAIT8(8 * (DEPTH - 1), PRE);                                         \
   store_chunk(BUF, PRE);                                                      \
@@ -307,6 +317,7 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
   __builtin_amdgcn_sched_barrier(0);
   for (int tile = 0; tile < ntile; ++tile) {
     load_tail(tile, tailv);
+    if constexpr (AUX) load_aux(tile, auxv);
     for (int q = 0; q < nfull; q += DEPTH) {
       if constexpr (DEPTH == 4) {
         HSGK_HALF_STEP(0, preA, q)
@@ -318,9 +329,9 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
         HSGK_HALF_STEP(1, preB, q + 1)
       }
     }
-    // the tail was issued before this tile's nfull >= DEPTH chunk sets
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(tailv) : "n"(8 * DEPTH));
-    finish_tile(tile, tailv);
+    // the tail (and aux) loads were issued before this tile's nfull >= DEPTH chunk sets
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(tailv), "+v"(auxv) : "n"(8 * DEPTH));
+    finish_tile(tile, tailv, auxv);
     zero_acc();
   }
   // drain the look-ahead sets; naming them keeps their registers reserved until here

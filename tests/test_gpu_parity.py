@@ -306,13 +306,15 @@ def test_exchange_list_api_on_gpu_vs_reference(dev):
 
 
 @pytest.mark.parametrize('B,HW,C,K', [(2, 4096, 32, 8), (1, 5000, 256, 64), (3, 2500, 128, 37),
-                                      (1, 300, 64, 64), (2, 3000, 384, 128), (1, 4000, 256, 100)])
+                                      (1, 300, 64, 64), (2, 3000, 384, 128), (1, 4000, 256, 100), (1, 3000, 256, 200),
+                                      (2, 2500, 256, 256)])
 def test_split_estep_matches_exact_labels(dev, oracle, B, HW, C, K):
   """Filtered E-steps == canonical fp32 argmax: unit_rows = 2 (fp16 copy ->
   bf16x3 on the undecided rows -> exact chains), 1 (bf16x3 -> exact) and 0 (pure
   fp32 kernel), including exact ties (duplicate centroids), near ties at the
   scale of each filter's gap (perturbed copies) and zero centroids.  64 < K <= 128 takes
-  the hi-plane fp16 filter straight to the exact chains (unit_rows = 2)."""
+  the hi-plane fp16 filter straight to the exact chains, 128 < K <= 256 the same in two
+  table halves (unit_rows = 2)."""
   import torch
   from hsg_amd import _lib
   D = C + 2
