@@ -216,7 +216,8 @@ __global__ __launch_bounds__(NW * 64) void update_sums_kernel(
 // table is flushed with global atomics only when the workgroup's image changes -- about 5 M
 // global atomics per launch instead of one flush per chunk (17 M), which is what bounded the
 // late iterations where only a few per cent of the rows move.
-template <int NW, int UNROLL>
+// NV: 16-byte vectors per lane and row (1: d <= 259, 2: d <= 515)
+template <int NW, int UNROLL, int NV>
 __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
     const float *__restrict__ x, int d, const int32_t *__restrict__ prev,
     const int32_t *__restrict__ cur, const int64_t *__restrict__ chunk_row0,
@@ -276,25 +277,26 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
       // (wave-private list: own LDS writes are visible to own reads in order)
       const float *xr = x + row0 * d;
       auto entry = [&](int i) { return list[min(i, total - 1)]; };
-      auto issue = [&](int i0, gvec_t (&v)[UNROLL][2], float (&t)[UNROLL]) {
+      auto issue = [&](int i0, gvec_t (&v)[UNROLL][NV], float (&t)[UNROLL]) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
           const int r = (int)(entry(i0 + u) >> 22);
           const float *src = xr + (int64_t)r * d;
-          v[u][0] = *reinterpret_cast<const gvec_t *>(src + 4 * min(lane, nq - 1));
-          v[u][1] = *reinterpret_cast<const gvec_t *>(src + 4 * min(lane + 64, nq - 1));
+#pragma unroll
+          for (int h = 0; h < NV; ++h)
+            v[u][h] = *reinterpret_cast<const gvec_t *>(src + 4 * min(lane + 64 * h, nq - 1));
           t[u] = src[min(tail0 + lane, d - 1)];
         }
       };
-      auto fold = [&](int i0, const gvec_t (&v)[UNROLL][2], const float (&t)[UNROLL]) {
+      auto fold = [&](int i0, const gvec_t (&v)[UNROLL][NV], const float (&t)[UNROLL]) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
           if (i0 + u < total) {
             const uint32_t e = entry(i0 + u);
             const int labs[2] = {(int)((e >> 11) & 2047u) - 1, (int)(e & 2047u) - 1};
-            long long q[2][4];
+            long long q[NV][4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < NV; ++h)
 #pragma unroll
               for (int j = 0; j < 4; ++j) q[h][j] = to_fixed(v[u][h][j]);
             const long long qt = to_fixed(t[u]);
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
               if (labs[side] < 0) continue;
               unsigned long long *rowp = tab + (size_t)labs[side] * d;
 #pragma unroll
-              for (int h = 0; h < 2; ++h) {
+              for (int h = 0; h < NV; ++h) {
                 const int q4 = lane + 64 * h;
                 if (q4 < nq) {
 #pragma unroll
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
           }
         }
       };
-      gvec_t va[UNROLL][2], vb[UNROLL][2];
+      gvec_t va[UNROLL][NV], vb[UNROLL][NV];
       float ta[UNROLL], tb[UNROLL];
       issue(0, va, ta);
       for (int i0 = 0; i0 < total; i0 += 2 * UNROLL) {
@@ -382,7 +384,7 @@ int launch_update_sums(const float *x, int d, const int32_t *prev, const int32_t
           (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         return cus > 0 ? cus : 256;
       }();
-      auto kp = update_sums_persistent_kernel<NWP, 8>;
+      auto kp = d / 4 <= 64 ? update_sums_persistent_kernel<NWP, 8, 1> : update_sums_persistent_kernel<NWP, 8, 2>;
       HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kp),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
       const int grid = max_chunks < n_cu ? max_chunks : n_cu;
