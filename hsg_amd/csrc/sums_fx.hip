@@ -44,8 +44,8 @@ __global__ __launch_bounds__(NW * 64) void update_sums_kernel(
     const int32_t *__restrict__ chunk_rows, const int32_t *__restrict__ chunk_img, int K,
     unsigned long long *__restrict__ sumq, const hsgk_segkm_meta *__restrict__ meta) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  unsigned long long *tab = reinterpret_cast<unsigned long long *>(lds_raw);          // [S][d]
-  uint32_t *list = reinterpret_cast<uint32_t *>(tab + (size_t)S * d);                 // [kFxRows] + 2 (zeroing tail)
+  unsigned long long *tab = reinterpret_cast<unsigned long long *>(lds_raw);          // [S][min(d, 512)]
+  uint32_t *list = reinterpret_cast<uint32_t *>(tab + (size_t)S * min(d, 515) + (d & 1));   // [kFxRows] + 2 (zeroing tail)
   int *wcount = reinterpret_cast<int *>(list + kFxRows + 2);                          // [NW], [NW] = touched clusters
   uint16_t *slot = reinterpret_cast<uint16_t *>(wcount + NW + 1);                     // [K] rank among the touched clusters (0xFFFF = untouched)
   constexpr int PARTS = HSGK_CHUNK / kFxRows;
@@ -120,91 +120,97 @@ __global__ __launch_bounds__(NW * 64) void update_sums_kernel(
   typedef float gvec_t __attribute__((ext_vector_type(4), aligned(4)));
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
   const float *xr = x + row0 * d;
-  const int nq = d / 4, tail0 = nq * 4;                         // quads, then d mod 4 scalar columns
+  const int dws = min(d, 515);                                  // table row stride: one column window
   const int nmine = (total - w + NW - 1) / NW;
   auto entry = [&](int i) { return list[min(w + i * NW, total - 1)]; };
   unsigned long long *gq = sumq + (int64_t)chunk_img[c] * K * d;
-  for (int base = 0; base < ntouched; base += S) {               // (one round unless > S clusters are touched)
-    // ---- zero the slots of this round
-    {
-      const int tot2 = (min(S, ntouched - base) * d + 1) / 2;      // (the list's 2 spare words absorb an odd tail)
-      u64x2 *t2 = reinterpret_cast<u64x2 *>(tab);
-      for (int i = tid; i < tot2; i += NW * 64) t2[i] = u64x2{0ull, 0ull};
-    }
-    __syncthreads();
-    // ---- every wave takes entries w, w + NW, ...: load the row once, add / subtract
-    auto issue = [&](int i0, gvec_t (&v)[UNROLL][2], float (&t)[UNROLL]) {
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        const int r = (int)(entry(i0 + u) >> 22);
-        const float *src = xr + (int64_t)r * d;
-        v[u][0] = *reinterpret_cast<const gvec_t *>(src + 4 * min(lane, nq - 1));
-        v[u][1] = *reinterpret_cast<const gvec_t *>(src + 4 * min(lane + 64, nq - 1));
-        t[u] = src[min(tail0 + lane, d - 1)];
+  for (int base = 0; base < ntouched; base += S)                 // (one round unless > S clusters are touched)
+    for (int cw = 0, dw = 0; cw < d; cw += dw) {                 // column windows of 512 (one for d <= 515)
+      dw = (d - cw <= 515) ? d - cw : 512;                       // the last window takes the d mod 4 tail along
+      const int nq = dw / 4, tail0 = nq * 4;                     // quads, then dw mod 4 scalar columns
+      // ---- zero the slots of this round
+      {
+        const int tot2 = (min(S, ntouched - base) * dws + 1) / 2;
+        u64x2 *t2 = reinterpret_cast<u64x2 *>(tab);
+        for (int i = tid; i < tot2; i += NW * 64) t2[i] = u64x2{0ull, 0ull};
       }
-    };
-    auto fold = [&](int i0, const gvec_t (&v)[UNROLL][2], const float (&t)[UNROLL]) {
+      __syncthreads();
+      // ---- every wave takes entries w, w + NW, ...: load the row's window once, add / subtract
+      auto issue = [&](int i0, gvec_t (&v)[UNROLL][2], float (&t)[UNROLL]) {
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        if (i0 + u < nmine) {
-          const uint32_t e = entry(i0 + u);
-          const int labs[2] = {(int)((e >> 11) & 2047u) - 1, (int)(e & 2047u) - 1};
-          int sl[2];
-#pragma unroll
-          for (int side = 0; side < 2; ++side) {
-            const int s0 = labs[side] >= 0 ? (int)slot[labs[side]] - base : -1;      // (listed labels are touched)
-            sl[side] = (s0 >= 0 && s0 < S) ? s0 : -1;
+        for (int u = 0; u < UNROLL; ++u) {
+          const int r = (int)(entry(i0 + u) >> 22);
+          const float *src = xr + (int64_t)r * d + cw;
+          v[u][0] = v[u][1] = gvec_t{0.f, 0.f, 0.f, 0.f};
+          if (nq > 0) {                                            // (uniform; rows shorter than one quad: scalar columns only)
+            v[u][0] = *reinterpret_cast<const gvec_t *>(src + 4 * min(lane, nq - 1));
+            v[u][1] = *reinterpret_cast<const gvec_t *>(src + 4 * min(lane + 64, nq - 1));
           }
-          if (sl[0] < 0 && sl[1] < 0) continue;                  // (uniform per entry)
-          long long q[2][4];
+          t[u] = src[min(tail0 + lane, dw - 1)];
+        }
+      };
+      auto fold = [&](int i0, const gvec_t (&v)[UNROLL][2], const float (&t)[UNROLL]) {
 #pragma unroll
-          for (int h = 0; h < 2; ++h)
+        for (int u = 0; u < UNROLL; ++u) {
+          if (i0 + u < nmine) {
+            const uint32_t e = entry(i0 + u);
+            const int labs[2] = {(int)((e >> 11) & 2047u) - 1, (int)(e & 2047u) - 1};
+            int sl[2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) q[h][j] = to_fixed(v[u][h][j]);
-          const long long qt = to_fixed(t[u]);
-#pragma unroll
-          for (int side = 0; side < 2; ++side) {
-            if (sl[side] < 0) continue;
-            unsigned long long *rowp = tab + (size_t)sl[side] * d;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const int q4 = lane + 64 * h;
-              if (q4 < nq) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                  atomicAdd(rowp + 4 * q4 + j, (unsigned long long)(side ? -q[h][j] : q[h][j]));
-              }
+            for (int side = 0; side < 2; ++side) {
+              const int s0 = labs[side] >= 0 ? (int)slot[labs[side]] - base : -1;      // (listed labels are touched)
+              sl[side] = (s0 >= 0 && s0 < S) ? s0 : -1;
             }
-            if (tail0 + lane < d) atomicAdd(rowp + tail0 + lane, (unsigned long long)(side ? -qt : qt));
+            if (sl[0] < 0 && sl[1] < 0) continue;                  // (uniform per entry)
+            long long q[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) q[h][j] = to_fixed(v[u][h][j]);
+            const long long qt = to_fixed(t[u]);
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+              if (sl[side] < 0) continue;
+              unsigned long long *rowp = tab + (size_t)sl[side] * dws;
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                const int q4 = lane + 64 * h;
+                if (q4 < nq) {
+#pragma unroll
+                  for (int j = 0; j < 4; ++j)
+                    atomicAdd(rowp + 4 * q4 + j, (unsigned long long)(side ? -q[h][j] : q[h][j]));
+                }
+              }
+              if (tail0 + lane < dw) atomicAdd(rowp + tail0 + lane, (unsigned long long)(side ? -qt : qt));
+            }
           }
         }
+      };
+      gvec_t va[UNROLL][2], vb[UNROLL][2];
+      float ta[UNROLL], tb[UNROLL];
+      issue(0, va, ta);
+      for (int i0 = 0; i0 < nmine; i0 += 2 * UNROLL) {
+        issue(i0 + UNROLL, vb, tb);
+        __builtin_amdgcn_sched_barrier(0);
+        fold(i0, va, ta);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(i0 + 2 * UNROLL, va, ta);
+        __builtin_amdgcn_sched_barrier(0);
+        fold(i0 + UNROLL, vb, tb);
+        __builtin_amdgcn_sched_barrier(0);
       }
-    };
-    gvec_t va[UNROLL][2], vb[UNROLL][2];
-    float ta[UNROLL], tb[UNROLL];
-    issue(0, va, ta);
-    for (int i0 = 0; i0 < nmine; i0 += 2 * UNROLL) {
-      issue(i0 + UNROLL, vb, tb);
-      __builtin_amdgcn_sched_barrier(0);
-      fold(i0, va, ta);
-      __builtin_amdgcn_sched_barrier(0);
-      issue(i0 + 2 * UNROLL, va, ta);
-      __builtin_amdgcn_sched_barrier(0);
-      fold(i0 + UNROLL, vb, tb);
-      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      // ---- flush the slots of this round / window into the image's table
+      for (int k = w; k < K; k += NW) {
+        const int s0 = slot[k] == 0xFFFF ? -1 : (int)slot[k] - base;
+        if (s0 >= 0 && s0 < S)
+          for (int i = lane; i < dw; i += 64) {
+            const unsigned long long v = tab[(size_t)s0 * dws + i];
+            if (v) atomicAdd(gq + (size_t)k * d + cw + i, v);
+          }
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    // ---- flush the slots of this round into the image's table
-    for (int k = w; k < K; k += NW) {
-      const int s0 = slot[k] == 0xFFFF ? -1 : (int)slot[k] - base;
-      if (s0 >= 0 && s0 < S)
-        for (int i = lane; i < d; i += 64) {
-          const unsigned long long v = tab[(size_t)s0 * d + i];
-          if (v) atomicAdd(gq + (size_t)k * d + i, v);
-        }
-    }
-    __syncthreads();
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
           const int r = (int)(entry(i0 + u) >> 22);
           const float *src = xr + (int64_t)r * d;
 #pragma unroll
-          for (int h = 0; h < NV; ++h)
+          for (int h = 0; h < NV; ++h)    // unconditional (d >= 4 here): a branch around a load costs the counted waits
             v[u][h] = *reinterpret_cast<const gvec_t *>(src + 4 * min(lane + 64 * h, nq - 1));
           t[u] = src[min(tail0 + lane, d - 1)];
         }
@@ -365,8 +371,8 @@ __global__ __launch_bounds__(256) void finalize_fx_kernel(const long long *__res
   for (int i = tid; i < d; i += 256) out[i] = row[i] / nrm;
 }
 
-// rows of d <= 515 columns (two 16-byte loads per lane + the d mod 4 scalar columns)
-bool sums_fx_eligible(int d) { return d >= 8 && d <= 515; }
+// any row length (the strip kernel walks the columns in windows of 512)
+bool sums_fx_eligible(int d) { return d >= 1; }
 
 int launch_update_sums(const float *x, int d, const int32_t *prev, const int32_t *cur,
                        const ChunkTable &t, int max_chunks, int K, long long *sumq,
@@ -377,7 +383,7 @@ int launch_update_sums(const float *x, int d, const int32_t *prev, const int32_t
     // persistent big-table variant when one image's table fits LDS
     constexpr int NWP = 8;
     const size_t ldsp = (size_t)K * d * 8 + 16 + (size_t)NWP * 256 * 4 + 32;
-    if (ldsp <= 150 * 1024) {
+    if (ldsp <= 150 * 1024 && d <= 515 && d >= 4) {
       static const int n_cu = [] {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess)
@@ -396,7 +402,7 @@ int launch_update_sums(const float *x, int d, const int32_t *prev, const int32_t
   }
   constexpr int NW = 4, S = 12;
   auto kern = update_sums_kernel<NW, 4, S>;
-  const size_t lds = (size_t)S * d * 8 + (size_t)(kFxRows + 2) * 4 + (NW + 1) * 4 + (size_t)K * 2 + 32;
+  const size_t lds = (size_t)S * (d < 515 ? d : 515) * 8 + 8 + (size_t)(kFxRows + 2) * 4 + (NW + 1) * 4 + (size_t)K * 2 + 32;
   HSGK_REQUIRE(lds <= 150 * 1024, "row too long for the exact-sum table");
   HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -731,7 +731,8 @@ def test_dmon_affinity_graph_larger_vs_oracle(dev, oracle):
   assert np.array_equal(got.cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize('B,HW,C,K', [(2, 5000, 256, 64), (3, 3000, 384, 128), (1, 700, 30, 5)])
+@pytest.mark.parametrize('B,HW,C,K', [(2, 5000, 256, 64), (3, 3000, 384, 128), (1, 700, 30, 5), (2, 900, 1030, 9),
+                                      (1, 600, 513, 20), (2, 400, 1, 3)])
 def test_exact_sum_mstep_full_and_incremental(dev, oracle, B, HW, C, K):
   """C2x M-step (hsgk_lloyd_mstep_exact): from scratch == oracle exact sums (centroids
   bit-exact) with adversarial labels (every strip touches every cluster; K * d beyond the
