@@ -14,10 +14,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
                 launch stream inside the timed region (libhsgk's event profiler);
                 roofline_mstep / roofline_prep / roofline_iteration: the same for
                 the M-step update, the prep kernel and one whole Lloyd iteration.
-                `traffic` is null: on gfx950 FETCH_SIZE counts between 0.5x and
-                ~0.94x of the bytes depending on the access pattern
-                (profiles/r01_pmc.txt, tools/probes/fetch_calib.hip), so no
-                defensible absolute exists for these row-segment loads;
+                `traffic`: HBM bytes per launch from the committed counter passes
+                (profiles/r01_pmc.txt), 2 x FETCH_SIZE + WRITE_SIZE as the guide
+                prescribes for gfx950 -- calibrated on these kernels' own aligned
+                streams (pmc_traffic); null for other workloads;
   cpu_baseline  oracle/torch_ref.py (same ATen op sequence as the reference's
                 CPU path) timed on the host cores, rank 0, N=1 only.
 """
@@ -39,6 +39,39 @@ WORKLOADS = {
     'cfg1': (4, 32, 64, 64, (2, 4), 10),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def pmc_traffic(kernels):
+  """HBM bytes per launch of the given kernels from the committed rocprofv3 counter passes
+  (profiles/r01_pmc.txt, collected by tools/collect_profiles.sh with one --pmc pass per
+  counter group), corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE (KB)
+  tallies 128-byte requests at 64 B, so it is doubled; WRITE_SIZE (KB) is taken as is (it
+  matches the expected bytes of the prep and label writes within 2 %).  Calibration on these
+  very access patterns: 2 x FETCH_SIZE of assign_half_kernel = 5.07 GB for 5.05 GB streamed,
+  of the M-step's full pass 10.2 GB for 9.98 GB.  None when the file is missing."""
+  path = os.path.join(ROOT, 'profiles', 'r01_pmc.txt')
+  try:
+    lines = open(path).read().splitlines()
+  except OSError:
+    return None
+  vals, section, kern = {}, None, None
+  for ln in lines:
+    if ln.startswith('## --pmc'):
+      section = ln
+      continue
+    if ln and not ln.startswith(' ') and not ln.startswith('#'):
+      kern = ln.strip()
+      continue
+    parts = ln.split()
+    if len(parts) >= 2 and parts[0] in ('FETCH_SIZE', 'WRITE_SIZE') and kern:
+      vals.setdefault(kern, {})[parts[0]] = float(parts[1]) * 1024.0      # KB -> B
+  total = 0.0
+  for k in kernels:
+    hit = [v for name, v in vals.items() if k in name]
+    if not hit:
+      return None
+    total += 2.0 * hit[0].get('FETCH_SIZE', 0.0) + hit[0].get('WRITE_SIZE', 0.0)
+  return int(total)
 
 
 def main():
@@ -173,6 +206,12 @@ def main():
             'group\'s duration.  By design the group STREAMS less than that -- the fp16 copy '
             '(2(D-2)+8 B per pixel), 4 B of labels and the fp32 rows of the ~1.5 % undecided pixels '
             '-- which is how frac can exceed 1; streamed_* price that traffic instead') if half_ok else None)
+  if roofline and half_ok and args.workload == 'cfg2' and B == 48:
+    # counters were collected on exactly this workload (per GPU); see pmc_traffic()
+    roofline['traffic'] = pmc_traffic(['assign_half_kernel', 'assign_split_rows_kernel',
+                                       'assign_requeue_rows_kernel'])
+    roofline['traffic_source'] = ('profiles/r01_pmc.txt: sum over the group of 2 x FETCH_SIZE + WRITE_SIZE '
+                                  '(gfx950 correction of MI355X_MICROARCH.md), bytes per launch')
   if roofline and half_ok:
     streamed = (2 * (D - 2) + 8 + 4 + 0.015 * 4 * D) * npx
     sg = streamed / (a_ms / a_n * 1e-3) / 1e9
@@ -186,6 +225,11 @@ def main():
            'reads the changed rows, so the average launch beats that stream')
   roofline_prep = rl('prep kernel (NCHW -> normalised rows, both float outputs, labels, fp16 copy)',
                      (8 * C + 4 * D + 24) * npx, p_ms, p_n)
+  if args.workload == 'cfg2' and B == 48:
+    if roofline_mstep:
+      roofline_mstep['traffic'] = pmc_traffic(['update_sums_persistent_kernel'])
+    if roofline_prep:
+      roofline_prep['traffic'] = pmc_traffic(['prep_fast32_kernel'])
   roofline_iteration = None
   if m_n and a_n and f_n:
     it_ms = m_ms / m_n + f_ms / f_n + a_ms / a_n
