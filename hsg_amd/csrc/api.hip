@@ -62,6 +62,8 @@ struct KmeansScratch {
   int64_t q1cap;
   size_t rows_cap;     // B * rows_per_image
   int max_chunks;
+  PrepM0 m0;           // partial sums of the first M-step, written by the prep kernel (or part == null)
+  int m0_wt;           // prep workgroups per image
 };
 
 static int max_chunks_for(int B, int64_t rows_per_img) {
@@ -92,6 +94,8 @@ static void carve_kmeans(Carver &cv, int B, int64_t rows_per_img, int d, int K,
     k->klab_prev = cv.take<int32_t>((size_t)B * rows_per_img + 1);
     k->sumq = cv.take<long long>((size_t)B * K * d + 1);
   }
+  k->m0 = PrepM0{nullptr, nullptr, nullptr, 0};
+  k->m0_wt = 0;
   k->xh = nullptr;
   k->xt = nullptr;
   k->q1 = k->q1count = nullptr;
@@ -109,6 +113,25 @@ static void carve_kmeans(Carver &cv, int B, int64_t rows_per_img, int d, int K,
   }
 }
 
+// segment_by_kmeans only: room for the first M-step's partial sums (prep.hip), when the
+// 32-pixel prep kernel and the exact sums both apply
+static void carve_m0(Carver &cv, int B, int C, int ntiles, int K, KmeansScratch *k) {
+  if (k->sumq == nullptr || (C % 64) != 0) return;
+  k->m0_wt = 2 * ntiles;
+  k->m0.part = cv.take<unsigned long long>((size_t)B * k->m0_wt * 2 * (C + 2));
+  k->m0.lab = cv.take<int32_t>((size_t)B * k->m0_wt * 2);
+  k->m0.sumq = reinterpret_cast<unsigned long long *>(k->sumq);
+  k->m0.K = K;
+}
+
+static bool fx_enabled() {            // HSGK_MSTEP=stream keeps the streaming C2 M-step
+  static const bool on = [] {
+    const char *e = getenv("HSGK_MSTEP");
+    return !(e && e[0] == 's');
+  }();
+  return on;
+}
+
 // HSGK_ASSIGN = "fp32": exact kernel only; "split": bf16x3 filter + exact; default: fp16 filter first
 static int assign_mode() {
   static const int mode = [] {
@@ -124,7 +147,7 @@ static int assign_mode() {
 // otherwise a separate pass makes it when the iteration count pays for it.
 static int lloyd(const float *x, int d, int K, int B, int iterations,
                  const KmeansScratch &k, const hsgk_segkm_meta *meta, hipStream_t s,
-                 bool unit_rows = false, bool half_ready = false) {
+                 bool unit_rows = false, bool half_ready = false, bool m0_ready = false) {
   const bool half_any = unit_rows && assign_mode() == 2 && k.xh && (half_ready || iterations >= 3);
   const bool half = half_any && assign_half_eligible(d, K);
   const bool wide = half_any && !half && assign_half_wide_eligible(d, K);
@@ -134,20 +157,19 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
     if (int rc = launch_to_half_rows(x, k.t, k.max_chunks, d, k.xh, k.xt, meta, s)) return rc;
   }
   // exact (fixed-point) segment sums, updated from the rows whose label changed: unit rows
-  // only (|x| <= 1 bounds the integer sums); HSGK_MSTEP=stream keeps the streaming C2 M-step
-  static const bool fx_on = [] {
-    const char *e = getenv("HSGK_MSTEP");
-    return !(e && e[0] == 's');
-  }();
-  const bool fx = unit_rows && fx_on && k.sumq != nullptr && k.max_chunks > 0;
-  if (fx) {
+  // only (|x| <= 1 bounds the integer sums).  m0_ready: the prep kernel already summed the
+  // rows under their seed labels (partials in k.m0, sumq zeroed before it ran).
+  const bool fx = unit_rows && fx_enabled() && k.sumq != nullptr && k.max_chunks > 0;
+  if (fx && !m0_ready) {
     HSGK_CHECK_HIP(hipMemsetAsync(k.klab_prev, 0xFF, sizeof(int32_t) * k.rows_cap, s));
     HSGK_CHECK_HIP(hipMemsetAsync(k.sumq, 0, sizeof(long long) * (size_t)B * K * d, s));
   }
   for (int it = 0; it < iterations; ++it) {
     if (fx) {
       { ProfScope p(HSGK_PROF_ACCUMULATE, s);
-        if (int rc = launch_update_sums(x, d, k.klab_prev, k.klab, k.t, k.max_chunks, K, k.sumq, meta, s))
+        if (it == 0 && m0_ready) {
+          if (int rc = launch_m0_reduce(k.m0, B, k.m0_wt, d, s)) return rc;
+        } else if (int rc = launch_update_sums(x, d, k.klab_prev, k.klab, k.t, k.max_chunks, K, k.sumq, meta, s))
           return rc;
         HSGK_CHECK_HIP(hipMemcpyAsync(k.klab_prev, k.klab, sizeof(int32_t) * k.rows_cap,
                                       hipMemcpyDeviceToDevice, s)); }
@@ -223,6 +245,7 @@ size_t hsgk_segment_by_kmeans_workspace_bytes(int B, int C, int H, int W, int K,
   cv.take<char>(align_up((size_t)B * ntiles, 64) * 4 + (size_t)B * 8);   // tile_off + img_cnt
   KmeansScratch k;
   carve_kmeans(cv, B, HW, C + 2, K, &k);
+  carve_m0(cv, B, C, ntiles, K, &k);
   cv.take<int32_t>((size_t)table_cap * 2);
   cv.take<int32_t>((size_t)table_cap / 2048 + 2);
   return cv.off + 256;
@@ -250,24 +273,29 @@ int hsgk_segment_by_kmeans(const hsgk_segkm_args *a, hsgk_stream_t stream) {
       cv.take<char>(align_up((size_t)a->B * ntiles, 64) * 4 + (size_t)a->B * 8));
   KmeansScratch k;
   carve_kmeans(cv, a->B, HW, D, a->K, &k);
+  carve_m0(cv, a->B, a->C, ntiles, a->K, &k);
   int32_t *table = cv.take<int32_t>((size_t)a->table_cap * 2);
   int32_t *scan_tmp = cv.take<int32_t>((size_t)a->table_cap / 2048 + 2);
 
   const bool compact = a->labels != nullptr && a->has_ignore;
   const bool want_half = assign_mode() == 2 && k.xh && a->iterations >= 1;
-  bool half_ready = false;
+  bool half_ready = false, m0_ready = false;
+  const bool want_m0 = k.m0.part && fx_enabled() && a->iterations >= 1 && k.max_chunks > 0;
   (void)hipGetLastError();   // drop stale errors left by other users of the runtime
   {
     ProfScope p(HSGK_PROF_PREP, s);
+    if (want_m0)
+      HSGK_CHECK_HIP(hipMemsetAsync(k.sumq, 0, sizeof(long long) * (size_t)a->B * a->K * D, s));
     if (int rc = launch_count_valid(a->labels, a->B, HW, a->has_ignore, a->ignore_index,
                                     tile_cnt, a->meta, s)) return rc;
     if (int rc = launch_build_tables(compact ? tile_cnt : nullptr, a->B, HW, ntiles, tile_off,
                                      k.t, k.max_chunks, a->meta, s)) return rc;
     if (int rc = launch_prep(*a, compact ? tile_off : nullptr, k.t, k.klab, s,
-                             want_half ? k.xh : nullptr, k.xt, &half_ready)) return rc;
+                             want_half ? k.xh : nullptr, k.xt, &half_ready,
+                             want_m0 ? &k.m0 : nullptr, &m0_ready)) return rc;
   }
   if (int rc = lloyd(a->out_embeddings_loc, D, a->K, a->B, a->iterations, k, a->meta, s,
-                     /*unit_rows=*/true, half_ready)) return rc;
+                     /*unit_rows=*/true, half_ready, m0_ready)) return rc;
   {
     ProfScope p(HSGK_PROF_RELABEL, s);
     if (int rc = launch_relabel(*a, k.t, k.max_chunks, k.klab, table, scan_tmp, s)) return rc;

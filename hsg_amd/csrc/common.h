@@ -67,6 +67,33 @@ struct ChunkTable {
 constexpr int kTilePix = 64;      // prep kernel tile (pixels)
 constexpr int kAssignTile = 256;  // assign kernel tile (rows)
 
+// fixed-point conversion of the exact sums (canonical order C2x):
+// q = rint(x * 2^40), round to nearest even
+#if defined(__HIPCC__)
+__device__ inline long long to_fixed(float x) {
+  // (the oracle computes q as an exactly rounded hi / lo split in fp32; this is the same
+  // integer in three instructions) x * 2^40 is exact in fp64, and adding 1.5 * 2^52 (ulp 1
+  // there) rounds it to the nearest-even integer, which then sits in the low mantissa bits
+  // (|x| * 2^40 < 2^51)
+  const double magic = 6755399441055744.0;
+  const double t = __builtin_fma((double)x, 1099511627776.0, magic);
+  return __builtin_bit_cast(long long, t) - __builtin_bit_cast(long long, magic);
+}
+#endif
+
+// First M-step fused into the prep kernel (the seed-grid labels are known there): every
+// 32-pixel prep workgroup leaves the exact sums of its rows, split over at most two seed
+// labels, in part [B][WT][2][D] / lab [B][WT][2] (WT = workgroups per image; lab = -1: unused);
+// pixels of a third label go to sumq with global atomics.  m0_reduce then folds the partials
+// into sumq.  part == nullptr: off.
+struct PrepM0 {
+  unsigned long long *part;
+  int32_t *lab;
+  unsigned long long *sumq;
+  int K;
+};
+int launch_m0_reduce(const PrepM0 &m0, int B, int WT, int d, hipStream_t s);
+
 // ---- kernels implemented across the .hip files (host launchers) -----------
 __global__ void init_meta_kernel(hsgk_segkm_meta *meta, int has_labels);
 int launch_count_valid(const int64_t *labels, int B, int64_t HW, int has_ignore,
@@ -77,7 +104,8 @@ int launch_build_tables(const int32_t *tile_cnt, int B, int64_t HW, int ntiles,
                         hsgk_segkm_meta *meta, hipStream_t s);
 int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off,
                 const ChunkTable &t, int32_t *klab, hipStream_t s, _Float16 *xm = nullptr,
-                uint2 *xt = nullptr, bool *wrote_half = nullptr);
+                uint2 *xt = nullptr, bool *wrote_half = nullptr, const PrepM0 *m0 = nullptr,
+                bool *wrote_m0 = nullptr);
 int launch_prep_bwd(const float *g_emb, const float *g_emb_loc, const float *emb,
                     const float *emb_loc, const float *norms, const int64_t *rowmap, int B, int C,
                     int H, int W, float eps, float *gx, hipStream_t s);

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void prep_kernel(
     float eps, float *__restrict__ emb, float *__restrict__ emb_loc,
     int64_t *__restrict__ labels_out, int32_t *__restrict__ klab,
     float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out,
-    _Float16 *__restrict__ xh, uint2 *__restrict__ xt) {
+    _Float16 *__restrict__ xh, uint2 *__restrict__ xt, PrepM0 m0) {
   extern __shared__ float lds[];
   const int S = C | 1;
   float *tile = lds;                       // [64][S]
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(
     float eps, float *__restrict__ emb, float *__restrict__ emb_loc,
     int64_t *__restrict__ labels_out, int32_t *__restrict__ klab,
     float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out,
-    _Float16 *__restrict__ xh, uint2 *__restrict__ xt) {
+    _Float16 *__restrict__ xh, uint2 *__restrict__ xt, PrepM0 m0) {
   extern __shared__ float lds[];
   float *tile = lds;                       // [64][C] swizzled
   float *nrm1 = lds + 64 * C;              // [64]
@@ -527,13 +527,17 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     float eps, float *__restrict__ emb, float *__restrict__ emb_loc,
     int64_t *__restrict__ labels_out, int32_t *__restrict__ klab,
     float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out,
-    _Float16 *__restrict__ xh, uint2 *__restrict__ xt) {
+    _Float16 *__restrict__ xh, uint2 *__restrict__ xt, PrepM0 m0) {
+  const bool m0on = m0.part != nullptr;
   extern __shared__ float lds[];
   float *tile = lds;                       // [32][C] swizzled
   float *nrm1 = lds + 32 * C;              // [32]
   float *nrm2 = nrm1 + 32;                 // [32]
   float *locv = nrm2 + 32;                 // [32][2]
   int64_t *rowi = reinterpret_cast<int64_t *>(locv + 64);   // [32]
+  int *seedl = reinterpret_cast<int *>(rowi + 32);          // [32] seed label of the kept pixels (-1: dropped)
+  int *m0l = seedl + 32;                                    // [2] the (at most) two labels with an LDS slot, [2..3] pad
+  unsigned long long *mtab = reinterpret_cast<unsigned long long *>(m0l + 4);   // [2][D] exact sums (fused first M-step)
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int t = blockIdx.x >> 1, sh = blockIdx.x & 1, b = blockIdx.y;
@@ -567,6 +571,7 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     }
     const unsigned long long mh = sh ? (m >> 32) : (m & 0xffffffffull);
     if (lane == 0) nrm1[0] = mh ? 1.0f : 0.0f;
+    if (m0on && (lane >> 5) == sh) seedl[lane & 31] = keep ? seed_map[pix] : -1;   // (fused first M-step)
   }
   __syncthreads();
   if (nrm1[0] == 0.0f) return;
@@ -616,6 +621,20 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     float n1 = sqrtf(ss);
     if (!(n1 >= eps)) n1 = eps;
     nrm1[jl] = n1;
+  } else if (m0on && w == 1) {
+    // fused first M-step, off the critical path (wave 0 walks the chains meanwhile): the
+    // first two distinct seed labels of this half tile get an LDS slot
+    const int sl = lane < 32 ? seedl[lane] : -1;
+    const unsigned long long mk = __ballot(sl >= 0);
+    int L0 = -1, L1 = -1;
+    if (mk) {
+      L0 = __builtin_amdgcn_readlane(sl, __builtin_ctzll(mk));
+      const unsigned long long m1 = __ballot(sl >= 0 && sl != L0);
+      if (m1) L1 = __builtin_amdgcn_readlane(sl, __builtin_ctzll(m1));
+    }
+    if (lane == 0) { m0l[0] = L0; m0l[1] = L1; }
+  } else if (m0on && w >= 2) {
+    for (int i = tid - 128; i < 2 * (C + 2); i += 128) mtab[i] = 0ull;
   }
   __syncthreads();
   // phase 2b
@@ -650,6 +669,25 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
   }
   __syncthreads();
   // phase 3
+  // fused first M-step: the exact sums of the wave's current run of rows with one seed label
+  // stay in registers (columns 4*lane.., lane 0: the two location columns too) and go to their
+  // place -- LDS slot 0 / 1, or the global table for a third label -- when the label changes
+  long long cur[4] = {0, 0, 0, 0}, tcur[2] = {0, 0};
+  int cslot = -1;                            // 0 / 1: LDS slot, 2: global (cg), -1: nowhere
+  unsigned long long *cg = nullptr;
+  auto m0_flush = [&]() {
+    if (cslot == 0 || cslot == 1) {
+      unsigned long long *t = mtab + cslot * D;
+      if (lane < NQ)
+        for (int i = 0; i < 4; ++i) atomicAdd(t + 4 * lane + i, (unsigned long long)cur[i]);   // ds_add_u64
+      if (lane == 0) { atomicAdd(t + C, (unsigned long long)tcur[0]); atomicAdd(t + C + 1, (unsigned long long)tcur[1]); }
+    } else if (cslot == 2) {
+      if (lane < NQ)
+        for (int i = 0; i < 4; ++i) atomicAdd(cg + 4 * lane + i, (unsigned long long)cur[i]);
+      if (lane == 0) { atomicAdd(cg + C, (unsigned long long)tcur[0]); atomicAdd(cg + C + 1, (unsigned long long)tcur[1]); }
+    }
+    cur[0] = cur[1] = cur[2] = cur[3] = 0; tcur[0] = tcur[1] = 0;
+  };
   for (int j = w; j < 32; j += 4) {
     const int64_t row = rowi[j];
     if (row < 0) continue;
@@ -666,13 +704,36 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const int sj = j & 15;
     float e2 = 0.0f;                         // |row - fp16(row)|^2, this lane's columns
-    for (int q = lane; q < NQ; q += 64) {
+    if (m0on) {
+      const int L = __builtin_amdgcn_readfirstlane(seedl[j]);
+      const int L0 = __builtin_amdgcn_readfirstlane(m0l[0]), L1 = __builtin_amdgcn_readfirstlane(m0l[1]);
+      const int slot = L < 0 ? -1 : L == L0 ? 0 : L == L1 ? 1 : L < m0.K ? 2 : -1;
+      unsigned long long *g = slot == 2 ? m0.sumq + ((int64_t)b * m0.K + L) * D : nullptr;
+      if (slot != cslot || g != cg) { m0_flush(); cslot = slot; cg = g; }
+    }
+    for (int it = 0, q = lane; q < NQ; ++it, q += 64) {
       const float4 v = *reinterpret_cast<const float4 *>(r + ((q ^ sj) << 2));
       *reinterpret_cast<float4 *>(eo + 4 * q) = v;
       float2 a, c2;
       a.x = v.x / n2; a.y = v.y / n2; c2.x = v.z / n2; c2.y = v.w / n2;
       *reinterpret_cast<float2 *>(lo + 4 * q) = a;
       *reinterpret_cast<float2 *>(lo + 4 * q + 2) = c2;
+      if (m0on) {                            // (uniform)
+        const long long f0 = to_fixed(a.x), f1 = to_fixed(a.y), f2 = to_fixed(c2.x), f3 = to_fixed(c2.y);
+        if (it == 0) {
+          cur[0] += f0; cur[1] += f1; cur[2] += f2; cur[3] += f3;
+        } else if (cslot >= 0) {             // wide rows, later column passes: straight to the table
+          if (cslot < 2) {
+            unsigned long long *t = mtab + cslot * D + 4 * q;
+            atomicAdd(t + 0, (unsigned long long)f0); atomicAdd(t + 1, (unsigned long long)f1);
+            atomicAdd(t + 2, (unsigned long long)f2); atomicAdd(t + 3, (unsigned long long)f3);
+          } else {
+            unsigned long long *t = cg + 4 * q;
+            atomicAdd(t + 0, (unsigned long long)f0); atomicAdd(t + 1, (unsigned long long)f1);
+            atomicAdd(t + 2, (unsigned long long)f2); atomicAdd(t + 3, (unsigned long long)f3);
+          }
+        }
+      }
       if (ho) {
         const h4 hv = {(_Float16)a.x, (_Float16)a.y, (_Float16)c2.x, (_Float16)c2.y};
         *reinterpret_cast<h4 *>(ho + 4 * q) = hv;
@@ -688,6 +749,7 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
       lv.x = locv[2 * j] / n2;
       lv.y = locv[2 * j + 1] / n2;
       *reinterpret_cast<float2 *>(lo + C) = lv;
+      if (m0on) { tcur[0] += to_fixed(lv.x); tcur[1] += to_fixed(lv.y); }
       if (ho) {
         const h2 hv = {(_Float16)lv.x, (_Float16)lv.y};
         const float e0 = lv.x - (float)hv[0], e1 = lv.y - (float)hv[1];
@@ -698,13 +760,27 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
       }
     }
   }
+  if (m0on) {                             // this workgroup's two partial sums
+    m0_flush();
+    __syncthreads();
+    const int64_t e0 = ((int64_t)b * gridDim.x + blockIdx.x) * 2;
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      if (m0l[sidx] < 0) continue;
+      if (tid == 0) m0.lab[e0 + sidx] = m0l[sidx];
+      unsigned long long *dst = m0.part + (e0 + sidx) * D;
+      for (int i = tid; i < D; i += 256) dst[i] = mtab[sidx * D + i];
+    }
+  }
 }
 
 // xh != nullptr asks for the fp16 copy of the emb_loc rows as well; *wrote_half tells
 // whether the selected kernel provides it (only the 32-pixel fast kernel does).
 int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTable &t,
-                int32_t *klab, hipStream_t s, _Float16 *xh, uint2 *xt, bool *wrote_half) {
+                int32_t *klab, hipStream_t s, _Float16 *xh, uint2 *xt, bool *wrote_half,
+                const PrepM0 *m0, bool *wrote_m0) {
   if (wrote_half) *wrote_half = false;
+  if (wrote_m0) *wrote_m0 = false;
+  PrepM0 m0v{nullptr, nullptr, nullptr, 0};
   const int64_t HW = (int64_t)a.H * a.W;
   const int ntiles = (int)((HW + kTilePix - 1) / kTilePix);
   const bool fast = (a.C % 64) == 0;
@@ -721,8 +797,13 @@ int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTa
   dim3 grid(ntiles, a.B);
   if (fast && tile32) {
     kern = prep_fast32_kernel;
-    lds = ((size_t)32 * a.C + 32 + 32 + 64) * 4 + 32 * 8;
+    lds = ((size_t)32 * a.C + 32 + 32 + 64) * 4 + 32 * 8 + 36 * 4 + (size_t)2 * (a.C + 2) * 8;
     grid.x = 2 * ntiles;
+    if (m0 && m0->part) {                     // fused first M-step (this kernel only)
+      m0v = *m0;
+      HSGK_CHECK_HIP(hipMemsetAsync(m0v.lab, 0xFF, sizeof(int32_t) * (size_t)a.B * grid.x * 2, s));
+      if (wrote_m0) *wrote_m0 = true;
+    }
   }
   if (fast && wrote_half) *wrote_half = xh != nullptr;      // both fast kernels write the fp16 copy
   HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -731,7 +812,7 @@ int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTa
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a.embeddings, a.C, HW, ntiles,
                      a.loc, a.loc_batch_stride, a.labels, a.has_ignore, a.ignore_index,
                      tile_off, t.img_row0, a.seed_map, HSGK_EPS, a.out_embeddings,
-                     a.out_embeddings_loc, a.out_labels, klab, a.out_norms, a.out_rowmap, xh, xt);
+                     a.out_embeddings_loc, a.out_labels, klab, a.out_norms, a.out_rowmap, xh, xt, m0v);
   HSGK_LAUNCH_CHECK();
   return 0;
 }

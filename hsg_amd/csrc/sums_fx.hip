@@ -28,13 +28,6 @@
 
 namespace hsgk {
 
-__device__ inline long long to_fixed(float x) {
-  const float v = x * 65536.0f;                      // exact
-  const float hi = rintf(v);
-  const float lo = rintf((v - hi) * 16777216.0f);    // exact remainder, exact scaling
-  return (long long)(int)hi * 16777216ll + (long long)(int)lo;
-}
-
 constexpr int kFxRows = 512;                         // rows per workgroup
 
 template <int NW, int UNROLL, int S>
@@ -369,6 +362,74 @@ __global__ __launch_bounds__(256) void finalize_fx_kernel(const long long *__res
   const float nrm = row[d];
   float *out = cent + ((int64_t)b * K + k) * d;
   for (int i = tid; i < d; i += 256) out[i] = row[i] / nrm;
+}
+
+// sumq[b][k][:] += the prep workgroups' partial sums whose label is k.  Workgroup per (k, image):
+// the image's label list is scanned 2048 entries at a time into an LDS list of the matching
+// entries (order is free: integer sums), then thread = column adds the listed partial rows,
+// four independent loads in flight per column pass.
+__global__ __launch_bounds__(256) void m0_reduce_kernel(const long long *__restrict__ part,
+                                                        const int32_t *__restrict__ lab, int entries,
+                                                        int d, int K, long long *__restrict__ sumq) {
+  __shared__ int list[2048];
+  __shared__ int cnt;
+  const int k = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int32_t *lb = lab + (int64_t)b * entries;
+  const long long *pb = part + (int64_t)b * entries * d;
+  for (int c0 = 0; c0 < d; c0 += 1024) {
+    long long acc[4] = {0, 0, 0, 0};
+    int col[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) col[p] = min(c0 + 256 * p + tid, d - 1);
+    for (int e0 = 0; e0 < entries; e0 += 2048) {
+      if (tid == 0) cnt = 0;
+      int l[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) l[u] = lb[min(e0 + 256 * u + tid, entries - 1)];
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 256 * u + tid;
+        const bool hit = e < entries && l[u] == k;
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&cnt, __popcll(m));
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (hit) list[base + __popcll(m & ((1ull << lane) - 1ull))] = e;
+        }
+      }
+      __syncthreads();
+      const int n = cnt;
+      for (int i = 0; i < n; i += 4) {
+        long long v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long long *row = pb + (int64_t)list[min(i + u, n - 1)] * d;
+#pragma unroll
+          for (int p = 0; p < 4; ++p) v[u][p] = row[col[p]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int p = 0; p < 4; ++p) acc[p] += (i + u < n) ? v[u][p] : 0ll;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      if (c0 + 256 * p + tid < d) sumq[((int64_t)b * K + k) * d + c0 + 256 * p + tid] += acc[p];
+  }
+}
+
+int launch_m0_reduce(const PrepM0 &m0, int B, int WT, int d, hipStream_t s) {
+  if (B <= 0 || m0.K <= 0) return 0;
+  hipLaunchKernelGGL(m0_reduce_kernel, dim3(m0.K, B), dim3(256), 0, s,
+                     reinterpret_cast<const long long *>(m0.part), m0.lab, 2 * WT, d, m0.K,
+                     reinterpret_cast<long long *>(m0.sumq));
+  HSGK_LAUNCH_CHECK();
+  return 0;
 }
 
 // any row length (the strip kernel walks the columns in windows of 512)
