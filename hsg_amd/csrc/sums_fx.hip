@@ -233,6 +233,12 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
   typedef float gvec_t __attribute__((ext_vector_type(4), aligned(4)));
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
   const int nq = d / 4, tail0 = nq * 4;
+  // the d mod 4 tail columns of a whole batch of UNROLL rows go through ONE load and one
+  // ds_add_u64 per side (lane = (row of the batch, tail column)): an LDS atomic costs the same
+  // ~9 cycles with 2 active lanes as with 64, and the LDS atomic rate is what bounds this kernel
+  const int tw = d - tail0;
+  const int tu = lane / max(tw, 1), tc = lane - tu * max(tw, 1);
+  const bool tact = tw > 0 && tu < UNROLL;
   constexpr int STRIP = 256, SPC = HSGK_CHUNK / STRIP;          // strips per chunk
   int c = c_begin;
   while (c < c_end) {
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
       // (wave-private list: own LDS writes are visible to own reads in order)
       const float *xr = x + row0 * d;
       auto entry = [&](int i) { return list[min(i, total - 1)]; };
-      auto issue = [&](int i0, gvec_t (&v)[UNROLL][NV], float (&t)[UNROLL]) {
+      auto issue = [&](int i0, gvec_t (&v)[UNROLL][NV], float &t) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
           const int r = (int)(entry(i0 + u) >> 22);
@@ -284,10 +290,10 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
 #pragma unroll
           for (int h = 0; h < NV; ++h)    // unconditional (d >= 4 here): a branch around a load costs the counted waits
             v[u][h] = *reinterpret_cast<const gvec_t *>(src + 4 * min(lane + 64 * h, nq - 1));
-          t[u] = src[min(tail0 + lane, d - 1)];
         }
+        t = xr[(int64_t)(entry(i0 + min(tu, UNROLL - 1)) >> 22) * d + min(tail0 + tc, d - 1)];
       };
-      auto fold = [&](int i0, const gvec_t (&v)[UNROLL][NV], const float (&t)[UNROLL]) {
+      auto fold = [&](int i0, const gvec_t (&v)[UNROLL][NV], const float &t) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
           if (i0 + u < total) {
@@ -298,7 +304,6 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
             for (int h = 0; h < NV; ++h)
 #pragma unroll
               for (int j = 0; j < 4; ++j) q[h][j] = to_fixed(v[u][h][j]);
-            const long long qt = to_fixed(t[u]);
 #pragma unroll
             for (int side = 0; side < 2; ++side) {
               if (labs[side] < 0) continue;
@@ -312,13 +317,19 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
                     atomicAdd(rowp + 4 * q4 + j, (unsigned long long)(side ? -q[h][j] : q[h][j]));
                 }
               }
-              if (tail0 + lane < d) atomicAdd(rowp + tail0 + lane, (unsigned long long)(side ? -qt : qt));
             }
           }
         }
+        if (tact && i0 + tu < total) {
+          const uint32_t e = entry(i0 + tu);
+          const long long qt = to_fixed(t);
+          const int ln = (int)((e >> 11) & 2047u) - 1, lo = (int)(e & 2047u) - 1;
+          if (ln >= 0) atomicAdd(tab + (size_t)ln * d + tail0 + tc, (unsigned long long)qt);
+          if (lo >= 0) atomicAdd(tab + (size_t)lo * d + tail0 + tc, (unsigned long long)(-qt));
+        }
       };
       gvec_t va[UNROLL][NV], vb[UNROLL][NV];
-      float ta[UNROLL], tb[UNROLL];
+      float ta, tb;
       issue(0, va, ta);
       for (int i0 = 0; i0 < total; i0 += 2 * UNROLL) {
         issue(i0 + UNROLL, vb, tb);

@@ -19,6 +19,9 @@ __global__ __launch_bounds__(256) void k(long long *out, int iters) {
     if (MODE == 1) t64[row * 64 + lane] += (unsigned long long)(it + lane);                      // plain 64-bit RMW
     if (MODE == 2) atomicAdd(&t32[row * 64 + lane], (float)(it + lane));                         // ds_add_f32
     if (MODE == 3) atomicAdd(reinterpret_cast<unsigned int *>(t32) + row * 64 + lane, (unsigned)(it + lane));  // ds_add_u32
+    if (MODE == 4 && lane < 2) atomicAdd(&t64[row * 64 + lane], (unsigned long long)(it + lane));   // ds_add_u64, 2 active lanes
+    if (MODE == 5 && lane < 16) atomicAdd(&t64[row * 64 + lane], (unsigned long long)(it + lane));  // ds_add_u64, 16 active lanes
+    if (MODE == 6) atomicAdd(&t64[((row + lane) & 63) * 64 + lane], (unsigned long long)(it + lane));  // ds_add_u64, a different row per lane
   }
   __syncthreads();
   const long long t1 = clock64();
@@ -28,13 +31,17 @@ __global__ __launch_bounds__(256) void k(long long *out, int iters) {
 int main() {
   long long *d; (void)hipMalloc(&d, 8 * 1024);
   const int iters = 20000;
-  const char *names[] = {"ds_add_u64 (atomic)", "64-bit plain RMW", "ds_add_f32 (atomic)", "ds_add_u32 (atomic)"};
-  for (int m = 0; m < 4; ++m) {
+  const char *names[] = {"ds_add_u64 (atomic)", "64-bit plain RMW", "ds_add_f32 (atomic)", "ds_add_u32 (atomic)",
+                         "ds_add_u64, 2 lanes", "ds_add_u64, 16 lanes", "ds_add_u64, row per lane"};
+  for (int m = 0; m < 7; ++m) {
     for (int grid : {1, 256}) {
       if (m == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), 32768, 0, d, iters);
       if (m == 1) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 32768, 0, d, iters);
       if (m == 2) hipLaunchKernelGGL(k<2>, dim3(grid), dim3(256), 32768, 0, d, iters);
       if (m == 3) hipLaunchKernelGGL(k<3>, dim3(grid), dim3(256), 32768, 0, d, iters);
+      if (m == 4) hipLaunchKernelGGL(k<4>, dim3(grid), dim3(256), 32768, 0, d, iters);
+      if (m == 5) hipLaunchKernelGGL(k<5>, dim3(grid), dim3(256), 32768, 0, d, iters);
+      if (m == 6) hipLaunchKernelGGL(k<6>, dim3(grid), dim3(256), 32768, 0, d, iters);
       long long h; (void)hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
       printf("%-22s grid %3d: %.1f clock64 ticks per wave instruction (4 waves per WG issuing concurrently)\n", names[m], grid,
              (double)h / iters);
