@@ -218,8 +218,10 @@ def main():
     roofline.update({'streamed_bytes_per_launch': int(streamed), 'streamed_GBps': round(sg, 1),
                      'streamed_frac': round(sg / HBM_PEAK_GBS, 4)})
   roofline_mstep = rl(
-      'M-step: update_sums kernel (exact fixed-point segment sums, updated from the rows whose '
-      'label changed; the first launches of a call touch every row, the later ones a few per cent)',
+      'M-step: exact fixed-point segment sums.  The first M-step of a call is summed inside the prep '
+      'kernel (seed-grid labels) and folded by m0_reduce_kernel; the other launches are the update_sums '
+      'kernel, which reads only the rows whose label changed (nearly all in its first launch, a few per '
+      'cent in the last)',
       4 * D * npx, m_ms, m_n,
       note='algorithmic bytes = one read of every fp32 row (4D B per pixel) per launch; the update only '
            'reads the changed rows, so the average launch beats that stream')
@@ -227,7 +229,9 @@ def main():
                      (8 * C + 4 * D + 24) * npx, p_ms, p_n)
   if args.workload == 'cfg2' and B == 48:
     if roofline_mstep:
-      roofline_mstep['traffic'] = pmc_traffic(['update_sums_persistent_kernel'])
+      t_u, t_r = pmc_traffic(['update_sums_persistent_kernel']), pmc_traffic(['m0_reduce_kernel'])
+      if t_u is not None and t_r is not None and iters >= 1:   # per call: one reduce + (iterations - 1) updates
+        roofline_mstep['traffic'] = int(((iters - 1) * t_u + t_r) / iters)
     if roofline_prep:
       roofline_prep['traffic'] = pmc_traffic(['prep_fast32_kernel'])
   roofline_iteration = None
