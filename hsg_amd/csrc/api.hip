@@ -6,6 +6,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -164,36 +165,44 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
     HSGK_CHECK_HIP(hipMemsetAsync(k.klab_prev, 0xFF, sizeof(int32_t) * k.rows_cap, s));
     HSGK_CHECK_HIP(hipMemsetAsync(k.sumq, 0, sizeof(long long) * (size_t)B * K * d, s));
   }
+  // The working labels ping-pong between k.klab and k.klab_prev (every E-step rewrites all
+  // rows): after the sums are brought up to date with `cur`, that buffer becomes `prev` and the
+  // E-step writes the other one -- no label copy per iteration.
+  int32_t *cur = k.klab, *prev = k.klab_prev;
   for (int it = 0; it < iterations; ++it) {
+    bool counters_zeroed = false;
     if (fx) {
       { ProfScope p(HSGK_PROF_ACCUMULATE, s);
         if (it == 0 && m0_ready) {
           if (int rc = launch_m0_reduce(k.m0, B, k.m0_wt, d, s)) return rc;
-        } else if (int rc = launch_update_sums(x, d, k.klab_prev, k.klab, k.t, k.max_chunks, K, k.sumq, meta, s))
+        } else if (int rc = launch_update_sums(x, d, prev, cur, k.t, k.max_chunks, K, k.sumq, meta, s))
           return rc;
-        HSGK_CHECK_HIP(hipMemcpyAsync(k.klab_prev, k.klab, sizeof(int32_t) * k.rows_cap,
-                                      hipMemcpyDeviceToDevice, s)); }
+        std::swap(cur, prev); }
       { ProfScope p(HSGK_PROF_FINALIZE, s);
-        if (int rc = launch_finalize_fx(k.sumq, d, K, B, HSGK_EPS, k.cent, s)) return rc; }
+        counters_zeroed = half;
+        if (int rc = launch_finalize_fx(k.sumq, d, K, B, HSGK_EPS, k.cent, s, half ? k.q1count : nullptr, B,
+                                        half ? k.qcount : nullptr)) return rc; }
     } else {
       { ProfScope p(HSGK_PROF_ACCUMULATE, s);
-        if (int rc = launch_accumulate(x, d, k.klab, k.t, k.max_chunks, K, k.partial, k.pmask, meta, s)) return rc; }
+        if (int rc = launch_accumulate(x, d, cur, k.t, k.max_chunks, K, k.partial, k.pmask, meta, s)) return rc; }
       { ProfScope p(HSGK_PROF_FINALIZE, s);
         if (int rc = launch_finalize(k.partial, k.pmask, d, K, B, k.t, k.max_chunks / B, HSGK_EPS, k.cent, s)) return rc; }
     }
     { ProfScope p(HSGK_PROF_ASSIGN, s);
-      if (int rc = half ? launch_assign_half(x, k.xh, k.xt, d, k.cent, K, B, k.t, k.max_chunks, k.klab, k.q1,
-                                             k.q1count, k.q1cap, k.qrows, k.qcount, meta, s)
-               : wide ? launch_assign_half_wide(x, k.xh, k.xt, d, k.cent, k.errc, K, B, k.t, k.max_chunks, k.klab,
+      if (int rc = half ? launch_assign_half(x, k.xh, k.xt, d, k.cent, K, B, k.t, k.max_chunks, cur, k.q1,
+                                             k.q1count, k.q1cap, k.qrows, k.qcount, meta, s, counters_zeroed)
+               : wide ? launch_assign_half_wide(x, k.xh, k.xt, d, k.cent, k.errc, K, B, k.t, k.max_chunks, cur,
                                                 k.qrows, k.qcount, meta, s)
                : wide2 ? launch_assign_half_wide2(x, k.xh, k.xt, d, k.cent, k.errc, K, B, k.t, k.max_chunks,
-                                                  k.klab, k.state, k.qrows, k.qcount, meta, s)
+                                                  cur, k.state, k.qrows, k.qcount, meta, s)
                : unit_rows && assign_mode() >= 1
-                   ? launch_assign_fast(x, d, k.cent, K, k.t, k.max_chunks, k.klab, k.best,
+                   ? launch_assign_fast(x, d, k.cent, K, k.t, k.max_chunks, cur, k.best,
                                         k.qrows, k.qcount, meta, s)
-                   : launch_assign(x, d, k.cent, K, k.t, k.max_chunks, k.klab, k.best, meta, s))
+                   : launch_assign(x, d, k.cent, K, k.t, k.max_chunks, cur, k.best, meta, s))
         return rc; }
   }
+  if (cur != k.klab)      // odd number of swaps: the final labels sit in the other buffer
+    HSGK_CHECK_HIP(hipMemcpyAsync(k.klab, cur, sizeof(int32_t) * k.rows_cap, hipMemcpyDeviceToDevice, s));
   return 0;
 }
 

@@ -135,8 +135,10 @@ bool sums_fx_eligible(int d);
 int launch_update_sums(const float *x, int d, const int32_t *prev, const int32_t *cur,
                        const ChunkTable &t, int max_chunks, int K, long long *sumq,
                        const hsgk_segkm_meta *meta, hipStream_t s);
+// zero_a[0 .. na) and zero_b[0] (optional): queue counters of the E-step that follows, reset
+// here instead of by two memsets per iteration
 int launch_finalize_fx(const long long *sumq, int d, int K, int B, float eps, float *cent,
-                       hipStream_t s);
+                       hipStream_t s, int32_t *zero_a = nullptr, int na = 0, int32_t *zero_b = nullptr);
 
 // three-level E-step (fp16 copy -> bf16x3 on the undecided rows -> exact chains)
 inline int half_main_cols_host(int d) { return d & ~63; }
@@ -157,7 +159,7 @@ int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt
 int launch_assign_half(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent, int K, int B,
                        const ChunkTable &t, int max_chunks, int32_t *klab, int32_t *q1,
                        int32_t *q1count, int64_t q1cap, void *qrows, int32_t *qcount,
-                       const hsgk_segkm_meta *meta, hipStream_t s);
+                       const hsgk_segkm_meta *meta, hipStream_t s, bool counters_zeroed = false);
 
 int launch_relabel(const hsgk_segkm_args &a, const ChunkTable &t, int max_chunks,
                    const int32_t *klab, int32_t *table, int32_t *scan_tmp,

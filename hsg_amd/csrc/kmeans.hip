@@ -1140,7 +1140,7 @@ bool assign_half_eligible(int d, int K) {
 int launch_assign_half(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent, int K, int B,
                        const ChunkTable &t, int max_chunks, int32_t *klab, int32_t *q1,
                        int32_t *q1count, int64_t q1cap, void *qrows, int32_t *qcount,
-                       const hsgk_segkm_meta *meta, hipStream_t s) {
+                       const hsgk_segkm_meta *meta, hipStream_t s, bool counters_zeroed) {
   if (max_chunks <= 0 || B <= 0) return 0;
   constexpr int NW = 8, TPX = NW * 32;
   static const int n_cu = [] {
@@ -1152,8 +1152,10 @@ int launch_assign_half(const float *x, const _Float16 *xm, const uint2 *xt, int 
   // one persistent workgroup per CU, fewer when the batch has fewer tiles
   const int64_t max_tiles = ((int64_t)max_chunks * HSGK_CHUNK + TPX - 1) / TPX;
   const int grid = (int)(max_tiles < n_cu ? max_tiles : n_cu);
-  HSGK_CHECK_HIP(hipMemsetAsync(q1count, 0, sizeof(int32_t) * B, s));
-  HSGK_CHECK_HIP(hipMemsetAsync(qcount, 0, sizeof(int32_t), s));
+  if (!counters_zeroed) {
+    HSGK_CHECK_HIP(hipMemsetAsync(q1count, 0, sizeof(int32_t) * B, s));
+    HSGK_CHECK_HIP(hipMemsetAsync(qcount, 0, sizeof(int32_t), s));
+  }
   {
     const bool deep = ((d / 64) & 3) == 0;
     auto kern = deep ? assign_half_kernel<NW, 4> : assign_half_kernel<NW, 2>;

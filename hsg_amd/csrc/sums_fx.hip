@@ -356,9 +356,15 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
 
 // centroid row = normalise((float)sum * 2^-40): one rounding per element, then the C1 norm chain
 __global__ __launch_bounds__(256) void finalize_fx_kernel(const long long *__restrict__ sumq, int d,
-                                                          int K, float eps, float *__restrict__ cent) {
+                                                          int K, float eps, float *__restrict__ cent,
+                                                          int32_t *__restrict__ zero_a, int na,
+                                                          int32_t *__restrict__ zero_b) {
   extern __shared__ float row[];    // [d] + 1
   const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  if (k == 0 && b == 0) {           // queue counters of the E-step that follows
+    for (int i = tid; i < na; i += 256) zero_a[i] = 0;
+    if (zero_b && tid == 0) zero_b[0] = 0;
+  }
   const long long *src = sumq + ((int64_t)b * K + k) * d;
   for (int i = tid; i < d; i += 256) row[i] = (float)src[i] * 9.094947017729282e-13f;   // 2^-40
   __syncthreads();
@@ -485,10 +491,11 @@ int launch_update_sums(const float *x, int d, const int32_t *prev, const int32_t
   return 0;
 }
 
-int launch_finalize_fx(const long long *sumq, int d, int K, int B, float eps, float *cent, hipStream_t s) {
+int launch_finalize_fx(const long long *sumq, int d, int K, int B, float eps, float *cent, hipStream_t s,
+                       int32_t *zero_a, int na, int32_t *zero_b) {
   if (B <= 0 || K <= 0) return 0;
   hipLaunchKernelGGL(finalize_fx_kernel, dim3(K, B), dim3(256), (size_t)(d + 1) * 4, s, sumq, d, K, eps,
-                     cent);
+                     cent, zero_a, zero_a ? na : 0, zero_b);
   HSGK_LAUNCH_CHECK();
   return 0;
 }
