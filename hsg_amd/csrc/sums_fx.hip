@@ -252,6 +252,35 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
       for (int i = tid; i < tot2; i += NW * 64) t2[i] = u64x2{0ull, 0ull};
     }
     __syncthreads();
+    // Run-length carries: consecutive changed rows that leave (side 1) or join (side 0) the
+    // same cluster add up in registers and reach the LDS table with one set of atomics per
+    // run -- pixels are in raster order, so on images (and for the seed-grid labels of the
+    // first update) the runs are long; the LDS atomic rate is what bounds this kernel.
+    int clab[2] = {-1, -1};
+    long long cq[2][NV][4];
+#pragma unroll
+    for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+      for (int h = 0; h < NV; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cq[sd][h][j] = 0;
+    auto flush_run = [&](int side) {
+      if (clab[side] >= 0) {
+        unsigned long long *rowp = tab + (size_t)clab[side] * d;
+#pragma unroll
+        for (int h = 0; h < NV; ++h) {
+          const int q4 = lane + 64 * h;
+          if (q4 < nq) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(rowp + 4 * q4 + j, (unsigned long long)cq[side][h][j]);
+          }
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < NV; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cq[side][h][j] = 0;
+    };
     // ---- strips of the run, dealt to the waves round robin; no barrier inside
     const int nstrips = (ce - c) * SPC;
     for (int st = w; st < nstrips; st += NW) {
@@ -306,17 +335,13 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
               for (int j = 0; j < 4; ++j) q[h][j] = to_fixed(v[u][h][j]);
 #pragma unroll
             for (int side = 0; side < 2; ++side) {
-              if (labs[side] < 0) continue;
-              unsigned long long *rowp = tab + (size_t)labs[side] * d;
+              const int lab = labs[side];              // (wave-uniform)
+              if (lab < 0) continue;
+              if (lab != clab[side]) { flush_run(side); clab[side] = lab; }
 #pragma unroll
-              for (int h = 0; h < NV; ++h) {
-                const int q4 = lane + 64 * h;
-                if (q4 < nq) {
+              for (int h = 0; h < NV; ++h)
 #pragma unroll
-                  for (int j = 0; j < 4; ++j)
-                    atomicAdd(rowp + 4 * q4 + j, (unsigned long long)(side ? -q[h][j] : q[h][j]));
-                }
-              }
+                for (int j = 0; j < 4; ++j) cq[side][h][j] += side ? -q[h][j] : q[h][j];
             }
           }
         }
@@ -342,6 +367,8 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    flush_run(0);
+    flush_run(1);
     __syncthreads();
     // ---- flush the image's table
     unsigned long long *gq = sumq + (int64_t)b * K * d;
