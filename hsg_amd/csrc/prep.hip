@@ -519,6 +519,13 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(
 // workgroup (wave 0 only) overlap the load / divide / store phases of three
 // others.  PMC on the 64-pixel kernel showed waves 69 % waiting (barriers +
 // memory) with only two workgroups per CU.  Same arithmetic, same outputs.
+#ifdef HSGK_PREP_TIMING
+__device__ unsigned long long g_prep_ts[8];
+#define HSGK_TS(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
+    atomicAdd(&g_prep_ts[i], now_ - ts_); ts_ = now_; } } while (0)
+#else
+#define HSGK_TS(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void prep_fast32_kernel(
     const float *__restrict__ in, int C, int64_t HW, int ntiles,
     const float *__restrict__ loc, int64_t loc_sb, const int64_t *__restrict__ labels,
@@ -529,6 +536,9 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out,
     _Float16 *__restrict__ xh, uint2 *__restrict__ xt, PrepM0 m0) {
   const bool m0on = m0.part != nullptr;
+#ifdef HSGK_PREP_TIMING
+  unsigned long long ts_ = __builtin_readcyclecounter();
+#endif
   extern __shared__ float lds[];
   float *tile = lds;                       // [32][C] swizzled
   float *nrm1 = lds + 32 * C;              // [32]
@@ -545,6 +555,24 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
   const int64_t q0 = p0 + 32 * sh;                 // start of this half
   const int D = C + 2;
   const int NQ = C >> 2;
+  const int jl = lane & 31, sub = lane >> 5;
+  const int sw = jl & 15;
+
+  // phase 1a: the first batch of plane loads (8 quads = 32 loads per thread; all of the tile
+  // for C <= 256) is issued BEFORE the bookkeeping of wave 0, whose dependent loads would
+  // otherwise put a second memory latency in front of them (18 % of a workgroup's lifetime
+  // by the phase timers, tools/probes/prep_timing.py).  Indices are clamped, not branched on.
+  const bool pix_ok = q0 + jl < HW;
+  const float *src = in + (int64_t)b * C * HW + (pix_ok ? q0 + jl : HW - 1);
+  float4 v0[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int q = min(2 * w + sub + 8 * u, NQ - 1);
+    v0[u].x = src[(int64_t)(4 * q + 0) * HW];
+    v0[u].y = src[(int64_t)(4 * q + 1) * HW];
+    v0[u].z = src[(int64_t)(4 * q + 2) * HW];
+    v0[u].w = src[(int64_t)(4 * q + 3) * HW];
+  }
 
   if (w == 0) {
     const int64_t pix = p0 + lane;
@@ -574,20 +602,23 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     if (m0on && (lane >> 5) == sh) seedl[lane & 31] = keep ? seed_map[pix] : -1;   // (fused first M-step)
   }
   __syncthreads();
+  HSGK_TS(0);
   if (nrm1[0] == 0.0f) return;
   __syncthreads();
+  HSGK_TS(1);
 
-  const int jl = lane & 31, sub = lane >> 5;
-  const int sw = jl & 15;
-  // phase 1: 4 channel planes -> one 16-byte LDS write per (pixel, quad)
+  // phase 1b: 4 channel planes -> one 16-byte LDS write per (pixel, quad)
   {
-    const int64_t pix = q0 + jl;
-    const bool ok = pix < HW;
-    const float *src = in + (int64_t)b * C * HW + (ok ? pix : HW - 1);
-    // batches of 8 quads per thread: all 32 loads of a batch are issued before the
-    // first LDS write (a load-use loop here exposes one memory latency per quad);
-    // indices are clamped, not branched on, so the loads stay unconditional
-    for (int q0b = 2 * w + sub; q0b < NQ; q0b += 64) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = 2 * w + sub + 8 * u;
+      if (q < NQ)
+        *reinterpret_cast<float4 *>(tile + jl * C + ((q ^ sw) << 2)) =
+            pix_ok ? v0[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // further batches (C > 256): all 32 loads of a batch are issued before its first LDS
+    // write (a load-use loop here exposes one memory latency per quad)
+    for (int q0b = 2 * w + sub + 64; q0b < NQ; q0b += 64) {
       float4 v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -602,11 +633,12 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
         const int q = q0b + 8 * u;
         if (q < NQ)
           *reinterpret_cast<float4 *>(tile + jl * C + ((q ^ sw) << 2)) =
-              ok ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+              pix_ok ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
   }
   __syncthreads();
+  HSGK_TS(2);
   // phase 2a: the C1 chain of pixel jl (wave 0, lanes 0..31)
   if (w == 0 && sub == 0) {
     const float *r = tile + jl * C;
@@ -637,6 +669,7 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     for (int i = tid - 128; i < 2 * (C + 2); i += 128) mtab[i] = 0ull;
   }
   __syncthreads();
+  HSGK_TS(3);
   // phase 2b
   {
     const float n1 = nrm1[jl];
@@ -649,6 +682,7 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     }
   }
   __syncthreads();
+  HSGK_TS(4);
   // phase 2c
   if (w == 0 && sub == 0) {
     const float *r = tile + jl * C;
@@ -668,6 +702,7 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     nrm2[jl] = n2;
   }
   __syncthreads();
+  HSGK_TS(5);
   // phase 3
   // fused first M-step: the exact sums of the wave's current run of rows with one seed label
   // stay in registers (columns 4*lane.., lane 0: the two location columns too) and go to their
@@ -763,6 +798,7 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
   if (m0on) {                             // this workgroup's two partial sums
     m0_flush();
     __syncthreads();
+  HSGK_TS(6);
     const int64_t e0 = ((int64_t)b * gridDim.x + blockIdx.x) * 2;
     for (int sidx = 0; sidx < 2; ++sidx) {
       if (m0l[sidx] < 0) continue;
@@ -771,10 +807,19 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
       for (int i = tid; i < D; i += 256) dst[i] = mtab[sidx * D + i];
     }
   }
+  HSGK_TS(7);
 }
 
-// xh != nullptr asks for the fp16 copy of the emb_loc rows as well; *wrote_half tells
-// whether the selected kernel provides it (only the 32-pixel fast kernel does).
+#ifdef HSGK_PREP_TIMING
+extern "C" __attribute__((visibility("default"))) int hsgk_debug_prep_timing(unsigned long long *out) {
+  unsigned long long h[8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prep_ts), sizeof(h)) != hipSuccess) return -1;
+  for (int i = 0; i < 8; ++i) out[i] = h[i];
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prep_ts), z, sizeof(z));
+  return 0;
+}
+#endif
 int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTable &t,
                 int32_t *klab, hipStream_t s, _Float16 *xh, uint2 *xt, bool *wrote_half,
                 const PrepM0 *m0, bool *wrote_m0) {
@@ -798,6 +843,9 @@ int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTa
   if (fast && tile32) {
     kern = prep_fast32_kernel;
     lds = ((size_t)32 * a.C + 32 + 32 + 64) * 4 + 32 * 8 + 36 * 4 + (size_t)2 * (a.C + 2) * 8;
+#ifdef HSGK_PREP_PAD_LDS
+    lds += HSGK_PREP_PAD_LDS;
+#endif
     grid.x = 2 * ntiles;
     if (m0 && m0->part) {                     // fused first M-step (this kernel only)
       m0v = *m0;
