@@ -410,6 +410,9 @@ def test_hierarchy_ops_vs_reference_golden(dev):
     ((1, 384, 32, 48), (8, 16), 6),      # cfg5-style C = 384, K = 128
     ((3, 256, 40, 56), (8, 8), 10),      # cfg2/3-style C = 256, K = 64: split E-step, ragged chunks
     ((2, 128, 33, 47), (5, 7), 7),       # odd sizes, K = 35, d = 130 (split shape ok: 4 chunks)
+    ((1, 512, 24, 40), (4, 5), 4),       # C = 512: two plane-load batches in prep, two 16-byte vectors per lane in the sums update
+    ((2, 64, 50, 30), (5, 3), 3),        # C = 64: quarter-filled waves in prep, d = 66 (no fp16 level)
+    ((1, 320, 20, 36), (2, 3), 5),       # C = 320 = 5 x 64: fp16 level with an odd number of 64-column steps
 ])
 def test_baseline_config_shapes_vs_oracle(dev, oracle, shape, grid, iters):
   """Reduced-size versions of BASELINE.json configs 2-5, bit-exact vs the oracle
