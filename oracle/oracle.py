@@ -67,19 +67,30 @@ def normalize_embedding(x, eps=EPS):
   return out
 
 
-def grid_seed_axis(k, n):
-  """round_half_even(linspace(0, k-1, n)) as exact integer arithmetic.
-
-  hsg/utils/segsort/common.py:145-148.  value_i = i*(k-1)/(n-1).
-  """
+def linspace_f32(start, end, n):
+  """torch.linspace(start, end, n) for float32 on the CPU, bit for bit, as ATen evaluates it
+  (aten/src/ATen/native/cpu/RangeFactoriesKernel.cpp, linspace_kernel): step =
+  (end - start) / (n - 1) in float32; element i is fma(step, i, start) in the lower half
+  (i < n // 2) and fma(-step, n - 1 - i, end) in the upper half -- one rounding per element
+  (the product of a float32 and a small integer is exact in float64, so is its sum with a
+  float32 of similar magnitude).  Checked against torch.linspace for every grid size up to
+  32 / image side up to 700 and for the location features in tests/test_cabi_and_host.py."""
   if n == 1:
-    return np.zeros(1, np.int64)
-  i = np.arange(n, dtype=np.int64)
-  num = i * (k - 1)
-  den = n - 1
-  q, r = np.divmod(num, den)
-  up = (2 * r > den) | ((2 * r == den) & (q % 2 == 1))
-  return q + up.astype(np.int64)
+    return np.full(1, np.float32(start))
+  s0, e0 = np.float32(start), np.float32(end)
+  step = np.float32((e0 - s0) / np.float32(n - 1))
+  i = np.arange(n)
+  lo = (np.float64(s0) + np.float64(step) * i).astype(np.float32)
+  hi = (np.float64(e0) - np.float64(step) * (n - 1 - i)).astype(np.float32)
+  return np.where(i < n // 2, lo, hi).astype(np.float32)
+
+
+def grid_seed_axis(k, n):
+  """linspace(0, k-1, n).round_().long() (hsg/utils/segsort/common.py:145-148): the float32
+  linspace of ATen (linspace_f32), rounded half to even.  The float32 rounding is part of the
+  reference's behaviour: the exactly rounded i*(k-1)/(n-1) differs from it for about 2 % of the
+  (k, n) pairs (e.g. k = 4, n = 43), which tools/fuzz_parity.py found."""
+  return np.rint(linspace_f32(0.0, float(k - 1), n)).astype(np.int64)
 
 
 def initialize_cluster_labels(num_clusters, img_dimensions):
@@ -87,6 +98,13 @@ def initialize_cluster_labels(num_clusters, img_dimensions):
   y = grid_seed_axis(num_clusters[0], img_dimensions[0])
   x = grid_seed_axis(num_clusters[1], img_dimensions[1])
   return y[:, None] + (y.max() + 1) * x[None, :]
+
+
+def generate_location_features(img_dimensions):
+  """hsg/utils/segsort/common.py:156-189, feature_type='float': [H, W, 2] (y, x) in [0, 1]."""
+  y = linspace_f32(0.0, 1.0, int(img_dimensions[0]))
+  x = linspace_f32(0.0, 1.0, int(img_dimensions[1]))
+  return np.stack(np.meshgrid(y, x, indexing='ij'), axis=2).astype(np.float32)
 
 
 def dense_relabel(v):
