@@ -1,7 +1,8 @@
 """Randomised parity of two building blocks against the CPU oracle, bit for bit:
   * segment_reduce (prototypes / means / raw sums, canonical order C2) on random (n, d, P) and id patterns;
   * the E-step C entry point (hsgk_lloyd_estep, all three filter settings) on random (B, HW, C, K) with
-    exact ties, near ties at the scale of each filter's gap and zero centroids.
+    exact ties, near ties at the scale of each filter's gap and zero centroids;
+  * SegSortLoss forward (both modes, random n / c / P / concentration): per-pixel nll and mean within 1e-4.
 Not part of the test suite; output appended to profiles/r01_fuzz_parity.txt.
 
   python tools/fuzz_ops.py [n_cases] [seed]
@@ -86,16 +87,54 @@ def estep_case(rng, dev):
   return 'lloyd_estep B=%d HW=%d C=%d K=%d' % (B, HW, C, K), ok
 
 
+def loss_case(rng, dev):
+  """SegSortLoss forward (both modes): the loss and every per-pixel nll within the north_star
+  tolerance 1e-4.  In 'segsort+' mode the reference forms the numerator as (sum over same-semantic
+  prototypes) - (own prototype) in fp32 (loss.py:63-66), which cancels when the own term dominates:
+  those pixels are summation-order noise in the reference itself (oracle and kernel sum in different
+  orders) and are left out of the '+' comparison (counted in the output)."""
+  from hsg_amd.utils.segsort.loss import SegSortLoss
+  n = int(rng.integers(1, 20000))
+  c = int(rng.choice([16, 32, 48, 64, 128, 256, int(rng.integers(2, 300))]))
+  P = int(rng.integers(1, 600))
+  nsem = int(rng.integers(1, 22))
+  kappa = int(rng.integers(4, 21))
+  seed = int(rng.integers(1, 1 << 30))
+  e = oracle.normalize_embedding(synth.gaussish(seed, n * c).reshape(n, c))
+  p = oracle.normalize_embedding(synth.gaussish(seed + 1, P * c).reshape(P, c))
+  inst = (synth.hash_u64(seed + 2, n) % np.uint64(P)).astype(np.int64)
+  psem = (synth.hash_u64(seed + 3, P) % np.uint64(nsem)).astype(np.int64)
+  sem = psem[inst]
+  t = lambda a: torch.from_numpy(a).to(dev)
+  # condition of the reference's own '+' numerator (same-semantic sum minus own term, fp32): pixels
+  # where the own term exceeds 100 x the remainder are summation-order noise in the reference
+  sims = np.exp(float(kappa) * (e.astype(np.float64) @ p.astype(np.float64).T))
+  own = sims[np.arange(n), inst]
+  same = (sims * (sem[:, None] == psem[None, :])).sum(1) - own
+  well = ~((same > 0) & (own > 100.0 * same))
+  ok, info = True, []
+  for mode in ('segsort+', 'segsort'):
+    nll = SegSortLoss(kappa, mode, reduction='none')(t(e), t(sem), t(inst), t(p), t(psem)).view(-1).cpu().numpy()
+    ref = oracle.segsort_nll(e, sem, inst, p, psem, float(kappa), mode)
+    sel = well if mode == 'segsort+' else np.ones(n, bool)
+    err = float(np.abs(nll - ref)[sel].max()) if sel.any() else 0.0
+    dm = abs(float(nll[sel].astype(np.float64).sum()) - float(ref[sel].astype(np.float64).sum())) / n
+    info.append('%s: |d loss| %.1e, max |d nll| %.1e' % (mode, dm, err))
+    ok = ok and dm <= 1e-4 and err <= 1e-4
+  return 'segsort_loss n=%d c=%d P=%d kappa=%d (%d ill-conditioned px) %s' % (
+      n, c, P, kappa, int((~well).sum()), '; '.join(info)), ok
+
+
 def main():
   n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
   rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
   dev = torch.device('cuda:0')
   bad, t0 = 0, time.time()
   for case in range(n_cases):
-    name, ok = (seg_case if case % 2 == 0 else estep_case)(rng, dev)
-    print('case %3d: %-52s %s' % (case, name, 'identical' if ok else 'DIFFERENT'), flush=True)
+    name, ok = (seg_case, estep_case, loss_case)[case % 3](rng, dev)
+    print('case %3d: %-60s  %s' % (case, name, ('within 1e-4' if name.startswith('segsort_loss') else 'identical') if ok else 'DIFFERENT'), flush=True)
     bad += 0 if ok else 1
-  print('%d of %d operator cases bit-identical to the oracle (%.0f s)' % (n_cases - bad, n_cases, time.time() - t0))
+  print('%d of %d operator cases agree with the oracle (bit-identical; loss: within 1e-4) (%.0f s)' % (n_cases - bad, n_cases, time.time() - t0))
   return 1 if bad else 0
 
 
