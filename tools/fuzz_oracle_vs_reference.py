@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Pins the ORACLE against the REAL reference on random inputs (runs only in the build container,
+where /root/reference exists; CPU only): hsg.utils.segsort.common.segment_by_kmeans (torch, CPU)
+against oracle.segment_by_kmeans on random shapes / grids / iteration counts / label maps.
+
+Integer outputs (labels, batch ids) must be identical and floats within 2e-6.  Cluster ids are
+identical unless a pixel sits on an fp32 near-tie between two centroids -- the reference's own
+float32 scatter_add sums and the oracle's exact sums differ in the last bits of the centroids --
+so a differing case is re-examined: every pixel whose id differs must have a top-2 score margin
+below 1e-5 in the iteration where the two runs first part.  The summary is committed as
+profiles/r01_oracle_vs_reference.txt.
+
+  python tools/fuzz_oracle_vs_reference.py [n_cases] [seed]
+"""
+import inspect
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, '/root/reference')
+
+import hsg.utils.segsort.common as ref_common         # noqa: E402
+from hsg_amd.utils import synth                       # noqa: E402
+from oracle import oracle                              # noqa: E402
+
+torch.set_num_threads(8)
+_src = inspect.getsource(ref_common.segment_by_kmeans)      # (same CPU shim as tools/gen_golden.py)
+_src = _src.replace('cur_cluster_indices.device.index', '(cur_cluster_indices.device.index or 0)')
+_ns = dict(ref_common.__dict__)
+exec(_src, _ns)
+ref_segment_by_kmeans = _ns['segment_by_kmeans']
+
+
+def main():
+  n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+  rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+  same = near = bad = 0
+  t0 = time.time()
+  for case in range(n_cases):
+    B = int(rng.integers(1, 4))
+    C = int(rng.choice([8, 16, 30, 32, 64, 100, 128, 256]))
+    H, W = int(rng.integers(8, 70)), int(rng.integers(8, 70))
+    gy, gx = int(rng.integers(1, min(H, 13))), int(rng.integers(1, min(W, 13)))
+    iters = int(rng.integers(0, 9))
+    kind = str(rng.choice(['iid', 'mixture']))
+    seed = int(rng.integers(1, 1 << 30))
+    mode = int(rng.integers(0, 3))
+    x = synth.embeddings_nchw(seed, (B, C, H, W), kind)
+    lab, ign = None, None
+    if mode == 1:
+      lab, ign = synth.overseg_labels(seed + 1, B, H, W, regions=int(rng.integers(2, 9)),
+                                      ignore_rows=int(rng.integers(0, 4))), 255
+    elif mode == 2:
+      lab = synth.overseg_labels(seed + 1, B, H, W, regions=int(rng.integers(2, 9)), ignore_rows=0)
+    ref = ref_segment_by_kmeans(torch.from_numpy(x), None if lab is None else torch.from_numpy(lab),
+                                [gy, gx], ignore_index=ign, iterations=iters)
+    ref = [t.numpy() for t in ref]
+    loc = oracle.generate_location_features((H, W)) - np.float32(0.5)
+    got = oracle.segment_by_kmeans(x, lab, (gy, gx), loc, ign, iters)
+    shapes = all(a.shape == b.shape for a, b in zip(got, ref))
+    ints = shapes and np.array_equal(got[2], ref[2]) and np.array_equal(got[4], ref[4])
+    flt = shapes and float(np.abs(got[0] - ref[0]).max(initial=0)) <= 2e-6 and \
+        float(np.abs(got[1] - ref[1]).max(initial=0)) <= 2e-6
+    ids = shapes and np.array_equal(got[3], ref[3])
+    verdict = 'identical'
+    if not (ints and flt):
+      verdict, bad = 'DIFFERENT (labels / batch ids / floats)', bad + 1
+    elif not ids:
+      # first iteration where the runs part, and the margins of the pixels that differ there
+      verdict = None
+      # (the Lloyd loop only uses the labels to drop ignored pixels; with all kept labels equal the
+      # returned ids are the k-means clusters themselves, not (cluster, label) pairs)
+      lab_a = None if (lab is None or ign is None) else np.where(lab == ign, ign, 0).astype(np.int64)
+      for it in range(iters + 1):
+        r_it = ref_segment_by_kmeans(torch.from_numpy(x), None if lab_a is None else torch.from_numpy(lab_a),
+                                     [gy, gx], ignore_index=ign, iterations=it)[3].numpy()
+        o_it = oracle.segment_by_kmeans(x, lab_a, (gy, gx), loc, ign, it)
+        if not np.array_equal(o_it[3], r_it):
+          diff = np.flatnonzero(o_it[3] != r_it)
+          # the two ids each differing pixel got, scored in fp64 under the centroids of the labels
+          # both runs still shared one iteration earlier
+          el = o_it[1].astype(np.float64)
+          worst = 1.0 if it == 0 else 0.0
+          if it > 0:
+            prev = oracle.segment_by_kmeans(x, lab_a, (gy, gx), loc, ign, it - 1)[3]
+            K = int(max(prev.max(), o_it[3].max(), r_it.max())) + 1
+            cent = np.zeros((K, el.shape[1]))
+            np.add.at(cent, prev, el)
+            cent /= np.maximum(np.linalg.norm(cent, axis=1, keepdims=True), 1e-12)
+            # (ids are dense ranks per call; map through the previous labels' id space: the E-step
+            # assigns ids of `prev`, relabelling keeps their order unless a cluster empties)
+            for px in diff:
+              img = o_it[4] == o_it[4][px]
+              sc = np.sort(cent[np.unique(prev[img])] @ el[px])
+              worst = max(worst, float(sc[-1] - sc[-2]) if len(sc) > 1 else 1.0)
+          verdict = 'near-tie: %d px part at iteration %d, largest top-2 margin %.1e' % (len(diff), it, worst)
+          if worst < 1e-5:
+            near += 1
+          else:
+            bad += 1
+            verdict = 'DIFFERENT (' + verdict + ')'
+          break
+    else:
+      same += 1
+    print('case %3d: B=%d C=%3d %2dx%2d grid %2dx%2d it=%d %-7s labels=%d seed=%d  %s' %
+          (case, B, C, H, W, gy, gx, iters, kind, mode, seed, verdict), flush=True)
+  print('%d cases: %d identical to the reference (cluster ids, labels, batch ids; floats <= 2e-6), '
+        '%d differ only on fp32 near-ties (margin < 1e-5), %d different  (%.0f s)' %
+        (n_cases, same, near, bad, time.time() - t0))
+  return 1 if bad else 0
+
+
+if __name__ == '__main__':
+  sys.exit(main())
