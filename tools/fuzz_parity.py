@@ -19,6 +19,9 @@ from hsg_amd.utils.segsort import common as sc   # noqa: E402
 from oracle import oracle                          # noqa: E402  (checker only)
 
 
+EXTREME = os.environ.get('HSGK_FUZZ_EXTREME') == '1'   # degenerate inputs instead of the two usual distributions
+
+
 def main():
   n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
   rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20260928)
@@ -31,9 +34,19 @@ def main():
     H, W = int(rng.integers(12, 90)), int(rng.integers(12, 90))
     gy, gx = int(rng.integers(1, min(H, 17))), int(rng.integers(1, min(W, 17)))
     iters = int(rng.integers(0, 9))
-    kind = str(rng.choice(['iid', 'mixture']))
+    kind = str(rng.choice(['iid', 'mixture'] if not EXTREME else ['zeros', 'const', 'tiny', 'huge', 'dup']))
     seed = int(rng.integers(1, 1 << 30))
-    x = synth.embeddings_nchw(seed, (B, C, H, W), kind)
+    x = synth.embeddings_nchw(seed, (B, C, H, W), 'mixture' if kind == 'mixture' else 'iid')
+    if kind == 'zeros':       # a third of the pixels are all-zero vectors (eps path of the first normalisation)
+      x = x * (synth.hash_u64(seed + 5, B * H * W) % np.uint64(3) != 0).astype(np.float32).reshape(B, 1, H, W)
+    elif kind == 'const':     # every pixel identical: all scores tie, location decides
+      x = np.broadcast_to(x[:, :, :1, :1], x.shape).copy()
+    elif kind == 'tiny':      # norms below eps
+      x = x * np.float32(1e-30)
+    elif kind == 'huge':      # squares near the top of the float32 range
+      x = x * np.float32(3e17)
+    elif kind == 'dup':       # pixel pairs with identical embeddings (exact score ties across neighbours)
+      x[:, :, :, 1::2] = x[:, :, :, 0:-1:2][:, :, :, :x[:, :, :, 1::2].shape[3]]
     mode = int(rng.integers(0, 3))          # 0: no labels, 1: oversegmentation + ignored rows, 2: labels without ignore
     lab, ign = None, 255
     if mode == 1:
