@@ -514,11 +514,16 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(
 
 // --------------------------------------------------------------------------
 // 32-pixel variant of the fast path: one workgroup handles HALF of a 64-pixel
-// compaction tile (blockIdx.x = 2 * tile + half).  33 KiB of LDS per workgroup
+// compaction tile (blockIdx.x = 2 * tile + half).  38 KiB of LDS per workgroup
 // instead of 66 -> four workgroups per CU, so the serial norm chains of one
 // workgroup (wave 0 only) overlap the load / divide / store phases of three
 // others.  PMC on the 64-pixel kernel showed waves 69 % waiting (barriers +
 // memory) with only two workgroups per CU.  Same arithmetic, same outputs.
+// The kernel is latency-bound (two workgroups per CU: +45 %; 15 % less VALU work: no
+// change), so the plane loads are issued before wave 0's bookkeeping, and it also
+// produces the first M-step of the Lloyd loop: the exact fixed-point sums of its rows
+// under their seed-grid labels (PrepM0, common.h).
+// Phase timers for tools/probes/prep_timing.py: make EXTRA=-DHSGK_PREP_TIMING.
 #ifdef HSGK_PREP_TIMING
 __device__ unsigned long long g_prep_ts[8];
 #define HSGK_TS(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \

@@ -215,6 +215,10 @@ __global__ __launch_bounds__(NW * 64) void update_sums_kernel(
 // table is flushed with global atomics only when the workgroup's image changes -- about 5 M
 // global atomics per launch instead of one flush per chunk (17 M), which is what bounded the
 // late iterations where only a few per cent of the rows move.
+// The LDS atomic rate bounds the kernel (tripling the atomics multiplies every launch by 2.4;
+// a ds_add_u64 costs ~9 cycles whatever the number of active lanes), hence: the d mod 4 tail
+// columns of a whole batch of rows share one atomic per side, and consecutive changed rows
+// of one cluster add up in registers first (run-length carries; pixels are in raster order).
 // NV: 16-byte vectors per lane and row (1: d <= 259, 2: d <= 515)
 template <int NW, int UNROLL, int NV>
 __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
