@@ -19,6 +19,7 @@ from hsg_amd.utils.segsort import common as sc   # noqa: E402
 from oracle import oracle                          # noqa: E402  (checker only)
 
 
+LARGE = os.environ.get('HSGK_FUZZ_LARGE') == '1'       # image sides 90..329: many chunks / passes per image
 EXTREME = os.environ.get('HSGK_FUZZ_EXTREME') == '1'   # degenerate inputs instead of the two usual distributions
 
 
@@ -31,7 +32,8 @@ def main():
   for case in range(n_cases):
     B = int(rng.integers(1, 4))
     C = int(rng.choice([32, 64, 128, 192, 256, 256, 320, 384, 30, 100]))
-    H, W = int(rng.integers(12, 90)), int(rng.integers(12, 90))
+    H, W = (int(rng.integers(12, 90)), int(rng.integers(12, 90))) if not LARGE else \
+        (int(rng.integers(90, 330)), int(rng.integers(90, 330)))
     gy, gx = int(rng.integers(1, min(H, 17))), int(rng.integers(1, min(W, 17)))
     iters = int(rng.integers(0, 9))
     kind = str(rng.choice(['iid', 'mixture'] if not EXTREME else ['zeros', 'const', 'tiny', 'huge', 'dup']))
