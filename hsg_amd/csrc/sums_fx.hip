@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void finalize_fx_kernel(const long long *__res
 // sumq[b][k][:] += the prep workgroups' partial sums whose label is k.  Workgroup per (k, image):
 // the image's label list is scanned 2048 entries at a time into an LDS list of the matching
 // entries (order is free: integer sums), then thread = column adds the listed partial rows,
-// four independent loads in flight per column pass.
+// sixteen independent loads in flight per column pass.
 __global__ __launch_bounds__(256) void m0_reduce_kernel(const long long *__restrict__ part,
                                                         const int32_t *__restrict__ lab, int entries,
                                                         int d, int K, long long *__restrict__ sumq) {
@@ -450,19 +450,16 @@ __global__ __launch_bounds__(256) void m0_reduce_kernel(const long long *__restr
       }
       __syncthreads();
       const int n = cnt;
-      for (int i = 0; i < n; i += 4) {
-        long long v[4][4];
+      const int npass = min(4, (d - c0 + 255) / 256);       // column passes of this window that exist
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const long long *row = pb + (int64_t)list[min(i + u, n - 1)] * d;
+      for (int p = 0; p < 4; ++p)
+        for (int i = 0; p < npass && i < n; i += 16) {       // 16 partial rows in flight per thread
+          long long v[16];
 #pragma unroll
-          for (int p = 0; p < 4; ++p) v[u][p] = row[col[p]];
+          for (int u = 0; u < 16; ++u) v[u] = pb[(int64_t)list[min(i + u, n - 1)] * d + col[p]];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc[p] += (i + u < n) ? v[u] : 0ll;
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int p = 0; p < 4; ++p) acc[p] += (i + u < n) ? v[u][p] : 0ll;
-      }
       __syncthreads();
     }
 #pragma unroll
