@@ -224,16 +224,23 @@ template <int NW, int UNROLL, int NV>
 __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
     const float *__restrict__ x, int d, const int32_t *__restrict__ prev,
     const int32_t *__restrict__ cur, const int64_t *__restrict__ chunk_row0,
-    const int32_t *__restrict__ chunk_rows, const int32_t *__restrict__ chunk_img, int K,
+    const int32_t *__restrict__ chunk_rows, const int32_t *__restrict__ chunk_img, int K, int P,
     unsigned long long *__restrict__ sumq, const hsgk_segkm_meta *__restrict__ meta) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  unsigned long long *tab = reinterpret_cast<unsigned long long *>(lds_raw);          // [K][d]
-  uint32_t *lists = reinterpret_cast<uint32_t *>(tab + (size_t)K * d + 2);            // [NW][256]
+  // P workgroups share one chunk range, each owning the clusters [k0, k0 + kn) (P = 1 when the
+  // whole table fits LDS): a workgroup reads the rows that leave or join ITS clusters
+  const int KP = (K + P - 1) / P;
+  const int part_k = (int)(blockIdx.x % (unsigned)P), range = (int)(blockIdx.x / (unsigned)P);
+  const int nranges = (int)(gridDim.x / (unsigned)P);
+  const int k0 = part_k * KP, kn = min(KP, K - k0);
+  unsigned long long *tab = reinterpret_cast<unsigned long long *>(lds_raw);          // [KP][d]
+  uint32_t *lists = reinterpret_cast<uint32_t *>(tab + (size_t)KP * d + 2);           // [NW][256]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   uint32_t *list = lists + w * 256;
   const int nc = (int)meta->n_chunks;
-  const int c_begin = (int)(((int64_t)blockIdx.x * nc) / gridDim.x);
-  const int c_end = (int)(((int64_t)(blockIdx.x + 1) * nc) / gridDim.x);
+  const int c_begin = (int)(((int64_t)range * nc) / nranges);
+  const int c_end = (int)(((int64_t)(range + 1) * nc) / nranges);
+  if (kn <= 0) return;
   typedef float gvec_t __attribute__((ext_vector_type(4), aligned(4)));
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
   const int nq = d / 4, tail0 = nq * 4;
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
     int ce = c + 1;
     while (ce < c_end && chunk_img[ce] == b) ++ce;
     {
-      const int tot2 = (K * d + 1) / 2;
+      const int tot2 = (kn * d + 1) / 2;
       u64x2 *t2 = reinterpret_cast<u64x2 *>(tab);
       for (int i = tid; i < tot2; i += NW * 64) t2[i] = u64x2{0ull, 0ull};
     }
@@ -304,11 +311,13 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
       int total = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const bool ch = pl[i] != cl[i];
+        // labels local to this workgroup's clusters, + 1 (0: not one of them / not added yet)
+        const uint32_t ln = (uint32_t)(cl[i] - k0) < (uint32_t)kn ? (uint32_t)(cl[i] - k0 + 1) : 0u;
+        const uint32_t lo = (uint32_t)(pl[i] - k0) < (uint32_t)kn ? (uint32_t)(pl[i] - k0 + 1) : 0u;
+        const bool ch = pl[i] != cl[i] && (ln | lo) != 0u;
         const unsigned long long m = __ballot(ch);
-        if (ch)   // row (8 bits) | new label + 1 (11 bits) | old label + 1 (11 bits, 0 = not added yet)
-          list[total + __popcll(m & ((1ull << lane) - 1ull))] =
-              ((uint32_t)(64 * i + lane) << 22) | ((uint32_t)(cl[i] + 1) << 11) | (uint32_t)(pl[i] + 1);
+        if (ch)   // row (8 bits) | new label + 1 (11 bits) | old label + 1 (11 bits)
+          list[total + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)(64 * i + lane) << 22) | (ln << 11) | lo;
         total += __popcll(m);
       }
       if (total == 0) continue;
@@ -375,8 +384,8 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
     flush_run(1);
     __syncthreads();
     // ---- flush the image's table
-    unsigned long long *gq = sumq + (int64_t)b * K * d;
-    for (int i = tid; i < K * d; i += NW * 64) {
+    unsigned long long *gq = sumq + ((int64_t)b * K + k0) * d;
+    for (int i = tid; i < kn * d; i += NW * 64) {
       const unsigned long long v = tab[i];
       if (v) atomicAdd(gq + i, v);
     }
@@ -486,9 +495,12 @@ int launch_update_sums(const float *x, int d, const int32_t *prev, const int32_t
   if (max_chunks <= 0) return 0;
   HSGK_REQUIRE(K <= 1023, "too many clusters for the exact-sum update (11-bit label fields)");
   {
-    // persistent big-table variant when one image's table fits LDS
+    // persistent variant: the image's table in LDS, split by clusters over P <= 8 workgroups
+    // when it does not fit one (every part re-scans the labels and reads the rows of its clusters)
     constexpr int NWP = 8;
-    const size_t ldsp = (size_t)K * d * 8 + 16 + (size_t)NWP * 256 * 4 + 32;
+    int P = 1;
+    while (P < 8 && (size_t)((K + P - 1) / P) * d * 8 + 16 + (size_t)NWP * 256 * 4 + 32 > 150 * 1024) ++P;
+    const size_t ldsp = (size_t)((K + P - 1) / P) * d * 8 + 16 + (size_t)NWP * 256 * 4 + 32;
     if (ldsp <= 150 * 1024 && d <= 515 && d >= 4) {
       static const int n_cu = [] {
         int dev = 0, cus = 256;
@@ -499,9 +511,9 @@ int launch_update_sums(const float *x, int d, const int32_t *prev, const int32_t
       auto kp = d / 4 <= 64 ? update_sums_persistent_kernel<NWP, 8, 1> : update_sums_persistent_kernel<NWP, 8, 2>;
       HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kp),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
-      const int grid = max_chunks < n_cu ? max_chunks : n_cu;
-      hipLaunchKernelGGL(kp, dim3(grid), dim3(NWP * 64), ldsp, s, x, d, prev, cur, t.chunk_row0,
-                         t.chunk_rows, t.chunk_img, K, reinterpret_cast<unsigned long long *>(sumq), meta);
+      const int nranges = max_chunks < n_cu / P ? max_chunks : (n_cu / P > 0 ? n_cu / P : 1);
+      hipLaunchKernelGGL(kp, dim3(nranges * P), dim3(NWP * 64), ldsp, s, x, d, prev, cur, t.chunk_row0,
+                         t.chunk_rows, t.chunk_img, K, P, reinterpret_cast<unsigned long long *>(sumq), meta);
       HSGK_LAUNCH_CHECK();
       return 0;
     }
