@@ -39,6 +39,7 @@ WORKLOADS = {
     'cfg3': (16, 256, 224, 224, (8, 8), 10),
     'cfg5': (24, 384, 224, 224, (8, 16), 10),
     'cfg1': (4, 32, 64, 64, (2, 4), 10),
+    'cfg4': (4, 256, 768, 768, (16, 16), 10),      # finest level of the 256/64/16 hierarchy, 4 of 16 images per GPU
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 
