@@ -1,0 +1,17 @@
+"""Exact-queue statistics per iteration (debug build: make -C hsg_amd/csrc EXTRA=-DHSGK_Q_STATS): entries by
+candidate count (1, 2, 3, all-K)."""
+import ctypes, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from hsg_amd import _lib
+from hsg_amd.utils.segsort import common as sc
+L = _lib.lib()
+B, C, H, W, grid = (4, 256, 768, 768, [16, 16]) if len(sys.argv) < 2 else (48, 256, 448, 448, [8, 8])
+x = torch.randn((B, C, H, W), device='cuda:0')
+out = (ctypes.c_ulonglong * 8)()
+prev = [0] * 8
+for it in range(1, 5):
+  sc.segment_by_kmeans(x, None, grid, iterations=it); torch.cuda.synchronize()
+  L.hsgk_debug_qstats(out)
+  cur = list(out)
+  print('iterations 1..%d: entries with 1 / 2 / 3 candidates, all-K: %s' % (it, cur[1:5]), ' of', B * H * W, 'rows per iteration')
