@@ -424,6 +424,9 @@ __device__ __forceinline__ float exact_chain(const float *__restrict__ ck, const
   return acc;
 }
 
+#ifdef HSGK_Q_STATS
+__device__ unsigned long long g_qstats[8];   // debug build: exact-queue entries by candidate count
+#endif
 __global__ __launch_bounds__(256) void assign_requeue_rows_kernel(
     const float *__restrict__ x, int d, const float *__restrict__ cent, int K,
     int32_t *__restrict__ klab, const SplitEntry *__restrict__ gqueue,
@@ -440,6 +443,9 @@ __global__ __launch_bounds__(256) void assign_requeue_rows_kernel(
     const int n = e < total ? (int)(ent.cand >> 24) : 0;
     const int k = (int)((ent.cand >> (8 * ci)) & 255u);
     const bool act = n != 255 && ci < n;
+#ifdef HSGK_Q_STATS
+    if (ci == 0 && e < total) atomicAdd(&g_qstats[n == 255 ? 4 : n], 1ull);   // (tools/probes/qstats.py)
+#endif
     float acc = -INFINITY;
     if (act) acc = exact_chain(cent + ((int64_t)ent.img * K + k) * d, x + (int64_t)ent.row * d, d);
     float bv = (act && acc == acc) ? acc : -INFINITY;     // NaN never wins
@@ -1260,3 +1266,14 @@ int launch_assign(const float *x, int d, const float *cent, int K, const ChunkTa
 }
 
 }  // namespace hsgk
+
+#ifdef HSGK_Q_STATS
+extern "C" __attribute__((visibility("default"))) int hsgk_debug_qstats(unsigned long long *out) {
+  unsigned long long h[8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(hsgk::g_qstats), sizeof(h)) != hipSuccess) return -1;
+  for (int i = 0; i < 8; ++i) out[i] = h[i];
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(hsgk::g_qstats), z, sizeof(z));
+  return 0;
+}
+#endif
