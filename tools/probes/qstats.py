@@ -6,7 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from hsg_amd import _lib
 from hsg_amd.utils.segsort import common as sc
 L = _lib.lib()
-B, C, H, W, grid = (4, 256, 768, 768, [16, 16]) if len(sys.argv) < 2 else (48, 256, 448, 448, [8, 8])
+SHAPES = {'cfg4': (4, 256, 768, 768, [16, 16]), 'cfg2': (48, 256, 448, 448, [8, 8]), 'cfg5': (24, 384, 224, 224, [8, 16]),
+          'cfg3': (16, 256, 224, 224, [8, 8])}
+B, C, H, W, grid = SHAPES[sys.argv[1] if len(sys.argv) > 1 else 'cfg4']
 x = torch.randn((B, C, H, W), device='cuda:0')
 out = (ctypes.c_ulonglong * 8)()
 prev = [0] * 8
