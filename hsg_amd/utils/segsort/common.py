@@ -125,7 +125,12 @@ class _SegmentByKmeans(torch.autograd.Function):
           out_rowmap=rowmap.data_ptr() if rowmap is not None else None,
           workspace=ws.data_ptr(), workspace_bytes=ws_bytes)
       _lib.check(L.hsgk_segment_by_kmeans(ctypes.byref(args), _lib.stream_ptr()))
-      m = meta.cpu().tolist()          # the operator's single host sync
+      if lab is None:
+        # no label map: every pixel is kept and neither data-dependent error can occur, so the
+        # row count is known on the host and the call stays asynchronous (no host sync at all)
+        m = [n_max, 0, 0, 0, 0, 0, 0, 0]
+      else:
+        m = meta.cpu().tolist()        # the operator's single host sync
     n, err = m[0], m[5]
     if err == 1:
       raise ValueError('segment_by_kmeans: negative labels are not supported')
