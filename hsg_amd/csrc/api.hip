@@ -188,27 +188,15 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
       { ProfScope p(HSGK_PROF_FINALIZE, s);
         if (int rc = launch_finalize(k.partial, k.pmask, d, K, B, k.t, k.max_chunks / B, HSGK_EPS, k.cent, s)) return rc; }
     }
-    // First E-step after the seed grid with a two-half table (128 < K <= 256): the seed centroids
-    // differ mostly in their location part, scores change slowly across a cell boundary, and the
-    // hi-plane fp16 filter (gap ~7e-4) leaves a band of ~4 pixels on each side of every boundary
-    // undecided -- 39 % of the rows at K = 256 on 768 x 768, a tenth of them with more than three
-    // candidates: 5.3 ms of exact chains.  The plain fp32 MFMA kernel is cheaper for that one
-    // iteration (19.5 -> 16.5 ms per call; not for K <= 128: measured).  HSGK_FIRST_EXACT=0: off.
-    static const bool first_exact = [] {
-      const char *e = getenv("HSGK_FIRST_EXACT");
-      return !(e && e[0] == '0');
-    }();
-    const bool exact_now = it == 0 && m0_ready && wide2 && first_exact;
     { ProfScope p(HSGK_PROF_ASSIGN, s);
-      if (int rc = exact_now ? launch_assign(x, d, k.cent, K, k.t, k.max_chunks, cur, k.best, meta, s)
-               : half ? launch_assign_half(x, k.xh, k.xt, d, k.cent, K, B, k.t, k.max_chunks, cur, k.q1,
+      if (int rc = half ? launch_assign_half(x, k.xh, k.xt, d, k.cent, K, B, k.t, k.max_chunks, cur, k.q1,
                                              k.q1count, k.q1cap, k.qrows, k.qcount, meta, s, counters_zeroed)
                : wide ? launch_assign_half_wide(x, k.xh, k.xt, d, k.cent, k.errc, K, B, k.t, k.max_chunks, cur,
                                                 k.qrows, k.qcount, meta, s)
                : wide2 ? launch_assign_half_wide2(x, k.xh, k.xt, d, k.cent, k.errc, K, B, k.t, k.max_chunks,
                                                   cur, k.state, k.qrows, k.qcount, meta, s)
                : unit_rows && assign_mode() >= 1
-                   ? launch_assign_fast(x, d, k.cent, K, k.t, k.max_chunks, cur, k.best,
+                   ? launch_assign_fast(x, d, k.cent, K, B, k.t, k.max_chunks, cur, k.best,
                                         k.qrows, k.qcount, meta, s)
                    : launch_assign(x, d, k.cent, K, k.t, k.max_chunks, cur, k.best, meta, s))
         return rc; }
@@ -437,7 +425,7 @@ int hsgk_lloyd_estep(const float *x, int B, int64_t rows_per_image, int d, int K
                                     k.state, k.qrows, k.qcount, meta, s);
   }
   if (unit_rows)
-    return launch_assign_fast(x, d, centroids, K, k.t, k.max_chunks, labels_out, k.best, k.qrows,
+    return launch_assign_fast(x, d, centroids, K, B, k.t, k.max_chunks, labels_out, k.best, k.qrows,
                               k.qcount, meta, s);
   return launch_assign(x, d, centroids, K, k.t, k.max_chunks, labels_out, k.best, meta, s);
 }

@@ -125,7 +125,7 @@ int launch_assign(const float *x, int d, const float *cent, int K,
 
 // unit-norm fast path (bf16 split filter + exact re-score); falls back to
 // launch_assign when the shape is not eligible or HSGK_ASSIGN=fp32
-int launch_assign_fast(const float *x, int d, const float *cent, int K, const ChunkTable &t,
+int launch_assign_fast(const float *x, int d, const float *cent, int K, int B, const ChunkTable &t,
                        int max_chunks, int32_t *klab, float *best, void *qrows,
                        int32_t *qcount, const hsgk_segkm_meta *meta, hipStream_t s);
 

@@ -253,7 +253,10 @@ __global__ __launch_bounds__(NW * 64) void assign_kernel(
 // superset of all exact maximisers, see score_tiles_bf16.h).  cand = up to three
 // indices in bytes 0..2 and their count in byte 3; count 255 = "more than three,
 // re-score all K".
-struct SplitEntry { int32_t row; uint32_t cand; int32_t img; };
+// Exact-queue entry: row id + up to seven candidate clusters.  cand = c0 | c1 << 8 | c2 << 16 |
+// n << 24 (n = 1..7 candidates; 255: re-score all K), cand_hi = c3 | c4 << 8 | c5 << 16 | c6 << 24.
+// The image of a row is found from the row offsets (binary search) by the exact pass.
+struct SplitEntry { int32_t row; uint32_t cand; uint32_t cand_hi; };
 constexpr int kSplitLdsList = 1024;      // per-workgroup staging of entries (6 B each)
 
 struct SplitEpi {
@@ -324,7 +327,7 @@ struct SplitEpi {
         qcand[pos] = cand;
       } else {                                               // staging full: straight to global
         const int g = atomicAdd(gcount, 1);
-        gqueue[g] = SplitEntry{(int32_t)grow, cand, img};
+        gqueue[g] = SplitEntry{(int32_t)grow, cand, 0u};
       }
     }
   }
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(NW * 64) void assign_split_kernel(
       __syncthreads();
       const int base = qnp[1];
       for (int i = threadIdx.x; i < qn; i += NW * 64)
-        gqueue[base + i] = SplitEntry{(int32_t)(crow0 + qpx[i]), qcand[i], b};
+        gqueue[base + i] = SplitEntry{(int32_t)(crow0 + qpx[i]), qcand[i], 0u};
     }
     __syncthreads();                        // queue drained before the next chunk resets it
   }
@@ -430,7 +433,7 @@ __device__ unsigned long long g_qstats[8];   // debug build: exact-queue entries
 __global__ __launch_bounds__(256) void assign_requeue_rows_kernel(
     const float *__restrict__ x, int d, const float *__restrict__ cent, int K,
     int32_t *__restrict__ klab, const SplitEntry *__restrict__ gqueue,
-    const int32_t *__restrict__ gcount) {
+    const int32_t *__restrict__ gcount, const int64_t *__restrict__ img_row0, int B) {
   const int lane = threadIdx.x & 63;
   const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
@@ -438,38 +441,59 @@ __global__ __launch_bounds__(256) void assign_requeue_rows_kernel(
   const int grp = lane >> 2, ci = lane & 3;
   for (int e0 = wave * 16; e0 < total; e0 += nwaves * 16) {
     const int e = e0 + grp;
-    SplitEntry ent{0, 0u, 0};
+    SplitEntry ent{0, 0u, 0u};
     if (e < total) ent = gqueue[e];
     const int n = e < total ? (int)(ent.cand >> 24) : 0;
-    const int k = (int)((ent.cand >> (8 * ci)) & 255u);
+    // image of the row: last b with img_row0[b] <= row
+    int img = 0;
+    {
+      int hi = B;
+      while (hi - img > 1) {
+        const int mid = (img + hi) >> 1;
+        if (img_row0[mid] <= (int64_t)ent.row) img = mid; else hi = mid;
+      }
+    }
+    // candidate ci, and candidate ci + 4 for the entries that carry more than four
+    const int ka = (int)(ci < 3 ? (ent.cand >> (8 * ci)) & 255u : ent.cand_hi & 255u);
+    const int kb = (int)((ent.cand_hi >> (8 * (ci + 1))) & 255u);           // (ci + 4 <= 6: ci <= 2)
     const bool act = n != 255 && ci < n;
+    const bool act2 = n != 255 && ci < 3 && ci + 4 < n;
 #ifdef HSGK_Q_STATS
-    if (ci == 0 && e < total) atomicAdd(&g_qstats[n == 255 ? 4 : n], 1ull);   // (tools/probes/qstats.py)
+    if (ci == 0 && e < total) atomicAdd(&g_qstats[n == 255 ? 7 : min(n, 6)], 1ull);   // (tools/probes/qstats.py)
 #endif
+    const float *xr = x + (int64_t)ent.row * d;
+    const float *ct = cent + (int64_t)img * K * d;
     float acc = -INFINITY;
-    if (act) acc = exact_chain(cent + ((int64_t)ent.img * K + k) * d, x + (int64_t)ent.row * d, d);
+    if (act) acc = exact_chain(ct + (int64_t)ka * d, xr, d);
     float bv = (act && acc == acc) ? acc : -INFINITY;     // NaN never wins
-    int bi = act ? k : 0x7fffffff;
+    int bi = act ? ka : 0x7fffffff;
+    if (__any(act2)) {
+      float acc2 = -INFINITY;
+      if (act2) acc2 = exact_chain(ct + (int64_t)kb * d, xr, d);
+      const float v2 = (act2 && acc2 == acc2) ? acc2 : -INFINITY;
+      const int i2 = act2 ? kb : 0x7fffffff;
+      if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+    }
 #pragma unroll
     for (int off = 1; off <= 2; off <<= 1) {
       const float ov = __shfl_xor(bv, off);
       const int oi = __shfl_xor(bi, off);
       if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
-    if (ci == 0 && n >= 1 && n <= 3) klab[ent.row] = bi == 0x7fffffff ? 0 : bi;
+    if (ci == 0 && n >= 1 && n <= 7) klab[ent.row] = bi == 0x7fffffff ? 0 : bi;
     // rare: entries that need all K centroids, one at a time on the whole wave
     unsigned long long hard = __ballot(ci == 0 && n == 255);
     while (hard) {
       const int src = __builtin_ctzll(hard);
       hard &= hard - 1;
       const int row = __builtin_amdgcn_readlane(ent.row, src);
-      const int img = __builtin_amdgcn_readlane(ent.img, src);
+      const int himg = __builtin_amdgcn_readlane(img, src);
       float hv = -INFINITY;
       int hi = 0x7fffffff;
       for (int k0 = 0; k0 < K; k0 += 64) {                    // lane = centroid k0 + lane, first maximum wins
         const int k = k0 + lane;
         float a = -INFINITY;
-        if (k < K) a = exact_chain(cent + ((int64_t)img * K + k) * d, x + (int64_t)row * d, d);
+        if (k < K) a = exact_chain(cent + ((int64_t)himg * K + k) * d, x + (int64_t)row * d, d);
         if (k < K && a == a && a > hv) { hv = a; hi = k; }
       }
       if (hi == 0x7fffffff) hi = lane;                         // (all NaN: lowest lane index, as before)
@@ -483,7 +507,7 @@ __global__ __launch_bounds__(256) void assign_requeue_rows_kernel(
   }
 }
 
-static int launch_assign_split(const float *x, int d, const float *cent, int K,
+static int launch_assign_split(const float *x, int d, const float *cent, int K, int B,
                                const ChunkTable &t, int max_chunks, int32_t *klab,
                                SplitEntry *gqueue, int32_t *gcount, const hsgk_segkm_meta *meta,
                                hipStream_t s) {
@@ -514,7 +538,7 @@ static int launch_assign_split(const float *x, int d, const float *cent, int K,
   // exact pass over the (chip-wide balanced) queue; its length is only known on
   // the device, so a fixed grid strides over it
   hipLaunchKernelGGL(assign_requeue_rows_kernel, dim3(2048), dim3(256), 0, s, x, d, cent, K, klab,
-                     gqueue, gcount);
+                     gqueue, gcount, t.img_row0, B);
   HSGK_LAUNCH_CHECK();
   return 0;
 }
@@ -694,9 +718,9 @@ struct HalfWideEpi {
     const bool amb = valid && !(t1 - t2 > gap);               // ambiguous (or NaN)
     if (h == 0 && valid) klab[crow0 + px] = ti;               // provisional for ambiguous rows
     if (!__any(amb)) return;
-    // candidates of this lane's half, merged with the partner half (<= 3, else "all")
+    // candidates of this lane's half, merged with the partner half (<= 7, else "all")
     const float thr = t1 - gap;
-    uint32_t list = 0;
+    unsigned long long list = 0;
     int cnt = 0;
 #pragma unroll
     for (int m = 0; m < MB; ++m)
@@ -707,20 +731,23 @@ struct HalfWideEpi {
         list = hit ? ((list << 8) | k) : list;
         cnt += hit ? 1 : 0;
       }
-    const uint32_t olist = __shfl_xor(list, 32);
+    const unsigned long long olist = __shfl_xor(list, 32);
     const int ocnt = __shfl_xor(cnt, 32);
     const int tot = cnt + ocnt;
-    uint32_t cand = 255u << 24;
-    if (tot <= 3 && tot >= 1 && t1 == t1)
-      cand = (list & ((1u << (8 * cnt)) - 1u)) | (olist << (8 * cnt)) | ((uint32_t)tot << 24);
+    uint32_t cand = 255u << 24, cand_hi = 0u;
+    if (tot <= 7 && tot >= 1 && t1 == t1) {
+      const unsigned long long all = (list & ((1ull << (8 * cnt)) - 1ull)) | (olist << (8 * cnt));
+      cand = (uint32_t)(all & 0xFFFFFFull) | ((uint32_t)tot << 24);
+      cand_hi = (uint32_t)(all >> 24);
+    }
     if (h == 0 && amb) {
-      const int pos = atomicAdd(qn, 1);
+      const int pos = tot <= 3 || tot > 7 ? atomicAdd(qn, 1) : kSplitLdsList;   // (the staging holds one word per entry)
       if (pos < kSplitLdsList) {
         qpx[pos] = (uint16_t)px;
         qcand[pos] = cand;
       } else {
         const int g = atomicAdd(gcount, 1);
-        gqueue[g] = SplitEntry{(int32_t)(crow0 + px), cand, img};
+        gqueue[g] = SplitEntry{(int32_t)(crow0 + px), cand, cand_hi};
       }
     }
   }
@@ -771,7 +798,7 @@ __global__ __launch_bounds__(NW * 64) void assign_half_wide_kernel(
       __syncthreads();
       const int base = qnp[1];
       for (int i = threadIdx.x; i < qn; i += NW * 64)
-        gqueue[base + i] = SplitEntry{(int32_t)(crow0 + qpx[i]), qcand[i], b};
+        gqueue[base + i] = SplitEntry{(int32_t)(crow0 + qpx[i]), qcand[i], 0u};
     }
     __syncthreads();
     r += nrows;
@@ -812,7 +839,7 @@ int launch_assign_half_wide(const float *x, const _Float16 *xm, const uint2 *xt,
     HSGK_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(assign_requeue_rows_kernel, dim3(2048), dim3(256), 0, s, x, d, cent, K, klab,
-                     reinterpret_cast<const SplitEntry *>(qrows), qcount);
+                     reinterpret_cast<const SplitEntry *>(qrows), qcount, t.img_row0, B);
   HSGK_LAUNCH_CHECK();
   return 0;
 }
@@ -825,54 +852,69 @@ int launch_assign_half_wide(const float *x, const _Float16 *xm, const uint2 *xt,
 // an undecided row is then known exactly unless three first-half scores lie within the gap
 // (such rows are re-scored against all K centroids by the whole-wave path).
 // running top-3 of a lane's scores (values) with the indices of the two best; branch-free
-struct Top3 {
-  float b1 = -INFINITY, b2 = -INFINITY, b3 = -INFINITY;
-  int i1 = 0, i2 = 0;
-  __device__ inline void push(float v, int k) {
-    const float n3 = fmaxf(b3, fminf(b2, v)), n2 = fmaxf(b2, fminf(b1, v));
-    i2 = v > b1 ? i1 : (v > b2 ? k : i2);
-    i1 = v > b1 ? k : i1;
-    b1 = fmaxf(b1, v);
-    b2 = n2;
-    b3 = n3;
-  }
-  // merge with the partner half-lane's (sorted) triple; lower index first on ties of the maxima
-  __device__ inline void merge(float o1, float o2, float o3, int oi1, int oi2) {
-    const bool mine = b1 > o1 || (b1 == o1 && i1 <= oi1);
-    const float w1 = mine ? b1 : o1, w2 = mine ? b2 : o2, w3 = mine ? b3 : o3;      // winner's triple
-    const float l1 = mine ? o1 : b1, l2 = mine ? o2 : b2;                              // loser's two best
-    const int wi1 = mine ? i1 : oi1, wi2 = mine ? i2 : oi2, li1 = mine ? oi1 : i1;
-    const bool second_w = w2 >= l1;                                // second overall: winner's 2nd or loser's 1st
-    b1 = w1; i1 = wi1;
-    b2 = second_w ? w2 : l1;
-    i2 = second_w ? wi2 : li1;
-    b3 = second_w ? fmaxf(w3, l1) : fmaxf(w2, l2);
-  }
-};
-
+// First half of a two-half pass: per row the best and second-best score (exact), the index of
+// the best, and the indices of ALL first-half centroids within the row's gap of that best (at
+// most four; more: flag) -- a superset of the first-half members of the final candidate set
+// {k : score >= overall best - gap}, whose threshold can only be higher.
+// Record: {best, second, idx0 | idx1 << 8 | idx2 << 16 | idx3 << 24 (idx0 = best), count (1..4; 255: more)}.
 template <int MB>
 struct HalfStateEpi {
   int K, nrows;
   int64_t crow0;
-  uint4 *state;                // {best, second, third value, index of best | index of second << 16}
-  __device__ inline void operator()(int tile, const f32x16 (&sacc)[MB], float) const {
+  float errc_max;
+  uint4 *state;
+  __device__ inline void operator()(int tile, const f32x16 (&sacc)[MB], float err) const {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int TPX = (int)(blockDim.x >> 1);
-    Top3 t;
+    float b1 = -INFINITY, b2 = -INFINITY;
+    int bi = 0;
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        t.push(k < K ? sacc[m][r] : -INFINITY, k);
+        const float v = k < K ? sacc[m][r] : -INFINITY;
+        b2 = fmaxf(b2, fminf(b1, v));
+        bi = v > b1 ? k : bi;
+        b1 = fmaxf(b1, v);
       }
-    t.merge(__shfl_xor(t.b1, 32), __shfl_xor(t.b2, 32), __shfl_xor(t.b3, 32), __shfl_xor(t.i1, 32),
-            __shfl_xor(t.i2, 32));
+    const float o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
+    const int oi = __shfl_xor(bi, 32);
+    float t1, t2;
+    int ti;
+    if (o1 > b1 || (o1 == b1 && oi < bi)) { t1 = o1; ti = oi; t2 = fmaxf(b1, o2); }
+    else { t1 = b1; ti = bi; t2 = fmaxf(o1, b2); }
+    const float gap = half_wide_gap(err, errc_max);
+    uint32_t idx = (uint32_t)ti, count = 1u;
+    if (__any(!(t1 - t2 > gap))) {                             // some row of the wave has close seconds
+      const float thr = t1 - gap;
+      uint32_t list = 0;
+      int cnt = 0;
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const bool hit = k < (uint32_t)K && k != (uint32_t)ti && sacc[m][r] >= thr;   // (NaN never hits)
+          list = hit ? ((list << 8) | k) : list;
+          cnt += hit ? 1 : 0;
+        }
+      const uint32_t olist = __shfl_xor(list, 32);
+      const int ocnt = __shfl_xor(cnt, 32);
+      const int tot = cnt + ocnt;                              // besides the best itself
+      if (tot <= 3) {
+        const uint32_t others = (cnt ? (list & ((1u << (8 * cnt)) - 1u)) : 0u) | (cnt < 4 ? olist << (8 * cnt) : 0u);
+        idx |= others << 8;
+        count = 1u + (uint32_t)tot;
+      } else {
+        count = 255u;
+      }
+      if (!(t1 == t1)) count = 255u;                           // NaN scores: leave it to the exact pass
+    }
     const int px = tile * TPX + w * 32 + j;
     if (h == 0 && px < nrows)
-      state[crow0 + px] = make_uint4(__float_as_uint(t.b1), __float_as_uint(t.b2), __float_as_uint(t.b3),
-                                     (uint32_t)t.i1 | ((uint32_t)t.i2 << 16));
+      state[crow0 + px] = make_uint4(__float_as_uint(t1), __float_as_uint(t2), idx, count);
   }
 };
 
@@ -911,22 +953,22 @@ struct HalfMergeEpi {
     if (o1 > b1 || (o1 == b1 && oi < bi)) { u1 = o1; ui = oi; u2 = fmaxf(b1, o2); }
     else { u1 = b1; ui = bi; u2 = fmaxf(o1, b2); }
     // merge with the first half (lower indices win ties)
-    const float a1 = __uint_as_float(st[0]), a2 = __uint_as_float(st[1]), a3 = __uint_as_float(st[2]);
-    const int ai1 = (int)(st[3] & 0xFFFFu), ai2 = (int)(st[3] >> 16);
+    const float a1 = __uint_as_float(st[0]), a2 = __uint_as_float(st[1]);
+    const uint32_t aidx = st[2], acount = st[3];
     float t1, t2;
     int ti;
     if (u1 > a1) { t1 = u1; ti = ui + KH; t2 = fmaxf(a1, u2); }
-    else { t1 = a1; ti = ai1; t2 = fmaxf(u1, a2); }
+    else { t1 = a1; ti = (int)(aidx & 255u); t2 = fmaxf(u1, a2); }
     const int px = tile * TPX + w * 32 + j;
     const bool valid = px < nrows;
     const float gap = half_wide_gap(err, errc_max);
     const bool amb = valid && !(t1 - t2 > gap);                    // ambiguous (or NaN)
     if (h == 0 && valid) klab[crow0 + px] = ti;                    // provisional for ambiguous rows
     if (!__any(amb)) return;
-    // candidate set {k : score >= best - gap}: second-half members from the registers, first-half
-    // members from the stored top three (a third one within the gap: re-score all K)
+    // candidate set {k : score >= best - gap}: second-half members from the registers; first-half
+    // members: the stored list (a superset) whenever the first half's best is itself within the gap
     const float thr = t1 - gap;
-    uint32_t list = 0;
+    unsigned long long list = 0;
     int cnt = 0;
 #pragma unroll
     for (int m = 0; m < MB; ++m)
@@ -934,29 +976,36 @@ struct HalfMergeEpi {
       for (int r = 0; r < 16; ++r) {
         const uint32_t k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const bool hit = k < (uint32_t)K2 && sacc[m][r] >= thr;     // NaN scores never hit
-        list = hit ? ((list << 8) | (k + KH)) : list;
+        list = hit ? ((list << 8) | (unsigned long long)(k + KH)) : list;
         cnt += hit ? 1 : 0;
       }
-    uint32_t olist = __shfl_xor(list, 32);
-    int ocnt = __shfl_xor(cnt, 32);
-    if (cnt + ocnt <= 3) {                                          // fold the partner half in
-      list = (list & ((1u << (8 * cnt)) - 1u)) | (olist << (8 * cnt));
-    }
+    const unsigned long long olist = __shfl_xor(list, 32);
+    const int ocnt = __shfl_xor(cnt, 32);
     int tot = cnt + ocnt;
-    const bool over = a3 >= thr || tot > 3;
-    if (!over) {
-      if (a1 >= thr) { list = (list << 8) | (uint32_t)ai1; ++tot; }
-      if (a2 >= thr) { list = (list << 8) | (uint32_t)ai2; ++tot; }
+    unsigned long long all = 0;
+    if (tot <= 7) all = (cnt ? (list & ((1ull << (8 * cnt)) - 1ull)) : 0ull) | (cnt < 8 ? olist << (8 * cnt) : 0ull);
+    const bool first_in = a1 >= thr;                               // (false for NaN)
+    bool over = tot > 7 || !(t1 == t1);
+    if (first_in && !over) {
+      if (acount == 255u || tot + (int)acount > 7) {
+        over = true;
+      } else {
+        all |= (unsigned long long)(aidx & (acount >= 4u ? 0xFFFFFFFFu : ((1u << (8 * acount)) - 1u))) << (8 * tot);
+        tot += (int)acount;
+      }
     }
-    uint32_t cand = 255u << 24;
-    if (!over && tot >= 1 && tot <= 3 && t1 == t1) cand = (list & 0xFFFFFFu) | ((uint32_t)tot << 24);
+    uint32_t cand = 255u << 24, cand_hi = 0u;
+    if (!over && tot >= 1) {
+      cand = (uint32_t)(all & 0xFFFFFFull) | ((uint32_t)tot << 24);
+      cand_hi = (uint32_t)(all >> 24);
+    }
     if (h == 0 && amb) {
-      const int pos = atomicAdd(qn, 1);
+      const int pos = over || tot <= 3 ? atomicAdd(qn, 1) : kSplitLdsList;   // (the staging holds one word per entry)
       if (pos < kSplitLdsList) {
         qpx[pos] = (uint16_t)px;
         qcand[pos] = cand;
       } else {
-        gqueue[atomicAdd(gcount, 1)] = SplitEntry{(int32_t)(crow0 + px), cand, img};
+        gqueue[atomicAdd(gcount, 1)] = SplitEntry{(int32_t)(crow0 + px), cand, cand_hi};
       }
     }
   }
@@ -991,7 +1040,7 @@ __global__ __launch_bounds__(NW * 64) void assign_half_wide2_kernel(
     for (int k = threadIdx.x & 63; k < K; k += 64) em = fmaxf(em, errc[(int64_t)b * K + k]);
     for (int off = 32; off > 0; off >>= 1) em = fmaxf(em, __shfl_xor(em, off));
     const float *tb = cent + (int64_t)b * K * d;
-    HalfStateEpi<MB> e0{KH, nrows, crow0, state};
+    HalfStateEpi<MB> e0{KH, nrows, crow0, em, state};
     score_tiles_half<NW, DEPTH, HalfStateEpi<MB>, MB, 1, 1>(xm, xt, d, tb, KH, crow0, nrows, lds_raw, e0, true);
     __syncthreads();
     if (threadIdx.x == 0) qnp[0] = 0;
@@ -1005,7 +1054,7 @@ __global__ __launch_bounds__(NW * 64) void assign_half_wide2_kernel(
       __syncthreads();
       const int base = qnp[1];
       for (int i = threadIdx.x; i < qn; i += NW * 64)
-        gqueue[base + i] = SplitEntry{(int32_t)(crow0 + qpx[i]), qcand[i], b};
+        gqueue[base + i] = SplitEntry{(int32_t)(crow0 + qpx[i]), qcand[i], 0u};
     }
     __syncthreads();
     r += nrows;
@@ -1048,7 +1097,7 @@ int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt
     HSGK_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(assign_requeue_rows_kernel, dim3(2048), dim3(256), 0, s, x, d, cent, K, klab,
-                     reinterpret_cast<const SplitEntry *>(qrows), qcount);
+                     reinterpret_cast<const SplitEntry *>(qrows), qcount, t.img_row0, B);
   HSGK_LAUNCH_CHECK();
   return 0;
 }
@@ -1085,7 +1134,7 @@ __global__ __launch_bounds__(NW * 64) void assign_split_rows_kernel(
     __syncthreads();
     const int base = qnp[1];
     for (int i = threadIdx.x; i < qn; i += NW * 64)
-      gqueue[base + i] = SplitEntry{list[qpx[i]], qcand[i], b};
+      gqueue[base + i] = SplitEntry{list[qpx[i]], qcand[i], 0u};
   }
 }
 
@@ -1186,12 +1235,12 @@ int launch_assign_half(const float *x, const _Float16 *xm, const uint2 *xt, int 
     HSGK_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(assign_requeue_rows_kernel, dim3(2048), dim3(256), 0, s, x, d, cent, K, klab,
-                     reinterpret_cast<const SplitEntry *>(qrows), qcount);
+                     reinterpret_cast<const SplitEntry *>(qrows), qcount, t.img_row0, B);
   HSGK_LAUNCH_CHECK();
   return 0;
 }
 
-int launch_assign_fast(const float *x, int d, const float *cent, int K, const ChunkTable &t,
+int launch_assign_fast(const float *x, int d, const float *cent, int K, int B, const ChunkTable &t,
                        int max_chunks, int32_t *klab, float *best, void *qrows,
                        int32_t *qcount, const hsgk_segkm_meta *meta, hipStream_t s) {
   if (max_chunks <= 0) return 0;
@@ -1200,7 +1249,7 @@ int launch_assign_fast(const float *x, int d, const float *cent, int K, const Ch
     return (e && e[0] == 'f') ? 0 : 1;
   }();
   if (mode == 1 && qrows && assign_split_eligible(d, K))
-    return launch_assign_split(x, d, cent, K, t, max_chunks, klab,
+    return launch_assign_split(x, d, cent, K, B, t, max_chunks, klab,
                                reinterpret_cast<SplitEntry *>(qrows), qcount, meta, s);
   return launch_assign(x, d, cent, K, t, max_chunks, klab, best, meta, s);
 }

@@ -1,5 +1,5 @@
 """Exact-queue statistics per iteration (debug build: make -C hsg_amd/csrc EXTRA=-DHSGK_Q_STATS): entries by
-candidate count (1, 2, 3, all-K)."""
+candidate count (1 .. 5, 6-7, all-K)."""
 import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -16,4 +16,4 @@ for it in range(1, 5):
   sc.segment_by_kmeans(x, None, grid, iterations=it); torch.cuda.synchronize()
   L.hsgk_debug_qstats(out)
   cur = list(out)
-  print('iterations 1..%d: entries with 1 / 2 / 3 candidates, all-K: %s' % (it, cur[1:5]), ' of', B * H * W, 'rows per iteration')
+  print('iterations 1..%d: entries with 1 / 2 / 3 / 4 / 5 / 6-7 candidates, all-K: %s' % (it, cur[1:8]), ' of', B * H * W, 'rows per iteration')
