@@ -400,8 +400,9 @@ __global__ __launch_bounds__(NW * 64) void assign_split_kernel(
 // each lane runs the canonical C1 chain acc = fmaf(c_k[dd], x[dd], acc) over
 // ascending dd for ITS (row, centroid) pair -- bit-identical to the fp32 MFMA
 // engine -- streaming both rows with 16-byte loads (8 in flight).  The group
-// keeps the largest exact score, lowest index on ties.  Entries with more than
-// three candidates (count 255: duplicate / empty clusters) take the whole wave:
+// keeps the largest exact score, lowest index on ties; entries with five to seven
+// candidates make each lane run a second chain.  Entries with more (count 255:
+// duplicate / empty clusters, wide near-ties) take the whole wave:
 // lane k = centroid k, row elements broadcast with v_readlane.
 __device__ __forceinline__ float exact_chain(const float *__restrict__ ck, const float *__restrict__ xr, int d) {
   typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));    // rows are 8-byte aligned
