@@ -329,6 +329,16 @@ def test_split_estep_matches_exact_labels(dev, oracle, B, HW, C, K):
     mid = cent[:, 4] + np.float32(4e-4) * cent[:, 7]
     cent[:, 0] = oracle.normalize_embedding(mid)              # gap ~1e-4: beyond the fp16 filter only
     cent[:, K - 1] = 0.0                                      # empty cluster
+  if K >= 24:
+    # a cloud of near copies of one centroid (gaps ~1e-5: inside every filter's gap): rows close to
+    # it carry 4..7 candidates in the exact queue, more than seven when the second table half joins in
+    for i, kk in enumerate((9, 10, 11, 12, 13)):
+      cent[:, kk] = oracle.normalize_embedding(cent[:, 8] + np.float32(1e-5 * (i + 1)) * cent[:, 14 + i])
+    if K > 140:
+      for i, kk in enumerate((130, 131, 133, 139)):
+        cent[:, kk] = oracle.normalize_embedding(cent[:, 8] + np.float32(1.5e-5 * (i + 1)) * cent[:, 20 + i])
+    # and rows that sit on that centroid
+    x[::17] = oracle.normalize_embedding(cent[0, 8][None, :] + np.float32(0.02) * x[::17])
   L = _lib.lib()
   xt = torch.from_numpy(x).to(dev)
   ct = torch.from_numpy(cent).to(dev)

@@ -73,6 +73,13 @@ def estep_case(rng, dev):
     cent[:, 6] = oracle.normalize_embedding(cent[:, 2] + np.float32(3e-6) * cent[:, 5])
     cent[:, 0] = oracle.normalize_embedding(cent[:, 4] + np.float32(4e-4) * cent[:, 7])
     cent[:, K - 1] = 0.0
+  if K >= 24 and rng.integers(0, 2):        # a cloud of near copies of one centroid: 4..7 and more candidates
+    for i, kk in enumerate((9, 10, 11, 12, 13)):
+      cent[:, kk] = oracle.normalize_embedding(cent[:, 8] + np.float32(1e-5 * (i + 1)) * cent[:, 14 + i])
+    if K > 140:
+      for i, kk in enumerate((130, 131, 133, 139)):
+        cent[:, kk] = oracle.normalize_embedding(cent[:, 8] + np.float32(1.5e-5 * (i + 1)) * cent[:, 20 + i])
+    x[::17] = oracle.normalize_embedding(cent[0, 8][None, :] + np.float32(0.02) * x[::17])
   L = _lib.lib()
   xt, ct = torch.from_numpy(x).to(dev), torch.from_numpy(cent).to(dev)
   wsb = L.hsgk_lloyd_workspace_bytes(B, HW, D, K)
