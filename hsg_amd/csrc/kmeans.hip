@@ -680,7 +680,7 @@ __device__ inline float half_wide_gap(float err, float errc_max) {
   return fmaf(2.0002f, err, fmaf(2.003f, errc_max, 8.5e-5f));
 }
 
-template <int MB>
+template <int MB, bool HILO = false>
 struct HalfWideEpi {
   int K, nrows, img;
   int64_t crow0;
@@ -715,7 +715,7 @@ struct HalfWideEpi {
     else { t1 = b1; ti = bi; t2 = fmaxf(o1, b2); }
     const int px = tile * TPX + w * 32 + j;
     const bool valid = px < nrows;
-    const float gap = half_wide_gap(err, errc_max);
+    const float gap = HILO ? half_gap(err) : half_wide_gap(err, errc_max);   // (hi + lo table planes: no table error term)
     const bool amb = valid && !(t1 - t2 > gap);               // ambiguous (or NaN)
     if (h == 0 && valid) klab[crow0 + px] = ti;               // provisional for ambiguous rows
     if (!__any(amb)) return;
@@ -754,7 +754,7 @@ struct HalfWideEpi {
   }
 };
 
-template <int NW, int DEPTH, int MB>
+template <int NW, int DEPTH, int MB, int PLANES = 1, int NBUF = 1>
 __global__ __launch_bounds__(NW * 64) void assign_half_wide_kernel(
     const _Float16 *__restrict__ xm, const uint2 *__restrict__ xt, int d,
     const float *__restrict__ cent, const float *__restrict__ errc, int K,
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(NW * 64) void assign_half_wide_kernel(
     const hsgk_segkm_meta *__restrict__ meta) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int TPX = NW * 32;
-  unsigned char *tail = lds_raw + half_lds_bytes<NW, MB, 1, 1>(d);
+  unsigned char *tail = lds_raw + half_lds_bytes<NW, MB, PLANES, NBUF>(d);
   int *qnp = reinterpret_cast<int *>(tail - 16);            // [0] count, [1] global base, [2] errc max bits
   uint32_t *qcand = reinterpret_cast<uint32_t *>(tail);     // [kSplitLdsList]
   uint16_t *qpx = reinterpret_cast<uint16_t *>(qcand + kSplitLdsList);
@@ -781,16 +781,16 @@ __global__ __launch_bounds__(NW * 64) void assign_half_wide_kernel(
     const int64_t seg_end = min(r_end, img_row0[b + 1]);
     const int nrows = (int)min(seg_end - r, (int64_t)(0xFFFF / TPX) * TPX);
     const int64_t crow0 = r;
-    if (b != staged_img) {                                     // largest table rounding error of this image
+    if (PLANES == 1 && b != staged_img) {                      // largest table rounding error of this image
       float m = 0.0f;
       for (int k = threadIdx.x & 63; k < K; k += 64) m = fmaxf(m, errc[(int64_t)b * K + k]);
       for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
       errc_max = m;
     }
     if (threadIdx.x == 0) qnp[0] = 0;
-    HalfWideEpi<MB> epi{K, nrows, b, crow0, errc_max, klab, qpx, qcand, qnp, gqueue, gcount};
-    score_tiles_half<NW, DEPTH, HalfWideEpi<MB>, MB, 1, 1>(xm, xt, d, cent + (int64_t)b * K * d, K, crow0,
-                                                           nrows, lds_raw, epi, b != staged_img);
+    HalfWideEpi<MB, PLANES == 2> epi{K, nrows, b, crow0, errc_max, klab, qpx, qcand, qnp, gqueue, gcount};
+    score_tiles_half<NW, DEPTH, HalfWideEpi<MB, PLANES == 2>, MB, PLANES, NBUF>(
+        xm, xt, d, cent + (int64_t)b * K * d, K, crow0, nrows, lds_raw, epi, b != staged_img);
     staged_img = b;
     __syncthreads();
     const int qn = min(qnp[0], kSplitLdsList);
@@ -1211,6 +1211,23 @@ int launch_assign_half(const float *x, const _Float16 *xm, const uint2 *xt, int 
   if (!counters_zeroed) {
     HSGK_CHECK_HIP(hipMemsetAsync(q1count, 0, sizeof(int32_t) * B, s));
     HSGK_CHECK_HIP(hipMemsetAsync(qcount, 0, sizeof(int32_t), s));
+  }
+  static const bool direct = [] {
+    const char *e = getenv("HSGK_L2");              // "0": undecided rows of the fp16 level go straight to the exact chains
+    return e && e[0] == '0';
+  }();
+  if (direct && ((d / 64) & 3) == 0) {
+    auto kern = assign_half_wide_kernel<NW, 4, 2, 2, 2>;
+    const size_t lds = half_lds_bytes<NW, 2, 2, 2>(d) + (size_t)kSplitLdsList * 6 + 16;
+    HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, xm, xt, d, cent, (const float *)nullptr, K,
+                       t.img_row0, B, klab, reinterpret_cast<SplitEntry *>(qrows), qcount, meta);
+    HSGK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(assign_requeue_rows_kernel, dim3(2048), dim3(256), 0, s, x, d, cent, K, klab,
+                       reinterpret_cast<const SplitEntry *>(qrows), qcount, t.img_row0, B);
+    HSGK_LAUNCH_CHECK();
+    return 0;
   }
   {
     const bool deep = ((d / 64) & 3) == 0;
