@@ -117,7 +117,9 @@ static void carve_kmeans(Carver &cv, int B, int64_t rows_per_img, int d, int K,
 // segment_by_kmeans only: room for the first M-step's partial sums (prep.hip), when the
 // 32-pixel prep kernel and the exact sums both apply
 static void carve_m0(Carver &cv, int B, int C, int ntiles, int K, KmeansScratch *k) {
-  if (k->sumq == nullptr || (C % 64) != 0) return;
+  // C <= 256 only: wider rows need further column passes with per-row atomics and an LDS footprint
+  // that costs the prep kernel a workgroup per CU (C = 384: prep 3.4 ms with, 1.3 ms without)
+  if (k->sumq == nullptr || (C % 64) != 0 || C > 256) return;
   k->m0_wt = 2 * ntiles;
   k->m0.part = cv.take<unsigned long long>((size_t)B * k->m0_wt * 2 * (C + 2));
   k->m0.lab = cv.take<int32_t>((size_t)B * k->m0_wt * 2);
@@ -289,7 +291,11 @@ int hsgk_segment_by_kmeans(const hsgk_segkm_args *a, hsgk_stream_t stream) {
   const bool compact = a->labels != nullptr && a->has_ignore;
   const bool want_half = assign_mode() == 2 && k.xh && a->iterations >= 1;
   bool half_ready = false, m0_ready = false;
-  const bool want_m0 = k.m0.part && fx_enabled() && a->iterations >= 1 && k.max_chunks > 0;
+  static const bool m0_env = [] {
+    const char *e = getenv("HSGK_M0");                 // "0": first M-step through the update kernel (debug)
+    return !(e && e[0] == '0');
+  }();
+  const bool want_m0 = k.m0.part && fx_enabled() && a->iterations >= 1 && k.max_chunks > 0 && m0_env;
   (void)hipGetLastError();   // drop stale errors left by other users of the runtime
   {
     ProfScope p(HSGK_PROF_PREP, s);

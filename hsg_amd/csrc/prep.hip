@@ -847,13 +847,14 @@ int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTa
   dim3 grid(ntiles, a.B);
   if (fast && tile32) {
     kern = prep_fast32_kernel;
-    lds = ((size_t)32 * a.C + 32 + 32 + 64) * 4 + 32 * 8 + 36 * 4 + (size_t)2 * (a.C + 2) * 8;
+    lds = ((size_t)32 * a.C + 32 + 32 + 64) * 4 + 32 * 8 + 36 * 4;
 #ifdef HSGK_PREP_PAD_LDS
     lds += HSGK_PREP_PAD_LDS;
 #endif
     grid.x = 2 * ntiles;
     if (m0 && m0->part) {                     // fused first M-step (this kernel only)
       m0v = *m0;
+      lds += (size_t)2 * (a.C + 2) * 8;       // its two LDS slots
       HSGK_CHECK_HIP(hipMemsetAsync(m0v.lab, 0xFF, sizeof(int32_t) * (size_t)a.B * grid.x * 2, s));
       if (wrote_m0) *wrote_m0 = true;
     }
