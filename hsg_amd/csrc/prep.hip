@@ -751,7 +751,7 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
       unsigned long long *g = slot == 2 ? m0.sumq + ((int64_t)b * m0.K + L) * D : nullptr;
       if (slot != cslot || g != cg) { m0_flush(); cslot = slot; cg = g; }
     }
-    for (int it = 0, q = lane; q < NQ; ++it, q += 64) {
+    for (int q = lane; q < NQ; q += 64) {
       const float4 v = *reinterpret_cast<const float4 *>(r + ((q ^ sj) << 2));
       *reinterpret_cast<float4 *>(eo + 4 * q) = v;
       float2 a, c2;
@@ -760,19 +760,7 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
       *reinterpret_cast<float2 *>(lo + 4 * q + 2) = c2;
       if (m0on) {                            // (uniform)
         const long long f0 = to_fixed(a.x), f1 = to_fixed(a.y), f2 = to_fixed(c2.x), f3 = to_fixed(c2.y);
-        if (it == 0) {
-          cur[0] += f0; cur[1] += f1; cur[2] += f2; cur[3] += f3;
-        } else if (cslot >= 0) {             // wide rows, later column passes: straight to the table
-          if (cslot < 2) {
-            unsigned long long *t = mtab + cslot * D + 4 * q;
-            atomicAdd(t + 0, (unsigned long long)f0); atomicAdd(t + 1, (unsigned long long)f1);
-            atomicAdd(t + 2, (unsigned long long)f2); atomicAdd(t + 3, (unsigned long long)f3);
-          } else {
-            unsigned long long *t = cg + 4 * q;
-            atomicAdd(t + 0, (unsigned long long)f0); atomicAdd(t + 1, (unsigned long long)f1);
-            atomicAdd(t + 2, (unsigned long long)f2); atomicAdd(t + 3, (unsigned long long)f3);
-          }
-        }
+        cur[0] += f0; cur[1] += f1; cur[2] += f2; cur[3] += f3;     // (C <= 256 with the fusion on: one column pass)
       }
       if (ho) {
         const h4 hv = {(_Float16)a.x, (_Float16)a.y, (_Float16)c2.x, (_Float16)c2.y};
@@ -852,7 +840,7 @@ int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTa
     lds += HSGK_PREP_PAD_LDS;
 #endif
     grid.x = 2 * ntiles;
-    if (m0 && m0->part) {                     // fused first M-step (this kernel only)
+    if (m0 && m0->part && a.C <= 256) {       // fused first M-step (this kernel only; one column pass per row)
       m0v = *m0;
       lds += (size_t)2 * (a.C + 2) * 8;       // its two LDS slots
       HSGK_CHECK_HIP(hipMemsetAsync(m0v.lab, 0xFF, sizeof(int32_t) * (size_t)a.B * grid.x * 2, s));
