@@ -41,34 +41,39 @@ int launch_normalize_rows(const float *x, int64_t n, int d, float eps, float *ou
 }
 
 // --------------------------------------------------------------------------
-// Per 64-pixel tile: number of kept pixels (+ min/max of kept labels).
-__global__ void count_valid_kernel(const int64_t *__restrict__ labels, int64_t HW,
-                                   int ntiles, int has_ignore, int64_t ignore,
-                                   int32_t *__restrict__ tile_cnt,
-                                   hsgk_segkm_meta *meta) {
-  const int lane = threadIdx.x & 63;
-  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+// Per 64-pixel tile: number of kept pixels (+ min/max of kept labels).  A workgroup walks
+// gridDim.x-strided groups of four tiles and issues ONE atomic min / max pair at the end (one
+// pair per tile on the same two words serialises in L2: 3.4 ms at 48 x 448 x 448).
+__global__ __launch_bounds__(256) void count_valid_kernel(const int64_t *__restrict__ labels, int64_t HW,
+                                                          int ntiles, int has_ignore, int64_t ignore,
+                                                          int32_t *__restrict__ tile_cnt,
+                                                          hsgk_segkm_meta *meta) {
+  __shared__ long long red[2][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int b = blockIdx.y;
-  if (t >= ntiles) return;
-  const int64_t pix = (int64_t)t * kTilePix + lane;
-  bool keep = false;
-  int64_t lab = 0;
-  if (pix < HW) {
-    lab = labels[(int64_t)b * HW + pix];
-    keep = !(has_ignore && lab == ignore);
+  int64_t lo = INT64_MAX, hi = INT64_MIN;
+  for (int t = blockIdx.x * 4 + w; t < ntiles; t += gridDim.x * 4) {
+    const int64_t pix = (int64_t)t * kTilePix + lane;
+    bool keep = false;
+    int64_t lab = 0;
+    if (pix < HW) {
+      lab = labels[(int64_t)b * HW + pix];
+      keep = !(has_ignore && lab == ignore);
+    }
+    const unsigned long long m = __ballot(keep);
+    if (keep) { lo = lab < lo ? lab : lo; hi = lab > hi ? lab : hi; }
+    if (lane == 0) tile_cnt[(int64_t)b * ntiles + t] = __popcll(m);
   }
-  unsigned long long m = __ballot(keep);
-  int64_t lo = keep ? lab : INT64_MAX;
-  int64_t hi = keep ? lab : INT64_MIN;
   for (int off = 32; off > 0; off >>= 1) {
-    int64_t olo = __shfl_xor(lo, off);
-    int64_t ohi = __shfl_xor(hi, off);
+    const int64_t olo = __shfl_xor(lo, off), ohi = __shfl_xor(hi, off);
     lo = olo < lo ? olo : lo;
     hi = ohi > hi ? ohi : hi;
   }
-  if (lane == 0) {
-    tile_cnt[(int64_t)b * ntiles + t] = __popcll(m);
-    if (m) {
+  if (lane == 0) { red[0][w] = lo; red[1][w] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 4; ++i) { lo = red[0][i] < lo ? red[0][i] : lo; hi = red[1][i] > hi ? red[1][i] : hi; }
+    if (lo <= hi) {
       atomicMin(reinterpret_cast<long long *>(&meta->label_min), (long long)lo);
       atomicMax(reinterpret_cast<long long *>(&meta->label_max), (long long)hi);
     }
@@ -93,7 +98,8 @@ int launch_count_valid(const int64_t *labels, int B, int64_t HW, int has_ignore,
   HSGK_LAUNCH_CHECK();
   if (!labels) return 0;
   int ntiles = (int)((HW + kTilePix - 1) / kTilePix);
-  dim3 grid((ntiles + 3) / 4, B);
+  const int gx = (ntiles + 3) / 4;
+  dim3 grid(gx < 32 ? gx : 32, B);
   hipLaunchKernelGGL(count_valid_kernel, grid, dim3(256), 0, s, labels, HW, ntiles,
                      has_ignore, ignore, tile_cnt, meta);
   HSGK_LAUNCH_CHECK();
