@@ -921,12 +921,13 @@ __global__ __launch_bounds__(256) void prep_bwd_kernel(
   }
 }
 
-// 32-pixel variant for C % 64 == 0, C <= 256 (one 16-byte quad per lane and row): a wave keeps
+// 32-pixel variant for C % 64 == 0, C <= 512 (NV 16-byte quads per lane and row): a wave keeps
 // four rows of all four streams in flight (g_emb, g_emb_loc, emb, emb_loc: vector loads, nothing
 // is read twice), both dot products come from registers, the result goes through an
 // XOR-swizzled LDS tile (33 KiB -> four workgroups per CU) and leaves as 128-byte plane segments.
 // (The 64-pixel kernel above -- scalar loads, one dependent load-reduce chain per row, LDS
 // read-modify-write -- ran at 31 ms for 48 x 256 x 448 x 448; gradients are tolerance quantities.)
+template <int NV>
 __global__ __launch_bounds__(256) void prep_bwd32_kernel(
     const float *__restrict__ g_emb, const float *__restrict__ g_emb_loc,
     const float *__restrict__ emb, const float *__restrict__ emb_loc,
@@ -939,11 +940,13 @@ __global__ __launch_bounds__(256) void prep_bwd32_kernel(
   const int b = blockIdx.y;
   const int64_t q0 = (int64_t)blockIdx.x * 32;      // first pixel of this half tile
   const int D = C + 2, NQ = C >> 2;
-  const bool qon = lane < NQ;
-  const int qc = min(lane, NQ - 1);
+  bool qon[NV];
+  int qc[NV];
+#pragma unroll
+  for (int h = 0; h < NV; ++h) { qon[h] = lane + 64 * h < NQ; qc[h] = min(lane + 64 * h, NQ - 1); }
   for (int j0 = w; j0 < 32; j0 += 16) {             // rows j0, j0 + 4, j0 + 8, j0 + 12 of this wave
     int64_t row[4];
-    f4u ge[4], gl[4], e[4], el[4];
+    f4u ge[4][NV], gl[4][NV], e[4][NV], el[4][NV];
     float2 tl[4], tg[4];
     float n1[4], n2[4];
 #pragma unroll
@@ -958,40 +961,57 @@ __global__ __launch_bounds__(256) void prep_bwd32_kernel(
       n1[u] = norms[2 * r];
       n2[u] = norms[2 * r + 1];
       const f4u z = {0.f, 0.f, 0.f, 0.f};
-      ge[u] = g_emb ? *reinterpret_cast<const f4u *>(g_emb + r * C + 4 * qc) : z;
-      gl[u] = g_emb_loc ? *reinterpret_cast<const f4u *>(g_emb_loc + r * D + 4 * qc) : z;
-      e[u] = *reinterpret_cast<const f4u *>(emb + r * C + 4 * qc);
-      el[u] = *reinterpret_cast<const f4u *>(emb_loc + r * D + 4 * qc);
+#pragma unroll
+      for (int h = 0; h < NV; ++h) {
+        ge[u][h] = g_emb ? *reinterpret_cast<const f4u *>(g_emb + r * C + 4 * qc[h]) : z;
+        gl[u][h] = g_emb_loc ? *reinterpret_cast<const f4u *>(g_emb_loc + r * D + 4 * qc[h]) : z;
+        e[u][h] = *reinterpret_cast<const f4u *>(emb + r * C + 4 * qc[h]);
+        el[u][h] = *reinterpret_cast<const f4u *>(emb_loc + r * D + 4 * qc[h]);
+      }
       tl[u] = make_float2(emb_loc[r * D + C], emb_loc[r * D + C + 1]);
       tg[u] = g_emb_loc ? make_float2(g_emb_loc[r * D + C], g_emb_loc[r * D + C + 1]) : make_float2(0.f, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int j = j0 + 4 * u;
-      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 o[NV];
+#pragma unroll
+      for (int h = 0; h < NV; ++h) o[h] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row[u] >= 0) {                              // (wave-uniform)
         float dot2 = 0.0f;
         if (g_emb_loc && n2[u] > eps) {
-          if (qon) dot2 = el[u].x * gl[u].x + el[u].y * gl[u].y + el[u].z * gl[u].z + el[u].w * gl[u].w;
+#pragma unroll
+          for (int h = 0; h < NV; ++h)
+            if (qon[h]) dot2 += el[u][h].x * gl[u][h].x + el[u][h].y * gl[u][h].y + el[u][h].z * gl[u][h].z + el[u][h].w * gl[u][h].w;
           if (lane == 0) dot2 += tl[u].x * tg[u].x + tl[u].y * tg[u].y;
           for (int off = 32; off > 0; off >>= 1) dot2 += __shfl_xor(dot2, off);
         }
-        float4 g = make_float4(ge[u].x, ge[u].y, ge[u].z, ge[u].w);
-        if (g_emb_loc) {
-          g.x += (gl[u].x - el[u].x * dot2) / n2[u];
-          g.y += (gl[u].y - el[u].y * dot2) / n2[u];
-          g.z += (gl[u].z - el[u].z * dot2) / n2[u];
-          g.w += (gl[u].w - el[u].w * dot2) / n2[u];
+        float4 g[NV];
+        float dot1 = 0.0f;
+#pragma unroll
+        for (int h = 0; h < NV; ++h) {
+          g[h] = make_float4(ge[u][h].x, ge[u][h].y, ge[u][h].z, ge[u][h].w);
+          if (g_emb_loc) {
+            g[h].x += (gl[u][h].x - el[u][h].x * dot2) / n2[u];
+            g[h].y += (gl[u][h].y - el[u][h].y * dot2) / n2[u];
+            g[h].z += (gl[u][h].z - el[u][h].z * dot2) / n2[u];
+            g[h].w += (gl[u][h].w - el[u][h].w * dot2) / n2[u];
+          }
+          if (qon[h]) dot1 += e[u][h].x * g[h].x + e[u][h].y * g[h].y + e[u][h].z * g[h].z + e[u][h].w * g[h].w;
         }
-        float dot1 = qon ? e[u].x * g.x + e[u].y * g.y + e[u].z * g.z + e[u].w * g.w : 0.0f;
         for (int off = 32; off > 0; off >>= 1) dot1 += __shfl_xor(dot1, off);
         if (!(n1[u] > eps)) dot1 = 0.0f;
-        o.x = (g.x - e[u].x * dot1) / n1[u];
-        o.y = (g.y - e[u].y * dot1) / n1[u];
-        o.z = (g.z - e[u].z * dot1) / n1[u];
-        o.w = (g.w - e[u].w * dot1) / n1[u];
+#pragma unroll
+        for (int h = 0; h < NV; ++h) {
+          o[h].x = (g[h].x - e[u][h].x * dot1) / n1[u];
+          o[h].y = (g[h].y - e[u][h].y * dot1) / n1[u];
+          o[h].z = (g[h].z - e[u][h].z * dot1) / n1[u];
+          o[h].w = (g[h].w - e[u][h].w * dot1) / n1[u];
+        }
       }
-      if (qon) *reinterpret_cast<float4 *>(tile + j * C + ((lane ^ (j & 15)) << 2)) = o;
+#pragma unroll
+      for (int h = 0; h < NV; ++h)
+        if (qon[h]) *reinterpret_cast<float4 *>(tile + j * C + (((lane + 64 * h) ^ (j & 15)) << 2)) = o[h];
     }
   }
   __syncthreads();
@@ -1015,11 +1035,12 @@ int launch_prep_bwd(const float *g_emb, const float *g_emb_loc, const float *emb
                     int H, int W, float eps, float *gx, hipStream_t s) {
   const int64_t HW = (int64_t)H * W;
   const int ntiles = (int)((HW + kTilePix - 1) / kTilePix);
-  if ((C % 64) == 0 && C <= 256) {
+  if ((C % 64) == 0 && C <= 512) {
     const size_t lds32 = (size_t)32 * C * 4;
-    HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(prep_bwd32_kernel),
+    auto kern = C <= 256 ? prep_bwd32_kernel<1> : prep_bwd32_kernel<2>;
+    HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
-    hipLaunchKernelGGL(prep_bwd32_kernel, dim3(2 * ntiles, B), dim3(256), lds32, s, g_emb, g_emb_loc, emb,
+    hipLaunchKernelGGL(kern, dim3(2 * ntiles, B), dim3(256), lds32, s, g_emb, g_emb_loc, emb,
                        emb_loc, norms, rowmap, C, HW, eps, gx);
     HSGK_LAUNCH_CHECK();
     return 0;

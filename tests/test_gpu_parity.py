@@ -283,6 +283,40 @@ def test_segment_by_kmeans_backward_vs_torch_autograd(dev, case):
   assert not labels.requires_grad and not cluster.requires_grad
 
 
+@pytest.mark.parametrize('shape,ignore_rows', [((2, 384, 21, 37), 3), ((1, 128, 40, 33), 0), ((2, 512, 9, 70), 2),
+                                               ((1, 320, 17, 19), 0)])
+def test_prep_backward_wide_rows_vs_torch_autograd(dev, shape, ignore_rows):
+  """The 32-pixel backward kernel with one / two quads per lane (C up to 512), ragged half tiles and
+  an ignore band, against torch autograd of the plain restatement."""
+  import torch
+  from hsg_amd.utils.segsort import common as sc
+  B, C, H, W = shape
+  x = synth.embeddings_nchw(77 + C, shape, 'iid')
+  lab = synth.overseg_labels(78, B, H, W, regions=5, ignore_rows=ignore_rows) if ignore_rows else None
+  ign = 255 if ignore_rows else None
+  xt = torch.from_numpy(x).to(dev)
+  lt = None if lab is None else torch.from_numpy(lab).to(dev)
+  a = xt.clone().requires_grad_(True)
+  emb, eloc, _, _, _ = sc.segment_by_kmeans(a, lt, [3, 2], ignore_index=ign, iterations=1)
+  n = emb.shape[0]
+  w1 = torch.from_numpy(synth.gaussish(5, n * C).reshape(n, C)).to(dev)
+  w2 = torch.from_numpy(synth.gaussish(6, n * (C + 2)).reshape(n, C + 2)).to(dev)
+  ((emb * w1).sum() + (eloc * w2).sum()).backward()
+  b = xt.clone().requires_grad_(True)
+  e = b.permute(0, 2, 3, 1).reshape(-1, C)
+  e = e / e.norm(dim=1, keepdim=True).clamp_min(1e-12)
+  loc = (sc.generate_location_features((H, W), dev, 'float') - 0.5).view(1, H * W, 2).expand(B, H * W, 2).reshape(-1, 2)
+  el = torch.cat([e, loc], 1)
+  el = el / el.norm(dim=1, keepdim=True).clamp_min(1e-12)
+  if lt is not None:
+    keep = (lt.view(-1) != ign).nonzero().view(-1)
+    e, el = e.index_select(0, keep), el.index_select(0, keep)
+  assert e.shape[0] == n
+  ((e * w1).sum() + (el * w2).sum()).backward()
+  scale = b.grad.abs().max().item()
+  assert (a.grad - b.grad).abs().max().item() <= 2e-5 * max(scale, 1.0)
+
+
 def test_exchange_list_api_on_gpu_vs_reference(dev):
   """hsg_amd.models.utils with the libhsgk kernels (segment sums, normalise)
   against the reference's outputs for the two-'GPU' fixture."""
