@@ -2,7 +2,9 @@
   * segment_reduce (prototypes / means / raw sums, canonical order C2) on random (n, d, P) and id patterns;
   * the E-step C entry point (hsgk_lloyd_estep, all three filter settings) on random (B, HW, C, K) with
     exact ties, near ties at the scale of each filter's gap and zero centroids;
-  * SegSortLoss forward (both modes, random n / c / P / concentration): per-pixel nll and mean within 1e-4.
+  * SegSortLoss forward (both modes, random n / c / P / concentration): per-pixel nll and mean within 1e-4;
+  * the hierarchy operators (grouping from logits, masked group means, pixel label lookup): labels identical,
+    probabilities within 1e-6, means within 1e-5.
 Not part of the test suite; output appended to profiles/r01_fuzz_parity.txt.
 
   python tools/fuzz_ops.py [n_cases] [seed]
@@ -132,13 +134,42 @@ def loss_case(rng, dev):
       n, c, P, kappa, int((~well).sum()), '; '.join(info)), ok
 
 
+def hier_case(rng, dev):
+  """a12-a14: softmax / argmax / Bayes-chain grouping, masked group means, pixel label lookup."""
+  from hsg_amd.models.embeddings import hierarchy as hz
+  B, M = int(rng.integers(1, 7)), int(rng.choice([16, 64, 256, int(rng.integers(2, 300))]))
+  KF, KC = int(rng.integers(2, 70)), int(rng.integers(1, 20))
+  C = int(rng.choice([16, 64, 256, int(rng.integers(2, 300))]))
+  seed = int(rng.integers(1, 1 << 30))
+  fl = (synth.gaussish(seed, B * KF * M).reshape(B, KF, M) * np.float32(2)).astype(np.float32)
+  cl = (synth.gaussish(seed + 1, B * KC * KF).reshape(B, KC, KF) * np.float32(2)).astype(np.float32)
+  t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+  f_lab, f_prob, c_lab, c_prob = hz.hierarchical_grouping_from_logits(t(fl), t(cl))
+  r = oracle.hierarchical_grouping_from_logits(fl, cl)
+  ok = np.array_equal(f_lab.cpu().numpy(), r[0]) and np.array_equal(c_lab.cpu().numpy(), r[2])
+  ok = ok and float(np.abs(f_prob.cpu().numpy() - r[1]).max()) <= 1e-6 and float(np.abs(c_prob.cpu().numpy() - r[3]).max()) <= 1e-6
+  protos = synth.gaussish(seed + 2, B * C * M).reshape(B, C, M)
+  masks = (synth.hash_u64(seed + 3, B * M) % np.uint64(5) == 0).reshape(B, M)
+  for normalized in (False, True):
+    got = hz.collect_nd_coarser_prototype(t(protos), t(r[0]), t(masks), KF, normalized).cpu().numpy()
+    ref = oracle.collect_nd_coarser_prototype(protos, r[0], masks, KF, normalized)
+    ok = ok and float(np.abs(got - ref).max()) <= 1e-5
+  n = int(rng.integers(1, 20000))
+  bidx = np.sort((synth.hash_u64(seed + 4, n) % np.uint64(B)).astype(np.int64)) * 3 + 5      # sparse image ids
+  if len(np.unique(bidx)) == B:
+    cby = (synth.hash_u64(seed + 5, n) % np.uint64(M)).astype(np.int64)
+    got = hz.collect_pixel_hierarchical_clustering_indices(t(cby), t(bidx), t(r[0])).cpu().numpy()
+    ok = ok and np.array_equal(got, oracle.collect_pixel_hierarchical_clustering_indices(cby, bidx, r[0]))
+  return 'hierarchy B=%d M=%d KF=%d KC=%d C=%d' % (B, M, KF, KC, C), ok
+
+
 def main():
   n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
   rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
   dev = torch.device('cuda:0')
   bad, t0 = 0, time.time()
   for case in range(n_cases):
-    name, ok = (seg_case, estep_case, loss_case)[case % 3](rng, dev)
+    name, ok = (seg_case, estep_case, loss_case, hier_case)[case % 4](rng, dev)
     print('case %3d: %-60s  %s' % (case, name, ('within 1e-4' if name.startswith('segsort_loss') else 'identical') if ok else 'DIFFERENT'), flush=True)
     bad += 0 if ok else 1
   print('%d of %d operator cases agree with the oracle (bit-identical; loss: within 1e-4) (%.0f s)' % (n_cases - bad, n_cases, time.time() - t0))
