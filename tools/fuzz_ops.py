@@ -163,13 +163,41 @@ def hier_case(rng, dev):
   return 'hierarchy B=%d M=%d KF=%d KC=%d C=%d' % (B, M, KF, KC, C), ok
 
 
+def topk_case(rng, dev):
+  """n1: top-k retrieval (indices wherever the score gaps exceed fp32 noise, values to rounding) against
+  torch mm + argsort on the GPU, and the majority labels of clusters against the oracle."""
+  from hsg_amd.utils.segsort import eval as ev
+  from hsg_amd.utils.segsort import common as sc
+  n, c, P = int(rng.integers(1, 6000)), int(rng.choice([16, 48, 128, 256, int(rng.integers(2, 300))])), int(rng.integers(1, 1500))
+  k = int(rng.integers(1, min(P, 24) + 1))
+  seed = int(rng.integers(1, 1 << 30))
+  e = torch.from_numpy(oracle.normalize_embedding(synth.gaussish(seed, n * c).reshape(n, c))).to(dev)
+  p = torch.from_numpy(oracle.normalize_embedding(synth.gaussish(seed + 1, P * c).reshape(P, c))).to(dev)
+  got_idx, got_val = ev.top_k_indices(e, p, k)
+  aff = torch.mm(e, p.t())
+  srt, idx = torch.sort(aff, 1, descending=True)
+  ok = float((got_val - srt[:, :k]).abs().max()) <= 2e-6
+  gap_ok = torch.ones((n, k), dtype=torch.bool, device=dev)
+  if P > k:
+    gap_ok &= (srt[:, :k] - srt[:, 1:k + 1]) > 1e-5
+  if k > 1:
+    gap_ok[:, 1:] &= (srt[:, :k - 1] - srt[:, 1:k]) > 1e-5
+  ok = ok and bool(torch.equal(got_idx[gap_ok], idx[:, :k][gap_ok]))
+  sem = (synth.hash_u64(seed + 2, n) % np.uint64(int(rng.integers(1, 22)))).astype(np.int64)
+  clu = (synth.hash_u64(seed + 3, n) % np.uint64(int(rng.integers(1, 80)))).astype(np.int64)
+  sel, maj = sc.find_majority_label_index(torch.from_numpy(sem).to(dev), torch.from_numpy(clu).to(dev))
+  r_sel, r_maj = oracle.find_majority_label_index(sem, clu)
+  ok = ok and np.array_equal(sel.cpu().numpy(), r_sel) and np.array_equal(maj.cpu().numpy(), r_maj)
+  return 'top_k n=%d c=%d P=%d k=%d + majority labels' % (n, c, P, k), ok
+
+
 def main():
   n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
   rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
   dev = torch.device('cuda:0')
   bad, t0 = 0, time.time()
   for case in range(n_cases):
-    name, ok = (seg_case, estep_case, loss_case, hier_case)[case % 4](rng, dev)
+    name, ok = (seg_case, estep_case, loss_case, hier_case, topk_case)[case % 5](rng, dev)
     print('case %3d: %-60s  %s' % (case, name, ('within 1e-4' if name.startswith('segsort_loss') else 'identical') if ok else 'DIFFERENT'), flush=True)
     bad += 0 if ok else 1
   print('%d of %d operator cases agree with the oracle (bit-identical; loss: within 1e-4) (%.0f s)' % (n_cases - bad, n_cases, time.time() - t0))
