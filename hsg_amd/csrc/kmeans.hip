@@ -1212,10 +1212,13 @@ int launch_assign_half(const float *x, const _Float16 *xm, const uint2 *xt, int 
     HSGK_CHECK_HIP(hipMemsetAsync(q1count, 0, sizeof(int32_t) * B, s));
     HSGK_CHECK_HIP(hipMemsetAsync(qcount, 0, sizeof(int32_t), s));
   }
-  static const bool direct = [] {
-    const char *e = getenv("HSGK_L2");              // "0": undecided rows of the fp16 level go straight to the exact chains
-    return e && e[0] == '0';
-  }();
+  // Small batches are bound by their ~5 dependent launches per iteration, not by bytes: below
+  // 1.5 M rows the undecided rows of the fp16 level go straight to the exact chains with their
+  // candidate sets (one launch less: -10 % at training resolutions, -5 % at 16 x 224 x 224;
+  // at 48 x 448 x 448 the bf16x3 level saves 3.6 ms per call).  HSGK_L2 = 0 / 1 forces either
+  // way (read per call, so that the tests can cover both).
+  const char *l2env = getenv("HSGK_L2");
+  const bool direct = l2env ? l2env[0] == '0' : (int64_t)max_chunks * HSGK_CHUNK <= 1500000;
   if (direct && ((d / 64) & 3) == 0) {
     auto kern = assign_half_wide_kernel<NW, 4, 2, 2, 2>;
     const size_t lds = half_lds_bytes<NW, 2, 2, 2>(d) + (size_t)kSplitLdsList * 6 + 16;

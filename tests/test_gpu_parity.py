@@ -473,6 +473,25 @@ def test_baseline_config_shapes_vs_oracle(dev, oracle, shape, grid, iters):
     assert np.array_equal(a, b), '%s: %d mismatching elements' % (name, int((a != b).sum()))
 
 
+@pytest.mark.parametrize('level2', ['1', '0'])
+@pytest.mark.parametrize('shape,grid,iters', [((3, 256, 40, 56), (8, 8), 6), ((2, 128, 33, 47), (5, 7), 4),
+                                              ((1, 256, 90, 70), (4, 6), 8)])
+def test_both_estep_routes_for_small_tables_vs_oracle(dev, oracle, monkeypatch, shape, grid, iters, level2):
+  """K <= 64: the undecided rows of the fp16 level go through the bf16x3 level (HSGK_L2=1: the route of
+  large batches) or straight to the exact chains (HSGK_L2=0: the default below 1.5 M rows) -- both bit-exact."""
+  from hsg_amd.utils.segsort import common as sc
+  monkeypatch.setenv('HSGK_L2', level2)
+  B, C, H, W = shape
+  x = synth.embeddings_nchw(synth.SEED_BASE + 5 * C + H, shape, 'mixture')
+  lab = synth.overseg_labels(synth.SEED_BASE + 4, B, H, W, regions=6, ignore_rows=2)
+  loc = oracle.generate_location_features((H, W)) - np.float32(0.5)
+  got = _run_segkm(dev, x, lab, grid, 255, iters)
+  ref = oracle.segment_by_kmeans(x, lab, grid, loc, 255, iters)
+  for name, a, b in zip(('emb', 'emb_loc', 'labels', 'cluster', 'batch'), got, ref):
+    assert a.shape == b.shape, name
+    assert np.array_equal(a, b), '%s: %d mismatching elements' % (name, int((a != b).sum()))
+
+
 def test_full_size_cfg2_properties_and_spot_parity(dev, oracle):
   """BASELINE.json configs[1] at FULL size (48x256x448x448, K=8x8, 10 iterations):
   size-independent properties on the whole batch and bit-exact parity of three
