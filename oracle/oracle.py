@@ -89,7 +89,7 @@ def grid_seed_axis(k, n):
   """linspace(0, k-1, n).round_().long() (hsg/utils/segsort/common.py:145-148): the float32
   linspace of ATen (linspace_f32), rounded half to even.  The float32 rounding is part of the
   reference's behaviour: the exactly rounded i*(k-1)/(n-1) differs from it for about 2 % of the
-  (k, n) pairs (e.g. k = 4, n = 43), which tools/fuzz_parity.py found."""
+  (k, n) pairs (e.g. k = 4, n = 43), which tests/checkers/fuzz_parity.py found."""
   return np.rint(linspace_f32(0.0, float(k - 1), n)).astype(np.int64)
 
 

@@ -3,7 +3,7 @@ iterations, seeded i.i.d. input) through the C ABI, EVERY image compared bit for
 CPU oracle (labels / cluster ids and both float outputs).  Prints one line per image and a
 summary; the committed output is profiles/r01_full_parity.txt.
 
-  python tools/full_parity_cfg2.py [n_images]
+  python tests/checkers/full_parity_cfg2.py [n_images]
 """
 import os
 import sys
@@ -12,7 +12,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from hsg_amd.utils.segsort import common as sc   # noqa: E402
 from oracle import oracle                          # noqa: E402  (checker only)

@@ -7,7 +7,7 @@
     probabilities within 1e-6, means within 1e-5.
 Not part of the test suite; output appended to profiles/r01_fuzz_parity.txt.
 
-  python tools/fuzz_ops.py [n_cases] [seed]
+  python tests/checkers/fuzz_ops.py [n_cases] [seed]
 """
 import ctypes
 import os
@@ -17,7 +17,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from hsg_amd import _lib, ops                      # noqa: E402
 from hsg_amd.utils import synth                   # noqa: E402

@@ -6,7 +6,7 @@ Floats within 2e-6 (prototypes; 2.5e-7 x the condition of the sum when that is l
 in the reference left out), integers identical (nearest prototype: unless the fp64 top-2 margin
 is below 1e-6).  Summary appended to profiles/r01_oracle_vs_reference.txt.
 
-  python tools/fuzz_oracle_ops_vs_reference.py [n_cases] [seed]
+  python tests/checkers/fuzz_oracle_ops_vs_reference.py [n_cases] [seed]
 """
 import os
 import sys
@@ -15,7 +15,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, '/root/reference')
 

@@ -10,7 +10,7 @@ so a differing case is re-examined: every pixel whose id differs must have a top
 below 1e-5 in the iteration where the two runs first part.  The summary is committed as
 profiles/r01_oracle_vs_reference.txt.
 
-  python tools/fuzz_oracle_vs_reference.py [n_cases] [seed]
+  python tests/checkers/fuzz_oracle_vs_reference.py [n_cases] [seed]
 """
 import inspect
 import os
@@ -20,7 +20,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, '/root/reference')
 
@@ -57,7 +57,7 @@ def main():
     seed = int(rng.integers(1, 1 << 30))
     mode = int(rng.integers(0, 3))
     x = synth.embeddings_nchw(seed, (B, C, H, W), 'mixture' if kind == 'mixture' else 'iid')
-    if kind == 'zeros':       # (the degenerate inputs of tools/fuzz_parity.py)
+    if kind == 'zeros':       # (the degenerate inputs of tests/checkers/fuzz_parity.py)
       x = x * (synth.hash_u64(seed + 5, B * H * W) % np.uint64(3) != 0).astype(np.float32).reshape(B, 1, H, W)
     elif kind == 'const':
       x = np.broadcast_to(x[:, :, :1, :1], x.shape).copy()

@@ -3,7 +3,7 @@ shapes / grids / iteration counts / label maps / input distributions, everything
 (both float outputs, labels, cluster ids, batch ids).  Not part of the test suite (minutes);
 the committed output is profiles/r01_fuzz_parity.txt.
 
-  python tools/fuzz_parity.py [n_cases] [seed]
+  python tests/checkers/fuzz_parity.py [n_cases] [seed]
 """
 import os
 import sys
@@ -12,7 +12,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from hsg_amd.utils import synth                   # noqa: E402
 from hsg_amd.utils.segsort import common as sc   # noqa: E402

@@ -495,7 +495,7 @@ def test_both_estep_routes_for_small_tables_vs_oracle(dev, oracle, monkeypatch, 
 def test_full_size_cfg2_properties_and_spot_parity(dev, oracle):
   """BASELINE.json configs[1] at FULL size (48x256x448x448, K=8x8, 10 iterations):
   size-independent properties on the whole batch and bit-exact parity of three
-  whole images against the oracle (all 48: tools/full_parity_cfg2.py)."""
+  whole images against the oracle (all 48: tests/checkers/full_parity_cfg2.py)."""
   import torch
   from hsg_amd.utils.segsort import common as sc
   B, C, H, W, grid, iters = 48, 256, 448, 448, (8, 8), 10
