@@ -291,11 +291,11 @@ int hsgk_segment_by_kmeans(const hsgk_segkm_args *a, hsgk_stream_t stream) {
   const bool compact = a->labels != nullptr && a->has_ignore;
   const bool want_half = assign_mode() == 2 && k.xh && a->iterations >= 1;
   bool half_ready = false, m0_ready = false;
-  static const bool m0_env = [] {
-    const char *e = getenv("HSGK_M0");                 // "0": first M-step through the update kernel (debug)
-    return !(e && e[0] == '0');
-  }();
-  const bool want_m0 = k.m0.part && fx_enabled() && a->iterations >= 1 && k.max_chunks > 0 && m0_env;
+  // HSGK_M0 = 0 / 1 (read per call, for the tests): never / whenever the shape allows
+  const char *m0e = getenv("HSGK_M0");
+  const bool m0_env = !(m0e && m0e[0] == '0'), m0_force = m0e && m0e[0] == '1';
+  const bool wide_cells = (double)a->H * (double)a->W >= 400.0 * (double)a->K;
+  const bool want_m0 = k.m0.part && fx_enabled() && a->iterations >= 1 && k.max_chunks > 0 && m0_env && (wide_cells || m0_force);
   (void)hipGetLastError();   // drop stale errors left by other users of the runtime
   {
     ProfScope p(HSGK_PROF_PREP, s);

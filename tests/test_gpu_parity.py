@@ -473,6 +473,24 @@ def test_baseline_config_shapes_vs_oracle(dev, oracle, shape, grid, iters):
     assert np.array_equal(a, b), '%s: %d mismatching elements' % (name, int((a != b).sum()))
 
 
+@pytest.mark.parametrize('m0', ['1', '0'])
+@pytest.mark.parametrize('shape,grid,iters', [((3, 256, 40, 56), (8, 8), 5), ((2, 128, 64, 96), (2, 3), 6),
+                                              ((2, 64, 33, 47), (5, 7), 3)])
+def test_first_mstep_fused_or_not_vs_oracle(dev, oracle, monkeypatch, shape, grid, iters, m0):
+  """The first M-step inside the prep kernel (HSGK_M0=1: forced also for narrow seed cells, where pixels of a
+  third label go through global atomics) or through the update kernel (HSGK_M0=0) -- both bit-exact."""
+  monkeypatch.setenv('HSGK_M0', m0)
+  B, C, H, W = shape
+  x = synth.embeddings_nchw(synth.SEED_BASE + 7 * C + W, shape, 'iid')
+  lab = synth.overseg_labels(synth.SEED_BASE + 6, B, H, W, regions=5, ignore_rows=3)
+  loc = oracle.generate_location_features((H, W)) - np.float32(0.5)
+  got = _run_segkm(dev, x, lab, grid, 255, iters)
+  ref = oracle.segment_by_kmeans(x, lab, grid, loc, 255, iters)
+  for name, a, b in zip(('emb', 'emb_loc', 'labels', 'cluster', 'batch'), got, ref):
+    assert a.shape == b.shape, name
+    assert np.array_equal(a, b), '%s: %d mismatching elements' % (name, int((a != b).sum()))
+
+
 @pytest.mark.parametrize('level2', ['1', '0'])
 @pytest.mark.parametrize('shape,grid,iters', [((3, 256, 40, 56), (8, 8), 6), ((2, 128, 33, 47), (5, 7), 4),
                                               ((1, 256, 90, 70), (4, 6), 8)])
