@@ -549,6 +549,17 @@ bool assign_split_eligible(int d, int K) {
          split_lds_bytes<8>(d) + (size_t)kSplitLdsList * 6 <= 160 * 1024;
 }
 
+// image of row r: last b in [0, B) with img_row0[b] <= r (binary search: a linear walk is one
+// dependent global load per image -- up to 30 us before a workgroup's first tile at B = 48)
+__device__ inline int image_of_row(const int64_t *__restrict__ img_row0, int B, int64_t r) {
+  int lo = 0, hi = B;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (img_row0[mid] <= r) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
 // ===========================================================================
 // Three-level E-step (unit-norm rows, K <= 64):
 //   1. assign_half_kernel       fp16 filter over the fp16 copy of the rows (half the
@@ -627,8 +638,7 @@ __global__ __launch_bounds__(NW * 64) void assign_half_kernel(
   int64_t r = (int64_t)blockIdx.x * per;
   const int64_t r_end = min(N, r + per);
   if (r >= r_end) return;
-  int b = 0;
-  while (b + 1 < B && img_row0[b + 1] <= r) ++b;                 // image of the first row
+  int b = image_of_row(img_row0, B, r);                          // image of the first row
   int staged_img = -1;
   while (r < r_end) {
     while (img_row0[b + 1] <= r) ++b;                            // (empty images are skipped)
@@ -772,8 +782,7 @@ __global__ __launch_bounds__(NW * 64) void assign_half_wide_kernel(
   int64_t r = (int64_t)blockIdx.x * per;
   const int64_t r_end = min(N, r + per);
   if (r >= r_end) return;
-  int b = 0;
-  while (b + 1 < B && img_row0[b + 1] <= r) ++b;
+  int b = image_of_row(img_row0, B, r);
   int staged_img = -1;
   float errc_max = 0.0f;
   while (r < r_end) {
@@ -1030,8 +1039,7 @@ __global__ __launch_bounds__(NW * 64) void assign_half_wide2_kernel(
   int64_t r = (int64_t)blockIdx.x * per;
   const int64_t r_end = min(N, r + per);
   if (r >= r_end) return;
-  int b = 0;
-  while (b + 1 < B && img_row0[b + 1] <= r) ++b;
+  int b = image_of_row(img_row0, B, r);
   while (r < r_end) {
     while (img_row0[b + 1] <= r) ++b;
     const int64_t seg_end = min(r_end, img_row0[b + 1]);
