@@ -6,24 +6,40 @@ One "step" = one segment_by_kmeans-equivalent pass (NCHW f32 in -> normalise ->
 synthetic batch already resident in HBM.  N=1 workload = BASELINE.json
 configs[1] (VOC12 stage-2 shape: 48x256x448x448, K=8x8).  N>1: every rank
 clusters its own shard of the same per-GPU shape (weak scaling; images are
-independent, the only exchange is the prototype-table step).
+independent, k-means itself has no collective); the batch-wide prototype-table
+exchange (one all_gather + one RCCL all_reduce over xGMI) is timed separately
+and reported as `exchange_ms`.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline      the dominant launch group (the E-step): algorithmic bytes (4D+8 per
-                pixel) over its average duration, measured with HIP events on the
-                launch stream inside the timed region (libhsgk's event profiler);
-                roofline_mstep / roofline_prep / roofline_iteration: the same for
-                the M-step update, the prep kernel and one whole Lloyd iteration.
-                `traffic`: HBM bytes per launch from the committed counter passes
-                (profiles/r01_pmc.txt), 2 x FETCH_SIZE + WRITE_SIZE as the guide
-                prescribes for gfx950 -- calibrated on these kernels' own aligned
-                streams (pmc_traffic); null for other workloads;
+Launch: `python bench.py --gpus N --steps K --warmup W`.  Under torchrun
+(`WORLD_SIZE` set) the script is one rank; otherwise, for N > 1, it re-launches
+itself as `python -m torch.distributed.run --nproc-per-node N ...` on
+127.0.0.1, one rank per GPU.
+
+Inputs come from the repo's portable integer-hash generator (hsg_amd/utils/synth.py,
+seed 0x48534700 + cfg id, global image index = rank * B + b), generated directly in HBM
+by libhsgk with the same bits numpy produces.
+
+Prints ONE JSON line on rank 0, including
+  roofline      the dominant launch group (the E-step).  `achieved` / `frac` price the HBM
+                bytes the group actually moves (PMC counters of profiles/, else the bytes it
+                streams by construction) over its average duration, measured with HIP events
+                on the launch stream inside the timed region (libhsgk's event profiler);
+                `algorithmic_*` is SURVEY 8(d)'s 4D+8 B per pixel over the same time (it can
+                exceed the peak: the filter level reads a half-size copy of the rows);
+                roofline_mstep / roofline_prep / roofline_iteration: M-step update, prep
+                kernel and one whole Lloyd iteration;
   cpu_baseline  oracle/torch_ref.py (same ATen op sequence as the reference's
-                CPU path) timed on the host cores, rank 0, N=1 only.
+                CPU path) timed on the host cores, rank 0, N=1 only: warm-up + median of 3
+                on 4 images, plus a 1-thread row;
+  extra_runs    the same call on the 'mixture' input and with an over-segmentation label
+                map + 4-row ignore band, N=1 only.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -34,60 +50,132 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (B per GPU, C, H, W, grid, iterations)
-    'cfg2': (48, 256, 448, 448, (8, 8), 10),
-    'cfg3': (16, 256, 224, 224, (8, 8), 10),
-    'cfg5': (24, 384, 224, 224, (8, 16), 10),
-    'cfg1': (4, 32, 64, 64, (2, 4), 10),
-    'cfg4': (4, 256, 768, 768, (16, 16), 10),      # finest level of the 256/64/16 hierarchy, 4 of 16 images per GPU
+    # name: (cfg id, B per GPU, C, H, W, grid, iterations)
+    'cfg2': (2, 48, 256, 448, 448, (8, 8), 10),
+    'cfg3': (3, 16, 256, 224, 224, (8, 8), 10),
+    'cfg5': (5, 24, 384, 224, 224, (8, 16), 10),
+    'cfg1': (1, 4, 32, 64, 64, (2, 4), 10),
+    'cfg4': (4, 4, 256, 768, 768, (16, 16), 10),      # finest level of the 256/64/16 hierarchy, 4 of 16 images per GPU
+    # the reference's training resolution (input / 16): fixed-cost-bound small maps
+    'train28': (6, 48, 256, 28, 28, (8, 8), 10),
+    'train14': (7, 16, 256, 14, 14, (4, 4), 10),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+PMC_FILES = ('r02_pmc.txt', 'r01_pmc.txt')
 
 
 def pmc_traffic(kernels):
   """HBM bytes per launch of the given kernels from the committed rocprofv3 counter passes
-  (profiles/r01_pmc.txt, collected by tools/collect_profiles.sh with one --pmc pass per
+  (profiles/rNN_pmc.txt, collected by tools/collect_profiles.sh with one --pmc pass per
   counter group), corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE (KB)
   tallies 128-byte requests at 64 B, so it is doubled; WRITE_SIZE (KB) is taken as is (it
   matches the expected bytes of the prep and label writes within 2 %).  Calibration on these
   very access patterns: 2 x FETCH_SIZE of assign_half_kernel = 5.07 GB for 5.05 GB streamed,
-  of the M-step's full pass 10.2 GB for 9.98 GB.  None when the file is missing."""
-  path = os.path.join(ROOT, 'profiles', 'r01_pmc.txt')
-  try:
-    lines = open(path).read().splitlines()
-  except OSError:
-    return None
-  vals, section, kern = {}, None, None
-  for ln in lines:
-    if ln.startswith('## --pmc'):
-      section = ln
+  of the M-step's full pass 10.2 GB for 9.98 GB.  (None, None) when no file has them."""
+  for fname in PMC_FILES:
+    path = os.path.join(ROOT, 'profiles', fname)
+    try:
+      lines = open(path).read().splitlines()
+    except OSError:
       continue
-    if ln and not ln.startswith(' ') and not ln.startswith('#'):
-      kern = ln.strip()
-      continue
-    parts = ln.split()
-    if len(parts) >= 2 and parts[0] in ('FETCH_SIZE', 'WRITE_SIZE') and kern:
-      vals.setdefault(kern, {})[parts[0]] = float(parts[1]) * 1024.0      # KB -> B
-  total = 0.0
-  for k in kernels:
-    hit = [v for name, v in vals.items() if k in name]
-    if not hit:
-      return None
-    total += 2.0 * hit[0].get('FETCH_SIZE', 0.0) + hit[0].get('WRITE_SIZE', 0.0)
-  return int(total)
+    vals, kern = {}, None
+    for ln in lines:
+      if ln.startswith('#'):
+        continue
+      if ln and not ln.startswith(' '):
+        kern = ln.strip()
+        continue
+      parts = ln.split()
+      if len(parts) >= 2 and parts[0] in ('FETCH_SIZE', 'WRITE_SIZE') and kern:
+        vals.setdefault(kern, {})[parts[0]] = float(parts[1]) * 1024.0      # KB -> B
+    total, ok = 0.0, True
+    for k in kernels:
+      hit = [v for name, v in vals.items() if k in name]
+      if not hit:
+        ok = False
+        break
+      total += 2.0 * hit[0].get('FETCH_SIZE', 0.0) + hit[0].get('WRITE_SIZE', 0.0)
+    if ok:
+      return int(total), 'profiles/' + fname
+  return None, None
 
 
-def main():
+def free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+def relaunch_as_ranks(n):
+  """`python bench.py --gpus N` outside torchrun: start N ranks of this script on this node."""
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+         '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
+         os.path.abspath(__file__)] + sys.argv[1:]
+  return subprocess.call(cmd)
+
+
+def parse_args():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=3)
   ap.add_argument('--warmup', type=int, default=1)
   ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
+  ap.add_argument('--flavour', default='iid', choices=['iid', 'mixture'],
+                  help='input distribution of the headline run (BASELINE.md: i.i.d. N(0,1))')
+  ap.add_argument('--labels', action='store_true',
+                  help='headline run with the over-segmentation label map + ignore band')
   ap.add_argument('--no-exchange', action='store_true',
-                  help='skip the untimed prototype-table exchange measurement')
-  ap.add_argument('--cpu-images', type=int, default=1,
+                  help='skip the prototype-table exchange measurement')
+  ap.add_argument('--no-extra', action='store_true', help='skip the mixture / labelled side runs')
+  ap.add_argument('--cpu-images', type=int, default=4,
                   help='images of the workload shape timed on the host CPU (0 = skip)')
-  args = ap.parse_args()
+  return ap.parse_args()
+
+
+def cpu_baseline(torch, x_cpu, grid, iters, shape_note):
+  """oracle/torch_ref.py on the host cores: thread counts 1 and
+  min(32, cores) (and min(64, cores) when the host has more: 256 oversubscribed MKL threads
+  ran 45x slower than 32 in round 1, so all-cores is not tried beyond 64), one warm-up,
+  median of 3 runs each; the 1-thread row uses one image."""
+  from oracle import torch_ref
+  nb, C, H, W = x_cpu.shape
+  ncpu = os.cpu_count() or 1
+  torch_ref.segment_by_kmeans(x_cpu[:1, :, :min(H, 64), :min(W, 64)].contiguous(), None, grid, None, None, 2)
+  rows = []
+  for threads in sorted({1, min(32, ncpu), min(64, ncpu)}):
+    torch.set_num_threads(threads)
+    xs = x_cpu[:1] if threads == 1 else x_cpu
+    runs = []
+    budget_t0 = time.perf_counter()
+    for i in range(4):                       # run 0 = warm-up
+      t0 = time.perf_counter()
+      torch_ref.segment_by_kmeans(xs, None, grid, None, None, iters)
+      dt = time.perf_counter() - t0
+      if i:
+        runs.append(dt)
+      if time.perf_counter() - budget_t0 > 25.0 and runs:
+        break
+    med = statistics.median(runs)
+    rows.append({'threads': threads, 'images': int(xs.shape[0]), 'median_s': round(med, 3),
+                 'runs_s': [round(r, 3) for r in runs],
+                 'pixels_per_s': round(xs.shape[0] * H * W / med, 1)})
+  best = max(rows, key=lambda r: r['pixels_per_s'])
+  one = [r for r in rows if r['threads'] == 1][0]
+  return {'value': best['pixels_per_s'], 'unit': 'pixels/s', 'cores': best['threads'], 'kind': 'port',
+          'single_thread_value': one['pixels_per_s'],
+          'sample': '%d of the workload\'s images (%s), %d iterations, oracle/torch_ref.py (ATen op sequence '
+                    'of the reference CPU path), warm-up + median of up to 3 runs per thread count; the '
+                    'reference loops over images serially, so the rate does not depend on the batch size; '
+                    'host has %d logical CPUs' % (nb, shape_note, iters, ncpu),
+          'rows': rows}
+
+
+def main():
+  args = parse_args()
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    sys.exit(relaunch_as_ranks(args.gpus))
 
   import torch
   rank = int(os.environ.get('RANK', '0'))
@@ -95,28 +183,38 @@ def main():
   local = int(os.environ.get('LOCAL_RANK', '0'))
   dist = None
   if world > 1 or os.environ.get('HSGK_BENCH_FORCE_DIST') == '1':   # (the switch exercises the RCCL path on one GPU)
+    import datetime
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29533')
     os.environ.setdefault('RANK', '0')
     os.environ.setdefault('WORLD_SIZE', '1')
     torch.cuda.set_device(local)
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    dist.init_process_group('nccl', device_id=torch.device('cuda', local),
+                            timeout=datetime.timedelta(seconds=300))
   dev = torch.device('cuda', local)
   torch.cuda.set_device(dev)
 
   from hsg_amd import _lib
+  from hsg_amd.utils import synth
   from hsg_amd.utils.segsort import common as segsort_common
 
-  B, C, H, W, grid, iters = WORKLOADS[args.workload]
+  cfg_id, B, C, H, W, grid, iters = WORKLOADS[args.workload]
   D = C + 2
-  gen = torch.Generator(device=dev)
-  gen.manual_seed(0x48534700 + 2 + 1000 * rank)
-  x = torch.randn((B, C, H, W), device=dev, dtype=torch.float32, generator=gen)
+  K = grid[0] * grid[1]
+  seed = synth.SEED_BASE + cfg_id
+  x = synth.device_embeddings_nchw(seed, (B, C, H, W), args.flavour, dev, first_image=rank * B)
 
-  def step():
-    out = segsort_common.segment_by_kmeans(x, None, list(grid), iterations=iters)
-    return out
+  def make_labels():
+    lab = synth.overseg_labels(seed + 0x100 + rank, B, H, W, regions=48, ignore_rows=4, ignore_index=255)
+    return torch.from_numpy(lab).to(dev)
+
+  labels = make_labels() if args.labels else None
+
+  def run(xin, lab):
+    if lab is None:
+      return segsort_common.segment_by_kmeans(xin, None, list(grid), iterations=iters)
+    return segsort_common.segment_by_kmeans(xin, lab, list(grid), ignore_index=255, iterations=iters)
 
   def fence():
     torch.cuda.synchronize(dev)
@@ -124,8 +222,22 @@ def main():
       dist.barrier()
       torch.cuda.synchronize(dev)
 
+  def timed(xin, lab, warmup, steps):
+    out = None
+    for _ in range(warmup):
+      out = run(xin, lab)
+      del out
+    fence()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+      del out
+      out = run(xin, lab)
+    fence()
+    return time.perf_counter() - t0, out
+
   for _ in range(args.warmup):
-    out = step()
+    out = run(x, labels)
     del out
   fence()
   _lib.profile_enable(True)
@@ -134,33 +246,40 @@ def main():
   out = None
   for _ in range(args.steps):
     del out
-    out = step()
+    out = run(x, labels)
   fence()
   elapsed = time.perf_counter() - t0
   prof = _lib.profile_collect()
   _lib.profile_enable(False)
 
-  # Untimed side measurement: the batch-wide prototype table of the step's
-  # output (local segment sums + ONE RCCL all_reduce over xGMI when N > 1,
-  # hsg_amd/models/utils.py).  Not part of `value` (BASELINE.md metric = the
-  # segment_by_kmeans call), reported in config for the multi-GPU runs.
+  # The batch-wide prototype table of the step's output (local segment sums, one all_gather of
+  # the segment keys and ONE RCCL all_reduce over xGMI when N > 1; hsg_amd/models/utils.py).
+  # Not part of `value` (BASELINE.md metric = the segment_by_kmeans call); timed on its own
+  # with the same fences, max over ranks.
   exch = None
   if not args.no_exchange:
-    # never let the side measurement take the headline line down with it
-    try:
+    try:        # never let the side measurement take the headline line down with it
       from hsg_amd.models import utils as model_utils
       emb, emb_loc, lab, cidx, bidx = out
       zeros = torch.zeros_like(lab)
-      times = []
-      for _ in range(3):
+      times, ncoll, res = [], 0, None
+      for _ in range(4):                    # run 0 = warm-up (RCCL channel setup)
+        del res
         fence()
+        c0 = model_utils.collective_calls
         t1 = time.perf_counter()
         res = model_utils.gather_clustering_and_update_prototypes(emb, emb_loc, cidx, bidx, lab, zeros)
         fence()
         times.append(time.perf_counter() - t1)
-      exch = {'ms': round(min(times) * 1e3, 3), 'segments': int(res[0].shape[0]),
+        ncoll = model_utils.collective_calls - c0
+      tt = torch.tensor(times[1:], device=dev, dtype=torch.float64)
+      if dist is not None:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+      tl = tt.tolist()
+      exch = {'ms': round(statistics.median(tl) * 1e3, 3), 'runs_ms': [round(t * 1e3, 3) for t in tl],
+              'segments_total': int(res[0].shape[0]), 'collectives_per_call': int(ncoll),
               'payload_MB': round(res[0].shape[0] * (2 * C + 2) * 4 / 1e6, 2)}
-      del res, emb, emb_loc, lab, cidx, bidx
+      del res, emb, emb_loc, lab, cidx, bidx, zeros
     except Exception as e:                      # noqa: BLE001
       exch = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
   del out
@@ -175,98 +294,97 @@ def main():
 
   # Rooflines (HBM-bound kernels; durations from libhsgk's HIP-event profiler, recorded on
   # the launch stream inside the timed region).  `roofline` is the DOMINANT launch group by
-  # time, the E-step (also the one north_star's 50 % target names); `roofline_mstep` is the
-  # exact-sum M-step update, `roofline_prep` the prep kernel, `roofline_iteration` one whole
-  # Lloyd iteration (M + finalize + E) against SURVEY 8(d)'s fused-iteration figure of
-  # 4D+8 bytes per pixel.
+  # time, the E-step (also the one north_star's 50 % target names).
   npx = B * H * W
   p_ms, p_n = prof['prep']
   m_ms, m_n = prof['accumulate']
   f_ms, f_n = prof['finalize']
   a_ms, a_n = prof['assign']
+  headline = args.workload == 'cfg2' and B == 48 and args.flavour == 'iid' and not args.labels
 
-  def rl(kernel, bytes_per_launch, ms, n, **extra):
+  def rl(kernel, algorithmic, moved, moved_source, ms, n, **extra):
+    """achieved / frac: the bytes the launch moves through HBM over its duration; algorithmic_*:
+    SURVEY 8(d)'s per-pixel figure over the same duration."""
     if not n:
       return None
     avg_s = ms / n * 1e-3
-    ach = bytes_per_launch / avg_s / 1e9
-    out = {'bound': 'hbm', 'kernel': kernel, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
-           'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
-           'avg_launch_ms': round(ms / n, 4), 'launches': int(n),
-           'algorithmic_bytes_per_launch': int(bytes_per_launch)}
-    out.update(extra)
-    return out
+    ach = moved / avg_s / 1e9
+    alg = algorithmic / avg_s / 1e9
+    res = {'bound': 'hbm', 'kernel': kernel, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
+           'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
+           'traffic': int(moved) if moved_source.startswith('profiles/') else None,
+           'bytes_source': moved_source, 'avg_launch_ms': round(ms / n, 4), 'launches': int(n),
+           'algorithmic_bytes_per_launch': int(algorithmic),
+           'algorithmic_achieved': round(alg, 1), 'algorithmic_frac': round(alg / HBM_PEAK_GBS, 4)}
+    res.update(extra)
+    return res
 
-  half_ok = (D % 64 == 2 and 128 <= D <= 322 and (D // 64) % 2 == 0 and grid[0] * grid[1] <= 64)
+  half_ok = (D % 64 == 2 and 128 <= D <= 322 and (D // 64) % 2 == 0 and K <= 64)
+  e_alg = (4 * D + 8) * npx
+  e_moved, e_src = e_alg, 'algorithmic (the exact engine reads every fp32 row once)'
+  if half_ok:
+    e_moved = (2 * (D - 2) + 8 + 4 + 0.015 * 4 * D) * npx
+    e_src = 'by construction: fp16 row copy 2(D-2)+8 B + 4 B label per pixel + the fp32 rows of ~1.5 % undecided pixels'
+  if headline and half_ok:
+    tr, src = pmc_traffic(['assign_half_kernel', 'assign_split_rows_kernel', 'assign_requeue_rows_kernel'])
+    if tr:
+      e_moved, e_src = tr, src + ': 2 x FETCH_SIZE + WRITE_SIZE summed over the group (gfx950 correction of MI355X_MICROARCH.md)'
   roofline = rl(
       'E-step launch group (dominant by time): assign_half_kernel (fp16 filter over the fp16 row '
       'copy) + assign_split_rows_kernel (bf16x3 on the undecided rows) + assign_requeue_rows_kernel '
       '(exact fp32 chains)' if half_ok else 'E-step launch group (dominant by time)',
-      (4 * D + 8) * npx, a_ms, a_n,
-      mfma_tflops=round(2.0 * D * (grid[0] * grid[1]) * npx / (a_ms / max(a_n, 1) * 1e-3) / 1e12, 2)
-      if a_n else None,
-      note=('achieved / frac follow the contract: SURVEY 8(d)\'s algorithmic 4D+8 B per pixel over the '
-            'group\'s duration.  By design the group STREAMS less than that -- the fp16 copy '
-            '(2(D-2)+8 B per pixel), 4 B of labels and the fp32 rows of the ~1.5 % undecided pixels '
-            '-- which is how frac can exceed 1; streamed_* price that traffic instead') if half_ok else None)
-  if roofline and half_ok and args.workload == 'cfg2' and B == 48:
-    # counters were collected on exactly this workload (per GPU); see pmc_traffic()
-    roofline['traffic'] = pmc_traffic(['assign_half_kernel', 'assign_split_rows_kernel',
-                                       'assign_requeue_rows_kernel'])
-    roofline['traffic_source'] = ('profiles/r01_pmc.txt: sum over the group of 2 x FETCH_SIZE + WRITE_SIZE '
-                                  '(gfx950 correction of MI355X_MICROARCH.md), bytes per launch')
-  if roofline and half_ok:
-    streamed = (2 * (D - 2) + 8 + 4 + 0.015 * 4 * D) * npx
-    sg = streamed / (a_ms / a_n * 1e-3) / 1e9
-    roofline.update({'streamed_bytes_per_launch': int(streamed), 'streamed_GBps': round(sg, 1),
-                     'streamed_frac': round(sg / HBM_PEAK_GBS, 4)})
+      e_alg, e_moved, e_src, a_ms, a_n,
+      mfma_tflops=round(2.0 * D * K * npx / (a_ms / max(a_n, 1) * 1e-3) / 1e12, 2) if a_n else None)
+
+  m_alg = 4 * D * npx
+  m_moved, m_src = m_alg, 'algorithmic upper bound (one read of every fp32 row; the update reads only changed rows)'
+  pr_alg = (8 * C + 4 * D + 24) * npx
+  pr_moved, pr_src = pr_alg + (2 * C + 12) * npx, 'by construction: input + both float outputs + labels + the fp16 row copy'
+  if headline:
+    t_u, s_u = pmc_traffic(['update_sums_persistent_kernel'])
+    t_r, _ = pmc_traffic(['m0_reduce_kernel'])
+    if t_u and t_r and iters >= 1:          # per call: one reduce + (iterations - 1) updates
+      m_moved, m_src = ((iters - 1) * t_u + t_r) / iters, s_u + ': 2 x FETCH_SIZE + WRITE_SIZE, averaged over the call\'s M-step launches'
+    t_p, s_p = pmc_traffic(['prep_fast32_kernel'])
+    if t_p:
+      pr_moved, pr_src = t_p, s_p + ': 2 x FETCH_SIZE + WRITE_SIZE'
   roofline_mstep = rl(
       'M-step: exact fixed-point segment sums.  The first M-step of a call is summed inside the prep '
       'kernel (seed-grid labels) and folded by m0_reduce_kernel; the other launches are the update_sums '
-      'kernel, which reads only the rows whose label changed (nearly all in its first launch, a few per '
-      'cent in the last)',
-      4 * D * npx, m_ms, m_n,
-      note='algorithmic bytes = one read of every fp32 row (4D B per pixel) per launch; the update only '
-           'reads the changed rows, so the average launch beats that stream')
-  roofline_prep = rl('prep kernel (NCHW -> normalised rows, both float outputs, labels, fp16 copy)',
-                     (8 * C + 4 * D + 24) * npx, p_ms, p_n)
-  if args.workload == 'cfg2' and B == 48:
-    if roofline_mstep:
-      t_u, t_r = pmc_traffic(['update_sums_persistent_kernel']), pmc_traffic(['m0_reduce_kernel'])
-      if t_u is not None and t_r is not None and iters >= 1:   # per call: one reduce + (iterations - 1) updates
-        roofline_mstep['traffic'] = int(((iters - 1) * t_u + t_r) / iters)
-    if roofline_prep:
-      roofline_prep['traffic'] = pmc_traffic(['prep_fast32_kernel'])
+      'kernel, which reads only the rows whose label changed', m_alg, m_moved, m_src, m_ms, m_n)
+  roofline_prep = rl('prep kernel (NCHW -> normalised rows, both float outputs, labels, fp16 copy, first M-step)',
+                     pr_alg, pr_moved, pr_src, p_ms, p_n)
   roofline_iteration = None
   if m_n and a_n and f_n:
     it_ms = m_ms / m_n + f_ms / f_n + a_ms / a_n
-    roofline_iteration = rl('one Lloyd iteration = sums update + finalize + E-step group, against one '
-                            'read of the fp32 rows + the label write', (4 * D + 8) * npx, it_ms, 1)
+    roofline_iteration = rl('one Lloyd iteration = sums update + finalize + E-step group',
+                            e_alg, e_moved + m_moved, 'sum of the E-step and M-step figures above', it_ms, 1)
     roofline_iteration['launches'] = int(a_n)
   phases = {k: round(v[0] / max(1, args.steps), 3) for k, v in prof.items()}
 
+  # Side runs on the other BASELINE.md inputs (N=1 only; 1 warm-up + 2 timed calls each).
+  extra = None
+  if rank == 0 and world == 1 and not args.no_extra:
+    extra = {}
+    try:
+      xm = synth.device_embeddings_nchw(seed, (B, C, H, W), 'mixture' if args.flavour == 'iid' else 'iid', dev)
+      dt, o = timed(xm, None, 1, 2)
+      extra['mixture' if args.flavour == 'iid' else 'iid'] = {
+          'ms_per_step': round(dt / 2 * 1e3, 3), 'pixels_per_s': round(npx * 2 / dt, 1)}
+      del o, xm
+      lab2 = make_labels()
+      dt, o = timed(x, lab2, 1, 2)
+      extra['iid_overseg_labels_ignore_band'] = {
+          'ms_per_step': round(dt / 2 * 1e3, 3), 'pixels_per_s': round(npx * 2 / dt, 1),
+          'kept_pixels': int(o[0].shape[0]), 'segments': int(o[3].max()) + 1}
+      del o, lab2
+    except Exception as e:                      # noqa: BLE001
+      extra['error'] = '%s: %s' % (type(e).__name__, str(e)[:200])
+
   cpu = None
   if rank == 0 and world == 1 and args.cpu_images > 0:
-    from oracle import torch_ref
     nb = min(args.cpu_images, B)
-    xc = x[:nb].cpu()
-    ncpu = os.cpu_count() or 1
-    runs = []
-    for threads in sorted({min(32, ncpu), ncpu}):
-      torch.set_num_threads(threads)
-      t0 = time.perf_counter()
-      torch_ref.segment_by_kmeans(xc, None, grid, None, None, iters)
-      runs.append((time.perf_counter() - t0, threads))
-      if runs[-1][0] > 40.0:
-        break
-    dt, threads = min(runs)
-    cpu = {'value': round(nb * H * W / dt, 1), 'unit': 'pixels/s', 'cores': threads,
-           'kind': 'port',
-           'sample': '%d of %d images of the same %dx%dx%d shape, %d iterations, '
-                     'oracle/torch_ref.py (ATen op sequence of the reference CPU path); '
-                     'host has %d logical CPUs; runs (seconds@threads): %s'
-                     % (nb, B, C, H, W, iters, ncpu,
-                        ', '.join('%.1f@%d' % r for r in runs))}
+    cpu = cpu_baseline(torch, x[:nb].cpu(), grid, iters, '%dx%dx%d each' % (C, H, W))
 
   if rank == 0:
     print(json.dumps({
@@ -275,12 +393,14 @@ def main():
         'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s: segment_by_kmeans %dx%dx%dx%d per GPU, K=%dx%d, %d Lloyd '
-                               'iterations, no labels' % (args.workload, B, C, H, W, grid[0],
-                                                          grid[1], iters),
+                               'iterations, %s input (portable generator, seed 0x%X), %s'
+                               % (args.workload, B, C, H, W, grid[0], grid[1], iters, args.flavour, seed,
+                                  'over-segmentation labels + ignore band' if args.labels else 'no labels'),
                    'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world,
-                   'phase_ms_per_step': phases, 'prototype_exchange_untimed': exch},
+                   'phase_ms_per_step': phases},
+        'exchange_ms': exch.get('ms') if exch else None, 'prototype_exchange': exch,
         'roofline': roofline, 'roofline_mstep': roofline_mstep, 'roofline_prep': roofline_prep,
-        'roofline_iteration': roofline_iteration, 'cpu_baseline': cpu}))
+        'roofline_iteration': roofline_iteration, 'cpu_baseline': cpu, 'extra_runs': extra}))
   if dist is not None:
     dist.destroy_process_group()
 

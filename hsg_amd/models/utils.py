@@ -7,8 +7,9 @@ table there and copies it back (3x per iteration, train.py:190,219).  Here
 each rank reduces its own pixels to per-segment SUMS with libhsgk
 (segment_reduce, mode 2) and only the small segment table crosses xGMI:
 
-    keys      all_gather of the sorted unique (image, cluster, sem, inst) keys
-    sums      one RCCL all_reduce(sum) over the zero-padded [P_total, C + D] table
+    keys      ONE fixed-capacity all_gather of the ranks' distinct
+              (image, cluster, sem, inst) tuples (row count in the buffer header)
+    sums      ONE RCCL all_reduce(sum) over the zero-padded [P_total, C + D] table
     labels    decoded from the keys (identical on every rank)
 
 A segment normally lives on one rank (an image is never split), so the
@@ -53,31 +54,53 @@ def _cat_to(tensors, device):
   return torch.cat([t.to(device) for t in tensors], 0)
 
 
-def _all_max(value, group):
-  """Global max of a 0-d integer tensor over the ranks of `group`."""
-  if _world(group) > 1:
-    value = value.clone()
-    dist.all_reduce(value, op=dist.ReduceOp.MAX, group=group)
-  return value
+# Rows per rank of the fixed-size gather buffers, per call site.  Every rank starts from the
+# same value and grows it from the same gathered counts, so the sizes agree without a
+# collective of their own.
+_capacity = {}
+_CAP_START = 4096
+collective_calls = 0        # incremented per collective issued (tests / bench read it)
 
 
-def _all_gather_varlen(t, group):
-  """Concatenation over ranks (rank order) of 1-D/2-D tensors whose first
-  dimension differs per rank; also returns this rank's offset."""
+def _all_gather_rows(t, group, tag):
+  """Concatenation over ranks (rank order) of tensors whose first dimension differs per
+  rank, in ONE collective and ONE host read: every rank contributes a fixed-capacity byte
+  buffer whose first 8 bytes hold its row count.  If some rank has more rows than the
+  capacity, every rank sees that in the same counts and repeats the gather with the next
+  power of two (kept for later calls).  Returns (rows, counts)."""
+  global collective_calls
   world = _world(group)
   if world == 1:
-    return t, 0
-  n = torch.tensor([t.shape[0]], dtype=torch.long, device=t.device)
-  counts = [torch.zeros_like(n) for _ in range(world)]
-  dist.all_gather(counts, n, group=group)
-  counts = [int(c.item()) for c in counts]
-  cap = max(max(counts), 1)
-  pad = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-  pad[:t.shape[0]] = t
-  bufs = [torch.empty_like(pad) for _ in range(world)]
-  dist.all_gather(bufs, pad, group=group)
-  rank = dist.get_rank(group)
-  return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0), sum(counts[:rank])
+    return t, [t.shape[0]]
+  t = t.contiguous()
+  n = t.shape[0]
+  row_shape = tuple(t.shape[1:])
+  row_bytes = t.element_size()
+  for s in row_shape:
+    row_bytes *= s
+  key = (tag, row_bytes)
+  while True:
+    cap = _capacity.get(key, _CAP_START)
+    send = torch.zeros((8 + cap * row_bytes,), dtype=torch.uint8, device=t.device)
+    send[:8] = torch.tensor([n], dtype=torch.int64).view(torch.uint8).to(t.device, non_blocking=True)
+    m = min(n, cap)
+    if m:
+      send[8:8 + m * row_bytes] = t[:m].reshape(-1).view(torch.uint8)
+    recv = torch.empty((world, 8 + cap * row_bytes), dtype=torch.uint8, device=t.device)
+    dist.all_gather_into_tensor(recv.view(-1), send, group=group)
+    collective_calls += 1
+    counts = recv[:, :8].contiguous().view(torch.int64).view(-1).tolist()     # the one host read
+    need = max(counts)
+    if need <= cap:
+      break
+    while cap < need:
+      cap *= 2
+    _capacity[key] = cap
+  parts = [recv[r, 8:8 + c * row_bytes] for r, c in enumerate(counts) if c]
+  if not parts:
+    return t[:0], counts
+  flat = torch.cat(parts, 0) if len(parts) > 1 else parts[0].contiguous()
+  return flat.view(t.dtype).view((-1,) + row_shape), counts
 
 
 class _AllReduceSum(torch.autograd.Function):
@@ -86,9 +109,11 @@ class _AllReduceSum(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, x, group):
+    global collective_calls
     ctx.group = group
     y = x.detach().clone()
     dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
+    collective_calls += 1
     return y
 
   @staticmethod
@@ -98,43 +123,78 @@ class _AllReduceSum(torch.autograd.Function):
     return g, None
 
 
+def _compose(tuples, rc, rl):
+  """(batch, cluster, semantic, instance) columns -> one sortable key."""
+  return ((tuples[:, 0] * rc + tuples[:, 1]) * rl + tuples[:, 2]) * rl + tuples[:, 3]
+
+
 # ---- hsg/models/utils.py:127-217 -----------------------------------------------
 def exchange_prototypes(embeddings, embeddings_with_loc, cluster_indices, batch_indices,
                         semantic_labels, instance_labels, group=None):
   """Per-rank tensors in, batch-wide prototype tables out (same 6 results as
-  the reference's gather_clustering_and_update_prototypes, un-listed)."""
+  the reference's gather_clustering_and_update_prototypes, un-listed).
+
+  Two collectives per call: one fixed-capacity all_gather of the ranks' distinct
+  (batch, cluster, semantic, instance) tuples and one all_reduce(sum) of the
+  zero-padded [P_total, C + D] segment sums.  The reference's dense ids are the
+  ranks of those tuples in lexicographic order (its two nested sorted
+  `unique`s, utils.py:181-193), which does not depend on the radices used to
+  pack them -- so each rank packs with its own maxima and no max-reduction is
+  needed before the gather."""
   dev = cluster_indices.device
-  c = cluster_indices.view(-1).long()
-  b = batch_indices.view(-1).long()
-  sem = semantic_labels.view(-1).long()
-  inst = instance_labels.view(-1).long()
-  zero = torch.zeros((), dtype=torch.long, device=dev)
+  c = cluster_indices.reshape(-1).long()
+  b = batch_indices.reshape(-1).long()
+  sem = semantic_labels.reshape(-1).long()
+  inst = instance_labels.reshape(-1).long()
+  world = _world(group)
 
-  # utils.py:181-189: key order = (batch, cluster, semantic, instance)
-  divisor = _all_max(c.max() + 1 if c.numel() else zero + 1, group)
-  lab_div = _all_max(torch.maximum(inst.max(), sem.max()) + 1 if c.numel() else zero + 1, group)
-  keys = ((b * divisor + c) * lab_div + sem) * lab_div + inst
-  local_keys, local_ids = torch.unique(keys, return_inverse=True)
+  if c.numel():
+    rc = c.max() + 1
+    rl = torch.maximum(inst.max(), sem.max()) + 1
+    keys = ((b * rc + c) * rl + sem) * rl + inst
+    local_keys, local_ids = torch.unique(keys, return_inverse=True)
+    rest, li = local_keys // rl, local_keys % rl
+    rest, ls = rest // rl, rest % rl
+    local_tuples = torch.stack([rest // rc, rest % rc, ls, li], 1)
+  else:
+    local_ids = torch.zeros((0,), dtype=torch.long, device=dev)
+    local_tuples = torch.zeros((0, 4), dtype=torch.long, device=dev)
 
-  gathered, _ = _all_gather_varlen(local_keys, group)
-  global_keys = torch.unique(gathered) if _world(group) > 1 else local_keys
+  if world > 1:
+    tuples, _ = _all_gather_rows(local_tuples, group, 'proto_keys')
+  else:
+    tuples = local_tuples
+  if tuples.shape[0]:
+    # utils.py:181-189: key order = (batch, cluster, semantic, instance)
+    divisor = tuples[:, 1].max() + 1
+    lab_div = tuples[:, 2:].max() + 1
+    if world > 1:
+      global_keys = torch.unique(_compose(tuples, divisor, lab_div))
+      slot = torch.searchsorted(global_keys, _compose(local_tuples, divisor, lab_div))
+    else:
+      global_keys = _compose(tuples, divisor, lab_div)        # already sorted and distinct
+      slot = None
+    updated_cluster_indices = slot[local_ids] if slot is not None else local_ids
+    # utils.py:193-197: labels of every prototype, decoded from the keys
+    prototype_instance_labels = global_keys % lab_div
+    prototype_semantic_labels = (global_keys // lab_div) % lab_div
+    prototype_batch_indices = (global_keys // (lab_div * lab_div)) // divisor
+  else:
+    global_keys = torch.zeros((0,), dtype=torch.long, device=dev)
+    slot = global_keys if world > 1 else None
+    updated_cluster_indices = local_ids
+    prototype_instance_labels = prototype_semantic_labels = prototype_batch_indices = global_keys
   P = global_keys.shape[0]
-  slot = torch.searchsorted(global_keys, local_keys)          # local segment -> global id
-  updated_cluster_indices = slot[local_ids]
-
-  # utils.py:193-197: labels of every prototype, decoded from the keys
-  prototype_instance_labels = global_keys % lab_div
-  prototype_semantic_labels = (global_keys // lab_div) % lab_div
-  prototype_batch_indices = (global_keys // (lab_div * lab_div)) // divisor
 
   # utils.py:199-202: segment sums -> (exchange) -> normalise
   C = embeddings.shape[-1]
+  D = embeddings_with_loc.shape[-1]
+  n_local = local_tuples.shape[0]
   local = torch.cat([
-      _segment_sums(embeddings.reshape(-1, C), local_ids, local_keys.shape[0]),
-      _segment_sums(embeddings_with_loc.reshape(-1, embeddings_with_loc.shape[-1]), local_ids,
-                    local_keys.shape[0])], 1)
-  if _world(group) > 1:
-    table = torch.zeros((P, local.shape[1]), dtype=local.dtype, device=dev)
+      _segment_sums(embeddings.reshape(-1, C), local_ids, n_local),
+      _segment_sums(embeddings_with_loc.reshape(-1, D), local_ids, n_local)], 1)
+  if world > 1:
+    table = torch.zeros((P, C + D), dtype=local.dtype, device=dev)
     table = table.index_add(0, slot, local)
     table = _AllReduceSum.apply(table, group)
   else:
@@ -192,7 +252,7 @@ def gather_and_reorder_image_indices(image_indices, anchor_device=None, group=No
   devices = [t.device for t in ids]
   anchor = torch.device(anchor_device) if anchor_device is not None else devices[0]
   local = _cat_to(ids, anchor).long() if len(ids) > 1 else ids[0].long()
-  gathered, _ = _all_gather_varlen(local, group)
+  gathered, _ = _all_gather_rows(local, group, 'image_ids')
   full = reorder_image_indices(gathered)
   if not listed:
     return full
@@ -210,15 +270,26 @@ def gather_and_update_cluster_mappings(cluster_indices_1, cluster_indices_2,
   anchor = torch.device(anchor_device) if anchor_device is not None else devices[0]
   a = _cat_to(c1, anchor).long() if len(c1) > 1 else c1[0].long()
   b = _cat_to(c2, anchor).long() if len(c2) > 1 else c2[0].long()
-  max_ind = _all_max(b.max() + 1, group)
-  size = _all_max(a.max() + 1, group)
-  pairs, _ = _all_gather_varlen(torch.unique(a * max_ind + b), group)
-  pairs = torch.unique(pairs)                                   # ascending: later writes win
-  mapping = torch.zeros((int(size),), dtype=torch.long, device=a.device)
-  # sorted order + last-write-wins == the reference's advanced-index assignment
-  keep = torch.ones_like(pairs, dtype=torch.bool)
-  keep[:-1] = (pairs[1:] // max_ind) != (pairs[:-1] // max_ind)
-  mapping[(pairs // max_ind)[keep]] = (pairs % max_ind)[keep]
+  if a.numel():
+    local_max = b.max() + 1
+    pk = torch.unique(a * local_max + b)
+    local_pairs = torch.stack([pk // local_max, pk % local_max], 1)
+  else:
+    local_pairs = torch.zeros((0, 2), dtype=torch.long, device=a.device)
+  # one collective: the ranks' distinct (index_1, index_2) pairs; the radices
+  # (utils.py:112,116) are the maxima over the gathered pairs
+  pairs2, _ = _all_gather_rows(local_pairs, group, 'cluster_pairs')
+  if pairs2.shape[0] == 0:
+    mapping = torch.zeros((0,), dtype=torch.long, device=a.device)
+  else:
+    max_ind = pairs2[:, 1].max() + 1
+    pairs = torch.unique(pairs2[:, 0] * max_ind + pairs2[:, 1])   # ascending: later writes win
+    size = int(pairs2[:, 0].max()) + 1
+    mapping = torch.zeros((size,), dtype=torch.long, device=a.device)
+    # sorted order + last-write-wins == the reference's advanced-index assignment on CPU
+    keep = torch.ones_like(pairs, dtype=torch.bool)
+    keep[:-1] = (pairs[1:] // max_ind) != (pairs[:-1] // max_ind)
+    mapping[(pairs // max_ind)[keep]] = (pairs % max_ind)[keep]
   if not listed:
     return mapping
   return [mapping.to(d) for d in devices]
@@ -232,7 +303,7 @@ def gather_and_update_datas(datas, anchor_device=None, group=None):
   anchor = torch.device(anchor_device) if anchor_device is not None else devices[0]
   local = _cat_to(items, anchor) if len(items) > 1 else items[0]
   flat = local.reshape(local.shape[0], -1)
-  gathered, _ = _all_gather_varlen(flat, group)
+  gathered, _ = _all_gather_rows(flat, group, 'datas')
   out = gathered.reshape((gathered.shape[0],) + tuple(local.shape[1:]))
   if not listed:
     return out

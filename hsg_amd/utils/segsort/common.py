@@ -87,13 +87,23 @@ def _default_loc(H, W, device):
   return hit
 
 
+def _batch_offset(B, dev):
+  """First batch index of this call's images (reference common.py:375-377: `N * gpu_id`,
+  one process driving every GPU).  With one process per GPU every rank may see its GPU as
+  device 0, so under torch.distributed the offset follows the global rank instead."""
+  import torch.distributed as dist
+  if dist.is_available() and dist.is_initialized():
+    return B * dist.get_rank()
+  return B * (dev.index or 0)
+
+
 class _SegmentByKmeans(torch.autograd.Function):
   """One libhsgk call; `embeddings` / `embeddings_with_loc` are differentiable
   w.r.t. the NCHW input (normalise -> concat -> normalise -> index_select),
   the three index outputs are not."""
 
   @staticmethod
-  def forward(ctx, x, lab, loc, loc_sb, seed_map, K, has_ignore, ign, iterations):
+  def forward(ctx, x, lab, loc, loc_sb, seed_map, K, has_ignore, ign, iterations, batch_offset):
     dev = x.device
     B, C, H, W = x.shape
     n_max = B * H * W
@@ -117,7 +127,7 @@ class _SegmentByKmeans(torch.autograd.Function):
           embeddings=xd.data_ptr(), labels=lab.data_ptr() if lab is not None else None,
           loc=loc.data_ptr(), loc_batch_stride=loc_sb, seed_map=seed_map.data_ptr(),
           B=B, C=C, H=H, W=W, K=K, iterations=int(iterations), has_ignore=int(has_ignore),
-          ignore_index=ign, batch_offset=B * (dev.index or 0), table_cap=table_cap,
+          ignore_index=ign, batch_offset=batch_offset, table_cap=table_cap,
           out_embeddings=out_emb.data_ptr(), out_embeddings_loc=out_loc.data_ptr(),
           out_labels=out_lab.data_ptr(), out_cluster=out_cluster.data_ptr(),
           out_batch=out_batch.data_ptr(), meta=meta.data_ptr(),
@@ -159,7 +169,7 @@ class _SegmentByKmeans(torch.autograd.Function):
           emb.data_ptr(), eloc.data_ptr(), norms.data_ptr(),
           rowmap.data_ptr() if rowmap is not None else None, B, C, H, W,
           ctypes.c_float(_lib.EPS), gx.data_ptr(), _lib.stream_ptr()))
-    return gx, None, None, None, None, None, None, None, None
+    return gx, None, None, None, None, None, None, None, None, None
 
 
 def segment_by_kmeans(embeddings,
@@ -168,7 +178,8 @@ def segment_by_kmeans(embeddings,
                       cluster_indices=None,
                       local_features=None,
                       ignore_index=None,
-                      iterations=10):
+                      iterations=10,
+                      batch_offset=None):
   """Per-image spherical k-means over pixel embeddings.
 
   Contract of reference common.py:270-408.  `embeddings` is [B,C,H,W] float32
@@ -176,7 +187,9 @@ def segment_by_kmeans(embeddings,
   labels [N], cluster_indices [N], batch_indices [N]) over the N pixels whose
   label differs from `ignore_index`, image-major, row-major inside an image.
   The two float outputs carry gradient back to `embeddings` (location
-  features are treated as constants).
+  features are treated as constants).  `batch_offset` (not in the reference:
+  there it is `B * gpu_id`) overrides the first batch index; the default is
+  `B * rank` under torch.distributed and `B * device.index` otherwise.
   """
   _require_gpu(embeddings, 'embeddings')
   if embeddings.dim() != 4:
@@ -214,8 +227,10 @@ def segment_by_kmeans(embeddings,
     lab = torch.zeros((B, H, W), dtype=torch.int64, device=dev)   # common.py:326-329
   has_ignore = ignore_index is not None
   ign = int(ignore_index) if has_ignore else 0
+  if batch_offset is None:
+    batch_offset = _batch_offset(B, dev)
   return _SegmentByKmeans.apply(x, lab, loc, loc_sb, seed_map, K, has_ignore, ign,
-                                int(iterations))
+                                int(iterations), int(batch_offset))
 
 
 def kmeans_with_initial_labels(embeddings, initial_labels, max_label=None, iterations=10):

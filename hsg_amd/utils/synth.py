@@ -58,9 +58,7 @@ def embeddings_nchw(seed, shape, flavour='iid'):
   if flavour != 'mixture':
     raise ValueError('flavour must be iid or mixture')
   ncentres = 20
-  cen = gaussish(seed ^ 0x5A5A, B * ncentres * C).reshape(B, ncentres, C).astype(np.float64)
-  cen /= np.sqrt((cen * cen).sum(-1, keepdims=True))
-  cen = cen.astype(np.float32)
+  cen = mixture_centres(seed, B, C, ncentres)
   # blob map: centre id depends on a coarse 2-D cell hashed per image
   cell = 8
   gy = (np.arange(H) // max(1, H // cell)).astype(np.uint64)
@@ -91,3 +89,45 @@ def overseg_labels(seed, B, H, W, regions=48, ignore_rows=4, ignore_index=255):
     if ignore_rows:
       lab[b, :ignore_rows, :] = ignore_index
   return lab
+
+
+def stream_key(seed):
+  """The 64-bit key hash_u64 mixes into every element index of stream `seed`."""
+  with np.errstate(over='ignore'):
+    return int(_splitmix64(np.uint64(seed) * np.uint64(0x2545F4914F6CDD1D) + np.uint64(1)))
+
+
+def mixture_centres(seed, B, C, ncentres=20):
+  """[B, ncentres, C] float32 unit centres of the 'mixture' flavour."""
+  cen = gaussish(seed ^ 0x5A5A, B * ncentres * C).reshape(B, ncentres, C).astype(np.float64)
+  cen /= np.sqrt((cen * cen).sum(-1, keepdims=True))
+  return cen.astype(np.float32)
+
+
+def device_embeddings_nchw(seed, shape, flavour='iid', device='cuda', first_image=0):
+  """embeddings_nchw(seed, (first_image + B, C, H, W), flavour)[first_image:] generated in
+  HBM by libhsgk (hsgk_synth_gaussish / hsgk_synth_mixture): bit-identical to the numpy
+  generator, so a full-size BASELINE batch needs no host memory and no PCIe transfer.
+  `first_image` is the global index of this rank's first image (per-GPU shard
+  offset = global image index)."""
+  import ctypes
+  import torch
+  from hsg_amd import _lib
+  B, C, H, W = shape
+  dev = torch.device(device)
+  L = _lib.lib()
+  with torch.cuda.device(dev):
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=dev)
+    offset = first_image * C * H * W
+    if flavour == 'iid':
+      _lib.check(L.hsgk_synth_gaussish(ctypes.c_uint64(stream_key(seed)), ctypes.c_uint64(offset),
+                                       out.numel(), out.data_ptr(), _lib.stream_ptr()))
+      return out
+    if flavour != 'mixture':
+      raise ValueError('flavour must be iid or mixture')
+    cen = torch.from_numpy(mixture_centres(seed, first_image + B, C)[first_image:].copy()).to(dev)
+    _lib.check(L.hsgk_synth_mixture(ctypes.c_uint64(stream_key(seed ^ 0xA5A5)), ctypes.c_uint64(seed),
+                                    cen.data_ptr(), cen.shape[1], first_image, B, C, H, W,
+                                    out.data_ptr(), _lib.stream_ptr()))
+    torch.cuda.current_stream().synchronize()      # `cen` dies here
+  return out

@@ -287,6 +287,18 @@ HSGK_API int hsgk_knn_affinity(const float *x, const float *affinity_in, int B, 
                                int binarize, float *affinity_tmp, float *out,
                                hsgk_stream_t stream);
 
+/* ---- synthetic inputs of the benchmark (hsg_amd/utils/synth.py; no reference counterpart:
+ * the reference ships no benchmark, BASELINE.md section 2 defines the generator) ------------
+ * out[i] = gaussish(hash(key, offset + i)); key = synth.stream_key(seed).  Bit-identical to
+ * the numpy generator that made the golden fixtures.                                        */
+HSGK_API int hsgk_synth_gaussish(uint64_t key, uint64_t offset, int64_t n, float *out,
+                                 hsgk_stream_t stream);
+/* 'mixture' flavour: out[b][c][y][x] = centres[b][blob(first_image + b, y, x)][c] + 0.05f * noise;
+ * images first_image .. first_image + B of the stream, centres [B][ncentres][C] of those images  */
+HSGK_API int hsgk_synth_mixture(uint64_t noise_key, uint64_t seed, const float *centres,
+                                int ncentres, int first_image, int B, int C, int H, int W,
+                                float *out, hsgk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,122 @@
+"""Multi-rank / launcher checks on real GPUs: the portable generator on the device, the
+bench launcher, and the prototype exchange over RCCL (`nccl` backend) -- the world-size-2
+case runs when the box shows at least two devices, the single-rank process-group case always."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import util
+from hsg_amd.utils import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FTOL = 2e-6
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+def test_device_generator_matches_numpy_bits():
+  import torch
+  dev = torch.device('cuda:0')
+  for shape in [(3, 5, 7, 9), (2, 32, 33, 17), (1, 1, 1, 1)]:
+    want = synth.embeddings_nchw(synth.SEED_BASE + 9, shape, 'iid')
+    got = synth.device_embeddings_nchw(synth.SEED_BASE + 9, shape, 'iid', dev).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    wantm = synth.embeddings_nchw(synth.SEED_BASE + 9, shape, 'mixture')
+    gotm = synth.device_embeddings_nchw(synth.SEED_BASE + 9, shape, 'mixture', dev).cpu().numpy()
+    assert np.array_equal(gotm.view(np.uint32), wantm.view(np.uint32))
+  # a rank's shard = the tail of the global batch (global image index = rank * B + b)
+  full = synth.embeddings_nchw(synth.SEED_BASE + 2, (5, 6, 10, 12), 'iid')
+  part = synth.device_embeddings_nchw(synth.SEED_BASE + 2, (2, 6, 10, 12), 'iid', dev, first_image=3).cpu().numpy()
+  assert np.array_equal(part, full[3:])
+  fullm = synth.embeddings_nchw(synth.SEED_BASE + 2, (5, 6, 10, 12), 'mixture')
+  partm = synth.device_embeddings_nchw(synth.SEED_BASE + 2, (2, 6, 10, 12), 'mixture', dev, first_image=3).cpu().numpy()
+  assert np.array_equal(partm, fullm[3:])
+
+
+def _bench(args, env_extra=None, timeout=600):
+  env = dict(os.environ)
+  env.update(env_extra or {})
+  env['MASTER_PORT'] = str(_free_port())
+  p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=env, cwd=ROOT,
+                     capture_output=True, text=True, timeout=timeout)
+  assert p.returncode == 0, p.stderr[-2000:]
+  lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+  assert len(lines) == 1, p.stdout[-2000:]
+  return json.loads(lines[0])
+
+
+def test_bench_line_single_rank_process_group():
+  """bench.py with an RCCL process group of one rank: contract fields, the exchange field."""
+  r = _bench(['--workload', 'cfg1', '--steps', '2', '--warmup', '1', '--cpu-images', '0', '--no-extra'],
+             {'HSGK_BENCH_FORCE_DIST': '1'})
+  assert r['n_gpus'] == 1 and r['steps'] == 2 and r['scaling'] == 'weak'
+  assert r['value'] > 0 and r['roofline']['frac'] <= 1.0
+  assert 'error' not in r['prototype_exchange'], r['prototype_exchange']
+  assert r['exchange_ms'] > 0
+
+
+def _nccl_worker(rank, world, port, result_dir):
+  import torch
+  import torch.distributed as dist
+  sys.path.insert(0, ROOT)
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  torch.cuda.set_device(rank)
+  dev = torch.device('cuda', rank)
+  dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+  try:
+    from hsg_amd.models import utils as mu
+    g = util.load('f8_exchange')
+    part = util.exchange_inputs(int(g['seed']))[rank]
+    T = lambda k: torch.from_numpy(part[k]).to(dev)
+    emb = T('emb').requires_grad_(True)
+    before = mu.collective_calls
+    protos, protos_loc, psem, pinst, pbatch, upd = mu.gather_clustering_and_update_prototypes(
+        emb, T('emb_loc'), T('cluster'), T('batch'), T('sem'), T('inst'))
+    assert mu.collective_calls - before == 2
+    assert np.array_equal(psem.cpu().numpy(), g['psem'])
+    assert np.array_equal(pinst.cpu().numpy(), g['pinst'])
+    assert np.array_equal(pbatch.cpu().numpy(), g['pbatch'])
+    assert np.array_equal(upd.cpu().numpy(), g['upd%d' % rank])
+    assert np.abs(protos.detach().cpu().numpy() - g['protos']).max() <= FTOL
+    assert np.abs(protos_loc.detach().cpu().numpy() - g['protos_loc']).max() <= FTOL
+    protos.sum().backward()
+    assert emb.grad is not None and torch.isfinite(emb.grad).all()
+    img = mu.gather_and_reorder_image_indices(T('image_id'))
+    assert np.array_equal(img.cpu().numpy(), g['img%d' % rank])
+    mapping = mu.gather_and_update_cluster_mappings(upd, T('cluster'))
+    assert np.array_equal(mapping.cpu().numpy(), g['mapping'])
+    open(os.path.join(result_dir, 'ok%d' % rank), 'w').write('ok')
+  finally:
+    dist.destroy_process_group()
+
+
+def test_exchange_world2_rccl(tmp_path):
+  import torch
+  if torch.cuda.device_count() < 2:
+    pytest.skip('needs two GPUs (the 8-GPU node of the driver); the world-2 logic runs on gloo in the CPU suite')
+  import torch.multiprocessing as mp
+  mp.spawn(_nccl_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+  assert (tmp_path / 'ok0').exists() and (tmp_path / 'ok1').exists()
+
+
+def test_bench_spawns_its_ranks():
+  import torch
+  if torch.cuda.device_count() < 2:
+    pytest.skip('needs two GPUs')
+  r = _bench(['--gpus', '2', '--workload', 'cfg3', '--steps', '2', '--warmup', '1', '--cpu-images', '0'])
+  assert r['n_gpus'] == 2 and r['config']['global_batch'] == 32
+  assert 'error' not in r['prototype_exchange'] and r['prototype_exchange']['collectives_per_call'] == 2
