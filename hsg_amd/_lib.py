@@ -58,6 +58,8 @@ SIGNATURES = {
     'hsgk_kmeans_with_initial_labels': (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _sz, _vp]),
     'hsgk_profile_enable': (None, [_i32]),
     'hsgk_profile_collect': (_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
+    'hsgk_verify_enable': (None, [_i32]),
+    'hsgk_verify_collect': (_i32, [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     'hsgk_lloyd_workspace_bytes': (_sz, [_i32, _i64, _i32, _i32]),
     'hsgk_lloyd_mstep': (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     'hsgk_lloyd_mstep_exact': (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -129,6 +131,18 @@ def profile_collect():
   cnt = (ctypes.c_int64 * len(PROF_KINDS))()
   check(lib().hsgk_profile_collect(ms, cnt))
   return {k: (ms[i], cnt[i]) for i, k in enumerate(PROF_KINDS)}
+
+
+def verify_enable(on):
+  lib().hsgk_verify_enable(int(bool(on)))
+
+
+def verify_collect():
+  """(rows compared, rows whose filtered label differs from the exact E-step) since the last
+  collect, on the current device; synchronises it."""
+  a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+  check(lib().hsgk_verify_collect(ctypes.byref(a), ctypes.byref(b)))
+  return int(a.value), int(b.value)
 
 
 def stream_ptr():

@@ -43,6 +43,26 @@ struct ProfScope {
   }
 };
 
+// ---- optional verification of the filtered E-steps --------------------------
+// While enabled, every filtered E-step of lloyd() is followed by the exact fp32-MFMA
+// E-step on the same rows and centroids (into a scratch label buffer) and a compare
+// pass: g_verify[0] counts the rows compared, g_verify[1] the rows whose labels differ.
+// The filters only ever label rows whose exact argmax is provably unique, so the second
+// counter must stay 0 (tests run every BASELINE config under this switch).
+static std::atomic<int> g_verify_on{0};
+__device__ unsigned long long g_verify[2];
+
+__global__ void verify_compare_kernel(const int32_t *__restrict__ a, const int32_t *__restrict__ b,
+                                      const hsgk_segkm_meta *__restrict__ meta, int64_t cap) {
+  const int64_t n = meta->n_rows < cap ? meta->n_rows : cap;
+  unsigned long long bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    bad += a[i] != b[i];
+  for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(&g_verify[1], bad);
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_verify[0], (unsigned long long)n);
+}
+
 struct KmeansScratch {
   ChunkTable t;
   int32_t *klab;
@@ -202,6 +222,13 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
                                         k.qrows, k.qcount, meta, s)
                    : launch_assign(x, d, k.cent, K, k.t, k.max_chunks, cur, k.best, meta, s))
         return rc; }
+    if (g_verify_on.load() && k.q1 && (half || wide || wide2 || (unit_rows && assign_mode() >= 1))) {
+      // k.q1 (the first level's row queue, consumed inside the launch group above) doubles as
+      // the scratch label buffer; k.best is only used by the exact kernel
+      if (int rc = launch_assign(x, d, k.cent, K, k.t, k.max_chunks, k.q1, k.best, meta, s)) return rc;
+      hipLaunchKernelGGL(verify_compare_kernel, dim3(1024), dim3(256), 0, s, cur, k.q1, meta, (int64_t)k.rows_cap);
+      HSGK_LAUNCH_CHECK();
+    }
   }
   if (cur != k.klab)      // odd number of swaps: the final labels sit in the other buffer
     HSGK_CHECK_HIP(hipMemcpyAsync(k.klab, cur, sizeof(int32_t) * k.rows_cap, hipMemcpyDeviceToDevice, s));
@@ -236,6 +263,18 @@ int hsgk_profile_collect(double *ms_sum, int64_t *count) {
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);
   }
+  return 0;
+}
+
+void hsgk_verify_enable(int on) { g_verify_on.store(on ? 1 : 0); }
+
+int hsgk_verify_collect(uint64_t *rows_compared, uint64_t *rows_differing) {
+  unsigned long long v[2] = {0, 0}, zero[2] = {0, 0};
+  HSGK_CHECK_HIP(hipDeviceSynchronize());
+  HSGK_CHECK_HIP(hipMemcpyFromSymbol(v, HIP_SYMBOL(g_verify), sizeof(v)));
+  HSGK_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_verify), zero, sizeof(zero)));
+  if (rows_compared) *rows_compared = v[0];
+  if (rows_differing) *rows_differing = v[1];
   return 0;
 }
 

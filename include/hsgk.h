@@ -61,6 +61,15 @@ HSGK_API const char *hsgk_last_error(void);
 HSGK_API void hsgk_profile_enable(int on);
 HSGK_API int hsgk_profile_collect(double *ms_sum, int64_t *count);
 
+/* ---- optional verification of the filtered E-steps ------------------------
+ * While enabled, every filtered E-step inside hsgk_segment_by_kmeans /
+ * hsgk_kmeans_with_initial_labels is re-done by the exact fp32 E-step and the two label
+ * vectors are compared on the device.  hsgk_verify_collect synchronises the current
+ * device, returns and clears the counters (rows compared, rows whose labels differ: the
+ * filters only label provably unique maxima, so the second must be 0).  Per device.    */
+HSGK_API void hsgk_verify_enable(int on);
+HSGK_API int hsgk_verify_collect(uint64_t *rows_compared, uint64_t *rows_differing);
+
 /* ---- device-side result block of hsgk_segment_by_kmeans ------------------ */
 typedef struct hsgk_segkm_meta {
   int64_t n_rows;        /* N: kept pixels over the whole batch                */

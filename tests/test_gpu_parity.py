@@ -549,6 +549,81 @@ def test_full_size_cfg2_properties_and_spot_parity(dev, oracle):
     assert np.array_equal((cluster[sl] - b * 64).cpu().numpy(), ref[3]), 'clusters image %d' % b
 
 
+@pytest.mark.parametrize('name,shape,grid,images', [
+    ('cfg2', (48, 256, 448, 448), (8, 8), (11,)),
+    ('cfg3', (16, 256, 224, 224), (8, 8), (0, 15)),
+    ('cfg4', (4, 256, 768, 768), (16, 16), (2,)),
+    ('cfg5', (24, 384, 224, 224), (8, 16), (5, 23)),
+])
+def test_full_size_configs_filters_verified_and_spot_parity(dev, oracle, name, shape, grid, images):
+  """The per-GPU shapes of BASELINE.json configs 2-5 at FULL size, inputs from the portable
+  generator (seed 0x48534700 + cfg), 10 iterations, run under the library's verify switch:
+  every filtered E-step of the call (fp16 level, hi-plane / two-half variants, bf16x3,
+  exact chains) is re-done by the exact fp32 E-step on the device and must agree on EVERY
+  row; plus size-independent properties of the outputs and bit-exact parity of whole images
+  against the oracle."""
+  import torch
+  from hsg_amd import _lib
+  from hsg_amd.utils.segsort import common as sc
+  B, C, H, W = shape
+  K, iters = grid[0] * grid[1], 10
+  x = synth.device_embeddings_nchw(synth.SEED_BASE + int(name[3:]), shape, 'iid', dev)
+  _lib.verify_collect()
+  _lib.verify_enable(True)
+  try:
+    emb, eloc, labels, cluster, batch = sc.segment_by_kmeans(x, None, list(grid), iterations=iters)
+    compared, differing = _lib.verify_collect()
+  finally:
+    _lib.verify_enable(False)
+  n = B * H * W
+  assert compared == n * iters, 'the filtered E-step route was not taken (%d rows compared)' % compared
+  assert differing == 0, '%d filter-decided labels differ from the exact E-step' % differing
+  assert emb.shape == (n, C) and eloc.shape == (n, C + 2)
+  assert (emb.norm(dim=1) - 1).abs().max().item() < 1e-5
+  assert (eloc.norm(dim=1) - 1).abs().max().item() < 1e-5
+  assert torch.equal(batch, torch.arange(B, device=dev).repeat_interleave(H * W))
+  # dense ids sorted by (image, cluster): image b+1 starts right after the last id of image b
+  per = cluster.view(B, H * W)
+  lo, hi = per.min(dim=1).values, per.max(dim=1).values
+  assert int(lo[0]) == 0 and torch.equal(lo[1:], hi[:-1] + 1) and int((hi - lo).max()) < K
+  assert torch.equal(labels, torch.zeros_like(labels))
+  loc = (sc.generate_location_features((H, W), 'cpu', 'float') - 0.5).numpy()
+  for b in images:
+    ref = oracle.segment_by_kmeans(x[b:b + 1].cpu().numpy(), None, grid, loc, None, iters)
+    sl = slice(b * H * W, (b + 1) * H * W)
+    assert np.array_equal(emb[sl].cpu().numpy(), ref[0]), 'emb image %d' % b
+    assert np.array_equal(eloc[sl].cpu().numpy(), ref[1]), 'emb_loc image %d' % b
+    # dense ids: image b owns the ids b*K .. b*K + K-1 when no cluster is empty
+    ids = cluster[sl].cpu().numpy()
+    assert np.array_equal(ids - ids.min(), ref[3] - ref[3].min()), 'clusters image %d' % b
+
+
+def test_cfg4_end_to_end_c256_grid16_labels_ignore_vs_oracle(dev, oracle):
+  """BASELINE.json configs[3] route end to end on a reduced map: C = 256 with a 16x16 seed
+  grid (K = 256 -> the two-half fp16 filter `assign_half_wide2_kernel`, the cluster-split
+  exact-sum M-step), over-segmentation labels + ignore band, mixture and i.i.d. inputs --
+  all five outputs bit-exact vs the oracle, every filtered label verified on the device."""
+  from hsg_amd import _lib
+  from hsg_amd.utils.segsort import common as sc
+  for flavour, shape, iters in (('iid', (2, 256, 96, 96), 10), ('mixture', (1, 256, 128, 80), 6)):
+    B, C, H, W = shape
+    x = synth.embeddings_nchw(synth.SEED_BASE + 4, shape, flavour)
+    lab = synth.overseg_labels(synth.SEED_BASE + 44, B, H, W, regions=11, ignore_rows=3)
+    loc = (sc.generate_location_features((H, W), 'cpu', 'float') - 0.5).numpy()
+    _lib.verify_collect()
+    _lib.verify_enable(True)
+    try:
+      got = _run_segkm(dev, x, lab, (16, 16), 255, iters)
+      compared, differing = _lib.verify_collect()
+    finally:
+      _lib.verify_enable(False)
+    assert compared == got[0].shape[0] * iters and differing == 0, (compared, differing)
+    ref = oracle.segment_by_kmeans(x, lab, (16, 16), loc, 255, iters)
+    for nm, a, b in zip(('emb', 'emb_loc', 'labels', 'cluster', 'batch'), got, ref):
+      assert a.shape == b.shape, nm
+      assert np.array_equal(a, b), '%s (%s): %d mismatching elements' % (nm, flavour, int((a != b).sum()))
+
+
 def test_train_step_slice_vs_reference(dev):
   """k-means -> batch prototype table -> two SegSort losses ->
   backward to the NCHW embeddings, against the reference running the same
