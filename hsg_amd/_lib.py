@@ -5,6 +5,7 @@ operators fails loudly -- there is no CPU / eager fallback.
 """
 import ctypes
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, 'csrc', 'libhsgk.so')
@@ -143,6 +144,45 @@ def verify_collect():
   a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
   check(lib().hsgk_verify_collect(ctypes.byref(a), ctypes.byref(b)))
   return int(a.value), int(b.value)
+
+
+# ---- deferred device-side error flags ---------------------------------------
+# Data-dependent errors (a label outside [0, P)) are detected by the kernels.  Reading the
+# flag right away would cost a host sync per call, so the flag is copied to pinned host
+# memory behind the kernels and looked at by later libhsgk calls once its event has
+# completed -- the error surfaces asynchronously, like a device-side assert of the
+# reference on a GPU.  HSGK_SYNC_ERRORS=1 checks immediately (one sync per call).
+_deferred_lock = threading.Lock()
+_deferred = []          # (event, pinned int32[1], message)
+
+
+def defer_status(status_dev, message):
+  import torch
+  if os.environ.get('HSGK_SYNC_ERRORS') == '1':
+    if int(status_dev.item()) != 0:
+      raise HsgkError(message)
+    return
+  host = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+  host.copy_(status_dev, non_blocking=True)
+  ev = torch.cuda.Event()
+  ev.record()
+  with _deferred_lock:
+    _deferred.append((ev, host, message))
+
+
+def poll_deferred(wait=False):
+  """Raises the first recorded device-side error whose kernels have finished (all of them
+  with wait=True, which synchronises)."""
+  with _deferred_lock:
+    pending, done = [], []
+    for item in _deferred:
+      if wait:
+        item[0].synchronize()
+      (done if item[0].query() else pending).append(item)
+    _deferred[:] = pending
+  for _ev, host, message in done:
+    if int(host[0]) != 0:
+      raise HsgkError(message)
 
 
 def stream_ptr():

@@ -7,67 +7,137 @@
 // plus their backward passes.  Summation order = C2 with chunks of 2048
 // consecutive rows of the flat row list.
 //
-// Any P is supported as long as the labels inside one chunk span at most
-// RMAX (= min(P, 512)) consecutive ids -- true for every call site of the
-// reference (ids are sorted ranks of (image, cluster, label), rows are image
-// major); a wider chunk raises status 1.
+// Any labels are supported.  A chunk's partial sums are stored by the RANK of a
+// segment id among the distinct ids of the chunk (a presence bitmap over the chunk's id
+// range, prefix popcounts), so the id range of a chunk does not matter as long as it has
+// at most RMAX (= min(P, 512)) distinct ids -- every realistic input: sorted ranks of
+// (image, cluster, label) over image-major rows, label-split clusters, several small
+// images per chunk.  A chunk with more distinct ids than that (fewer than 4 rows per
+// segment on average) or an id range beyond the bitmap is left to the per-segment
+// kernel, which scans such a chunk's labels itself and adds up the matching rows in row
+// order: the same canonical order C2, no extra memory, just slower.
+// Labels outside [0, P) are skipped and flagged in *status (bit 1).
 #include "accumulate.h"
 #include "common.h"
 
 namespace hsgk {
 
 constexpr int kSegRmax = 512;
+constexpr int kSegBitWords = 1024;                 // presence bitmap: 32768 ids per chunk
+constexpr int kSegBitRange = kSegBitWords * 32;
 
-struct SegWin { int64_t lmin; int64_t range; };
+// lmin / lmax: id range of the chunk's valid labels (lmax < lmin: none); ndist: distinct ids
+// (fast chunks: their partial rows are partial[c][0 .. ndist), ids in seg_ids[c][.]); slow = 1:
+// no partial rows, the per-segment kernel scans the chunk
+struct SegWin { int64_t lmin; int64_t lmax; int32_t ndist; int32_t slow; };
 
 template <int VEC, int UNROLL>
 __global__ __launch_bounds__(256) void segreduce_chunk_kernel(
     const float *__restrict__ x, int64_t n, int d, const int64_t *__restrict__ labels,
     int64_t P, int rmax, int rlds, float *__restrict__ partial, SegWin *__restrict__ win,
-    int32_t *__restrict__ status) {
-  extern __shared__ float sums[];   // [rlds][DS] then the row list
+    int64_t *__restrict__ seg_ids, int32_t *__restrict__ status) {
+  extern __shared__ float sums[];   // [rlds][DS], the row list, the bitmap, its prefix, the slots
   __shared__ int wcount[4];
   __shared__ int64_t red[8];
+  __shared__ int wtot[4];
   const int c = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int DS = (d + VEC - 1) / VEC * VEC;
-  uint32_t *rlist = reinterpret_cast<uint32_t *>(sums + rlds * DS);
+  uint32_t *rlist = reinterpret_cast<uint32_t *>(sums + rlds * DS);      // [HSGK_CHUNK]
+  uint32_t *bits = rlist + HSGK_CHUNK;                                    // [kSegBitWords]
+  int32_t *wpre = reinterpret_cast<int32_t *>(bits + kSegBitWords);       // [kSegBitWords]
+  int32_t *slots = wpre + kSegBitWords;                                   // [HSGK_CHUNK]
   const int64_t row0 = (int64_t)c * HSGK_CHUNK;
   const int nrows = (int)((n - row0) < HSGK_CHUNK ? (n - row0) : HSGK_CHUNK);
   const int64_t *lab = labels + row0;
 
-  // label range of this chunk (labels outside [0,P) are ignored)
+  // label range of this chunk (labels outside [0,P) are skipped and flagged)
   int64_t lo = INT64_MAX, hi = INT64_MIN;
+  bool bad = false;
   for (int r = tid; r < nrows; r += 256) {
     const int64_t l = lab[r];
-    if (l >= 0 && l < P) { lo = l < lo ? l : lo; hi = l > hi ? l : hi; }
+    if (l >= 0 && l < P) { lo = l < lo ? l : lo; hi = l > hi ? l : hi; } else bad = true;
   }
+  if (__ballot(bad) && lane == 0) atomicOr(status, 2);
   for (int off = 32; off > 0; off >>= 1) {
     const int64_t olo = __shfl_xor(lo, off), ohi = __shfl_xor(hi, off);
     lo = olo < lo ? olo : lo;
     hi = ohi > hi ? ohi : hi;
   }
   if (lane == 0) { red[w] = lo; red[4 + w] = hi; }
+  for (int i = tid; i < kSegBitWords; i += 256) bits[i] = 0u;
   __syncthreads();
   lo = red[0]; hi = red[4];
   for (int i = 1; i < 4; ++i) { lo = red[i] < lo ? red[i] : lo; hi = red[4 + i] > hi ? red[4 + i] : hi; }
-  int64_t range = hi >= lo ? hi - lo + 1 : 0;
-  if (range > rmax) {
-    if (tid == 0) atomicMax(status, 1);
-    range = rmax;
+  if (hi < lo) {                                   // no valid row in this chunk
+    if (tid == 0) win[c] = SegWin{0, -1, 0, 0};
+    return;
   }
-  if (tid == 0) { win[c].lmin = range ? lo : 0; win[c].range = range; }
+  if (hi - lo >= kSegBitRange) {
+    if (tid == 0) win[c] = SegWin{lo, hi, 0, 1};
+    return;
+  }
+  // presence bitmap over [lo, hi] -> rank of every id among the chunk's distinct ids
+  for (int r = tid; r < nrows; r += 256) {
+    const int64_t l = lab[r];
+    if (l >= 0 && l < P) atomicOr(&bits[(l - lo) >> 5], 1u << ((l - lo) & 31));
+  }
+  __syncthreads();
+  {
+    int cnt[kSegBitWords / 256], tot = 0;
+#pragma unroll
+    for (int i = 0; i < kSegBitWords / 256; ++i) { cnt[i] = __popc(bits[tid * (kSegBitWords / 256) + i]); tot += cnt[i]; }
+    int inc = tot;                                  // inclusive scan over the 256 threads
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(inc, off);
+      if (lane >= off) inc += o;
+    }
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    int base = inc - tot;
+    for (int i = 0; i < w; ++i) base += wtot[i];
+#pragma unroll
+    for (int i = 0; i < kSegBitWords / 256; ++i) { wpre[tid * (kSegBitWords / 256) + i] = base; base += cnt[i]; }
+  }
+  __syncthreads();
+  const int ndist = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+  if (ndist > rmax) {
+    if (tid == 0) win[c] = SegWin{lo, hi, ndist, 1};
+    return;
+  }
+  if (tid == 0) win[c] = SegWin{lo, hi, ndist, 0};
+  int64_t *ids = seg_ids + (int64_t)c * rmax;
+  for (int i = tid; i < kSegBitWords; i += 256) {
+    uint32_t m = bits[i];
+    int pos = wpre[i];
+    while (m) {
+      const int b = __ffs(m) - 1;
+      ids[pos++] = lo + 32 * i + b;
+      m &= m - 1;
+    }
+  }
+  for (int r = tid; r < HSGK_CHUNK; r += 256) {
+    int sl = -1;
+    if (r < nrows) {
+      const int64_t l = lab[r];
+      if (l >= 0 && l < P) {
+        const int64_t o = l - lo;
+        sl = wpre[o >> 5] + __popc(bits[o >> 5] & ((1u << (o & 31)) - 1u));
+      }
+    }
+    slots[r] = sl;
+  }
 
   float *out = partial + (int64_t)c * rmax * d;
-  for (int64_t p0 = 0; p0 < range; p0 += rlds) {
-    const int cur = (int)((range - p0) < rlds ? (range - p0) : rlds);
+  for (int p0 = 0; p0 < ndist; p0 += rlds) {
+    const int cur = (ndist - p0) < rlds ? (ndist - p0) : rlds;
     __syncthreads();
     for (int i = tid; i < cur * DS; i += 256) sums[i] = 0.0f;
-    chunk_accumulate<VEC, UNROLL, int64_t>(x + row0 * d, d, DS, lab, nrows, lo + p0, cur, sums,
+    chunk_accumulate<VEC, UNROLL, int32_t>(x + row0 * d, d, DS, slots, nrows, p0, cur, sums,
                                            rlist, wcount);
     __syncthreads();
     for (int k = w; k < cur; k += 4)
-      for (int i = lane; i < d; i += 64) out[(p0 + k) * d + i] = sums[k * DS + i];
+      for (int i = lane; i < d; i += 64) out[(int64_t)(p0 + k) * d + i] = sums[k * DS + i];
   }
 }
 
@@ -81,15 +151,18 @@ __global__ void count_labels_kernel(const int64_t *__restrict__ labels, int64_t 
 }
 
 // One workgroup per segment: chunk partials in chunk order (C2), then the
-// mode's epilogue.  aux[k] = clamped norm (mode 0) or count (mode 1).
+// mode's epilogue.  aux[k] = clamped norm (mode 0) or count (mode 1).  A slow chunk has no
+// partial row: its labels are scanned here and the matching rows summed in row order.
 __global__ __launch_bounds__(256) void segreduce_final_kernel(
-    const float *__restrict__ partial, const SegWin *__restrict__ win, int nchunks, int rmax,
-    int d, int mode, float eps, const int32_t *__restrict__ counts, float *__restrict__ out,
-    float *__restrict__ aux) {
-  extern __shared__ float row[];             // [d + 1] then the chunk list
+    const float *__restrict__ partial, const SegWin *__restrict__ win, const int64_t *__restrict__ seg_ids,
+    int nchunks, int rmax, int d, int mode, float eps, const int32_t *__restrict__ counts,
+    const float *__restrict__ x, const int64_t *__restrict__ labels, int64_t n,
+    float *__restrict__ out, float *__restrict__ aux) {
+  extern __shared__ float row[];             // [d + 1], the chunk list, the row list of a slow chunk
   __shared__ int wn[4];
   __shared__ int total;
-  int32_t *clist = reinterpret_cast<int32_t *>(row + d + 1);   // [nchunks]
+  int32_t *clist = reinterpret_cast<int32_t *>(row + d + 1);   // [nchunks][2]: chunk, slot (-1: slow)
+  uint16_t *rows = reinterpret_cast<uint16_t *>(clist + 2 * (size_t)nchunks);   // [HSGK_CHUNK]
   const int64_t k = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid == 0) total = 0;
@@ -97,28 +170,87 @@ __global__ __launch_bounds__(256) void segreduce_final_kernel(
   for (int c0 = 0; c0 < nchunks; c0 += 256) {
     const int c = c0 + tid;
     bool hit = false;
+    int slot = -1;
     if (c < nchunks) {
       const SegWin wv = win[c];
-      hit = k >= wv.lmin && k < wv.lmin + wv.range;
+      if (k >= wv.lmin && k <= wv.lmax) {
+        if (wv.slow) {
+          hit = true;
+        } else {                                       // binary search in the chunk's sorted id list
+          const int64_t *ids = seg_ids + (int64_t)c * rmax;
+          int a = 0, b = wv.ndist - 1;
+          while (a < b) {
+            const int m = (a + b) >> 1;
+            if (ids[m] < k) a = m + 1; else b = m;
+          }
+          if (ids[a] == k) { hit = true; slot = a; }
+        }
+      }
     }
     const unsigned long long m = __ballot(hit);
     if (lane == 0) wn[w] = __popcll(m);
     __syncthreads();
     int base = total;
     for (int i = 0; i < w; ++i) base += wn[i];
-    if (hit) clist[base + __popcll(m & ((1ull << lane) - 1ull))] = c;
+    if (hit) {
+      const int q = base + __popcll(m & ((1ull << lane) - 1ull));
+      clist[2 * q] = c;
+      clist[2 * q + 1] = slot;
+    }
     __syncthreads();
     if (tid == 0) total += wn[0] + wn[1] + wn[2] + wn[3];
     __syncthreads();
   }
   const int nl = total;
-  for (int i = tid; i < d; i += 256) {
-    float t = 0.0f;
+  float t[4] = {0.0f, 0.0f, 0.0f, 0.0f};              // columns tid, tid + 256, ... (d <= 1024 here; wider: loop)
+  const int ncol = (d + 255) / 256;
+  for (int cb = 0; cb < ncol; cb += 4) {
+    for (int u = 0; u < 4; ++u) t[u] = 0.0f;
     for (int q = 0; q < nl; ++q) {
-      const int c = clist[q];
-      t = t + partial[((int64_t)c * rmax + (k - win[c].lmin)) * d + i];
+      const int c = clist[2 * q], slot = clist[2 * q + 1];
+      if (slot >= 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = (cb + u) * 256 + tid;
+          if (i < d) t[u] = t[u] + partial[((int64_t)c * rmax + slot) * d + i];
+        }
+      } else {
+        // slow chunk: ordered list of its rows that carry label k, then their sum in row order
+        const int64_t r0 = (int64_t)c * HSGK_CHUNK;
+        const int nr = (int)((n - r0) < HSGK_CHUNK ? (n - r0) : HSGK_CHUNK);
+        __syncthreads();
+        if (tid == 0) total = 0;
+        __syncthreads();
+        for (int b0 = 0; b0 < nr; b0 += 256) {
+          const int r = b0 + tid;
+          const bool mine = r < nr && labels[r0 + r] == k;
+          const unsigned long long m = __ballot(mine);
+          if (lane == 0) wn[w] = __popcll(m);
+          __syncthreads();
+          int base = total;
+          for (int i = 0; i < w; ++i) base += wn[i];
+          if (mine) rows[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)r;
+          __syncthreads();
+          if (tid == 0) total += wn[0] + wn[1] + wn[2] + wn[3];
+          __syncthreads();
+        }
+        const int nm = total;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = (cb + u) * 256 + tid;
+          if (i < d) {
+            float sacc = 0.0f;
+            for (int e = 0; e < nm; ++e) sacc = sacc + x[(r0 + rows[e]) * d + i];
+            t[u] = t[u] + sacc;
+          }
+        }
+      }
     }
-    row[i] = t;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = (cb + u) * 256 + tid;
+      if (i < d) row[i] = t[u];
+    }
   }
   __syncthreads();
   if (tid == 0) {
@@ -192,6 +324,7 @@ size_t hsgk_segment_reduce_workspace_bytes(int64_t n, int d, int64_t P) {
   Carver cv(nullptr);
   cv.take<float>((size_t)(nch > 0 ? nch : 1) * seg_rmax(P) * d);
   cv.take<SegWin>((size_t)(nch > 0 ? nch : 1));
+  cv.take<int64_t>((size_t)(nch > 0 ? nch : 1) * seg_rmax(P));
   cv.take<int32_t>((size_t)(P > 0 ? P : 1));
   return cv.off + 256;
 }
@@ -211,11 +344,12 @@ int hsgk_segment_reduce(const float *x, int64_t n, int d, const int64_t *labels,
   Carver cv(workspace);
   float *partial = cv.take<float>((size_t)(nch > 0 ? nch : 1) * rmax * d);
   SegWin *win = cv.take<SegWin>((size_t)(nch > 0 ? nch : 1));
+  int64_t *seg_ids = cv.take<int64_t>((size_t)(nch > 0 ? nch : 1) * rmax);
   int32_t *counts = cv.take<int32_t>((size_t)P);
 
   const bool wide = d >= 256;
   const int DS = wide ? (d + 3) / 4 * 4 : d;
-  const size_t list_bytes = (size_t)HSGK_CHUNK * 4;
+  const size_t list_bytes = (size_t)HSGK_CHUNK * 4 * 2 + (size_t)kSegBitWords * 4 * 2;   // row list, slots, bitmap, prefix
   // table rows per pass: two workgroups per CU when that still covers a useful
   // window, otherwise one workgroup with the whole LDS
   const int rl2 = (int)((76 * 1024 - list_bytes) / ((size_t)DS * 4));
@@ -230,7 +364,7 @@ int hsgk_segment_reduce(const float *x, int64_t n, int d, const int64_t *labels,
     HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(158 * 1024)));
     hipLaunchKernelGGL(kern, dim3(nch), dim3(256), lds, s, x, n, d, labels, P, rmax, rlds, partial,
-                       win, status);
+                       win, seg_ids, status);
     HSGK_LAUNCH_CHECK();
   }
   if (mode == 1) {
@@ -242,12 +376,12 @@ int hsgk_segment_reduce(const float *x, int64_t n, int d, const int64_t *labels,
       HSGK_LAUNCH_CHECK();
     }
   }
-  const size_t lds = (size_t)(d + 1) * 4 + (size_t)(nch > 0 ? nch : 1) * 4;
+  const size_t lds = (size_t)(d + 1) * 4 + (size_t)(nch > 0 ? nch : 1) * 8 + (size_t)HSGK_CHUNK * 2;
   HSGK_REQUIRE(lds <= 150 * 1024, "too many chunks for the finalize list");
   HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(segreduce_final_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024)));
-  hipLaunchKernelGGL(segreduce_final_kernel, dim3((unsigned)P), dim3(256), lds, s, partial, win, nch,
-                     rmax, d, mode, eps, counts, out, aux);
+  hipLaunchKernelGGL(segreduce_final_kernel, dim3((unsigned)P), dim3(256), lds, s, partial, win, seg_ids,
+                     nch, rmax, d, mode, eps, counts, x, labels, n, out, aux);
   HSGK_LAUNCH_CHECK();
   return 0;
 }

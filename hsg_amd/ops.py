@@ -15,8 +15,9 @@ def require_gpu(t, name):
                          'no CPU path' % (name, t.device))
 
 
-def _segment_reduce_fwd(x, labels, P, mode):
+def _segment_reduce_fwd(x, labels, P, mode, strict=False):
   n, d = x.shape
+  _lib.poll_deferred()
   L = _lib.lib()
   dev = x.device
   with torch.cuda.device(dev):
@@ -28,10 +29,8 @@ def _segment_reduce_fwd(x, labels, P, mode):
     _lib.check(L.hsgk_segment_reduce(
         x.data_ptr(), n, d, labels.data_ptr(), P, mode, ctypes.c_float(EPS), out.data_ptr(),
         aux.data_ptr(), status.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr()))
-    if int(status.item()) != 0:
-      raise _lib.HsgkError(
-          'segment_reduce: one 2048-row chunk spans more than 512 consecutive segment ids; '
-          'rows must be grouped by segment id range (image-major rows, sorted ids)')
+    if strict:      # the reference's scatter_add_ rejects such labels; reported asynchronously
+      _lib.defer_status(status, 'segment_reduce: a label lies outside [0, %d)' % P)
   return out, aux
 
 
@@ -39,9 +38,9 @@ class SegmentReduce(torch.autograd.Function):
   """mode 0 prototypes (normalised sums), 1 means, 2 raw sums."""
 
   @staticmethod
-  def forward(ctx, x, labels, P, mode):
+  def forward(ctx, x, labels, P, mode, strict=False):
     x = x.contiguous()
-    out, aux = _segment_reduce_fwd(x.detach(), labels, P, mode)
+    out, aux = _segment_reduce_fwd(x.detach(), labels, P, mode, strict)
     ctx.save_for_backward(out, aux, labels)
     ctx.meta = (x.shape[0], x.shape[1], P, mode)
     return out
@@ -58,10 +57,12 @@ class SegmentReduce(torch.autograd.Function):
       _lib.check(_lib.lib().hsgk_segment_reduce_bwd(
           gout.data_ptr(), out.data_ptr(), aux.data_ptr(), labels.data_ptr(), n, d, P, mode,
           ctypes.c_float(EPS), gseg.data_ptr(), gx.data_ptr(), _lib.stream_ptr()))
-    return gx, None, None, None
+    return gx, None, None, None, None
 
 
-def segment_reduce(x, labels, P, mode):
+def segment_reduce(x, labels, P, mode, strict=False):
+  """Rows whose label lies outside [0, P) are skipped; with `strict` that is an error (raised by a
+  later libhsgk call once the kernels have run, or at once with HSGK_SYNC_ERRORS=1)."""
   require_gpu(x, 'x')
   if x.dtype != torch.float32:
     raise TypeError('x must be float32')
@@ -69,7 +70,7 @@ def segment_reduce(x, labels, P, mode):
   lab = labels.reshape(-1).to(torch.int64).contiguous()
   if lab.shape[0] != x2.shape[0]:
     raise ValueError('labels and rows disagree: %d vs %d' % (lab.shape[0], x2.shape[0]))
-  return SegmentReduce.apply(x2, lab, int(P), int(mode))
+  return SegmentReduce.apply(x2, lab, int(P), int(mode), bool(strict))
 
 
 class NormalizeRows(torch.autograd.Function):

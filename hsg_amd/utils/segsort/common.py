@@ -279,7 +279,7 @@ def calculate_prototypes_from_labels(embeddings, labels, max_label=None):
   (prototypes carry gradient in the reference's training step)."""
   if max_label is None:
     max_label = int(labels.max()) + 1
-  return ops.segment_reduce(embeddings, labels, int(max_label), 0)
+  return ops.segment_reduce(embeddings, labels, int(max_label), 0, strict=True)
 
 
 def prepare_prototype_labels(semantic_labels, instance_labels, offset=256):

@@ -189,8 +189,12 @@ HSGK_API int hsgk_find_nearest_prototypes(const float *x, int64_t n, int d,
  * x [n,d], labels int64 [n] (rows with labels outside [0,P) are skipped).
  * mode 0: L2-normalised segment sums; mode 1: means (count 0 -> 1); mode 2: raw
  * sums.  out [P,d]; aux [P] (nullable) receives the clamped norm (mode 0) or
- * the count (mode 1) for the backward pass.  *status (device int32) becomes 1
- * if one 2048-row chunk spans more than 512 consecutive segment ids.          */
+ * the count (mode 1) for the backward pass.  Labels may be arbitrary: the
+ * per-chunk partial sums are stored by the rank of an id among the chunk's distinct ids;
+ * chunks with more than 512 distinct ids (or an id range beyond 32768) are summed by the
+ * per-segment kernel instead (same order C2, slower).  *status (device int32): bit 1 is
+ * set if a label lay outside [0,P) (such rows are skipped; the reference's scatter_add_
+ * raises).                                                                      */
 HSGK_API size_t hsgk_segment_reduce_workspace_bytes(int64_t n, int d, int64_t P);
 HSGK_API int hsgk_segment_reduce(const float *x, int64_t n, int d, const int64_t *labels,
                                  int64_t P, int mode, float eps, float *out, float *aux,

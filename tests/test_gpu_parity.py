@@ -167,6 +167,67 @@ def test_segment_reduce_sorted_ids_vs_oracle(dev, oracle, n, d, P):
     assert np.array_equal(got, ref), (mode, int((got != ref).sum()))
 
 
+@pytest.mark.parametrize('n,d,P,pattern', [
+    (30000, 34, 3000, 'random'),        # ~1500 distinct ids per 2048-row chunk: per-segment scan path
+    (9000, 258, 5000, 'random'),
+    (20000, 66, 40000, 'stride'),       # few distinct ids per chunk, id range 30000+: rank path
+    (20000, 130, 200000, 'huge'),       # id range beyond the bitmap: scan path
+    (6000, 20, 4000, 'small_images'),   # several small images per chunk, label-split clusters
+])
+def test_segment_reduce_arbitrary_ids_vs_oracle(dev, oracle, n, d, P, pattern):
+  """Scattered segment ids (the reference's scatter_add_ accepts any labels): more than 512
+  distinct ids per chunk, wide id ranges with few distinct ids, ranges beyond the bitmap --
+  all bit-exact vs the oracle's order C2, forward and backward."""
+  import ctypes
+  import torch
+  from hsg_amd import ops
+  x = synth.gaussish(11 + n, n * d).reshape(n, d).copy()
+  h = synth.hash_u64(5 + n, n)
+  if pattern == 'random':
+    lab = (h % np.uint64(P)).astype(np.int64)
+  elif pattern == 'stride':
+    lab = ((np.arange(n) // 500) * 997 + (h % np.uint64(3)).astype(np.int64) * 9973) % P
+  elif pattern == 'huge':
+    lab = ((h % np.uint64(40)).astype(np.int64) * 49999 + 7) % P
+  else:
+    lab = (np.arange(n) // 300) * 200 + (h % np.uint64(190)).astype(np.int64)
+    lab = np.minimum(lab, P - 1)
+  lab = lab.astype(np.int64)
+  xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+  lt = torch.from_numpy(lab).to(dev)
+  ref = np.empty((P, d), np.float32)
+  oracle.lib().orc_segment_sums(
+      x.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), ctypes.c_int64(n), d,
+      lab.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), ctypes.c_int64(P), oracle.CHUNK,
+      ref.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+  got = ops.segment_reduce(xt, lt, P, 2)
+  assert np.array_equal(got.detach().cpu().numpy(), ref), int((got.detach().cpu().numpy() != ref).sum())
+  w = torch.from_numpy(synth.gaussish(13 + n, P * d).reshape(P, d).copy()).to(dev)
+  (got * w).sum().backward()
+  assert torch.equal(xt.grad, w[lt])
+  protos = ops.segment_reduce(xt.detach(), lt, P, 0).cpu().numpy()
+  assert np.array_equal(protos, oracle.calculate_prototypes_from_labels(x, lab, P))
+
+
+def test_segment_reduce_out_of_range_label_is_reported(dev, monkeypatch):
+  """calculate_prototypes_from_labels mirrors the reference's scatter_add_: a label outside
+  [0, max_label) is an error -- raised at once with HSGK_SYNC_ERRORS=1, otherwise by a later call."""
+  import torch
+  from hsg_amd import _lib
+  from hsg_amd.utils.segsort import common as sc
+  x = torch.randn((100, 8), device=dev)
+  lab = torch.arange(100, device=dev) % 7
+  lab[13] = 9
+  monkeypatch.setenv('HSGK_SYNC_ERRORS', '1')
+  with pytest.raises(_lib.HsgkError):
+    sc.calculate_prototypes_from_labels(x, lab, max_label=7)
+  monkeypatch.delenv('HSGK_SYNC_ERRORS')
+  sc.calculate_prototypes_from_labels(x, lab, max_label=7)          # flag travels behind the kernels
+  with pytest.raises(_lib.HsgkError):
+    _lib.poll_deferred(wait=True)
+  _lib.poll_deferred(wait=True)                                     # reported once
+
+
 def test_prototype_gradients_match_torch_autograd(dev):
   """Backward of calculate_prototypes_from_labels / segment_mean against a
   plain torch (ATen, fp32) restatement of the same op on the GPU."""
