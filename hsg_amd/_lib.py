@@ -41,6 +41,11 @@ class SegkmArgs(ctypes.Structure):
       ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t)]
 
 
+class LossSet(ctypes.Structure):
+  _fields_ = [('sem', ctypes.c_void_p), ('psem', ctypes.c_void_p), ('kappa', ctypes.c_float),
+              ('mode', ctypes.c_int32)]
+
+
 _lib = None
 
 _vp, _i64, _i32, _f32, _sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
@@ -68,11 +73,12 @@ SIGNATURES = {
     'hsgk_segment_reduce_workspace_bytes': (_sz, [_i64, _i32, _i64]),
     'hsgk_segment_reduce': (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
     'hsgk_segment_reduce_bwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _f32, _vp, _vp, _vp]),
-    'hsgk_segsort_loss_workspace_bytes': (_sz, [_i64, _i32, _i64]),
-    'hsgk_segsort_loss_fwd': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _f32, _i32, _vp, _vp,
+    'hsgk_segsort_loss_workspace_bytes': (_sz, [_i64, _i32, _i64, _i32]),
+    'hsgk_segsort_loss_fwd': (_i32, [_vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp,
+                                     _vp, _sz, _vp]),
+    'hsgk_segsort_loss_bwd_workspace_bytes': (_sz, [_i64, _i32, _i64, _i32]),
+    'hsgk_segsort_loss_bwd': (_i32, [_vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _vp, _vp, _sz, _vp]),
-    'hsgk_segsort_loss_bwd_weights': (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _f32, _i32,
-                                             _vp, _vp, _vp, _vp, _vp, _vp]),
     'hsgk_lloyd_requeued_rows': (_i32, [_i32, _i64, _i32, _i32, _vp, _sz, _vp, _vp]),
     'hsgk_hier_assign': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'hsgk_group_mean': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),

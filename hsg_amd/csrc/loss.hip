@@ -1,23 +1,45 @@
 // loss.hip -- pixel-to-segment contrastive ("SegSort") loss, reference
-// hsg/utils/segsort/loss.py:15-82 (_calculate_log_likelihood) and :149-190.
+// hsg/utils/segsort/loss.py:15-82 (_calculate_log_likelihood), :85-130 (multi-label
+// variant) and :149-251, for up to THREE label sets per pass -- the three losses of
+// hsg/models/predictions/hsg.py:78-155 (image similarity, fine and coarse hierarchy)
+// contrast the SAME pixel embeddings against the SAME prototype table and differ only
+// in the labels, so E P^T is computed once instead of three times.
 //
-// The reference materialises S = exp(kappa * E P^T) as an [N,P] matrix plus
-// seven [N,P] temporaries.  Here the fp32-MFMA engine of score_tiles.h streams
-// the pixel rows against 64-prototype blocks and the epilogue folds every
-// score straight into three per-row sums (own / same-semantic / different-
-// semantic); nothing of size N x P exists in the forward pass.  Tolerance
-// quantity (north_star: loss within 1e-4): the dot products are still the
-// canonical C1 chains, the sums over prototypes run in ascending prototype
-// order per lane, then lane pair, then block order -- deterministic.
+// Forward.  The reference materialises S = exp(kappa * E P^T) as an [N,P] matrix plus
+// seven [N,P] temporaries.  Here the fp32-MFMA engine of score_tiles.h streams the pixel
+// rows against 64-prototype blocks and the epilogue folds every score straight into
+// three per-row sums per label set (own / same-semantic / different-semantic); nothing
+// of size N x P exists.  Tolerance quantity (north_star: loss within 1e-4): the dot
+// products are the canonical C1 chains, the sums over prototypes run in ascending
+// prototype order per lane, then lane pair, then block order -- deterministic.
 //
-// Backward: the per-pair weights dL/d(e_i . p_j) are produced by the same
-// engine, written transposed (W^T [P,N], coalesced along rows) and contracted
-// with the two plain library GEMMs g_E = W P and g_P = W^T E on the host side
-// (torch.mm -> rocBLAS), as the task allows for plain GEMMs.
+// Backward.  Nothing of size N x P either: loss_bwd_kernel recomputes the score tiles
+// and contracts them on the spot.  With W[i][p] = dL/d(e_i . p_p),
+//     g_emb = W P        (owner rows = pixels,     streamed rows = prototypes)
+//     g_proto = W^T E    (owner rows = prototypes, streamed rows = pixels)
+// are the same computation with the roles of the two matrices swapped, so ONE kernel
+// template serves both: a wave keeps 32 owner rows as the MFMA B operand in registers and
+// their C output columns in accumulators, streams 32-row blocks of the other matrix
+// through LDS, forms the 32 x 32 score tile (v_mfma_f32_32x32x2_f32, k over channels),
+// turns it into W in place -- the accumulator layout of the score tile IS the B operand
+// layout of the second contraction, no transpose -- and accumulates W x (streamed rows)
+// with k over the streamed rows.  The streamed dimension is split over workgroups to
+// fill the chip; the per-split partial outputs are summed in split order.
 #include "common.h"
 #include "score_tiles.h"
 
 namespace hsgk {
+
+constexpr int kMaxSets = HSGK_LOSS_MAX_SETS;
+
+struct LossSets {
+  const int64_t *sem[kMaxSets];
+  const int64_t *psem[kMaxSets];
+  float kappa[kMaxSets];
+  int plus[kMaxSets];       // 'segsort+'
+  int setm[kMaxSets];       // set mode (multi-hot labels as class bit masks)
+  int L;
+};
 
 // "same semantic label": equal labels (SegSortLoss), or -- set mode, SetSegSortLoss --
 // a non-zero label affinity: sem / psem then carry one bit per class and the affinity
@@ -29,10 +51,9 @@ __device__ inline bool same_semantic(int64_t a, int64_t b, int set_mode) {
 struct LossFwdEpi {
   int kb0, nrows, pb;
   int64_t P, N, crow0;
-  float kappa;
-  const int64_t *sem, *inst, *psem;
-  float *part;                                   // [npb][N][3]
-  int set_mode;
+  const int64_t *inst;
+  LossSets ls;
+  float *part;                                   // [npb][N][3 L]
   template <int MB>
   __device__ inline void operator()(int tile, const f32x16 (&acc)[MB]) const {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -41,65 +62,39 @@ struct LossFwdEpi {
     const int px = tile * TPX + w * 32 + j;
     const bool valid = px < nrows;
     const int64_t row = crow0 + (valid ? px : 0);
-    const int64_t sj = sem[row], ij = inst[row];
-    float own = 0.0f, same = 0.0f, diff = 0.0f;
+    const int64_t ij = inst[row];
+    int64_t sj[kMaxSets];
+    float own[kMaxSets], same[kMaxSets], diff[kMaxSets];
+#pragma unroll
+    for (int l = 0; l < kMaxSets; ++l) {
+      sj[l] = l < ls.L ? ls.sem[l][row] : 0;
+      own[l] = same[l] = diff[l] = 0.0f;
+    }
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t p = kb0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (p < P) {
-          const float s = expf(acc[m][r] * kappa);
-          if (p == ij) own += s;
-          if (same_semantic(psem[p], sj, set_mode)) same += s; else diff += s;
+          float s = 0.0f;
+#pragma unroll
+          for (int l = 0; l < kMaxSets; ++l)
+            if (l < ls.L) {
+              if (l == 0 || ls.kappa[l] != ls.kappa[l - 1]) s = expf(acc[m][r] * ls.kappa[l]);
+              if (p == ij) own[l] += s;
+              if (same_semantic(ls.psem[l][p], sj[l], ls.setm[l])) same[l] += s; else diff[l] += s;
+            }
         }
       }
-    own += __shfl_xor(own, 32);
-    same += __shfl_xor(same, 32);
-    diff += __shfl_xor(diff, 32);
-    if (h == 0 && valid) {
-      float *o = part + ((int64_t)pb * N + row) * 3;
-      o[0] = own; o[1] = same; o[2] = diff;
-    }
-  }
-};
-
-struct LossBwdEpi {
-  int kb0, nrows, group_plus;
-  int64_t P, N, crow0;
-  float kappa;
-  const int64_t *sem, *inst, *psem;
-  const float *num, *den, *gscale;
-  const int32_t *use_same;
-  float *wt;                                     // [P][N]
-  int set_mode;
-  template <int MB>
-  __device__ inline void operator()(int tile, const f32x16 (&acc)[MB]) const {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    const int TPX = (int)(blockDim.x >> 1);
-    const int px = tile * TPX + w * 32 + j;
-    const bool valid = px < nrows;
-    const int64_t row = crow0 + (valid ? px : 0);
-    const int64_t sj = sem[row], ij = inst[row];
-    const float inv_num = 1.0f / num[row], inv_den = 1.0f / den[row];
-    const float gs = gscale[row] * kappa;
-    const bool us = use_same[row] != 0;
 #pragma unroll
-    for (int m = 0; m < MB; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t p = kb0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (p < P && valid) {
-          const float s = expf(acc[m][r] * kappa);
-          // nll = -log(num / den), den = diff + num; with a = d num / d s_p, b = d diff / d s_p:
-          // d nll / d s_p = a (1/den - 1/num) + b / den.  num = sum_same - own ('segsort+',
-          // positive) else own; the own prototype can also sit in the "different" sum
-          // (labels without affinity), loss.py:71-78 / 118-127
-          const bool same = same_semantic(psem[p], sj, set_mode);
-          const float a = (group_plus && us) ? (float)((int)same - (int)(p == ij)) : (p == ij ? 1.0f : 0.0f);
-          const float g = a * (inv_den - inv_num) + (same ? 0.0f : inv_den);
-          wt[p * N + row] = g * s * gs;
+    for (int l = 0; l < kMaxSets; ++l)
+      if (l < ls.L) {
+        const float o = own[l] + __shfl_xor(own[l], 32);
+        const float sm = same[l] + __shfl_xor(same[l], 32);
+        const float df = diff[l] + __shfl_xor(diff[l], 32);
+        if (h == 0 && valid) {
+          float *dst = part + (((int64_t)pb * N + row) * ls.L + l) * 3;
+          dst[0] = o; dst[1] = sm; dst[2] = df;
         }
       }
   }
@@ -122,36 +117,38 @@ __global__ __launch_bounds__(NW * 64) void loss_tiles_kernel(
   epi.kb0 = pb * KB;
   epi.nrows = nrows;
   epi.crow0 = c_row0 + (int64_t)part * tps * TPX;
-  if constexpr (requires { epi.pb; }) epi.pb = pb;
+  epi.pb = pb;
   const int kvalid = (int)((P - (int64_t)pb * KB) < KB ? (P - (int64_t)pb * KB) : KB);
   score_tiles<KB, NW, KC, EVEN_D>(emb, c, proto + (int64_t)pb * KB * c, kvalid, epi.crow0, nrows,
                                   lds, epi);
 }
 
 // per-row finish: sums over prototype blocks in block order, then
-// loss.py:63-80 (numerator choice, -log(num / (num + diff)))
-__global__ void loss_rows_kernel(const float *__restrict__ part, int npb, int64_t N,
-                                 int group_plus, float *__restrict__ nll, float *__restrict__ num_o,
+// loss.py:63-80 (numerator choice, -log(num / (num + diff))); outputs [L][N]
+__global__ void loss_rows_kernel(const float *__restrict__ part, int npb, int64_t N, int L, int plus_mask,
+                                 float *__restrict__ nll, float *__restrict__ num_o,
                                  float *__restrict__ den_o, int32_t *__restrict__ use_same) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= N) return;
-  float own = 0.0f, same = 0.0f, diff = 0.0f;
-  for (int b = 0; b < npb; ++b) {
-    const float *p = part + ((int64_t)b * N + r) * 3;
-    own += p[0]; same += p[1]; diff += p[2];
+  for (int l = 0; l < L; ++l) {
+    float own = 0.0f, same = 0.0f, diff = 0.0f;
+    for (int b = 0; b < npb; ++b) {
+      const float *p = part + (((int64_t)b * N + r) * L + l) * 3;
+      own += p[0]; same += p[1]; diff += p[2];
+    }
+    float num = own;
+    int us = 0;
+    if ((plus_mask >> l) & 1) {
+      const float same_wo = same - own;
+      us = same_wo > 0.0f;
+      num = us ? same_wo : own;
+    }
+    const float den = diff + num;
+    nll[(int64_t)l * N + r] = -logf(num / den);
+    num_o[(int64_t)l * N + r] = num;
+    den_o[(int64_t)l * N + r] = den;
+    use_same[(int64_t)l * N + r] = us;
   }
-  float num = own;
-  int us = 0;
-  if (group_plus) {
-    const float same_wo = same - own;
-    us = same_wo > 0.0f;
-    num = us ? same_wo : own;
-  }
-  const float den = diff + num;
-  nll[r] = -logf(num / den);
-  num_o[r] = num;
-  den_o[r] = den;
-  use_same[r] = us;
 }
 
 template <class Epi>
@@ -181,50 +178,430 @@ static int launch_loss_tiles(const float *emb, int64_t N, int c, const float *pr
   return -1;
 }
 
+// =============================================================================
+// backward
+// =============================================================================
+// Per pixel and label set, from the forward state (nll = -log(num / den), den = diff + num):
+//   d nll / d s_p = a_p (1/den - 1/num) + b_p / den,   a = d num / d s_p, b = d diff / d s_p,
+//   a_p = same_p - own_p ('segsort+' with a positive same-sum) or own_p, b_p = !same_p
+// (the own prototype can also sit in the "different" sum: labels without affinity,
+// loss.py:71-78 / 118-127).  With the upstream gradient g and s_p = exp(kappa e.p):
+//   W[i][p] = sum over sets of  s_p * (a_p * A + (same_p ? 0 : B)),
+//   A = g kappa (1/den - 1/num),  B = g kappa / den.
+struct PxMeta { float A, B; int32_t plus_us; int32_t pad; };      // [L][N]
+
+__global__ void loss_bwd_prep_kernel(const float *__restrict__ num, const float *__restrict__ den,
+                                     const int32_t *__restrict__ use_same, const float *__restrict__ gscale,
+                                     int64_t N, LossSets ls, PxMeta *__restrict__ meta) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= N) return;
+  for (int l = 0; l < ls.L; ++l) {
+    const int64_t i = (int64_t)l * N + r;
+    const float gs = gscale[i] * ls.kappa[l];
+    const float inv_num = 1.0f / num[i], inv_den = 1.0f / den[i];
+    meta[i] = PxMeta{gs * (inv_den - inv_num), gs * inv_den, (ls.plus[l] && use_same[i]) ? 1 : 0, 0};
+  }
+}
+
+struct BwdArgs {
+  const float *owner;        // [n_owner][c]
+  const float *stream;       // [n_stream][c]
+  int64_t n_owner, n_stream, N, P;
+  int c;
+  const int64_t *inst;       // [N]
+  const PxMeta *meta;        // [L][N]
+  LossSets ls;
+  float *out;                // [split][n_owner][c]
+  int split, blocks_per_split;
+};
+
+// CT = ceil(c / 32) channel tiles; OWNER_PX: owner rows are pixels (output g_emb) else prototypes
+// (output g_proto).  256 threads = 4 waves, one per SIMD, 32 owner rows each.
+// CG <= CT channel tiles are accumulated per launch, starting at tile cg0 (C = 384: two
+// launches of 6 tiles keep the accumulators + the owner operand inside the 512 registers).
+template <int CT, int CG, bool OWNER_PX, bool VEC4>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void loss_bwd_kernel(BwdArgs a, int cg0) {
+  constexpr int CP = CT * 32;            // padded channels
+  constexpr int RS = CP + 1;             // LDS row stride (odd: conflict-free column reads)
+  constexpr int KS = CP / 2;             // k-steps of the score contraction
+  constexpr int L4 = CP / 32;            // float4 (or 4 scalars) per thread per staged block
+  extern __shared__ float lds[];
+  float *tbuf = lds;                                        // [2][32][RS]
+  char *mbase = reinterpret_cast<char *>(lds + 2 * 32 * RS);
+  // per staged block: label words and (stream = pixels) the per-pixel weights
+  int64_t *m_lab = reinterpret_cast<int64_t *>(mbase);       // [2][kMaxSets][32]
+  PxMeta *m_px = reinterpret_cast<PxMeta *>(m_lab + 2 * kMaxSets * 32);   // [2][kMaxSets][32]
+  int32_t *m_inst = reinterpret_cast<int32_t *>(m_px + 2 * kMaxSets * 32);  // [2][32]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int c = a.c, L = a.ls.L;
+  const int64_t o_row = (int64_t)blockIdx.x * 128 + w * 32 + j;
+  const bool o_valid = o_row < a.n_owner;
+  const int64_t o_ld = o_valid ? o_row : a.n_owner - 1;
+  const int sp = blockIdx.y;
+  const int64_t nblocks = (a.n_stream + 31) / 32;
+  const int64_t b_begin = (int64_t)sp * a.blocks_per_split;
+  const int64_t b_end = min(nblocks, b_begin + a.blocks_per_split);
+
+  // ---- owner rows: B operand of the score contraction, lane (j, h) holds O[o][2 s + h]
+  float bop[KS];
+  {
+    const float *orow = a.owner + o_ld * c;
+    // (one dword per k-step: a float4 per lane would fetch both half-waves' elements and keep
+    //  four times the registers live while the loads are in flight)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) bop[s] = (2 * s + h) < c ? orow[2 * s + h] : 0.0f;
+  }
+  // ---- owner-side labels / weights
+  int64_t o_lab[kMaxSets];
+  PxMeta o_px[kMaxSets];
+  int32_t o_inst = -1;
+#pragma unroll
+  for (int l = 0; l < kMaxSets; ++l) {
+    o_lab[l] = 0;
+    o_px[l] = PxMeta{0.f, 0.f, 0, 0};
+    if (l < L) {
+      if constexpr (OWNER_PX) {
+        o_lab[l] = a.ls.sem[l][o_ld];
+        o_px[l] = a.meta[(int64_t)l * a.N + o_ld];
+      } else {
+        o_lab[l] = a.ls.psem[l][o_ld];
+      }
+    }
+  }
+  if constexpr (OWNER_PX) o_inst = (int32_t)a.inst[o_ld];
+
+  f32x16 gacc[CG];
+#pragma unroll
+  for (int ct = 0; ct < CG; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gacc[ct][r] = 0.0f;
+
+  // ---- staging of streamed block b into LDS buffer `buf` (rows past the end: zeros)
+  float4 pre[L4];
+  auto load_block = [&](int64_t b) {
+#pragma unroll
+    for (int u = 0; u < L4; ++u) {
+      const int f = tid + 256 * u;                 // float4 index inside the [32][CP] block
+      const int row = f / (CP / 4), c4 = (f - row * (CP / 4)) * 4;
+      const int64_t t = b * 32 + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < a.n_stream) {
+        const float *src = a.stream + t * c + c4;
+        if constexpr (VEC4) {
+          if (c4 < c) v = *reinterpret_cast<const float4 *>(src);
+        } else {
+          if (c4 < c) v.x = src[0];
+          if (c4 + 1 < c) v.y = src[1];
+          if (c4 + 2 < c) v.z = src[2];
+          if (c4 + 3 < c) v.w = src[3];
+        }
+      }
+      pre[u] = v;
+    }
+  };
+  auto store_block = [&](int buf, int64_t b) {
+    float *dst = tbuf + buf * (32 * RS);
+#pragma unroll
+    for (int u = 0; u < L4; ++u) {
+      const int f = tid + 256 * u;
+      const int row = f / (CP / 4), c4 = (f - row * (CP / 4)) * 4;
+      float *d = dst + row * RS + c4;
+      d[0] = pre[u].x; d[1] = pre[u].y; d[2] = pre[u].z; d[3] = pre[u].w;
+    }
+    if (tid < 32 * kMaxSets) {                      // labels / weights of the 32 streamed rows
+      const int l = tid >> 5, row = tid & 31;
+      const int64_t t = b * 32 + row;
+      if (l < L) {
+        int64_t lab = 0;
+        PxMeta pm = PxMeta{0.f, 0.f, 0, 0};
+        if (t < a.n_stream) {
+          if constexpr (OWNER_PX) {
+            lab = a.ls.psem[l][t];
+          } else {
+            lab = a.ls.sem[l][t];
+            pm = a.meta[(int64_t)l * a.N + t];
+          }
+        }
+        m_lab[(buf * kMaxSets + l) * 32 + row] = lab;
+        if constexpr (!OWNER_PX) m_px[(buf * kMaxSets + l) * 32 + row] = pm;
+      }
+      if constexpr (!OWNER_PX)
+        if (l == 0) m_inst[buf * 32 + row] = t < a.n_stream ? (int32_t)a.inst[t] : -1;
+    }
+  };
+
+  if (b_begin < b_end) {
+    load_block(b_begin);
+    store_block(0, b_begin);
+  }
+  for (int64_t b = b_begin; b < b_end; ++b) {
+    const int buf = (int)((b - b_begin) & 1);
+    if (b + 1 < b_end) load_block(b + 1);          // in flight during the MFMAs below
+    __syncthreads();                                // buffer `buf` is complete
+    const float *tb = tbuf + buf * (32 * RS);
+
+    // ---- score tile: S[t][o] = sum_k T[t][k] O[o][k], canonical ascending-k chain
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
+    {
+      // LDS operands four k-steps at a time, one group ahead of the MFMAs that use them
+      const float *ap = tb + j * RS + h;
+      float an[4], ac[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) an[u] = ap[2 * u];
+#pragma unroll
+      for (int s0 = 0; s0 < KS; s0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ac[u] = an[u];
+        if (s0 + 4 < KS) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) an[u] = ap[2 * (s0 + 4 + u)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bop[s0 + u], sacc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- W in place: lane (j, h) register r <-> streamed row t = trow(r, h), owner row o = j
+    const int64_t *bl = m_lab + buf * kMaxSets * 32;
+    const PxMeta *bp = m_px + buf * kMaxSets * 32;
+    const int32_t *bi = m_inst + buf * 32;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      // (four registers = four consecutive streamed rows at a time: the scheduler must not hoist
+      //  the label / weight reads of all sixteen, that alone costs > 200 registers)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * rg + e;
+        const int tr = e + 8 * rg + 4 * h;
+        const int64_t t = b * 32 + tr;
+        float wv = 0.0f, s = 0.0f;
+        bool own;
+        if constexpr (OWNER_PX) own = (int64_t)o_inst == t; else own = (int64_t)bi[tr] == o_row;
+#pragma unroll
+        for (int l = 0; l < kMaxSets; ++l)
+          if (l < L) {
+            if (l == 0 || a.ls.kappa[l] != a.ls.kappa[l - 1]) s = expf(sacc[r] * a.ls.kappa[l]);
+            const PxMeta pm = OWNER_PX ? o_px[l] : bp[l * 32 + tr];
+            const bool same = same_semantic(bl[l * 32 + tr], o_lab[l], a.ls.setm[l]);
+            const float av = pm.plus_us ? (float)((int)same - (int)own) : (own ? 1.0f : 0.0f);
+            wv += s * (av * pm.A + (same ? 0.0f : pm.B));
+          }
+        sacc[r] = (o_valid && t < a.n_stream) ? wv : 0.0f;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- second contraction: G[c][o] += sum_t T[t][c] W[t][o]; k-step r pairs the streamed rows
+    //      trow(r, 0) / trow(r, 1), exactly the rows the two half-waves hold in register r
+    {
+      float an[CG], ac[CG];
+      const float *ap0 = tb + (4 * h) * RS + cg0 * 32 + j;
+#pragma unroll
+      for (int ct = 0; ct < CG; ++ct) an[ct] = ap0[ct * 32];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int ct = 0; ct < CG; ++ct) ac[ct] = an[ct];
+        if (r + 1 < 16) {
+          const float *ap = tb + (((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * h) * RS + cg0 * 32 + j;
+#pragma unroll
+          for (int ct = 0; ct < CG; ++ct) an[ct] = ap[ct * 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ct = 0; ct < CG; ++ct)
+          gacc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[ct], sacc[r], gacc[ct], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (b + 1 < b_end) store_block(buf ^ 1, b + 1);
+  }
+
+  // ---- partial output: lane (j, h) holds G[c = ct*32 + 8 q + 4 h + e][o = j] in gacc[ct][4 q + e]
+  if (o_valid) {
+    float *orow = a.out + ((int64_t)sp * a.n_owner + o_row) * c;
+#pragma unroll
+    for (int ct = 0; ct < CG; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c0 = (cg0 + ct) * 32 + 8 * q + 4 * h;
+        if constexpr (VEC4) {
+          if (c0 < c)
+            *reinterpret_cast<float4 *>(orow + c0) =
+                make_float4(gacc[ct][4 * q], gacc[ct][4 * q + 1], gacc[ct][4 * q + 2], gacc[ct][4 * q + 3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c0 + e < c) orow[c0 + e] = gacc[ct][4 * q + e];
+        }
+      }
+  }
+}
+
+// out[i] = sum over splits (split order) of part[s][i]
+__global__ void loss_bwd_reduce_kernel(const float *__restrict__ part, int split, int64_t total,
+                                       float *__restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float t = 0.0f;
+    for (int s = 0; s < split; ++s) t += part[(int64_t)s * total + i];
+    out[i] = t;
+  }
+}
+
+static int bwd_split_for(int64_t n_owner, int64_t n_stream) {
+  const int64_t tiles = (n_owner + 127) / 128, blocks = (n_stream + 31) / 32;
+  int64_t split = 1;
+  while (tiles * split < 512 && split * 8 <= blocks) split *= 2;     // >= 8 streamed blocks per workgroup
+  return (int)split;
+}
+
+template <bool OWNER_PX>
+static int launch_loss_bwd(BwdArgs a, float *out, float *scratch, hipStream_t s) {
+  if (a.n_owner <= 0) return 0;
+  if (a.n_stream <= 0) {
+    HSGK_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)a.n_owner * a.c, s));
+    return 0;
+  }
+  const int split = bwd_split_for(a.n_owner, a.n_stream);
+  const int64_t blocks = (a.n_stream + 31) / 32;
+  a.split = split;
+  a.blocks_per_split = (int)((blocks + split - 1) / split);
+  a.out = split == 1 ? out : scratch;
+  const int ct = (a.c + 31) / 32;
+  const bool vec4 = (a.c % 4) == 0;
+  auto go = [&](auto kern, int CT, int CG) -> int {
+    const size_t lds = (size_t)2 * 32 * (CT * 32 + 1) * 4 + (size_t)2 * kMaxSets * 32 * (8 + sizeof(PxMeta)) + 2 * 32 * 4;
+    HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int cg0 = 0; cg0 < CT && cg0 * 32 < a.c; cg0 += CG) {
+      hipLaunchKernelGGL(kern, dim3((unsigned)((a.n_owner + 127) / 128), split), dim3(256), lds, s, a, cg0);
+      HSGK_LAUNCH_CHECK();
+    }
+    return 0;
+  };
+  int rc;
+#define HSGK_BWD_CASE(CTV, CGV)                                                                 \
+  rc = vec4 ? go(loss_bwd_kernel<CTV, CGV, OWNER_PX, true>, CTV, CGV)                           \
+            : go(loss_bwd_kernel<CTV, CGV, OWNER_PX, false>, CTV, CGV)
+  if (ct <= 1) HSGK_BWD_CASE(1, 1);
+  else if (ct <= 2) HSGK_BWD_CASE(2, 2);
+  else if (ct <= 4) HSGK_BWD_CASE(4, 4);
+  else if (ct <= 8) HSGK_BWD_CASE(8, 8);
+  else if (ct <= 12) HSGK_BWD_CASE(12, 6);
+  else {
+    set_error("segsort loss backward: embedding dimension %d > 384 is not supported", a.c);
+    return -1;
+  }
+#undef HSGK_BWD_CASE
+  if (rc) return rc;
+  if (split > 1) {
+    const int64_t total = a.n_owner * a.c;
+    const int64_t g = (total + 255) / 256;
+    hipLaunchKernelGGL(loss_bwd_reduce_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, scratch,
+                       split, total, out);
+    HSGK_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+static int make_sets(int L, const hsgk_loss_set *sets, LossSets *ls) {
+  HSGK_REQUIRE(L >= 1 && L <= kMaxSets && sets != nullptr, "1..3 label sets");
+  ls->L = L;
+  for (int l = 0; l < kMaxSets; ++l) {
+    const hsgk_loss_set &src = sets[l < L ? l : 0];
+    HSGK_REQUIRE(src.sem && src.psem, "null label pointer");
+    ls->sem[l] = src.sem;
+    ls->psem[l] = src.psem;
+    ls->kappa[l] = src.kappa;
+    ls->plus[l] = src.mode & 1;
+    ls->setm[l] = (src.mode >> 1) & 1;
+  }
+  return 0;
+}
+
 }  // namespace hsgk
 
 using namespace hsgk;
 
 extern "C" {
 
-size_t hsgk_segsort_loss_workspace_bytes(int64_t n, int c, int64_t P) {
+size_t hsgk_segsort_loss_workspace_bytes(int64_t n, int c, int64_t P, int L) {
   (void)c;
   const int64_t npb = (P + 63) / 64;
-  return (size_t)(npb > 0 ? npb : 1) * (size_t)(n > 0 ? n : 1) * 3 * sizeof(float) + 256;
+  return (size_t)(npb > 0 ? npb : 1) * (size_t)(n > 0 ? n : 1) * 3 * (size_t)(L > 0 ? L : 1) * sizeof(float) + 256;
 }
 
-int hsgk_segsort_loss_fwd(const float *emb, int64_t n, int c, const int64_t *sem,
-                          const int64_t *inst, const float *proto, int64_t P, const int64_t *psem,
-                          float kappa, int group_plus, float *nll, float *num, float *den,
+int hsgk_segsort_loss_fwd(const float *emb, int64_t n, int c, const int64_t *inst, const float *proto,
+                          int64_t P, int L, const hsgk_loss_set *sets, float *nll, float *num, float *den,
                           int32_t *use_same, void *workspace, size_t workspace_bytes,
                           hsgk_stream_t stream) {
   HSGK_REQUIRE(n >= 0 && c >= 1 && P >= 1, "bad shape");
-  HSGK_REQUIRE(workspace_bytes >= hsgk_segsort_loss_workspace_bytes(n, c, P), "workspace too small");
+  LossSets ls;
+  if (int rc = make_sets(L, sets, &ls)) return rc;
+  HSGK_REQUIRE(workspace_bytes >= hsgk_segsort_loss_workspace_bytes(n, c, P, L), "workspace too small");
   if (n == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   (void)hipGetLastError();
   float *part = static_cast<float *>(workspace);
-  LossFwdEpi epi{0, 0, 0, P, n, 0, kappa, sem, inst, psem, part, (group_plus >> 1) & 1};
+  LossFwdEpi epi{0, 0, 0, P, n, 0, inst, ls, part};
   if (int rc = launch_loss_tiles(emb, n, c, proto, P, epi, s)) return rc;
   const int npb = (int)((P + 63) / 64);
+  int plus_mask = 0;
+  for (int l = 0; l < L; ++l) plus_mask |= ls.plus[l] << l;
   hipLaunchKernelGGL(loss_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, npb,
-                     n, group_plus & 1, nll, num, den, use_same);
+                     n, L, plus_mask, nll, num, den, use_same);
   HSGK_LAUNCH_CHECK();
   return 0;
 }
 
-int hsgk_segsort_loss_bwd_weights(const float *emb, int64_t n, int c, const int64_t *sem,
-                                  const int64_t *inst, const float *proto, int64_t P,
-                                  const int64_t *psem, float kappa, int group_plus,
-                                  const float *num, const float *den, const int32_t *use_same,
-                                  const float *gscale, float *wt, hsgk_stream_t stream) {
+size_t hsgk_segsort_loss_bwd_workspace_bytes(int64_t n, int c, int64_t P, int L) {
+  Carver cv(nullptr);
+  cv.take<PxMeta>((size_t)(L > 0 ? L : 1) * (size_t)(n > 0 ? n : 1));
+  const size_t a = (size_t)bwd_split_for(n, P) * (size_t)(n > 0 ? n : 1) * c;
+  const size_t b = (size_t)bwd_split_for(P, n) * (size_t)(P > 0 ? P : 1) * c;
+  cv.take<float>(a > b ? a : b);
+  return cv.off + 256;
+}
+
+int hsgk_segsort_loss_bwd(const float *emb, int64_t n, int c, const int64_t *inst, const float *proto,
+                          int64_t P, int L, const hsgk_loss_set *sets, const float *num, const float *den,
+                          const int32_t *use_same, const float *gscale, float *g_emb, float *g_proto,
+                          void *workspace, size_t workspace_bytes, hsgk_stream_t stream) {
   HSGK_REQUIRE(n >= 0 && c >= 1 && P >= 1, "bad shape");
-  if (n == 0) return 0;
+  LossSets ls;
+  if (int rc = make_sets(L, sets, &ls)) return rc;
+  HSGK_REQUIRE(workspace_bytes >= hsgk_segsort_loss_bwd_workspace_bytes(n, c, P, L), "workspace too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
   (void)hipGetLastError();
-  LossBwdEpi epi{0, 0, group_plus & 1, P, n, 0, kappa, sem, inst, psem, num, den, gscale, use_same, wt,
-                 (group_plus >> 1) & 1};
-  return launch_loss_tiles(emb, n, c, proto, P, epi, s);
+  if (n == 0) {
+    if (g_proto) HSGK_CHECK_HIP(hipMemsetAsync(g_proto, 0, sizeof(float) * (size_t)P * c, s));
+    return 0;
+  }
+  Carver cv(workspace);
+  PxMeta *meta = cv.take<PxMeta>((size_t)L * n);
+  float *scratch = reinterpret_cast<float *>(cv.base + cv.off);
+  hipLaunchKernelGGL(loss_bwd_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, num, den,
+                     use_same, gscale, n, ls, meta);
+  HSGK_LAUNCH_CHECK();
+  BwdArgs a{};
+  a.N = n; a.P = P; a.c = c; a.inst = inst; a.meta = meta; a.ls = ls;
+  if (g_emb) {
+    a.owner = emb; a.stream = proto; a.n_owner = n; a.n_stream = P;
+    if (int rc = launch_loss_bwd<true>(a, g_emb, scratch, s)) return rc;
+  }
+  if (g_proto) {
+    a.owner = proto; a.stream = emb; a.n_owner = P; a.n_stream = n;
+    if (int rc = launch_loss_bwd<false>(a, g_proto, scratch, s)) return rc;
+  }
+  return 0;
 }
 
 }  // extern "C"

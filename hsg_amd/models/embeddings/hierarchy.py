@@ -2,7 +2,8 @@
 reference's embedding models (hsg/models/embeddings/resnet_fcn_hsg.py),
 as free functions with the same argument / return conventions:
 
-  calculate_kmeans_prototypes                 :455-577  (_calculate_kmeans_prototypes)
+  calculate_kmeans_prototypes                 :455-577, :1005-1136  (_calculate_kmeans_prototypes,
+                                              base and multiview variants)
   hierarchical_grouping_from_logits           :638-672  (tail of _hierarchical_grouping)
   collect_nd_coarser_prototype                :683-748
   collect_pixel_hierarchical_clustering_indices :751-780
@@ -25,15 +26,29 @@ from hsg_amd import _lib, ops
 
 
 # ---------------------------------------------------------------------------
-def calculate_kmeans_prototypes(cluster_embeddings, cluster_indices, cluster_batch_indices,
-                                cluster_pos_embeddings, cluster_labels, label_divisor=256,
-                                max_num_clusters=256):
-  """Per-image padded prototypes of the k-means segments (reference :455-577).
+def _group_order(group_of_row):
+  """Permutation that lists the rows group by group (ascending group, row order inside a
+  group) -- the order in which the reference concatenates its per-image results -- or None
+  when the rows already are in that order (image-major rows: the usual case)."""
+  if group_of_row.numel() < 2 or bool((group_of_row[1:] >= group_of_row[:-1]).all()):
+    return None
+  return torch.argsort(group_of_row, stable=True)
 
-  Returns (prototypes [B,C,M], pos_prototypes [B,C,M] or None, padding masks
-  [B,M] bool, prototype_labels [B,M], prototype_batch_indices [B,M],
-  cluster_indices_by_image [N]); padded entries are 0 / True / -1 / -1.
-  Segment ids inside an image are the ranks of (cluster index, label) pairs.
+
+def calculate_kmeans_prototypes(cluster_embeddings, cluster_indices, cluster_batch_indices,
+                                cluster_pos_embeddings, cluster_labels, image_indices=None,
+                                label_divisor=256, max_num_clusters=256):
+  """Per-image padded prototypes of the k-means segments: reference
+  `ResnetFcn._calculate_kmeans_prototypes` (:455-577) and, with `image_indices` [batch]
+  (the image id of every view), `MultiviewResnetFcn._calculate_kmeans_prototypes`
+  (:1005-1136), which stacks the segments of all views of one image in one row.
+
+  Returns (prototypes [B',C,M], pos_prototypes [B',C,M] or None, padding masks
+  [B',M] bool, prototype_labels [B',M], prototype_batch_indices [B',M],
+  cluster_indices_by_image [N]); B' = distinct images (ascending id), padded entries are
+  0 / True / -1 / -1.  Segment ids inside an image are the ranks of (cluster index,
+  batch index, label) triples (prepare_prototype_labels, :1082); like the reference,
+  `cluster_indices_by_image` lists the pixels image by image.
   """
   ops.require_gpu(cluster_embeddings, 'cluster_embeddings')
   dev = cluster_embeddings.device
@@ -41,23 +56,30 @@ def calculate_kmeans_prototypes(cluster_embeddings, cluster_indices, cluster_bat
   b = cluster_batch_indices.view(-1).long()
   c = cluster_indices.view(-1).long()
   lab = cluster_labels.view(-1).long()
-  # one sorted unique over (batch, cluster, label) replaces the per-image loop:
-  # rows of one image are ranked by (cluster, batch*div^2 + label) there (:519-523)
+  img = b if image_indices is None else image_indices.view(-1).long()[b]      # (:1051-1054)
+  # one sorted unique over (image, cluster, batch * div^2 + label) replaces the per-image loop
   ldiv = int(label_divisor) ** 2
-  cdiv = int(c.max()) + 1 if c.numel() else 1
-  lmax = int(lab.max()) + 1 if lab.numel() else 1
-  keys = (b * cdiv + c) * max(lmax, 1) + lab
+  bl = b * ldiv + lab                                                  # (:1079-1080) batch index rides on the label
+  if c.numel():
+    radix = torch.stack([c.max(), bl.max()]).cpu().tolist()
+    cdiv, blmax = radix[0] + 1, radix[1] + 1
+  else:
+    cdiv = blmax = 1
+  keys = (img * cdiv + c) * blmax + bl
   ukeys, gid = torch.unique(keys, return_inverse=True)
-  ubatch = ukeys // (cdiv * max(lmax, 1))
-  ulab = ukeys % max(lmax, 1)
-  images, img_of_seg = torch.unique(ubatch, return_inverse=True)      # ascending batch index
+  ubl = ukeys % blmax
+  uimg = ukeys // (blmax * cdiv)
+  images, img_of_seg = torch.unique(uimg, return_inverse=True)        # ascending image id
   B = images.shape[0]
-  first = torch.searchsorted(ubatch, images)                           # first global id per image
+  first = torch.searchsorted(uimg, images)                             # first global id per image
   local = torch.arange(ukeys.shape[0], device=dev) - first[img_of_seg]
   if int(local.max()) >= M if local.numel() else False:
     raise IndexError('an image has more than max_num_clusters=%d segments' % M)
   slot = img_of_seg * M + local                                        # position in the padded table
   cluster_indices_by_image = local[gid]
+  order = _group_order(img_of_seg[gid])
+  if order is not None:
+    cluster_indices_by_image = cluster_indices_by_image[order]
 
   P = ukeys.shape[0]
   C = cluster_embeddings.shape[-1]
@@ -72,9 +94,9 @@ def calculate_kmeans_prototypes(cluster_embeddings, cluster_indices, cluster_bat
   masks = torch.ones((B * M,), dtype=torch.bool, device=dev)
   masks[slot] = False
   plabs = torch.full((B * M,), -1, dtype=torch.long, device=dev)
-  plabs[slot] = (ubatch * ldiv + ulab) % ldiv                          # (:524-525)
+  plabs[slot] = ubl % ldiv                                             # (:524-525 / :1084-1085)
   pbatch = torch.full((B * M,), -1, dtype=torch.long, device=dev)
-  pbatch[slot] = (ubatch * ldiv + ulab) // ldiv
+  pbatch[slot] = ubl // ldiv
   return (prototypes, pos_prototypes, masks.view(B, M), plabs.view(B, M), pbatch.view(B, M),
           cluster_indices_by_image)
 
@@ -196,19 +218,24 @@ def collect_nd_coarser_prototype(prototypes, prototype_grouping_labels,
 def collect_pixel_hierarchical_clustering_indices(cluster_indices_by_batch,
                                                   cluster_batch_indices,
                                                   finehrchy_prototype_grouping_labels):
-  """Group label of every pixel (reference :751-780): the i-th distinct batch
-  index (ascending) reads row i of the [B, M] grouping-label table."""
+  """Group label of every pixel (reference :751-780): the i-th distinct batch (or image)
+  index, ascending, reads row i of the [B', M] grouping-label table at the entries of
+  `cluster_indices_by_batch` that sit at ITS pixels' positions; the per-image results are
+  concatenated image by image, exactly as the reference's loop does."""
   ops.require_gpu(cluster_indices_by_batch, 'cluster_indices_by_batch')
   seg = cluster_indices_by_batch.view(-1).long().contiguous()
   _, img = torch.unique(cluster_batch_indices.view(-1).long(), return_inverse=True)
   img = img.contiguous()
   table = finehrchy_prototype_grouping_labels.long().contiguous()
   out = torch.empty_like(seg)
+  if seg.numel() == 0:
+    return out
   with torch.cuda.device(seg.device):
     _lib.check(_lib.lib().hsgk_gather_labels(table.data_ptr(), table.shape[1], img.data_ptr(),
                                              seg.data_ptr(), seg.shape[0], out.data_ptr(),
                                              _lib.stream_ptr()))
-  return out
+  order = _group_order(img)
+  return out if order is None else out[order]
 
 
 class _ClusterTopk(torch.autograd.Function):

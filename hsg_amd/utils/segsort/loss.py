@@ -4,9 +4,11 @@ Same constructors and forward signatures as the reference module
 (hsg/utils/segsort/loss.py:133-190, 193-251).  The [N,P] similarity matrix of the
 reference is never built in the forward pass: libhsgk streams the pixels
 against 64-prototype blocks on fp32 MFMA and folds exp(kappa * cos) straight
-into per-pixel own / same / different sums (csrc/loss.hip).  Backward
-recomputes the scores, writes the per-pair weights transposed and finishes
-with two library GEMMs.
+into per-pixel own / same / different sums (csrc/loss.hip), for up to three
+label sets per pass (`segsort_losses`: the three losses of
+hsg/models/predictions/hsg.py:78-155 share E P^T).  Backward recomputes the
+score tiles and contracts them in place (g_emb = W P, g_proto = W^T E) -- no
+[N,P] storage there either.
 """
 import ctypes
 
@@ -16,66 +18,117 @@ from torch.nn.modules.loss import _Loss
 from hsg_amd import _lib, ops
 
 
+MAX_LABEL_SETS = 3
+
+
+def _make_sets(sems, psems, kappas, modes):
+  arr = (_lib.LossSet * len(sems))()
+  for i, (a, b, k, m) in enumerate(zip(sems, psems, kappas, modes)):
+    arr[i].sem, arr[i].psem, arr[i].kappa, arr[i].mode = a.data_ptr(), b.data_ptr(), float(k), int(m)
+  return arr
+
+
 class _SegSortNLL(torch.autograd.Function):
-  """Per-pixel negative log-likelihood (reference loss.py:15-82)."""
+  """Per-pixel negative log-likelihood (reference loss.py:15-82) of up to three label sets
+  over the same embeddings / own-prototype indices / prototype table: [L, n]."""
 
   @staticmethod
-  def forward(ctx, embeddings, semantic_labels, instance_labels, prototypes,
-              prototype_semantic_labels, concentration, group_plus):
+  def forward(ctx, embeddings, instance_labels, prototypes, kappas, modes, *labels):
+    L = len(kappas)
+    sems, psems = labels[:L], labels[L:]
     emb = embeddings.detach().contiguous()
     proto = prototypes.detach().contiguous()
     n, c = emb.shape
     P = proto.shape[0]
     dev = emb.device
-    L = _lib.lib()
+    lib = _lib.lib()
     with torch.cuda.device(dev):
-      nll = torch.empty((n,), dtype=torch.float32, device=dev)
-      num = torch.empty((n,), dtype=torch.float32, device=dev)
-      den = torch.empty((n,), dtype=torch.float32, device=dev)
-      use_same = torch.empty((n,), dtype=torch.int32, device=dev)
-      wsb = L.hsgk_segsort_loss_workspace_bytes(n, c, P)
+      nll = torch.empty((L, n), dtype=torch.float32, device=dev)
+      num = torch.empty((L, n), dtype=torch.float32, device=dev)
+      den = torch.empty((L, n), dtype=torch.float32, device=dev)
+      use_same = torch.empty((L, n), dtype=torch.int32, device=dev)
+      wsb = lib.hsgk_segsort_loss_workspace_bytes(n, c, P, L)
       ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
-      _lib.check(L.hsgk_segsort_loss_fwd(
-          emb.data_ptr(), n, c, semantic_labels.data_ptr(), instance_labels.data_ptr(),
-          proto.data_ptr(), P, prototype_semantic_labels.data_ptr(),
-          ctypes.c_float(concentration), int(group_plus), nll.data_ptr(), num.data_ptr(),
-          den.data_ptr(), use_same.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr()))
-    ctx.save_for_backward(emb, proto, semantic_labels, instance_labels,
-                          prototype_semantic_labels, num, den, use_same)
-    ctx.cfg = (float(concentration), int(group_plus))
+      sets = _make_sets(sems, psems, kappas, modes)
+      _lib.check(lib.hsgk_segsort_loss_fwd(
+          emb.data_ptr(), n, c, instance_labels.data_ptr(), proto.data_ptr(), P, L, sets,
+          nll.data_ptr(), num.data_ptr(), den.data_ptr(), use_same.data_ptr(), ws.data_ptr(), wsb,
+          _lib.stream_ptr()))
+    ctx.save_for_backward(emb, proto, instance_labels, num, den, use_same, *labels)
+    ctx.cfg = (tuple(float(k) for k in kappas), tuple(int(m) for m in modes))
     return nll
 
   @staticmethod
   def backward(ctx, gnll):
-    emb, proto, sem, inst, psem, num, den, use_same = ctx.saved_tensors
-    kappa, group_plus = ctx.cfg
+    emb, proto, inst, num, den, use_same = ctx.saved_tensors[:6]
+    labels = ctx.saved_tensors[6:]
+    kappas, modes = ctx.cfg
+    L = len(kappas)
     n, c = emb.shape
     P = proto.shape[0]
     dev = emb.device
+    lib = _lib.lib()
     gscale = gnll.detach().to(torch.float32).contiguous()
+    want_e, want_p = ctx.needs_input_grad[0], ctx.needs_input_grad[2]
+    g_emb = g_proto = None
     with torch.cuda.device(dev):
-      wt = torch.empty((P, n), dtype=torch.float32, device=dev)
-      _lib.check(_lib.lib().hsgk_segsort_loss_bwd_weights(
-          emb.data_ptr(), n, c, sem.data_ptr(), inst.data_ptr(), proto.data_ptr(), P,
-          psem.data_ptr(), ctypes.c_float(kappa), group_plus, num.data_ptr(), den.data_ptr(),
-          use_same.data_ptr(), gscale.data_ptr(), wt.data_ptr(), _lib.stream_ptr()))
-      g_emb = torch.mm(wt.t(), proto) if ctx.needs_input_grad[0] else None
-      g_proto = torch.mm(wt, emb) if ctx.needs_input_grad[3] else None
-    return g_emb, None, None, g_proto, None, None, None
+      if want_e:
+        g_emb = torch.empty((n, c), dtype=torch.float32, device=dev)
+      if want_p:
+        g_proto = torch.empty((P, c), dtype=torch.float32, device=dev)
+      if want_e or want_p:
+        wsb = lib.hsgk_segsort_loss_bwd_workspace_bytes(n, c, P, L)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+        sets = _make_sets(labels[:L], labels[L:], kappas, modes)
+        _lib.check(lib.hsgk_segsort_loss_bwd(
+            emb.data_ptr(), n, c, inst.data_ptr(), proto.data_ptr(), P, L, sets, num.data_ptr(),
+            den.data_ptr(), use_same.data_ptr(), gscale.data_ptr(),
+            g_emb.data_ptr() if want_e else None, g_proto.data_ptr() if want_p else None,
+            ws.data_ptr(), wsb, _lib.stream_ptr()))
+    return (g_emb, None, g_proto, None, None) + (None,) * len(labels)
+
+
+def _nll_sets(embeddings, instance_labels, prototypes, label_sets):
+  """label_sets: list of (semantic_labels [n], prototype_semantic_labels [P], concentration,
+  mode) with mode bit 0 = 'segsort+', bit 1 = class-mask labels -> nll [L, n]."""
+  ops.require_gpu(embeddings, 'embeddings')
+  if not 1 <= len(label_sets) <= MAX_LABEL_SETS:
+    raise ValueError('1..%d label sets per pass' % MAX_LABEL_SETS)
+  emb = embeddings.reshape(-1, embeddings.shape[-1]).to(torch.float32)
+  proto = prototypes.reshape(-1, prototypes.shape[-1]).to(torch.float32)
+  inst = instance_labels.reshape(-1).to(torch.int64).contiguous()
+  sems = [ls[0].reshape(-1).to(torch.int64).contiguous() for ls in label_sets]
+  psems = [ls[1].reshape(-1).to(torch.int64).contiguous() for ls in label_sets]
+  for a, b in zip(sems, psems):
+    if a.shape[0] != emb.shape[0] or b.shape[0] != proto.shape[0]:
+      raise ValueError('label vectors do not match the embeddings / prototypes')
+  return _SegSortNLL.apply(emb, inst, proto, tuple(ls[2] for ls in label_sets),
+                           tuple(ls[3] for ls in label_sets), *sems, *psems)
+
+
+def segsort_losses(embeddings, instance_labels, prototypes, label_sets, reduction='mean'):
+  """Several SegSortLoss values in ONE pass over E P^T: `label_sets` is a list of up to three
+  (semantic_labels, prototype_semantic_labels, concentration, group_mode) tuples that share the
+  embeddings, the own-prototype indices (`instance_labels`) and the prototype table -- the three
+  contrastive losses of hsg/models/predictions/hsg.py:78-155.  Returns one loss per set, each
+  equal to SegSortLoss(concentration, group_mode, reduction)(embeddings, semantic_labels,
+  instance_labels, prototypes, prototype_semantic_labels)."""
+  sets = [(s, p, float(k), 1 if g == 'segsort+' else 0) for s, p, k, g in label_sets]
+  nll = _nll_sets(embeddings, instance_labels, prototypes, sets)
+  if reduction == 'mean':
+    return [nll[i].mean() for i in range(len(sets))]
+  if reduction == 'sum':
+    return [nll[i].sum() for i in range(len(sets))]
+  return [nll[i].view(-1, 1) for i in range(len(sets))]
 
 
 def _calculate_log_likelihood(embeddings, semantic_labels, instance_labels, prototypes,
                               prototype_semantic_labels, concentration, group_mode):
   """Reference loss.py:15-82; returns [num_pixels, 1] like the reference."""
-  ops.require_gpu(embeddings, 'embeddings')
-  emb = embeddings.reshape(-1, embeddings.shape[-1]).to(torch.float32)
-  proto = prototypes.reshape(-1, prototypes.shape[-1]).to(torch.float32)
-  sem = semantic_labels.reshape(-1).to(torch.int64).contiguous()
-  inst = instance_labels.reshape(-1).to(torch.int64).contiguous()
-  psem = prototype_semantic_labels.reshape(-1).to(torch.int64).contiguous()
-  nll = _SegSortNLL.apply(emb, sem, inst, proto, psem, float(concentration),
-                          group_mode == 'segsort+')
-  return nll.view(-1, 1)
+  nll = _nll_sets(embeddings, instance_labels, prototypes,
+                  [(semantic_labels, prototype_semantic_labels, float(concentration),
+                    1 if group_mode == 'segsort+' else 0)])
+  return nll[0].view(-1, 1)
 
 
 class SegSortLoss(_Loss):
@@ -125,17 +178,13 @@ def _one_hot_calculate_log_likelihood(embeddings, semantic_labels, instance_labe
   """Reference loss.py:85-130 (multi-label variant: "same semantic label" = non-zero
   label affinity); returns [num_pixels, 1] like the reference.  Same kernels as
   `_calculate_log_likelihood` with the class masks in place of the labels."""
-  ops.require_gpu(embeddings, 'embeddings')
-  emb = embeddings.reshape(-1, embeddings.shape[-1]).to(torch.float32)
-  proto = prototypes.reshape(-1, prototypes.shape[-1]).to(torch.float32)
   sem = _class_masks(semantic_labels.reshape(-1, semantic_labels.shape[-1]), 'semantic_labels')
   psem = _class_masks(prototype_semantic_labels.reshape(-1, prototype_semantic_labels.shape[-1]),
                       'prototype_semantic_labels')
-  inst = instance_labels.reshape(-1).to(torch.int64).contiguous()
-  # group_plus bit 0 = 'segsort+', bit 1 = set mode (include/hsgk.h)
-  nll = _SegSortNLL.apply(emb, sem, inst, proto, psem, float(concentration),
-                          (1 if group_mode == 'segsort+' else 0) | 2)
-  return nll.view(-1, 1)
+  # mode bit 0 = 'segsort+', bit 1 = set mode (include/hsgk.h)
+  nll = _nll_sets(embeddings, instance_labels, prototypes,
+                  [(sem, psem, float(concentration), (1 if group_mode == 'segsort+' else 0) | 2)])
+  return nll[0].view(-1, 1)
 
 
 class SetSegSortLoss(_Loss):

@@ -206,28 +206,41 @@ HSGK_API int hsgk_segment_reduce_bwd(const float *gout, const float *out, const 
                                      int mode, float eps, float *gseg, float *gx,
                                      hsgk_stream_t stream);
 
-/* ---- hsg/utils/segsort/loss.py:15-82,149-190 SegSortLoss --------------------
- * emb [n,c] f32, sem/inst int64 [n] (inst indexes the prototype table),
- * proto [P,c] f32, psem int64 [P], kappa = concentration, group_plus bit 0 = 1 for
- * 'segsort+', 0 for 'segsort'; bit 1 = set mode (SetSegSortLoss, loss.py:85-130,
- * 193-251): sem / psem carry one bit per class of the multi-hot labels (<= 64 classes)
- * and "same semantic label" means a non-zero label affinity, i.e. the masks meet.
- * fwd writes the per-pixel negative log
- * likelihood nll[n] and the backward state num[n], den[n], use_same[n].
- * bwd_weights writes W^T [P,n] with W^T[p][i] = gscale[i] * dnll_i/d(e_i.p_p);
- * the caller finishes with two plain GEMMs: g_emb = W proto, g_proto = W^T emb. */
-HSGK_API size_t hsgk_segsort_loss_workspace_bytes(int64_t n, int c, int64_t P);
-HSGK_API int hsgk_segsort_loss_fwd(const float *emb, int64_t n, int c, const int64_t *sem,
-                                   const int64_t *inst, const float *proto, int64_t P,
-                                   const int64_t *psem, float kappa, int group_plus, float *nll,
-                                   float *num, float *den, int32_t *use_same, void *workspace,
-                                   size_t workspace_bytes, hsgk_stream_t stream);
-HSGK_API int hsgk_segsort_loss_bwd_weights(const float *emb, int64_t n, int c, const int64_t *sem,
-                                           const int64_t *inst, const float *proto, int64_t P,
-                                           const int64_t *psem, float kappa, int group_plus,
-                                           const float *num, const float *den,
-                                           const int32_t *use_same, const float *gscale,
-                                           float *wt, hsgk_stream_t stream);
+/* ---- hsg/utils/segsort/loss.py:15-82,149-190 SegSortLoss (and :85-130,193-251
+ *      SetSegSortLoss), for up to three label sets in one pass -----------------------
+ * hsg/models/predictions/hsg.py:78-155 evaluates the loss three times on the SAME
+ * embeddings, instance labels and prototype table with different semantic labels
+ * (image similarity, fine and coarse hierarchy); here E P^T is formed once.
+ * emb [n,c] f32, inst int64 [n] (index of the pixel's own prototype), proto [P,c] f32.
+ * Label set l (host array `sets`, L <= HSGK_LOSS_MAX_SETS): sem int64 [n], psem int64
+ * [P], kappa = concentration, mode bit 0 = 'segsort+' (else 'segsort'), bit 1 = set mode:
+ * sem / psem carry one bit per class of the multi-hot labels (<= 63 classes) and "same
+ * semantic label" means a non-zero label affinity, i.e. the masks meet.
+ * fwd writes, per set, the per-pixel negative log likelihood nll[L][n] and the backward
+ * state num[L][n], den[L][n], use_same[L][n]; no [n,P] matrix exists.
+ * bwd takes gscale[L][n] = dLoss/dnll and writes g_emb [n,c] and / or g_proto [P,c]
+ * (either may be null): the score tiles are recomputed and contracted in place, memory
+ * stays O(n c + P c).  c <= 384 for bwd.                                             */
+#define HSGK_LOSS_MAX_SETS 3
+typedef struct hsgk_loss_set {
+  const int64_t *sem;    /* [n] semantic label (or class mask) of every pixel       */
+  const int64_t *psem;   /* [P] semantic label (or class mask) of every prototype   */
+  float kappa;
+  int32_t mode;
+} hsgk_loss_set;
+HSGK_API size_t hsgk_segsort_loss_workspace_bytes(int64_t n, int c, int64_t P, int L);
+HSGK_API int hsgk_segsort_loss_fwd(const float *emb, int64_t n, int c, const int64_t *inst,
+                                   const float *proto, int64_t P, int L,
+                                   const hsgk_loss_set *sets, float *nll, float *num, float *den,
+                                   int32_t *use_same, void *workspace, size_t workspace_bytes,
+                                   hsgk_stream_t stream);
+HSGK_API size_t hsgk_segsort_loss_bwd_workspace_bytes(int64_t n, int c, int64_t P, int L);
+HSGK_API int hsgk_segsort_loss_bwd(const float *emb, int64_t n, int c, const int64_t *inst,
+                                   const float *proto, int64_t P, int L,
+                                   const hsgk_loss_set *sets, const float *num, const float *den,
+                                   const int32_t *use_same, const float *gscale, float *g_emb,
+                                   float *g_proto, void *workspace, size_t workspace_bytes,
+                                   hsgk_stream_t stream);
 
 /* ---- hsg/models/embeddings/resnet_fcn_hsg.py:638-672 _hierarchical_grouping tail
  * fine_logits [B,KF,N], coarse_logits [B,KC,KF] (nullable).  fine_prob = softmax

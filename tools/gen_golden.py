@@ -342,27 +342,36 @@ def f8():
     sg.gather = sg_gather
 
 
-# ---- F7 hierarchical prototypes / grouping (resnet_fcn_hsg.py:455-780) ----------
-def f7():
+# ---- F7 hierarchical prototypes / grouping (resnet_fcn_hsg.py:455-780, :1005-1136) ----------
+def _f7_case(name, seed, B, C, H, W, grid, M, KF, KC2, regions, image_indices=None, iters=4,
+             flavour='mixture'):
+  """The reference's own methods called on a stub `self`.  image_indices given: the multiview
+  variant (MultiviewResnetFcn._calculate_kmeans_prototypes, the one train.py runs) and the
+  pixel lookups keyed by image id as in MultiviewResnetFcn.generate_clusters:942-957."""
   import types
   import hsg.models.embeddings.resnet_fcn_hsg as ref_model
   cls = ref_model.ResnetFcn
-  seed = synth.SEED_BASE + 61
-  B, C, H, W, grid = 3, 16, 24, 20, (3, 3)
-  x = synth.embeddings_nchw(seed, (B, C, H, W), 'mixture')
-  lab = synth.overseg_labels(seed + 7, B, H, W, regions=5, ignore_rows=2, ignore_index=255)
+  x = synth.embeddings_nchw(seed, (B, C, H, W), flavour)
+  lab = synth.overseg_labels(seed + 7, B, H, W, regions=regions, ignore_rows=2, ignore_index=255)
   emb, emb_loc, labels, cidx, bidx = ref_segment_by_kmeans(
-      torch.from_numpy(x), torch.from_numpy(lab), list(grid), ignore_index=255, iterations=4)
+      torch.from_numpy(x), torch.from_numpy(lab), list(grid), ignore_index=255, iterations=iters)
   n = emb.shape[0]
   pos = torch.from_numpy(synth.gaussish(seed + 1, n * C).reshape(n, C).copy())
-  M, KF, KC2 = 64, 6, 3
   stub = types.SimpleNamespace(label_divisor=256, max_num_clusters=M, fine_hrchy_clusters=KF)
-  protos, pos_protos, masks, plabs, pbatch, c_by_img = cls._calculate_kmeans_prototypes(
-      stub, emb, cidx, bidx, pos, labels)
-  fine_logits = torch.from_numpy(synth.gaussish(seed + 2, B * KF * M).reshape(B, KF, M).copy()) * 2
-  coarse_logits = torch.from_numpy(synth.gaussish(seed + 3, B * KC2 * KF).reshape(B, KC2, KF).copy()) * 2
-  cent_f = torch.from_numpy(synth.gaussish(seed + 4, B * C * KF).reshape(B, C, KF).copy())
-  cent_c = torch.from_numpy(synth.gaussish(seed + 5, B * C * KC2).reshape(B, C, KC2).copy())
+  if image_indices is None:
+    protos, pos_protos, masks, plabs, pbatch, c_by_img = cls._calculate_kmeans_prototypes(
+        stub, emb, cidx, bidx, pos, labels)
+    px_ids = bidx
+  else:
+    img = torch.tensor(image_indices, dtype=torch.long)
+    protos, pos_protos, masks, plabs, pbatch, c_by_img = (
+        ref_model.MultiviewResnetFcn._calculate_kmeans_prototypes(stub, emb, cidx, bidx, pos, labels, img))
+    px_ids = torch.gather(img, 0, bidx)
+  Bp = protos.shape[0]
+  fine_logits = torch.from_numpy(synth.gaussish(seed + 2, Bp * KF * M).reshape(Bp, KF, M).copy()) * 2
+  coarse_logits = torch.from_numpy(synth.gaussish(seed + 3, Bp * KC2 * KF).reshape(Bp, KC2, KF).copy()) * 2
+  cent_f = torch.from_numpy(synth.gaussish(seed + 4, Bp * C * KF).reshape(Bp, C, KF).copy())
+  cent_c = torch.from_numpy(synth.gaussish(seed + 5, Bp * C * KC2).reshape(Bp, C, KC2).copy())
   stub.fine_query_embed = lambda: None
   stub.coarse_query_embed = lambda: None
   stub.fine_hrchy_transformer = lambda **kw: (cent_f, cent_f, fine_logits, kw['src'])
@@ -373,16 +382,31 @@ def f7():
                                                normalized=False)
   fine_pos_n = cls._collect_nd_coarser_prototype(stub, protos, f_lab, masks, num_groups=KF,
                                                  normalized=True)
-  px_fine = cls._collect_pixel_hierarchical_clustering_indices(stub, c_by_img, bidx, f_lab)
-  px_coarse = cls._collect_pixel_hierarchical_clustering_indices(stub, c_by_img, bidx, c_lab)
-  save('f7_hierarchy', seed=seed, shape=np.array([B, C, H, W]), grid=np.array(grid), M=M, KF=KF, KC=KC2,
-       label_seed=seed + 7, ylin=lin01(H), xlin=lin01(W),
+  px_fine = cls._collect_pixel_hierarchical_clustering_indices(stub, c_by_img, px_ids, f_lab)
+  px_coarse = cls._collect_pixel_hierarchical_clustering_indices(stub, c_by_img, px_ids, c_lab)
+  big = emb.numel() > 200000              # large cases: strided rows of the float tensors
+  save(name, seed=seed, shape=np.array([B, C, H, W]), grid=np.array(grid), M=M, KF=KF, KC=KC2,
+       label_seed=seed + 7, regions=regions, iters=iters, flavour=flavour, ylin=lin01(H), xlin=lin01(W),
+       image_indices=np.array(image_indices if image_indices is not None else [], np.int64),
        emb=emb.numpy(), cidx=cidx.numpy(), bidx=bidx.numpy(), labels=labels.numpy(),
        protos=protos.numpy(), pos_protos=pos_protos.numpy(), masks=masks.numpy(),
        plabs=plabs.numpy(), pbatch=pbatch.numpy(), c_by_img=c_by_img.numpy(),
-       f_lab=f_lab.numpy(), f_prob=f_prob.numpy(), c_lab=c_lab.numpy(), c_prob=c_prob.numpy(),
+       f_lab=f_lab.numpy(), f_prob=f_prob.numpy() if not big else f_prob.numpy()[:, ::7],
+       c_lab=c_lab.numpy(), c_prob=c_prob.numpy(),
        fine_pos=fine_pos.numpy(), fine_pos_n=fine_pos_n.numpy(), px_fine=px_fine.numpy(),
        px_coarse=px_coarse.numpy())
+
+
+def f7():
+  _f7_case('f7_hierarchy', synth.SEED_BASE + 61, 3, 16, 24, 20, (3, 3), 64, 6, 3, 5)
+  # the multiview variant train.py runs: two views per image, views of one image not adjacent
+  _f7_case('f7_hierarchy_multiview', synth.SEED_BASE + 62, 4, 16, 20, 24, (3, 3), 128, 6, 3, 5,
+           image_indices=[0, 1, 0, 1])
+  _f7_case('f7_hierarchy_multiview_b', synth.SEED_BASE + 63, 4, 8, 16, 16, (2, 3), 96, 5, 2, 4,
+           image_indices=[1, 0, 0, 1])
+  # BASELINE.json configs[3]'s hierarchy sizes: up to 256 segments per image -> 64 -> 16
+  _f7_case('f7_hierarchy_m256', synth.SEED_BASE + 64, 2, 32, 48, 48, (6, 6), 256, 64, 16, 6, iters=5,
+           flavour='iid')
 
 
 # ---- F10 TransformerClustering tail (transformer_clusters.py:99-114) -------------
