@@ -753,6 +753,69 @@ def test_cfg4_end_to_end_c256_grid16_labels_ignore_vs_oracle(dev, oracle):
       assert np.array_equal(a, b), '%s (%s): %d mismatching elements' % (nm, flavour, int((a != b).sum()))
 
 
+def test_whole_train_step_vs_reference(dev):
+  """one WHOLE training step around a stub backbone -- train.py:165-269 restated in
+  tests/util.run_train_step -- through the hsg_amd model-level mirrors (MultiviewResnetFcn's
+  clustering half, the prototype exchange x3, the cluster mappings, Hsg.forward with the three
+  contrastive losses in ONE E.P^T pass + DMon + centroid contrast, backward to the embeddings)
+  against the same step run by the reference's own modules (tests/golden/f14_train_step_full.npz):
+  every integer output identical, losses within 1e-4, gradients within 1e-5 of their scale."""
+  import torch
+  from hsg_amd.models import utils as mu
+  from hsg_amd.models.embeddings import resnet_fcn_hsg as em
+  from hsg_amd.models.predictions import hsg as pm
+  from hsg_amd.utils.segsort import common as sc
+  g = util.load('f14_train_step_full')
+  inp = util.train_step_inputs(int(g['seed']))
+  loc_fn = lambda hw, d: sc.generate_location_features(hw, d, 'float') - 0.5
+  out = util.run_train_step(dict(embedding_cls=em.MultiviewClusteringMixin, prediction_cls=pm.Hsg,
+                                 model_utils=mu, loc_fn=loc_fn), inp, dev)
+  for k in ('image_index', 'cluster_index', 'finehrchy_cluster_index', 'coarsehrchy_cluster_index',
+            'finehrchy_mapping_index', 'coarsehrchy_mapping_index', 'n_prototypes'):
+    assert np.array_equal(out[k].cpu().numpy(), g[k]), k
+  for k in ('img_sim_loss', 'hrchy_group_loss', 'clustering_loss'):
+    assert abs(float(out[k]) - float(g[k])) <= 1e-4, (k, float(out[k]), float(g[k]))
+  assert abs(float(out['accuracy']) - float(g['accuracy'])) <= 1e-6
+  for k in ('grad', 'g_fine_logits', 'g_coarse_logits', 'g_cent_f'):
+    ref = g[k]
+    scale = max(float(np.abs(ref).max()), 1e-6)
+    err = float(np.abs(out[k].cpu().numpy() - ref).max())
+    assert err <= 1e-5 * scale + 1e-8, (k, err, scale)
+
+
+def test_patch_reference_rebinds_a_reference_shaped_package(dev, tmp_path, monkeypatch):
+  """hsg_amd.patch_reference() on a package laid out like twke18/HSG (the real one is not on the GPU
+  box): module functions, model methods and Hsg.losses are rebound, and a patched call runs on libhsgk."""
+  import importlib
+  import sys
+  import torch
+  import hsg_amd
+  root = tmp_path / 'fakehsg'
+  for sub in ('', 'utils', 'utils/segsort', 'utils/general', 'models', 'models/embeddings', 'models/predictions'):
+    (root / sub).mkdir(parents=True, exist_ok=True)
+    (root / sub / '__init__.py').write_text('')
+  (root / 'utils/segsort/common.py').write_text('def segment_by_kmeans(*a, **k):\n  raise RuntimeError("reference path")\n'
+                                                'def calculate_prototypes_from_labels(*a, **k):\n  raise RuntimeError("reference path")\n')
+  (root / 'utils/general/common.py').write_text('def normalize_embedding(*a, **k):\n  raise RuntimeError("reference path")\n')
+  (root / 'models/embeddings/resnet_fcn_hsg.py').write_text(
+      'import fakehsg.utils.segsort.common as segsort_common\n'
+      'class ResnetFcn:\n  def generate_clusters(self):\n    return "reference"\n'
+      'class MultiviewResnetFcn(ResnetFcn):\n  pass\n')
+  (root / 'models/predictions/hsg.py').write_text('class Hsg:\n  def losses(self, datas, targets={}):\n    return "reference"\n')
+  monkeypatch.syspath_prepend(str(tmp_path))
+  done = hsg_amd.patch_reference('fakehsg')
+  assert 'fakehsg.utils.segsort.common.segment_by_kmeans' in done
+  assert 'fakehsg.models.embeddings.resnet_fcn_hsg.MultiviewResnetFcn.generate_clusters' in done
+  assert 'fakehsg.models.predictions.hsg.Hsg.losses' in done
+  model = importlib.import_module('fakehsg.models.embeddings.resnet_fcn_hsg')
+  x = torch.from_numpy(synth.embeddings_nchw(5, (1, 8, 12, 12), 'iid')).to(dev)
+  out = model.segsort_common.segment_by_kmeans(x, None, [2, 2], iterations=2)       # the alias sees the rebinding
+  assert out[0].shape == (144, 8) and out[3].max().item() == 3
+  for name in list(sys.modules):
+    if name.startswith('fakehsg'):
+      del sys.modules[name]
+
+
 def test_train_step_slice_vs_reference(dev):
   """k-means -> batch prototype table -> two SegSort losses ->
   backward to the NCHW embeddings, against the reference running the same

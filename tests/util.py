@@ -129,3 +129,118 @@ def graph_inputs(seed, B, C, N, K):
   return x.astype(np.float32), pad, seg, logits
 
 
+
+
+# ---- one whole training step around a stub backbone ---------------------------
+# Restates pyscripts/train/train.py:165-269 for ONE process driving ONE device (lists of
+# length 1), with the module set as a parameter: tools/gen_golden.py runs it with the
+# reference's modules on CPU, the GPU test with the hsg_amd mirrors.  (train.py itself
+# needs cv2 / tensorboardX / the data pipeline and cannot be imported.)
+TRAIN_STEP = dict(B=4, C=16, H=20, W=24, grid=(3, 3), iters=5, M=128, KF=6, KC=3, label_divisor=256,
+                  ignore=255, kappa=16.0, dmon_knn=3, image_ids=[7, 3, 7, 3])
+
+
+def train_step_config():
+  import types
+  c = TRAIN_STEP
+  ns = types.SimpleNamespace
+  return ns(
+      train=ns(img_sim_loss_types='segsort', img_sim_concentration=c['kappa'], img_sim_loss_weight=1.0,
+               fine_hrchy_loss_types='segsort', fine_hrchy_concentration=c['kappa'], fine_hrchy_loss_weight=0.5,
+               coarse_hrchy_loss_types='segsort', coarse_hrchy_concentration=c['kappa'],
+               coarse_hrchy_loss_weight=0.25, dmon_loss_types='dmon', dmon_knn=c['dmon_knn'],
+               dmon_loss_weight=0.1, centroid_cont_loss_types='segsort', centroid_cont_concentration=c['kappa'],
+               centroid_cont_loss_weight=0.05, fine_hrchy_clusters=c['KF'], coarse_hrchy_clusters=c['KC']),
+      dataset=ns(semantic_ignore_index=c['ignore'], num_classes=21),
+      network=ns(label_divisor=c['label_divisor']))
+
+
+def train_step_inputs(seed):
+  """numpy inputs of the step: 'backbone output' embeddings [B,C,H,W], position embeddings,
+  semantic / instance label maps, image ids (two views per image, not adjacent), and the
+  fixed outputs of the two (stubbed) clustering transformers."""
+  c = TRAIN_STEP
+  B, C, H, W, M, KF, KC = c['B'], c['C'], c['H'], c['W'], c['M'], c['KF'], c['KC']
+  x = synth.embeddings_nchw(seed, (B, C, H, W), 'mixture')
+  pos = synth.gaussish(seed + 1, B * C * H * W).reshape(B, C, H, W).copy()
+  over = synth.overseg_labels(seed + 7, B, H, W, regions=6, ignore_rows=2, ignore_index=c['ignore'])
+  sem = np.where(over == c['ignore'], c['ignore'], over % 3).astype(np.int64)
+  inst = np.where(over == c['ignore'], 0, over // 3).astype(np.int64)
+  Bp = len(set(c['image_ids']))
+  g = lambda k, *shape: synth.gaussish(seed + k, int(np.prod(shape))).reshape(shape).copy()
+  return dict(x=x, pos=pos, sem=sem, inst=inst, image_id=np.array(c['image_ids'], np.int64),
+              fine_logits=g(2, Bp, KF, M) * 2, coarse_logits=g(3, Bp, KC, KF) * 2,
+              cent_f=g(4, Bp, C, KF), cent_c=g(5, Bp, C, KC))
+
+
+def run_train_step(mods, inp, device):
+  """mods: dict(embedding_cls, prediction_cls, model_utils, loc_fn); returns a dict of tensors
+  (losses, accuracy, gradient w.r.t. the embeddings, the integer bookkeeping of the step)."""
+  import types
+  import torch
+  c = TRAIN_STEP
+  T = lambda k: torch.from_numpy(inp[k]).to(device)
+  mu = mods['model_utils']
+  cfg = train_step_config()
+  cent_f, cent_c = T('cent_f').requires_grad_(True), T('cent_c').requires_grad_(True)
+  fine_logits, coarse_logits = T('fine_logits').requires_grad_(True), T('coarse_logits').requires_grad_(True)
+  emb_cls = mods['embedding_cls']
+  stub = types.SimpleNamespace(
+      label_divisor=c['label_divisor'], max_num_clusters=c['M'], fine_hrchy_clusters=c['KF'],
+      coarse_hrchy_clusters=c['KC'], semantic_ignore_index=c['ignore'],
+      kmeans_num_clusters=list(c['grid']), kmeans_iterations=c['iters'],
+      fine_query_embed=lambda: None, coarse_query_embed=lambda: None,
+      fine_hrchy_transformer=lambda **kw: (cent_f, cent_f * 0.5 + 1.0, fine_logits, kw['src']),
+      coarse_hrchy_transformer=lambda **kw: (cent_c, cent_c, coarse_logits, kw['src']))
+  for name in ('_calculate_kmeans_prototypes', '_hierarchical_grouping', '_collect_nd_coarser_prototype',
+               '_collect_pixel_hierarchical_clustering_indices'):
+    setattr(stub, name, types.MethodType(getattr(emb_cls, name), stub))
+  x = T('x').requires_grad_(True)
+  loc = mods['loc_fn']((c['H'], c['W']), device).unsqueeze(0).expand(c['B'], c['H'], c['W'], 2)
+
+  # train.py:170-174
+  image_indices = mu.gather_and_reorder_image_indices([T('image_id')], device)
+  label = {'image_index': image_indices[0]}
+  # train.py:177 (MultiviewResnetFcn.forward:993-1000 after the backbone)
+  emb = emb_cls.generate_clusters(stub, x, T('sem'), T('inst'), label['image_index'], loc, T('pos'))
+  # train.py:180-202
+  (prototypes, prototypes_with_loc, psem, pinst, pbatch, cluster_indices) = (
+      mu.gather_clustering_and_update_prototypes(
+          [emb['cluster_embedding']], [emb['cluster_embedding_with_loc']], [emb['cluster_index']],
+          [emb['cluster_batch_index']], [emb['cluster_semantic_label']],
+          [emb['cluster_instance_label']], device))
+  label.update({'prototype': prototypes[0], 'prototype_with_loc': prototypes_with_loc[0],
+                'prototype_semantic_label': psem[0], 'prototype_instance_label': pinst[0],
+                'prototype_batch_index': pbatch[0]})
+  emb['cluster_index'] = cluster_indices[0]
+  # train.py:204-228
+  for name in ['finehrchy', 'coarsehrchy']:
+    inds = torch.gather(label['image_index'], 0, emb['cluster_batch_index'])
+    zeros = torch.zeros_like(emb[name + '_cluster_index'])
+    protos, protos_loc, _, _, _, c_inds = mu.gather_clustering_and_update_prototypes(
+        [emb['cluster_embedding']], [emb['cluster_embedding_with_loc']], [emb[name + '_cluster_index']],
+        [inds], [zeros], [zeros], device)
+    label[name + '_prototype'] = protos[0]
+    label[name + '_prototype_with_loc'] = protos_loc[0]
+    emb[name + '_cluster_index'] = c_inds[0]
+  # train.py:231-239
+  for name in ['finehrchy_', 'coarsehrchy_']:
+    label[name + 'mapping_index'] = mu.gather_and_update_cluster_mappings(
+        [emb['cluster_index']], [emb[name + 'cluster_index']], device)[0]
+  # train.py:244-251
+  for key in ['finehrchy_nd_prototype_grouping_centroid', 'coarsehrchy_nd_prototype_grouping_centroid']:
+    label[key] = mu.gather_and_update_datas([emb[key].clone()])[0]
+  # train.py:260-269
+  pred = mods['prediction_cls'](cfg)
+  out = pred(emb, label)
+  total = out['img_sim_loss'] + out['hrchy_group_loss'] + out['clustering_loss']
+  total.backward()
+  return dict(img_sim_loss=out['img_sim_loss'].detach(), hrchy_group_loss=out['hrchy_group_loss'].detach(),
+              clustering_loss=out['clustering_loss'].detach(), accuracy=out['accuracy'].detach(),
+              grad=x.grad, g_fine_logits=fine_logits.grad, g_coarse_logits=coarse_logits.grad,
+              g_cent_f=cent_f.grad, image_index=label['image_index'], cluster_index=emb['cluster_index'],
+              finehrchy_cluster_index=emb['finehrchy_cluster_index'],
+              coarsehrchy_cluster_index=emb['coarsehrchy_cluster_index'],
+              finehrchy_mapping_index=label['finehrchy_mapping_index'],
+              coarsehrchy_mapping_index=label['coarsehrchy_mapping_index'],
+              n_prototypes=torch.tensor(label['prototype'].shape[0]))

@@ -463,8 +463,37 @@ def f9():
     sg.gather = sg_gather
 
 
+# ---- F14 one WHOLE training step around a stub backbone ----------------------------
+def f14():
+  """tests/util.run_train_step with the reference's own modules on CPU: MultiviewResnetFcn's
+  clustering half, the cross-GPU glue of hsg/models/utils.py (one 'GPU'), Hsg.forward with all
+  five losses, backward to the embeddings."""
+  import torch.nn.parallel.scatter_gather as sg
+  import hsg.models.utils as ref_mu
+  import hsg.models.embeddings.resnet_fcn_hsg as ref_model
+  import hsg.models.predictions.hsg as ref_pred
+  from tests import util as tutil
+  sg_gather = sg.gather
+  sg.gather = lambda xs, dev=None, dim=0: torch.cat(list(xs), 0)
+  ref_mu.scatter_gather.gather = sg.gather
+  saved = ref_common.segment_by_kmeans
+  ref_common.segment_by_kmeans = ref_segment_by_kmeans          # the CPU-safe shim (device.index or 0)
+  try:
+    seed = synth.SEED_BASE + 91
+    inp = tutil.train_step_inputs(seed)
+    loc_fn = lambda hw, dev: ref_common.generate_location_features(hw, dev, 'float') - 0.5
+    out = tutil.run_train_step(dict(embedding_cls=ref_model.MultiviewResnetFcn, prediction_cls=ref_pred.Hsg,
+                                    model_utils=ref_mu, loc_fn=loc_fn), inp, 'cpu')
+    print({k: float(out[k]) for k in ('img_sim_loss', 'hrchy_group_loss', 'clustering_loss', 'accuracy')},
+          'prototypes', int(out['n_prototypes']))
+    save('f14_train_step_full', seed=seed, **{k: v.detach().numpy() for k, v in out.items()})
+  finally:
+    sg.gather = sg_gather
+    ref_common.segment_by_kmeans = saved
+
+
 if __name__ == '__main__':
   os.makedirs(OUT, exist_ok=True)
-  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13']
+  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13', 'f14']
   for w in which:
     globals()[w]()
