@@ -187,6 +187,23 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
     HSGK_CHECK_HIP(hipMemsetAsync(k.klab_prev, 0xFF, sizeof(int32_t) * k.rows_cap, s));
     HSGK_CHECK_HIP(hipMemsetAsync(k.sumq, 0, sizeof(long long) * (size_t)B * K * d, s));
   }
+  // Small feature maps (training resolution): one workgroup per image runs the whole loop in one
+  // launch (kmeans.hip: lloyd_small_kernel).  HSGK_SMALL = 0 / 1 forces the per-kernel / the fused
+  // route (read per call, so that the tests cover both); the verify switch keeps the per-kernel route.
+  {
+    const char *se = getenv("HSGK_SMALL");
+    const int64_t rows_per_image = B > 0 ? (int64_t)(k.rows_cap / (size_t)B) : 0;
+    const bool can = fx && half && iterations >= 1 && k.q1count && lloyd_small_eligible(d, K, rows_per_image) &&
+                     !g_verify_on.load();
+    const bool want = se ? se[0] == '1' : true;
+    if (can && want) {
+      if (m0_ready)
+        if (int rc = launch_m0_reduce(k.m0, B, k.m0_wt, d, s)) return rc;
+      ProfScope p(HSGK_PROF_ASSIGN, s);
+      return launch_lloyd_small(x, k.xh, k.xt, d, K, B, iterations, k.t, k.klab, k.klab_prev, k.sumq, k.cent,
+                                k.qrows, k.q1count, m0_ready, s);
+    }
+  }
   // The working labels ping-pong between k.klab and k.klab_prev (every E-step rewrites all
   // rows): after the sums are brought up to date with `cur`, that buffer becomes `prev` and the
   // E-step writes the other one -- no label copy per iteration.

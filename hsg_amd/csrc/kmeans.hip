@@ -431,6 +431,68 @@ __device__ __forceinline__ float exact_chain(const float *__restrict__ ck, const
 #ifdef HSGK_Q_STATS
 __device__ unsigned long long g_qstats[8];   // debug build: exact-queue entries by candidate count
 #endif
+// One batch of 16 exact-queue entries on a wave: lanes 4 g .. 4 g + 3 serve entry g (`ent`, `have`
+// and `img` are per-group values, identical on the four lanes); writes the exact label of the row.
+__device__ __forceinline__ void exact_rescore16(const SplitEntry ent, const bool have, const int img,
+                                                const float *__restrict__ x, int d,
+                                                const float *__restrict__ cent, int K,
+                                                int32_t *__restrict__ klab) {
+  const int lane = threadIdx.x & 63;
+  const int ci = lane & 3;
+  const int n = have ? (int)(ent.cand >> 24) : 0;
+  // candidate ci, and candidate ci + 4 for the entries that carry more than four
+  const int ka = (int)(ci < 3 ? (ent.cand >> (8 * ci)) & 255u : ent.cand_hi & 255u);
+  const int kb = (int)((ent.cand_hi >> (8 * (ci + 1))) & 255u);           // (ci + 4 <= 6: ci <= 2)
+  const bool act = n != 255 && ci < n;
+  const bool act2 = n != 255 && ci < 3 && ci + 4 < n;
+#ifdef HSGK_Q_STATS
+  if (ci == 0 && have) atomicAdd(&g_qstats[n == 255 ? 7 : min(n, 6)], 1ull);   // (tools/probes/qstats.py)
+#endif
+  const float *xr = x + (int64_t)ent.row * d;
+  const float *ct = cent + (int64_t)img * K * d;
+  float acc = -INFINITY;
+  if (act) acc = exact_chain(ct + (int64_t)ka * d, xr, d);
+  float bv = (act && acc == acc) ? acc : -INFINITY;     // NaN never wins
+  int bi = act ? ka : 0x7fffffff;
+  if (__any(act2)) {
+    float acc2 = -INFINITY;
+    if (act2) acc2 = exact_chain(ct + (int64_t)kb * d, xr, d);
+    const float v2 = (act2 && acc2 == acc2) ? acc2 : -INFINITY;
+    const int i2 = act2 ? kb : 0x7fffffff;
+    if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+  }
+#pragma unroll
+  for (int off = 1; off <= 2; off <<= 1) {
+    const float ov = __shfl_xor(bv, off);
+    const int oi = __shfl_xor(bi, off);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (ci == 0 && n >= 1 && n <= 7) klab[ent.row] = bi == 0x7fffffff ? 0 : bi;
+  // rare: entries that need all K centroids, one at a time on the whole wave
+  unsigned long long hard = __ballot(ci == 0 && n == 255);
+  while (hard) {
+    const int src = __builtin_ctzll(hard);
+    hard &= hard - 1;
+    const int row = __builtin_amdgcn_readlane(ent.row, src);
+    const int himg = __builtin_amdgcn_readlane(img, src);
+    float hv = -INFINITY;
+    int hi = 0x7fffffff;
+    for (int k0 = 0; k0 < K; k0 += 64) {                    // lane = centroid k0 + lane, first maximum wins
+      const int k = k0 + lane;
+      float a = -INFINITY;
+      if (k < K) a = exact_chain(cent + ((int64_t)himg * K + k) * d, x + (int64_t)row * d, d);
+      if (k < K && a == a && a > hv) { hv = a; hi = k; }
+    }
+    if (hi == 0x7fffffff) hi = lane;                         // (all NaN: lowest lane index, as before)
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(hv, off);
+      const int oi = __shfl_xor(hi, off);
+      if (ov > hv || (ov == hv && oi < hi)) { hv = ov; hi = oi; }
+    }
+    if (lane == 0) klab[row] = hi < K ? hi : 0;
+  }
+}
+
 __global__ __launch_bounds__(256) void assign_requeue_rows_kernel(
     const float *__restrict__ x, int d, const float *__restrict__ cent, int K,
     int32_t *__restrict__ klab, const SplitEntry *__restrict__ gqueue,
@@ -439,12 +501,11 @@ __global__ __launch_bounds__(256) void assign_requeue_rows_kernel(
   const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
   const int total = *gcount;
-  const int grp = lane >> 2, ci = lane & 3;
+  const int grp = lane >> 2;
   for (int e0 = wave * 16; e0 < total; e0 += nwaves * 16) {
     const int e = e0 + grp;
     SplitEntry ent{0, 0u, 0u};
     if (e < total) ent = gqueue[e];
-    const int n = e < total ? (int)(ent.cand >> 24) : 0;
     // image of the row: last b with img_row0[b] <= row
     int img = 0;
     {
@@ -454,57 +515,7 @@ __global__ __launch_bounds__(256) void assign_requeue_rows_kernel(
         if (img_row0[mid] <= (int64_t)ent.row) img = mid; else hi = mid;
       }
     }
-    // candidate ci, and candidate ci + 4 for the entries that carry more than four
-    const int ka = (int)(ci < 3 ? (ent.cand >> (8 * ci)) & 255u : ent.cand_hi & 255u);
-    const int kb = (int)((ent.cand_hi >> (8 * (ci + 1))) & 255u);           // (ci + 4 <= 6: ci <= 2)
-    const bool act = n != 255 && ci < n;
-    const bool act2 = n != 255 && ci < 3 && ci + 4 < n;
-#ifdef HSGK_Q_STATS
-    if (ci == 0 && e < total) atomicAdd(&g_qstats[n == 255 ? 7 : min(n, 6)], 1ull);   // (tools/probes/qstats.py)
-#endif
-    const float *xr = x + (int64_t)ent.row * d;
-    const float *ct = cent + (int64_t)img * K * d;
-    float acc = -INFINITY;
-    if (act) acc = exact_chain(ct + (int64_t)ka * d, xr, d);
-    float bv = (act && acc == acc) ? acc : -INFINITY;     // NaN never wins
-    int bi = act ? ka : 0x7fffffff;
-    if (__any(act2)) {
-      float acc2 = -INFINITY;
-      if (act2) acc2 = exact_chain(ct + (int64_t)kb * d, xr, d);
-      const float v2 = (act2 && acc2 == acc2) ? acc2 : -INFINITY;
-      const int i2 = act2 ? kb : 0x7fffffff;
-      if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
-    }
-#pragma unroll
-    for (int off = 1; off <= 2; off <<= 1) {
-      const float ov = __shfl_xor(bv, off);
-      const int oi = __shfl_xor(bi, off);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    if (ci == 0 && n >= 1 && n <= 7) klab[ent.row] = bi == 0x7fffffff ? 0 : bi;
-    // rare: entries that need all K centroids, one at a time on the whole wave
-    unsigned long long hard = __ballot(ci == 0 && n == 255);
-    while (hard) {
-      const int src = __builtin_ctzll(hard);
-      hard &= hard - 1;
-      const int row = __builtin_amdgcn_readlane(ent.row, src);
-      const int himg = __builtin_amdgcn_readlane(img, src);
-      float hv = -INFINITY;
-      int hi = 0x7fffffff;
-      for (int k0 = 0; k0 < K; k0 += 64) {                    // lane = centroid k0 + lane, first maximum wins
-        const int k = k0 + lane;
-        float a = -INFINITY;
-        if (k < K) a = exact_chain(cent + ((int64_t)himg * K + k) * d, x + (int64_t)row * d, d);
-        if (k < K && a == a && a > hv) { hv = a; hi = k; }
-      }
-      if (hi == 0x7fffffff) hi = lane;                         // (all NaN: lowest lane index, as before)
-      for (int off = 32; off > 0; off >>= 1) {
-        const float ov = __shfl_xor(hv, off);
-        const int oi = __shfl_xor(hi, off);
-        if (ov > hv || (ov == hv && oi < hi)) { hv = ov; hi = oi; }
-      }
-      if (lane == 0) klab[row] = hi < K ? hi : 0;
-    }
+    exact_rescore16(ent, e < total, img, x, d, cent, K, klab);
   }
 }
 
@@ -1267,6 +1278,285 @@ int launch_assign_half(const float *x, const _Float16 *xm, const uint2 *xt, int 
                      reinterpret_cast<const SplitEntry *>(qrows), qcount, t.img_row0, B);
   HSGK_LAUNCH_CHECK();
   return 0;
+}
+
+// ===========================================================================
+// Small feature maps (the reference's TRAINING resolution: input / 16, e.g. 48 x 256 x 28 x 28): the
+// whole Lloyd loop of one image in ONE workgroup, one launch per call.
+// With the per-kernel route a call is ~5 dependent launches per iteration whose fixed costs (a
+// persistent kernel's start-up, its table staging, its drain) add up to ~50 us per iteration for
+// 37 K rows.  Here workgroup b owns image b for all iterations and the phases of an iteration are
+// separated by workgroup barriers only:
+//   M  exact fixed-point sums (order C2x, sums_fx.hip): the rows whose label changed are added to
+//      / subtracted from an int64 [K][d] LDS table with ds_add_u64, the table is folded into the
+//      image's running sums in global memory (L2), and the same threads leave the unnormalised
+//      fp32 centroid in LDS;
+//   F  one lane per centroid walks the canonical norm chain, all threads divide -> cent (global);
+//   E  the fp16 filter engine (score_tiles_f16.h, hi + lo table planes) over the image's rows,
+//      ambiguous rows with their candidate sets into an LDS / global list;
+//   X  the exact fp32 chains of those candidates (exact_rescore16).
+// Same arithmetic, same labels as the per-kernel route (tests run both: HSGK_SMALL=0 / 1).
+// One CU per image bounds it: 0.29 ms instead of 0.58 for 16 x 256 x 14 x 14, 0.51 instead of
+// 0.66 for 48 x 256 x 28 x 28, slower than the per-kernel route from ~1500 rows per image on.
+// (Tried and dropped: the table as MFMA A operands in the registers of four 512-register waves,
+// rows straight from the fp16 copy as B operands, sums persistent in LDS -- every phase turned
+// latency-bound with one wave per SIMD, 0.95 ms for the 28 x 28 batch.)
+constexpr int kSmallRowsMax = 1024;       // rows per image the fused kernel accepts
+#ifdef HSGK_SMALL_TIMING                   // tools/probes/small_timing.py: cycles per phase, workgroup 0
+__device__ unsigned long long g_small_ts[8];
+#define HSGK_STS(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
+    atomicAdd(&g_small_ts[i], now_ - sts_); sts_ = now_; } } while (0)
+#else
+#define HSGK_STS(i) do { } while (0)
+#endif
+
+__host__ __device__ inline size_t lloyd_small_lds_bytes(int d, int K, int NW) {
+  const size_t mstep = (size_t)K * d * 8 + 16 + (size_t)NW * 64 * 4 + (size_t)K * 4;
+  const size_t estep = half_lds_bytes<8, 2, 2, 2>(d) + (size_t)kSplitLdsList * 6 + 16;
+  return mstep > estep ? mstep : estep;
+}
+
+template <int NW, int DEPTH, int NV>
+__global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
+    const float *__restrict__ x, const _Float16 *__restrict__ xm, const uint2 *__restrict__ xt, int d, int K,
+    int iterations, const int64_t *__restrict__ img_row0, int32_t *__restrict__ lab_a,
+    int32_t *__restrict__ lab_b, long long *__restrict__ sumq, float *__restrict__ cent,
+    SplitEntry *__restrict__ gqueue, int32_t *__restrict__ gcount, int first_sums_ready, float eps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int b = blockIdx.x;
+  const int64_t r0 = img_row0[b];
+  const int n = (int)(img_row0[b + 1] - r0);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // phase M / F view of the LDS
+  unsigned long long *tab = reinterpret_cast<unsigned long long *>(lds_raw);            // [K][d]
+  float *ftab = reinterpret_cast<float *>(lds_raw);                                     // fp32 value of slot i at [2 i]
+  uint32_t *lists = reinterpret_cast<uint32_t *>(tab + (size_t)K * d + 2);              // [NW][64]
+  float *nrm = reinterpret_cast<float *>(lists + NW * 64);                              // [K]
+  // phase E / X view
+  unsigned char *etail = lds_raw + half_lds_bytes<8, 2, 2, 2>(d);
+  int *qnp = reinterpret_cast<int *>(etail);                                            // [0] LDS-list length
+  uint32_t *qcand = reinterpret_cast<uint32_t *>(etail + 16);                           // [kSplitLdsList]
+  uint16_t *qpx = reinterpret_cast<uint16_t *>(qcand + kSplitLdsList);
+  long long *sq = sumq + (int64_t)b * K * d;
+  float *ct = cent + (int64_t)b * K * d;
+  SplitEntry *gq = gqueue + r0;                   // this image's overflow region (<= n entries)
+  int32_t *gc = gcount + b;
+  int32_t *cur = lab_a, *prev = lab_b;
+  typedef float gvec_t __attribute__((ext_vector_type(4), aligned(4)));
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  const int nq = d / 4, tail0 = nq * 4, tw = d - tail0;
+  constexpr int UNROLL = 8;
+  const int tu = lane / max(tw, 1), tc = lane - tu * max(tw, 1);
+  const bool tact = tw > 0 && tu < UNROLL;
+  uint32_t *list = lists + w * 64;
+#ifdef HSGK_SMALL_TIMING
+  unsigned long long sts_ = __builtin_readcyclecounter();
+#endif
+
+  for (int it = 0; it < iterations && n > 0; ++it) {
+    // ---------------------------------------------------------------- M: exact sums of the changed rows
+    const bool skip_m = it == 0 && first_sums_ready;
+    {
+      const int tot2 = (K * d + 1) / 2;
+      u64x2 *t2 = reinterpret_cast<u64x2 *>(tab);
+      for (int i = tid; i < tot2; i += NW * 64) t2[i] = u64x2{0ull, 0ull};
+    }
+    __syncthreads();
+    if (!skip_m) {
+      for (int st = w; st * 64 < n; st += NW) {
+        const int rb = st * 64, nr = min(64, n - rb);
+        const int rr = min(lane, nr - 1);
+        int pl = prev[r0 + rb + rr];
+        const int cl = cur[r0 + rb + rr];
+        if (lane >= nr) pl = cl;
+        const bool ch = pl != cl;
+        const unsigned long long m = __ballot(ch);
+        const int total = __popcll(m);
+        if (total == 0) continue;
+        if (ch)   // row (6 bits) | new label + 1 (11 bits) | old label + 1 (11 bits, 0: not added yet)
+          list[__popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)lane << 22) | ((uint32_t)(cl + 1) << 11) | (uint32_t)(pl + 1);
+        // (wave-private list: own LDS writes are visible to own reads in order)
+        const float *xr = x + (r0 + rb) * d;
+        auto entry = [&](int i) { return list[min(i, total - 1)]; };
+        auto issue = [&](int i0, gvec_t (&v)[UNROLL][NV], float &t) {
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u) {
+            const float *src = xr + (int64_t)(entry(i0 + u) >> 22) * d;
+#pragma unroll
+            for (int h = 0; h < NV; ++h)
+              v[u][h] = *reinterpret_cast<const gvec_t *>(src + 4 * min(lane + 64 * h, nq - 1));
+          }
+          t = xr[(int64_t)(entry(i0 + min(tu, UNROLL - 1)) >> 22) * d + min(tail0 + tc, d - 1)];
+        };
+        auto fold = [&](int i0, const gvec_t (&v)[UNROLL][NV], const float &t) {
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u) {
+            if (i0 + u < total) {
+              const uint32_t e = entry(i0 + u);
+              const int labs[2] = {(int)((e >> 11) & 2047u) - 1, (int)(e & 2047u) - 1};
+              long long q[NV][4];
+#pragma unroll
+              for (int h = 0; h < NV; ++h)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) q[h][jj] = to_fixed(v[u][h][jj]);
+#pragma unroll
+              for (int side = 0; side < 2; ++side) {
+                if (labs[side] < 0) continue;                  // (wave-uniform)
+                unsigned long long *rowp = tab + (size_t)labs[side] * d;
+#pragma unroll
+                for (int h = 0; h < NV; ++h) {
+                  const int q4 = lane + 64 * h;
+                  if (q4 < nq) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                      atomicAdd(rowp + 4 * q4 + jj, (unsigned long long)(side ? -q[h][jj] : q[h][jj]));
+                  }
+                }
+              }
+            }
+          }
+          if (tact && i0 + tu < total) {
+            const uint32_t e = entry(i0 + tu);
+            const long long qt = to_fixed(t);
+            const int ln = (int)((e >> 11) & 2047u) - 1, lo = (int)(e & 2047u) - 1;
+            if (ln >= 0) atomicAdd(tab + (size_t)ln * d + tail0 + tc, (unsigned long long)qt);
+            if (lo >= 0) atomicAdd(tab + (size_t)lo * d + tail0 + tc, (unsigned long long)(-qt));
+          }
+        };
+        gvec_t va[UNROLL][NV], vb[UNROLL][NV];
+        float ta, tb;
+        issue(0, va, ta);
+        for (int i0 = 0; i0 < total; i0 += 2 * UNROLL) {
+          issue(i0 + UNROLL, vb, tb);
+          __builtin_amdgcn_sched_barrier(0);
+          fold(i0, va, ta);
+          __builtin_amdgcn_sched_barrier(0);
+          issue(i0 + 2 * UNROLL, va, ta);
+          __builtin_amdgcn_sched_barrier(0);
+          fold(i0 + UNROLL, vb, tb);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    __syncthreads();
+    HSGK_STS(0);
+    { int32_t *t = cur; cur = prev; prev = t; }      // the sums now hold `prev`; the E-step writes `cur`
+    // running sums += table; unnormalised fp32 centroid into the low word of the same slot.
+    // Eight independent L2 loads per thread in flight (a load-use loop would expose one L2 round
+    // trip per element: 32 of them per thread and iteration).
+    {
+      const int total = K * d;
+      for (int i0 = tid; i0 < total; i0 += 8 * NW * 64) {
+        long long g[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) g[u] = sq[min(i0 + u * NW * 64, total - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u * NW * 64;
+          if (i < total) {
+            const long long tv = (long long)tab[i];
+            const long long v = g[u] + tv;
+            if (tv) sq[i] = v;
+            ftab[2 * i] = (float)v * 9.094947017729282e-13f;      // 2^-40, one rounding (finalize_fx_kernel)
+          }
+        }
+      }
+    }
+    __syncthreads();
+    HSGK_STS(1);
+    // ---------------------------------------------------------------- F: norm chain, divide
+    // one lane per centroid walks the canonical chain; its LDS reads are issued 16 at a time
+    if (tid < K) {
+      const float *r = ftab + (size_t)2 * tid * d;
+      float ss = 0.0f;
+      int i = 0;
+      for (; i + 16 <= d; i += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = r[2 * (i + u)];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) ss = fmaf(v[u], v[u], ss);
+      }
+      for (; i < d; ++i) ss = fmaf(r[2 * i], r[2 * i], ss);
+      float nv = sqrtf(ss);
+      if (!(nv >= eps)) nv = eps;
+      nrm[tid] = nv;
+    }
+    __syncthreads();
+    for (int k = w; k < K; k += NW) {
+      const float nv = nrm[k];
+      for (int i = lane; i < d; i += 64) ct[(size_t)k * d + i] = ftab[2 * ((size_t)k * d + i)] / nv;
+    }
+    if (tid == 0) qnp[0] = 0;                       // (past the table: not part of the M / F view)
+    __syncthreads();
+    HSGK_STS(2);
+    // ---------------------------------------------------------------- E: fp16 filter over the image's rows
+    {
+      HalfWideEpi<2, true> epi{K, n, b, r0, 0.0f, cur, qpx, qcand, qnp, gq, gc};
+      score_tiles_half<NW, DEPTH, HalfWideEpi<2, true>, 2, 2, 2>(xm, xt, d, ct, K, r0, n, lds_raw, epi, true);
+    }
+    __syncthreads();
+    HSGK_STS(3);
+    // ---------------------------------------------------------------- X: exact chains of the ambiguous rows
+    {
+      const int qn = min(qnp[0], kSplitLdsList);
+      const int gn = (int)__hip_atomic_load(gc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int total = qn + gn;
+      const int grp = lane >> 2;
+      for (int e0 = w * 16; e0 < total; e0 += NW * 16) {
+        const int e = e0 + grp;
+        SplitEntry ent{0, 0u, 0u};
+        if (e < qn) ent = SplitEntry{(int32_t)(r0 + qpx[e]), qcand[e], 0u};
+        else if (e < total) ent = gq[e - qn];
+        exact_rescore16(ent, e < total, b, x, d, cent, K, cur);
+      }
+      __syncthreads();
+      if (tid == 0 && gn) __hip_atomic_store(gc, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    HSGK_STS(4);
+  }
+  // the caller expects the final labels in lab_a
+  if (cur != lab_a)
+    for (int i = tid; i < n; i += NW * 64) lab_a[r0 + i] = cur[r0 + i];
+}
+
+#ifdef HSGK_SMALL_TIMING
+extern "C" __attribute__((visibility("default"))) int hsgk_debug_small_timing(unsigned long long *out) {
+  unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_small_ts), sizeof(h)) != hipSuccess) return -1;
+  for (int i = 0; i < 8; ++i) out[i] = h[i];
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_small_ts), z, sizeof(z));
+  return 0;
+}
+#endif
+
+bool lloyd_small_eligible(int d, int K, int64_t rows_per_image) {
+  return assign_half_eligible(d, K) && rows_per_image <= kSmallRowsMax && d <= 515 &&
+         lloyd_small_lds_bytes(d, K, 8) <= 160 * 1024;
+}
+
+// lab_a: current labels (in / out), lab_b: the labels the sums hold (-1: row not added yet);
+// sumq / cent: [B][K][d]; qrows: >= one SplitEntry per row; qcount: >= B int32.
+int launch_lloyd_small(const float *x, const _Float16 *xm, const uint2 *xt, int d, int K, int B, int iterations,
+                       const ChunkTable &t, int32_t *lab_a, int32_t *lab_b, long long *sumq, float *cent,
+                       void *qrows, int32_t *qcount, bool first_sums_ready, hipStream_t s) {
+  if (B <= 0 || iterations <= 0) return 0;
+  constexpr int NW = 8;
+  const bool deep = ((d / 64) & 3) == 0;
+  const size_t lds = lloyd_small_lds_bytes(d, K, NW);
+  HSGK_CHECK_HIP(hipMemsetAsync(qcount, 0, sizeof(int32_t) * B, s));
+  auto go = [&](auto kern) -> int {
+    HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(B), dim3(NW * 64), lds, s, x, xm, xt, d, K, iterations, t.img_row0, lab_a,
+                       lab_b, sumq, cent, reinterpret_cast<SplitEntry *>(qrows), qcount,
+                       first_sums_ready ? 1 : 0, HSGK_EPS);
+    HSGK_LAUNCH_CHECK();
+    return 0;
+  };
+  if (d <= 259) return deep ? go(lloyd_small_kernel<NW, 4, 1>) : go(lloyd_small_kernel<NW, 2, 1>);
+  return deep ? go(lloyd_small_kernel<NW, 4, 2>) : go(lloyd_small_kernel<NW, 2, 2>);
 }
 
 int launch_assign_fast(const float *x, int d, const float *cent, int K, int B, const ChunkTable &t,

@@ -275,15 +275,21 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
       for (int h = 0; h < NV; ++h)
 #pragma unroll
         for (int j = 0; j < 4; ++j) cq[sd][h][j] = 0;
+    // LDS layout of a table row: the four columns 4 q + j of quad q = lane + 64 h sit at
+    // 256 h + j * nh + lane (nh = quads of that 64-quad block), so that one ds_add_u64 -- fixed j,
+    // all lanes -- touches CONSECUTIVE 8-byte words (two conflict-free LDS passes) instead of
+    // words 32 bytes apart (eight lanes per bank pair: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+    // was 0.69 with the natural layout).  The tail columns keep their place; the flush undoes it.
     auto flush_run = [&](int side) {
       if (clab[side] >= 0) {
         unsigned long long *rowp = tab + (size_t)clab[side] * d;
 #pragma unroll
         for (int h = 0; h < NV; ++h) {
           const int q4 = lane + 64 * h;
+          const int nh = min(64, nq - 64 * h);
           if (q4 < nq) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) atomicAdd(rowp + 4 * q4 + j, (unsigned long long)cq[side][h][j]);
+            for (int j = 0; j < 4; ++j) atomicAdd(rowp + 256 * h + j * nh + lane, (unsigned long long)cq[side][h][j]);
           }
         }
       }
@@ -386,7 +392,13 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
     // ---- flush the image's table
     unsigned long long *gq = sumq + ((int64_t)b * K + k0) * d;
     for (int i = tid; i < kn * d; i += NW * 64) {
-      const unsigned long long v = tab[i];
+      const int kk = i / d, col = i - kk * d;
+      int src = col;                                  // tail columns: in place
+      if (col < tail0) {
+        const int h = col >> 8, cb = col & 255, nh = min(64, nq - 64 * h);
+        src = 256 * h + (cb & 3) * nh + (cb >> 2);
+      }
+      const unsigned long long v = tab[kk * d + src];
       if (v) atomicAdd(gq + i, v);
     }
     __syncthreads();
@@ -409,8 +421,18 @@ __global__ __launch_bounds__(256) void finalize_fx_kernel(const long long *__res
   for (int i = tid; i < d; i += 256) row[i] = (float)src[i] * 9.094947017729282e-13f;   // 2^-40
   __syncthreads();
   if (tid == 0) {
+    // the canonical chain; its LDS reads are issued 16 at a time (one dependent read per fmaf cost
+    // ~8 us per launch: most of this kernel at training resolutions)
     float ss = 0.0f;
-    for (int i = 0; i < d; ++i) ss = fmaf(row[i], row[i], ss);
+    int i = 0;
+    for (; i + 16 <= d; i += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = row[i + u];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) ss = fmaf(v[u], v[u], ss);
+    }
+    for (; i < d; ++i) ss = fmaf(row[i], row[i], ss);
     float nrm = sqrtf(ss);
     if (!(nrm >= eps)) nrm = eps;
     row[d] = nrm;

@@ -602,6 +602,30 @@ def test_baseline_config_shapes_vs_oracle(dev, oracle, shape, grid, iters):
     assert np.array_equal(a, b), '%s: %d mismatching elements' % (name, int((a != b).sum()))
 
 
+@pytest.mark.parametrize('small', ['1', '0'])
+@pytest.mark.parametrize('shape,grid,iters,flavour', [
+    ((5, 256, 28, 28), (8, 8), 10, 'iid'),        # the reference's training resolution (448 / 16), K = 64
+    ((3, 256, 14, 14), (8, 8), 7, 'mixture'),     # 224 / 16: clusters empty out
+    ((2, 128, 20, 31), (4, 5), 5, 'iid'),         # C = 128 (d = 130: prefetch depth 2), ragged
+    ((4, 256, 24, 16), (6, 6), 1, 'mixture'),     # a single iteration (labels end in the other buffer)
+    ((2, 256, 32, 32), (8, 8), 4, 'iid'),         # 1024 rows: the largest image the fused kernel takes
+])
+def test_small_maps_fused_and_per_kernel_routes_vs_oracle(dev, oracle, monkeypatch, shape, grid, iters, flavour, small):
+  """Training-resolution feature maps: the whole Lloyd loop of an image in one workgroup
+  (lloyd_small_kernel, HSGK_SMALL=1, the default below 1024 rows per image) and the per-kernel route
+  (HSGK_SMALL=0) -- both bit-exact vs the oracle, with labels + ignore band and without labels."""
+  monkeypatch.setenv('HSGK_SMALL', small)
+  B, C, H, W = shape
+  x = synth.embeddings_nchw(synth.SEED_BASE + 3 * C + H, shape, flavour)
+  loc = oracle.generate_location_features((H, W)) - np.float32(0.5)
+  for lab, ign in ((synth.overseg_labels(synth.SEED_BASE + 8, B, H, W, regions=4, ignore_rows=2), 255), (None, None)):
+    got = _run_segkm(dev, x, lab, grid, ign, iters)
+    ref = oracle.segment_by_kmeans(x, lab, grid, loc, ign, iters)
+    for name, a, b in zip(('emb', 'emb_loc', 'labels', 'cluster', 'batch'), got, ref):
+      assert a.shape == b.shape, name
+      assert np.array_equal(a, b), '%s: %d mismatching elements' % (name, int((a != b).sum()))
+
+
 @pytest.mark.parametrize('m0', ['1', '0'])
 @pytest.mark.parametrize('shape,grid,iters', [((3, 256, 40, 56), (8, 8), 5), ((2, 128, 64, 96), (2, 3), 6),
                                               ((2, 64, 33, 47), (5, 7), 3)])
