@@ -90,6 +90,7 @@ SIGNATURES = {
     'hsgk_knn_affinity': (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     'hsgk_topk_workspace_bytes': (_sz, [_i64, _i32, _i64, _i32]),
     'hsgk_topk_prototypes': (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),
+    'hsgk_topk_prototypes_grouped': (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'hsgk_synth_gaussish': (_i32, [ctypes.c_uint64, ctypes.c_uint64, _i64, _vp, _vp]),
     'hsgk_synth_mixture': (_i32, [ctypes.c_uint64, ctypes.c_uint64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     'hsgk_assign_workspace_bytes': (_sz, [_i64, _i32, _i32]),

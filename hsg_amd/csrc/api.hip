@@ -111,7 +111,10 @@ static void carve_kmeans(Carver &cv, int B, int64_t rows_per_img, int d, int K,
   k->qcount = cv.take<int32_t>(4);
   k->klab_prev = nullptr;
   k->sumq = nullptr;
-  if (sums_fx_eligible(d)) {
+  // exact sums: the update kernels address clusters with 10-bit fields (K <= 1023) and a 2^40
+  // fixed-point sum of unit rows stays inside int64 for <= 2^22 rows per segment; beyond either
+  // bound the Lloyd loop keeps the streaming M-step of order C2
+  if (sums_fx_eligible(d) && K <= 1023 && rows_per_img <= (int64_t)1 << 22) {
     k->klab_prev = cv.take<int32_t>((size_t)B * rows_per_img + 1);
     k->sumq = cv.take<long long>((size_t)B * K * d + 1);
   }

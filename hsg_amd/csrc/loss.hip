@@ -32,20 +32,45 @@ namespace hsgk {
 
 constexpr int kMaxSets = HSGK_LOSS_MAX_SETS;
 
+constexpr int kMaskWords = HSGK_LOSS_MASK_WORDS;      // class-mask words of a set-mode label (set 0 only)
+constexpr int kLabSlots = kMaxSets + kMaskWords - 1;   // label words kept per row: set 0 words, then sets 1..
+
 struct LossSets {
   const int64_t *sem[kMaxSets];
   const int64_t *psem[kMaxSets];
   float kappa[kMaxSets];
   int plus[kMaxSets];       // 'segsort+'
   int setm[kMaxSets];       // set mode (multi-hot labels as class bit masks)
+  int words;                // words per label of set 0 (1 unless set mode with > 63 classes; then L == 1)
   int L;
 };
 
+// slot of (set l, word w) in a row's label words
+__device__ __forceinline__ int lab_slot(int l, int w) { return l == 0 ? w : kMaskWords - 1 + l; }
+
+// the label words of row r of set l into out[lab_slot(l, .)]
+__device__ __forceinline__ void load_labels(const LossSets &ls, bool proto, int l, int64_t r, int64_t (&out)[kLabSlots]) {
+  const int64_t *src = proto ? ls.psem[l] : ls.sem[l];
+  if (l == 0) {
+#pragma unroll
+    for (int w = 0; w < kMaskWords; ++w) out[w] = w < ls.words ? src[r * ls.words + w] : 0;
+  } else {
+    out[kMaskWords - 1 + l] = src[r];
+  }
+}
+
 // "same semantic label": equal labels (SegSortLoss), or -- set mode, SetSegSortLoss --
-// a non-zero label affinity: sem / psem then carry one bit per class and the affinity
-// sum_c sem[i,c] * psem[p,c] of non-negative multi-hot labels is > 0 iff the masks meet
-__device__ inline bool same_semantic(int64_t a, int64_t b, int set_mode) {
-  return set_mode ? (a & b) != 0 : a == b;
+// a non-zero label affinity: sem / psem then carry one bit per class (63 per word) and the
+// affinity sum_c sem[i,c] * psem[p,c] of non-negative multi-hot labels is > 0 iff the masks meet
+__device__ __forceinline__ bool same_semantic(const int64_t (&a)[kLabSlots], const int64_t (&b)[kLabSlots], int l,
+                                              int set_mode) {
+  if (l != 0) return set_mode ? (a[kMaskWords - 1 + l] & b[kMaskWords - 1 + l]) != 0
+                              : a[kMaskWords - 1 + l] == b[kMaskWords - 1 + l];
+  if (!set_mode) return a[0] == b[0];
+  int64_t any = 0;
+#pragma unroll
+  for (int w = 0; w < kMaskWords; ++w) any |= a[w] & b[w];
+  return any != 0;
 }
 
 struct LossFwdEpi {
@@ -63,11 +88,13 @@ struct LossFwdEpi {
     const bool valid = px < nrows;
     const int64_t row = crow0 + (valid ? px : 0);
     const int64_t ij = inst[row];
-    int64_t sj[kMaxSets];
+    int64_t sj[kLabSlots];
     float own[kMaxSets], same[kMaxSets], diff[kMaxSets];
 #pragma unroll
+    for (int i = 0; i < kLabSlots; ++i) sj[i] = 0;
+#pragma unroll
     for (int l = 0; l < kMaxSets; ++l) {
-      sj[l] = l < ls.L ? ls.sem[l][row] : 0;
+      if (l < ls.L) load_labels(ls, false, l, row, sj);
       own[l] = same[l] = diff[l] = 0.0f;
     }
 #pragma unroll
@@ -77,12 +104,16 @@ struct LossFwdEpi {
         const int64_t p = kb0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (p < P) {
           float s = 0.0f;
+          int64_t pj[kLabSlots];
+#pragma unroll
+          for (int i = 0; i < kLabSlots; ++i) pj[i] = 0;
 #pragma unroll
           for (int l = 0; l < kMaxSets; ++l)
             if (l < ls.L) {
               if (l == 0 || ls.kappa[l] != ls.kappa[l - 1]) s = expf(acc[m][r] * ls.kappa[l]);
               if (p == ij) own[l] += s;
-              if (same_semantic(ls.psem[l][p], sj[l], ls.setm[l])) same[l] += s; else diff[l] += s;
+              load_labels(ls, true, l, p, pj);
+              if (same_semantic(pj, sj, l, ls.setm[l])) same[l] += s; else diff[l] += s;
             }
         }
       }
@@ -230,8 +261,8 @@ void loss_bwd_kernel(BwdArgs a, int cg0) {
   float *tbuf = lds;                                        // [2][32][RS]
   char *mbase = reinterpret_cast<char *>(lds + 2 * 32 * RS);
   // per staged block: label words and (stream = pixels) the per-pixel weights
-  int64_t *m_lab = reinterpret_cast<int64_t *>(mbase);       // [2][kMaxSets][32]
-  PxMeta *m_px = reinterpret_cast<PxMeta *>(m_lab + 2 * kMaxSets * 32);   // [2][kMaxSets][32]
+  int64_t *m_lab = reinterpret_cast<int64_t *>(mbase);       // [2][kLabSlots][32]
+  PxMeta *m_px = reinterpret_cast<PxMeta *>(m_lab + 2 * kLabSlots * 32);  // [2][kMaxSets][32]
   int32_t *m_inst = reinterpret_cast<int32_t *>(m_px + 2 * kMaxSets * 32);  // [2][32]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -255,20 +286,17 @@ void loss_bwd_kernel(BwdArgs a, int cg0) {
     for (int s = 0; s < KS; ++s) bop[s] = (2 * s + h) < c ? orow[2 * s + h] : 0.0f;
   }
   // ---- owner-side labels / weights
-  int64_t o_lab[kMaxSets];
+  int64_t o_lab[kLabSlots];
   PxMeta o_px[kMaxSets];
   int32_t o_inst = -1;
 #pragma unroll
+  for (int i = 0; i < kLabSlots; ++i) o_lab[i] = 0;
+#pragma unroll
   for (int l = 0; l < kMaxSets; ++l) {
-    o_lab[l] = 0;
     o_px[l] = PxMeta{0.f, 0.f, 0, 0};
     if (l < L) {
-      if constexpr (OWNER_PX) {
-        o_lab[l] = a.ls.sem[l][o_ld];
-        o_px[l] = a.meta[(int64_t)l * a.N + o_ld];
-      } else {
-        o_lab[l] = a.ls.psem[l][o_ld];
-      }
+      load_labels(a.ls, !OWNER_PX, l, o_ld, o_lab);
+      if constexpr (OWNER_PX) o_px[l] = a.meta[(int64_t)l * a.N + o_ld];
     }
   }
   if constexpr (OWNER_PX) o_inst = (int32_t)a.inst[o_ld];
@@ -315,17 +343,20 @@ void loss_bwd_kernel(BwdArgs a, int cg0) {
       const int l = tid >> 5, row = tid & 31;
       const int64_t t = b * 32 + row;
       if (l < L) {
-        int64_t lab = 0;
+        int64_t labw[kLabSlots];
+#pragma unroll
+        for (int i = 0; i < kLabSlots; ++i) labw[i] = 0;
         PxMeta pm = PxMeta{0.f, 0.f, 0, 0};
         if (t < a.n_stream) {
-          if constexpr (OWNER_PX) {
-            lab = a.ls.psem[l][t];
-          } else {
-            lab = a.ls.sem[l][t];
-            pm = a.meta[(int64_t)l * a.N + t];
-          }
+          load_labels(a.ls, OWNER_PX, l, t, labw);
+          if constexpr (!OWNER_PX) pm = a.meta[(int64_t)l * a.N + t];
         }
-        m_lab[(buf * kMaxSets + l) * 32 + row] = lab;
+        if (l == 0) {
+#pragma unroll
+          for (int w = 0; w < kMaskWords; ++w) m_lab[(buf * kLabSlots + w) * 32 + row] = labw[w];
+        } else {
+          m_lab[(buf * kLabSlots + kMaskWords - 1 + l) * 32 + row] = labw[kMaskWords - 1 + l];
+        }
         if constexpr (!OWNER_PX) m_px[(buf * kMaxSets + l) * 32 + row] = pm;
       }
       if constexpr (!OWNER_PX)
@@ -369,7 +400,7 @@ void loss_bwd_kernel(BwdArgs a, int cg0) {
       }
     }
     // ---- W in place: lane (j, h) register r <-> streamed row t = trow(r, h), owner row o = j
-    const int64_t *bl = m_lab + buf * kMaxSets * 32;
+    const int64_t *bl = m_lab + buf * kLabSlots * 32;
     const PxMeta *bp = m_px + buf * kMaxSets * 32;
     const int32_t *bi = m_inst + buf * 32;
 #pragma unroll
@@ -385,12 +416,15 @@ void loss_bwd_kernel(BwdArgs a, int cg0) {
         float wv = 0.0f, s = 0.0f;
         bool own;
         if constexpr (OWNER_PX) own = (int64_t)o_inst == t; else own = (int64_t)bi[tr] == o_row;
+        int64_t tl[kLabSlots];
+#pragma unroll
+        for (int i = 0; i < kLabSlots; ++i) tl[i] = (i == 0 || i < a.ls.words || i >= kMaskWords) ? bl[i * 32 + tr] : 0;
 #pragma unroll
         for (int l = 0; l < kMaxSets; ++l)
           if (l < L) {
             if (l == 0 || a.ls.kappa[l] != a.ls.kappa[l - 1]) s = expf(sacc[r] * a.ls.kappa[l]);
             const PxMeta pm = OWNER_PX ? o_px[l] : bp[l * 32 + tr];
-            const bool same = same_semantic(bl[l * 32 + tr], o_lab[l], a.ls.setm[l]);
+            const bool same = same_semantic(tl, o_lab, l, a.ls.setm[l]);
             const float av = pm.plus_us ? (float)((int)same - (int)own) : (own ? 1.0f : 0.0f);
             wv += s * (av * pm.A + (same ? 0.0f : pm.B));
           }
@@ -478,7 +512,7 @@ static int launch_loss_bwd(BwdArgs a, float *out, float *scratch, hipStream_t s)
   const int ct = (a.c + 31) / 32;
   const bool vec4 = (a.c % 4) == 0;
   auto go = [&](auto kern, int CT, int CG) -> int {
-    const size_t lds = (size_t)2 * 32 * (CT * 32 + 1) * 4 + (size_t)2 * kMaxSets * 32 * (8 + sizeof(PxMeta)) + 2 * 32 * 4;
+    const size_t lds = (size_t)2 * 32 * (CT * 32 + 1) * 4 + (size_t)2 * 32 * (kLabSlots * 8 + kMaxSets * sizeof(PxMeta)) + 2 * 32 * 4;
     HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (int cg0 = 0; cg0 < CT && cg0 * 32 < a.c; cg0 += CG) {
@@ -515,6 +549,13 @@ static int launch_loss_bwd(BwdArgs a, float *out, float *scratch, hipStream_t s)
 static int make_sets(int L, const hsgk_loss_set *sets, LossSets *ls) {
   HSGK_REQUIRE(L >= 1 && L <= kMaxSets && sets != nullptr, "1..3 label sets");
   ls->L = L;
+  ls->words = 1;
+  if ((sets[0].mode >> 1) & 1) {
+    const int wds = sets[0].mode >> 8;               // words per class mask (0 = 1)
+    ls->words = wds > 0 ? wds : 1;
+    HSGK_REQUIRE(ls->words <= kMaskWords, "too many class-mask words");
+    HSGK_REQUIRE(ls->words == 1 || L == 1, "multi-word class masks: one label set per call");
+  }
   for (int l = 0; l < kMaxSets; ++l) {
     const hsgk_loss_set &src = sets[l < L ? l : 0];
     HSGK_REQUIRE(src.sem && src.psem, "null label pointer");

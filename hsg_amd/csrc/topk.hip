@@ -18,6 +18,7 @@ struct TopkEpi {
   int64_t P, N, crow0;
   float *cval;                  // [npb][N][topk]
   int32_t *cidx;
+  const int64_t *qgroup, *pgroup;    // optional: only prototypes of the query's group compete
   template <int MB>
   __device__ inline void operator()(int tile, const f32x16 (&acc)[MB]) const {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -26,12 +27,15 @@ struct TopkEpi {
     const int px = tile * TPX + w * 32 + j;
     const bool valid = px < nrows;
     float v[MB][16];
+    const int64_t qg = qgroup ? qgroup[crow0 + (valid ? px : 0)] : 0;
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t p = kb0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        v[m][r] = p < P ? acc[m][r] : -INFINITY;
+        bool ok = p < P;
+        if (ok && pgroup) ok = pgroup[p] == qg;
+        v[m][r] = ok ? acc[m][r] : -INFINITY;
       }
     const int64_t base = ((int64_t)pb * N + crow0 + (valid ? px : 0)) * topk;
     for (int t = 0; t < topk; ++t) {
@@ -136,6 +140,15 @@ size_t hsgk_topk_workspace_bytes(int64_t n, int c, int64_t P, int topk) {
 int hsgk_topk_prototypes(const float *queries, int64_t n, int c, const float *proto, int64_t P,
                          int topk, int64_t *out_idx, float *out_val, void *workspace,
                          size_t workspace_bytes, hsgk_stream_t stream) {
+  return hsgk_topk_prototypes_grouped(queries, n, c, proto, P, topk, nullptr, nullptr, out_idx, out_val,
+                                      workspace, workspace_bytes, stream);
+}
+
+int hsgk_topk_prototypes_grouped(const float *queries, int64_t n, int c, const float *proto, int64_t P,
+                                 int topk, const int64_t *query_group, const int64_t *proto_group,
+                                 int64_t *out_idx, float *out_val, void *workspace,
+                                 size_t workspace_bytes, hsgk_stream_t stream) {
+  HSGK_REQUIRE((query_group == nullptr) == (proto_group == nullptr), "both group vectors or neither");
   HSGK_REQUIRE(n >= 0 && c >= 1 && P >= 1, "bad shape");
   HSGK_REQUIRE(topk >= 1 && topk <= kTopkMax && topk <= P, "top_k must be in [1, min(32, P)]");
   HSGK_REQUIRE(workspace_bytes >= hsgk_topk_workspace_bytes(n, c, P, topk), "workspace too small");
@@ -145,7 +158,7 @@ int hsgk_topk_prototypes(const float *queries, int64_t n, int c, const float *pr
   const int npb = (int)((P + 63) / 64);
   float *cval = static_cast<float *>(workspace);
   int32_t *cidx = reinterpret_cast<int32_t *>(cval + (size_t)npb * n * topk + 64);
-  TopkEpi epi{0, 0, 0, topk, P, n, 0, cval, cidx};
+  TopkEpi epi{0, 0, 0, topk, P, n, 0, cval, cidx, query_group, proto_group};
   const int nch = (int)((n + HSGK_CHUNK - 1) / HSGK_CHUNK);
   const bool even = (c & 1) == 0;
   auto go = [&](auto kern, size_t lds) -> int {

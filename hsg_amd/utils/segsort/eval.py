@@ -12,8 +12,10 @@ from hsg_amd import _lib, ops
 from hsg_amd.utils.general import common as common_utils
 
 
-def top_k_indices(embeddings, prototypes, top_k):
-  """[N, top_k] prototype indices by descending inner product."""
+def top_k_indices(embeddings, prototypes, top_k, query_groups=None, prototype_groups=None):
+  """[N, top_k] prototype indices by descending inner product (and the products).  With the
+  two group vectors only prototypes of the query's own group compete; unfilled slots come
+  back as index 0 with value -inf."""
   ops.require_gpu(embeddings, 'embeddings')
   q = embeddings.detach().reshape(-1, embeddings.shape[-1]).float().contiguous()
   p = prototypes.detach().reshape(-1, prototypes.shape[-1]).float().contiguous()
@@ -24,9 +26,14 @@ def top_k_indices(embeddings, prototypes, top_k):
     val = torch.empty((n, top_k), dtype=torch.float32, device=q.device)
     wsb = L.hsgk_topk_workspace_bytes(n, c, p.shape[0], int(top_k))
     ws = torch.empty((wsb,), dtype=torch.uint8, device=q.device)
-    _lib.check(L.hsgk_topk_prototypes(q.data_ptr(), n, c, p.data_ptr(), p.shape[0], int(top_k),
-                                      idx.data_ptr(), val.data_ptr(), ws.data_ptr(), wsb,
-                                      _lib.stream_ptr()))
+    qg = pg = None
+    if query_groups is not None:
+      qg = query_groups.reshape(-1).to(torch.int64).contiguous()
+      pg = prototype_groups.reshape(-1).to(torch.int64).contiguous()
+    _lib.check(L.hsgk_topk_prototypes_grouped(
+        q.data_ptr(), n, c, p.data_ptr(), p.shape[0], int(top_k),
+        qg.data_ptr() if qg is not None else None, pg.data_ptr() if pg is not None else None,
+        idx.data_ptr(), val.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr()))
   return idx, val
 
 

@@ -97,11 +97,15 @@ def _nll_sets(embeddings, instance_labels, prototypes, label_sets):
   emb = embeddings.reshape(-1, embeddings.shape[-1]).to(torch.float32)
   proto = prototypes.reshape(-1, prototypes.shape[-1]).to(torch.float32)
   inst = instance_labels.reshape(-1).to(torch.int64).contiguous()
-  sems = [ls[0].reshape(-1).to(torch.int64).contiguous() for ls in label_sets]
-  psems = [ls[1].reshape(-1).to(torch.int64).contiguous() for ls in label_sets]
-  for a, b in zip(sems, psems):
-    if a.shape[0] != emb.shape[0] or b.shape[0] != proto.shape[0]:
+  sems, psems = [], []
+  for ls in label_sets:
+    words = (ls[3] >> 8) or 1                       # class-mask words per row (1 for plain labels)
+    a = ls[0].reshape(-1).to(torch.int64).contiguous()
+    b = ls[1].reshape(-1).to(torch.int64).contiguous()
+    if a.shape[0] != emb.shape[0] * words or b.shape[0] != proto.shape[0] * words:
       raise ValueError('label vectors do not match the embeddings / prototypes')
+    sems.append(a)
+    psems.append(b)
   return _SegSortNLL.apply(emb, inst, proto, tuple(ls[2] for ls in label_sets),
                            tuple(ls[3] for ls in label_sets), *sems, *psems)
 
@@ -156,21 +160,30 @@ class SegSortLoss(_Loss):
     return log_likelihood
 
 
+MASK_BITS = 63          # classes per int64 mask word (the sign bit stays clear)
+MAX_MASK_WORDS = 4      # include/hsgk.h HSGK_LOSS_MASK_WORDS
+
+
 def _class_masks(multi_hot, what):
-  """[n, num_classes] non-negative multi-hot labels -> one int64 bit mask per row
-  (bit c set iff column c is non-zero).  With non-negative entries the reference's
-  label affinity `sem @ psem.T` (loss.py:108-110) is > 0 exactly where two masks meet
-  and == 0 where they do not."""
+  """[n, num_classes] non-negative multi-hot labels -> [n, W] int64 bit masks, 63 classes
+  per word (bit c % 63 of word c // 63 set iff column c is non-zero).  With non-negative
+  entries the reference's label affinity `sem @ psem.T` (loss.py:108-110) is > 0 exactly
+  where two masks meet and == 0 where they do not."""
   if multi_hot.dim() != 2:
     raise ValueError('%s must be [num_rows, num_classes]' % what)
   nc = multi_hot.shape[1]
-  if nc > 63:
-    raise ValueError('%s: at most 63 classes are supported (got %d)' % (what, nc))
+  words = max(1, -(-nc // MASK_BITS))
+  if words > MAX_MASK_WORDS:
+    raise ValueError('%s: at most %d classes are supported (got %d)' % (what, MASK_BITS * MAX_MASK_WORDS, nc))
   if bool((multi_hot < 0).any()):
     raise ValueError('%s must be non-negative' % what)
-  weights = (torch.ones((), dtype=torch.int64, device=multi_hot.device) << torch.arange(
-      nc, dtype=torch.int64, device=multi_hot.device))
-  return ((multi_hot != 0).to(torch.int64) * weights).sum(dim=1).contiguous()
+  dev = multi_hot.device
+  bits = (multi_hot != 0).to(torch.int64)
+  pad = words * MASK_BITS - nc
+  if pad:
+    bits = torch.cat([bits, torch.zeros((bits.shape[0], pad), dtype=torch.int64, device=dev)], 1)
+  weights = torch.ones((), dtype=torch.int64, device=dev) << torch.arange(MASK_BITS, dtype=torch.int64, device=dev)
+  return (bits.view(-1, words, MASK_BITS) * weights).sum(dim=2).contiguous()
 
 
 def _one_hot_calculate_log_likelihood(embeddings, semantic_labels, instance_labels, prototypes,
@@ -181,9 +194,9 @@ def _one_hot_calculate_log_likelihood(embeddings, semantic_labels, instance_labe
   sem = _class_masks(semantic_labels.reshape(-1, semantic_labels.shape[-1]), 'semantic_labels')
   psem = _class_masks(prototype_semantic_labels.reshape(-1, prototype_semantic_labels.shape[-1]),
                       'prototype_semantic_labels')
-  # mode bit 0 = 'segsort+', bit 1 = set mode (include/hsgk.h)
-  nll = _nll_sets(embeddings, instance_labels, prototypes,
-                  [(sem, psem, float(concentration), (1 if group_mode == 'segsort+' else 0) | 2)])
+  # mode bit 0 = 'segsort+', bit 1 = set mode, bits 8.. = mask words per row (include/hsgk.h)
+  mode = (1 if group_mode == 'segsort+' else 0) | 2 | (sem.shape[1] << 8)
+  nll = _nll_sets(embeddings, instance_labels, prototypes, [(sem, psem, float(concentration), mode)])
   return nll[0].view(-1, 1)
 
 

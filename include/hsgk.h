@@ -214,14 +214,16 @@ HSGK_API int hsgk_segment_reduce_bwd(const float *gout, const float *out, const 
  * emb [n,c] f32, inst int64 [n] (index of the pixel's own prototype), proto [P,c] f32.
  * Label set l (host array `sets`, L <= HSGK_LOSS_MAX_SETS): sem int64 [n], psem int64
  * [P], kappa = concentration, mode bit 0 = 'segsort+' (else 'segsort'), bit 1 = set mode:
- * sem / psem carry one bit per class of the multi-hot labels (<= 63 classes) and "same
- * semantic label" means a non-zero label affinity, i.e. the masks meet.
+ * sem / psem carry one bit per class of the multi-hot labels, 63 classes per int64 word,
+ * W = mode >> 8 words per row (0 means 1; sem [n][W], psem [P][W]; W > 1 only with L = 1),
+ * and "same semantic label" means a non-zero label affinity, i.e. the masks meet.
  * fwd writes, per set, the per-pixel negative log likelihood nll[L][n] and the backward
  * state num[L][n], den[L][n], use_same[L][n]; no [n,P] matrix exists.
  * bwd takes gscale[L][n] = dLoss/dnll and writes g_emb [n,c] and / or g_proto [P,c]
  * (either may be null): the score tiles are recomputed and contracted in place, memory
  * stays O(n c + P c).  c <= 384 for bwd.                                             */
 #define HSGK_LOSS_MAX_SETS 3
+#define HSGK_LOSS_MASK_WORDS 4   /* set mode: <= 4 x 63 = 252 classes */
 typedef struct hsgk_loss_set {
   const int64_t *sem;    /* [n] semantic label (or class mask) of every pixel       */
   const int64_t *psem;   /* [P] semantic label (or class mask) of every prototype   */
@@ -280,6 +282,14 @@ HSGK_API size_t hsgk_topk_workspace_bytes(int64_t n, int c, int64_t P, int topk)
 HSGK_API int hsgk_topk_prototypes(const float *queries, int64_t n, int c, const float *proto,
                                   int64_t P, int topk, int64_t *out_idx, float *out_val,
                                   void *workspace, size_t workspace_bytes, hsgk_stream_t stream);
+/* The same with groups (hsg/models/utils.py:243-309, nearest labelled segments of the SAME image):
+ * only prototypes with proto_group[p] == query_group[i] compete for query i; slots that no such
+ * prototype fills get index 0 and value -inf.  Both vectors int64, both null = no grouping.      */
+HSGK_API int hsgk_topk_prototypes_grouped(const float *queries, int64_t n, int c, const float *proto,
+                                          int64_t P, int topk, const int64_t *query_group,
+                                          const int64_t *proto_group, int64_t *out_idx,
+                                          float *out_val, void *workspace, size_t workspace_bytes,
+                                          hsgk_stream_t stream);
 
 /* ---- full-resolution inference around k-means ---------------------------------
  * pyscripts/inference/prototype.py:141-177 (inference.py:165-196): crop [C,h,w] (NCHW

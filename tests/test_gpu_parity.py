@@ -998,6 +998,55 @@ def test_set_segsort_loss_vs_golden_and_oracle(dev, oracle):
     SetSegSortLoss()(e.detach(), -sem, inst, proto.detach(), psem)
 
 
+def test_segsort_model_predictions_losses_multiset_vs_reference(dev):
+  """Rows n1 / n3 at the model level, against the reference's own `Segsort` module and glue
+  (tests/golden/f15_segsort_model.npz): nearest-neighbour prediction against a memory bank (top-20
+  retrieval + majority vote: every label identical), the three SegSort losses with backward,
+  `gather_multiset_labels_per_batch_by_nearest_neighbor` (identical multi-hot labels), and
+  SetSegSortLoss with 90 classes (two 63-bit mask words)."""
+  import torch
+  from hsg_amd.models import utils as mu
+  from hsg_amd.models.predictions import segsort as sm
+  from hsg_amd.utils.segsort.loss import SetSegSortLoss
+  g = util.load('f15_segsort_model')
+  inp = util.segsort_inputs(int(g['seed']))
+  T = lambda k: torch.from_numpy(inp[k]).to(dev)
+  model = sm.Segsort(util.segsort_config())
+  datas = {'cluster_embedding': T('emb').requires_grad_(True), 'cluster_embedding_with_loc': T('emb_loc'),
+           'cluster_index': T('cidx'), 'cluster_semantic_label': T('sem'), 'cluster_instance_label': T('inst'),
+           'cluster_batch_index': T('bidx')}
+  targets = {'semantic_memory_prototype': T('mem'), 'semantic_memory_prototype_label': T('mem_lab'),
+             'prototype': T('protos').requires_grad_(True), 'prototype_semantic_label': T('psem'),
+             'prototype_batch_index': T('pbatch'), 'semantic_tag': T('tags'), 'prototype_semantic_tag': T('ptags')}
+  out = model(datas, targets, with_loss=True, with_prediction=True)
+  assert np.array_equal(out['semantic_prediction'].cpu().numpy(), g['pred'])
+  assert np.array_equal(out['semantic_score'].cpu().numpy(), g['topk'])
+  for k, ref in (('sem_ann_loss', 'sem_ann'), ('sem_occ_loss', 'sem_occ'), ('img_sim_loss', 'img_sim')):
+    assert abs(float(out[k]) - float(g[ref])) <= 1e-4, (k, float(out[k]), float(g[ref]))
+  assert abs(float(out['accuracy']) - float(g['acc'])) <= 1e-6
+  (out['sem_ann_loss'] + out['sem_occ_loss'] + out['img_sim_loss']).backward()
+  for got, ref in ((datas['cluster_embedding'].grad, g['g_emb']), (targets['prototype'].grad, g['g_protos'])):
+    scale = float(np.abs(ref).max())
+    err = np.abs(got.cpu().numpy() - ref)
+    assert np.quantile(err, 0.99) <= 1e-4 * scale and err.max() <= 1e-2 * scale, (float(err.max()), scale)
+  multi = mu.gather_multiset_labels_per_batch_by_nearest_neighbor(
+      T('emb'), T('protos'), T('psem'), T('bidx'), T('pbatch'), num_classes=int(inp['num_classes']), top_k=3,
+      threshold=0.3)
+  assert np.array_equal(multi.cpu().numpy(), g['multi'])
+  # SetSegSortLoss, 90 classes
+  e, inst, sem, psem = util.set_loss_inputs(int(g['seed']) + 7, 400, 24, 37, 90)
+  et = torch.from_numpy(e).to(dev)
+  et = (et / et.norm(dim=1, keepdim=True)).requires_grad_(True)
+  for mode, tag in (('segsort+', 'plus'), ('segsort', 'plain')):
+    pt = torch.from_numpy(g['set90_proto']).to(dev).requires_grad_(True)
+    loss = SetSegSortLoss(12, mode)(et, torch.from_numpy(sem).to(dev), torch.from_numpy(inst).to(dev), pt,
+                                    torch.from_numpy(psem).to(dev))
+    ge, gp = torch.autograd.grad(loss, [et, pt])
+    assert abs(loss.item() - float(g['set90_%s_loss' % tag])) <= 1e-4
+    assert np.abs(ge.cpu().numpy() - g['set90_%s_gemb' % tag]).max() <= 2e-5 * max(1.0, float(np.abs(g['set90_%s_gemb' % tag]).max()) * 100)
+    assert np.abs(gp.cpu().numpy() - g['set90_%s_gproto' % tag]).max() <= 2e-4
+
+
 def test_inference_pieces_vs_reference_golden(dev, oracle):
   """n2: find_majority_label_index (histogram / argmax / select kernels) and the
   overlap-averaged patch accumulation (normalise + accumulate + divide kernels) against

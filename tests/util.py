@@ -244,3 +244,45 @@ def run_train_step(mods, inp, device):
               finehrchy_mapping_index=label['finehrchy_mapping_index'],
               coarsehrchy_mapping_index=label['coarsehrchy_mapping_index'],
               n_prototypes=torch.tensor(label['prototype'].shape[0]))
+
+
+# ---- Segsort predictions / losses fixture (tools/gen_golden.py f15) -------------------
+def segsort_config():
+  import types
+  ns = types.SimpleNamespace
+  return ns(train=ns(sem_ann_loss_types='segsort', sem_ann_concentration=10.0, sem_ann_loss_weight=1.0,
+                     sem_occ_loss_types='segsort', sem_occ_concentration=10.0, sem_occ_loss_weight=0.5,
+                     img_sim_loss_types='segsort', img_sim_concentration=10.0, img_sim_loss_weight=0.25,
+                     feat_aff_loss_types='none', feat_aff_concentration=10.0, feat_aff_loss_weight=0.0),
+            dataset=ns(semantic_ignore_index=255, num_classes=7), network=ns(label_divisor=256))
+
+
+def segsort_inputs(seed, n=1500, C=24, B=3, K=9, M=60):
+  """Pixels of B images in K k-means segments each (ids unique over the batch), 6 semantic classes
+  plus an ignored one (255), a memory bank of M labelled prototypes, image-level tags."""
+  nc = 7
+  g = lambda k, *shape: synth.gaussish(seed + k, int(np.prod(shape))).reshape(shape).copy()
+  nrm = lambda a: (a / np.sqrt((a.astype(np.float64) ** 2).sum(1, keepdims=True))).astype(np.float32)
+  bidx = np.sort((synth.hash_u64(seed + 1, n) % np.uint64(B)).astype(np.int64))
+  cidx = bidx * K + (synth.hash_u64(seed + 2, n) % np.uint64(K)).astype(np.int64)
+  seg_sem = (synth.hash_u64(seed + 3, B * K) % np.uint64(nc)).astype(np.int64)
+  seg_sem[seg_sem == 6] = 255                                       # an ignored class
+  sem = seg_sem[cidx]
+  inst = (synth.hash_u64(seed + 4, n) % np.uint64(3)).astype(np.int64)
+  cen = nrm(g(5, B * K, C))
+  emb = nrm(cen[cidx] + np.float32(0.35) * g(6, n, C))
+  emb_loc = nrm(np.concatenate([emb, np.float32(0.2) * g(7, n, 2)], 1))
+  protos = nrm(np.stack([emb[cidx == s].sum(0) if (cidx == s).any() else np.ones(C, np.float32)
+                         for s in range(B * K)]))
+  pbatch = np.repeat(np.arange(B, dtype=np.int64), K)
+  tags = np.zeros((B, nc), np.int64)
+  for b in range(B):
+    for s in seg_sem[b * K:(b + 1) * K]:
+      if s < nc:
+        tags[b, s] = 1
+  mem = nrm(g(8, M, C))
+  mem[:B * K] = nrm(protos + np.float32(0.1) * g(9, B * K, C))        # near copies: meaningful retrievals
+  mem_lab = (synth.hash_u64(seed + 10, M) % np.uint64(nc - 1)).astype(np.int64)
+  return dict(emb=emb, emb_loc=emb_loc, cidx=cidx, sem=sem, inst=inst, bidx=bidx, protos=protos,
+              psem=seg_sem, pbatch=pbatch, tags=tags, ptags=tags[pbatch], mem=mem, mem_lab=mem_lab,
+              num_classes=np.int64(nc))

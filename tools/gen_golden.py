@@ -492,8 +492,51 @@ def f14():
     ref_common.segment_by_kmeans = saved
 
 
+# ---- F15 Segsort predictions / losses, multiset labels, SetSegSortLoss with > 63 classes ------
+def f15():
+  import types
+  import hsg.models.predictions.segsort as ref_seg
+  import hsg.models.utils as ref_mu
+  from tests import util as tutil
+  seed = synth.SEED_BASE + 95
+  inp = tutil.segsort_inputs(seed)
+  T = lambda k: torch.from_numpy(inp[k])
+  cfg = tutil.segsort_config()
+  model = ref_seg.Segsort(cfg)
+  datas = {'cluster_embedding': T('emb').requires_grad_(True), 'cluster_embedding_with_loc': T('emb_loc'),
+           'cluster_index': T('cidx'), 'cluster_semantic_label': T('sem'), 'cluster_instance_label': T('inst'),
+           'cluster_batch_index': T('bidx')}
+  targets = {'semantic_memory_prototype': T('mem'), 'semantic_memory_prototype_label': T('mem_lab'),
+             'prototype': T('protos').requires_grad_(True), 'prototype_semantic_label': T('psem'),
+             'prototype_batch_index': T('pbatch'), 'semantic_tag': T('tags'),
+             'prototype_semantic_tag': T('ptags')}
+  pred, topk = model.predictions(datas, targets)
+  sem_ann, sem_occ, img_sim, acc = model.losses(datas, targets)
+  (sem_ann + sem_occ + img_sim).backward()
+  multi = ref_mu.gather_multiset_labels_per_batch_by_nearest_neighbor(
+      T('emb'), T('protos'), T('psem'), T('bidx'), T('pbatch'), num_classes=int(inp['num_classes']), top_k=3,
+      threshold=0.3)
+  # SetSegSortLoss with 90 classes (MSCOCO has 80+): more than one 63-bit mask word
+  e, inst, sem, psem = tutil.set_loss_inputs(seed + 7, 400, 24, 37, 90)
+  et = torch.from_numpy(ref_general.normalize_embedding(torch.from_numpy(e)).numpy()).requires_grad_(True)
+  pt = ref_common.calculate_prototypes_from_labels(et.detach(), torch.from_numpy(inst), 37).requires_grad_(True)
+  big = {}
+  for mode in ('segsort+', 'segsort'):
+    loss = ref_loss.SetSegSortLoss(12, mode)(et, torch.from_numpy(sem), torch.from_numpy(inst), pt,
+                                             torch.from_numpy(psem))
+    ge, gp = torch.autograd.grad(loss, [et, pt])
+    tag = 'plus' if mode == 'segsort+' else 'plain'
+    big.update({'set90_%s_loss' % tag: np.float64(loss.item()), 'set90_%s_gemb' % tag: ge.numpy(),
+                'set90_%s_gproto' % tag: gp.numpy()})
+  save('f15_segsort_model', seed=seed, pred=pred.numpy(), topk=topk.numpy(),
+       sem_ann=np.float64(sem_ann.item()), sem_occ=np.float64(sem_occ.item()),
+       img_sim=np.float64(img_sim.item()), acc=np.float64(acc.item()),
+       g_emb=datas['cluster_embedding'].grad.numpy(), g_protos=targets['prototype'].grad.numpy(),
+       multi=multi.numpy(), set90_proto=pt.detach().numpy(), **big)
+
+
 if __name__ == '__main__':
   os.makedirs(OUT, exist_ok=True)
-  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13', 'f14']
+  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13', 'f14', 'f15']
   for w in which:
     globals()[w]()
