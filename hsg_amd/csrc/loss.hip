@@ -18,12 +18,13 @@
 //     g_emb = W P        (owner rows = pixels,     streamed rows = prototypes)
 //     g_proto = W^T E    (owner rows = prototypes, streamed rows = pixels)
 // are the same computation with the roles of the two matrices swapped, so ONE kernel
-// template serves both: a wave keeps 32 owner rows as the MFMA B operand in registers and
-// their C output columns in accumulators, streams 32-row blocks of the other matrix
-// through LDS, forms the 32 x 32 score tile (v_mfma_f32_32x32x2_f32, k over channels),
+// template serves both: a wave keeps 16 owner rows as the MFMA B operand in registers and
+// their C output columns in accumulators, streams 16-row blocks of the other matrix
+// through LDS, forms the 16 x 16 score tile (v_mfma_f32_16x16x4_f32, k over channels),
 // turns it into W in place -- the accumulator layout of the score tile IS the B operand
 // layout of the second contraction, no transpose -- and accumulates W x (streamed rows)
-// with k over the streamed rows.  The streamed dimension is split over workgroups to
+// with k over the streamed rows.  (C/4 + C/4 + 4 registers per lane: two waves per SIMD; the
+// first version on 32 x 32 x 2 tiles needed ~450 registers at C = 256 and one wave per SIMD.)  The streamed dimension is split over workgroups to
 // fill the chip; the per-split partial outputs are summed in split order.
 #include "common.h"
 #include "score_tiles.h"
@@ -248,42 +249,47 @@ struct BwdArgs {
 
 // CT = ceil(c / 32) channel tiles; OWNER_PX: owner rows are pixels (output g_emb) else prototypes
 // (output g_proto).  256 threads = 4 waves, one per SIMD, 32 owner rows each.
-// CG <= CT channel tiles are accumulated per launch, starting at tile cg0 (C = 384: two
-// launches of 6 tiles keep the accumulators + the owner operand inside the 512 registers).
-template <int CT, int CG, bool OWNER_PX, bool VEC4>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void loss_bwd_kernel(BwdArgs a, int cg0) {
-  constexpr int CP = CT * 32;            // padded channels
-  constexpr int RS = CP + 1;             // LDS row stride (odd: conflict-free column reads)
-  constexpr int KS = CP / 2;             // k-steps of the score contraction
-  constexpr int L4 = CP / 32;            // float4 (or 4 scalars) per thread per staged block
+// CT: 16-channel tiles (c <= 16 CT); OWNER_PX: owner rows are pixels (output g_emb) else prototypes
+// (output g_proto); NW waves, 16 owner rows each.  v_mfma_f32_16x16x4_f32: lane (j = l & 15, g = l >> 4)
+// supplies A[j][g], B[g][j] and receives D[4 g + r][j] in register r -- so after the score contraction
+// (A = streamed rows, B = owner rows, k over channels) register r of lane (j, g) holds the score of
+// streamed row 4 g + r against owner row j, which is exactly the B operand B[k = g][j] of k-step r of
+// the second contraction (A = streamed rows transposed, k over the 16 streamed rows).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int CT, int NW, bool OWNER_PX, bool VEC4>
+__global__ __launch_bounds__(NW * 64) void loss_bwd_kernel(BwdArgs a) {
+  constexpr int CP = CT * 16;            // padded channels
+  constexpr int RS = CP + 4;             // LDS row stride = 4 * odd: both operand read patterns are conflict-free
+  constexpr int KS = CP / 4;             // k-steps of the score contraction
+  constexpr int NT = NW * 64;
+  constexpr int L4 = (4 * CP + NT - 1) / NT;   // float4 per thread per staged 16-row block
+  constexpr int OT = NW * 16;            // owner rows per workgroup
   extern __shared__ float lds[];
-  float *tbuf = lds;                                        // [2][32][RS]
-  char *mbase = reinterpret_cast<char *>(lds + 2 * 32 * RS);
+  float *tbuf = lds;                                        // [2][16][RS]
+  char *mbase = reinterpret_cast<char *>(lds + 2 * 16 * RS);
   // per staged block: label words and (stream = pixels) the per-pixel weights
-  int64_t *m_lab = reinterpret_cast<int64_t *>(mbase);       // [2][kLabSlots][32]
-  PxMeta *m_px = reinterpret_cast<PxMeta *>(m_lab + 2 * kLabSlots * 32);  // [2][kMaxSets][32]
-  int32_t *m_inst = reinterpret_cast<int32_t *>(m_px + 2 * kMaxSets * 32);  // [2][32]
+  int64_t *m_lab = reinterpret_cast<int64_t *>(mbase);       // [2][kLabSlots][16]
+  PxMeta *m_px = reinterpret_cast<PxMeta *>(m_lab + 2 * kLabSlots * 16);  // [2][kMaxSets][16]
+  int32_t *m_inst = reinterpret_cast<int32_t *>(m_px + 2 * kMaxSets * 16);  // [2][16]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int j = lane & 31, h = lane >> 5;
+  const int j = lane & 15, g = lane >> 4;
   const int c = a.c, L = a.ls.L;
-  const int64_t o_row = (int64_t)blockIdx.x * 128 + w * 32 + j;
+  const int64_t o_row = (int64_t)blockIdx.x * OT + w * 16 + j;
   const bool o_valid = o_row < a.n_owner;
   const int64_t o_ld = o_valid ? o_row : a.n_owner - 1;
   const int sp = blockIdx.y;
-  const int64_t nblocks = (a.n_stream + 31) / 32;
+  const int64_t nblocks = (a.n_stream + 15) / 16;
   const int64_t b_begin = (int64_t)sp * a.blocks_per_split;
   const int64_t b_end = min(nblocks, b_begin + a.blocks_per_split);
 
-  // ---- owner rows: B operand of the score contraction, lane (j, h) holds O[o][2 s + h]
+  // ---- owner rows: B operand of the score contraction, lane (j, g) holds O[o][4 s + g]
   float bop[KS];
   {
     const float *orow = a.owner + o_ld * c;
-    // (one dword per k-step: a float4 per lane would fetch both half-waves' elements and keep
-    //  four times the registers live while the loads are in flight)
 #pragma unroll
-    for (int s = 0; s < KS; ++s) bop[s] = (2 * s + h) < c ? orow[2 * s + h] : 0.0f;
+    for (int s = 0; s < KS; ++s) bop[s] = (4 * s + g) < c ? orow[4 * s + g] : 0.0f;
   }
   // ---- owner-side labels / weights
   int64_t o_lab[kLabSlots];
@@ -301,22 +307,20 @@ void loss_bwd_kernel(BwdArgs a, int cg0) {
   }
   if constexpr (OWNER_PX) o_inst = (int32_t)a.inst[o_ld];
 
-  f32x16 gacc[CG];
+  f32x4 gacc[CT];
 #pragma unroll
-  for (int ct = 0; ct < CG; ++ct)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) gacc[ct][r] = 0.0f;
+  for (int ct = 0; ct < CT; ++ct) gacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- staging of streamed block b into LDS buffer `buf` (rows past the end: zeros)
   float4 pre[L4];
   auto load_block = [&](int64_t b) {
 #pragma unroll
     for (int u = 0; u < L4; ++u) {
-      const int f = tid + 256 * u;                 // float4 index inside the [32][CP] block
+      const int f = tid + NT * u;                  // float4 index inside the [16][CP] block
       const int row = f / (CP / 4), c4 = (f - row * (CP / 4)) * 4;
-      const int64_t t = b * 32 + row;
+      const int64_t t = b * 16 + row;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t < a.n_stream) {
+      if (f < 4 * CP && t < a.n_stream) {
         const float *src = a.stream + t * c + c4;
         if constexpr (VEC4) {
           if (c4 < c) v = *reinterpret_cast<const float4 *>(src);
@@ -331,17 +335,16 @@ void loss_bwd_kernel(BwdArgs a, int cg0) {
     }
   };
   auto store_block = [&](int buf, int64_t b) {
-    float *dst = tbuf + buf * (32 * RS);
+    float *dst = tbuf + buf * (16 * RS);
 #pragma unroll
     for (int u = 0; u < L4; ++u) {
-      const int f = tid + 256 * u;
+      const int f = tid + NT * u;
       const int row = f / (CP / 4), c4 = (f - row * (CP / 4)) * 4;
-      float *d = dst + row * RS + c4;
-      d[0] = pre[u].x; d[1] = pre[u].y; d[2] = pre[u].z; d[3] = pre[u].w;
+      if (f < 4 * CP) *reinterpret_cast<float4 *>(dst + row * RS + c4) = pre[u];      // RS % 4 == 0
     }
-    if (tid < 32 * kMaxSets) {                      // labels / weights of the 32 streamed rows
-      const int l = tid >> 5, row = tid & 31;
-      const int64_t t = b * 32 + row;
+    if (tid < 16 * kMaxSets) {                      // labels / weights of the 16 streamed rows
+      const int l = tid >> 4, row = tid & 15;
+      const int64_t t = b * 16 + row;
       if (l < L) {
         int64_t labw[kLabSlots];
 #pragma unroll
@@ -353,14 +356,14 @@ void loss_bwd_kernel(BwdArgs a, int cg0) {
         }
         if (l == 0) {
 #pragma unroll
-          for (int w = 0; w < kMaskWords; ++w) m_lab[(buf * kLabSlots + w) * 32 + row] = labw[w];
+          for (int ww = 0; ww < kMaskWords; ++ww) m_lab[(buf * kLabSlots + ww) * 16 + row] = labw[ww];
         } else {
-          m_lab[(buf * kLabSlots + kMaskWords - 1 + l) * 32 + row] = labw[kMaskWords - 1 + l];
+          m_lab[(buf * kLabSlots + kMaskWords - 1 + l) * 16 + row] = labw[kMaskWords - 1 + l];
         }
-        if constexpr (!OWNER_PX) m_px[(buf * kMaxSets + l) * 32 + row] = pm;
+        if constexpr (!OWNER_PX) m_px[(buf * kMaxSets + l) * 16 + row] = pm;
       }
       if constexpr (!OWNER_PX)
-        if (l == 0) m_inst[buf * 32 + row] = t < a.n_stream ? (int32_t)a.inst[t] : -1;
+        if (l == 0) m_inst[buf * 16 + row] = t < a.n_stream ? (int32_t)a.inst[t] : -1;
     }
   };
 
@@ -372,110 +375,66 @@ void loss_bwd_kernel(BwdArgs a, int cg0) {
     const int buf = (int)((b - b_begin) & 1);
     if (b + 1 < b_end) load_block(b + 1);          // in flight during the MFMAs below
     __syncthreads();                                // buffer `buf` is complete
-    const float *tb = tbuf + buf * (32 * RS);
+    const float *tb = tbuf + buf * (16 * RS);
 
-    // ---- score tile: S[t][o] = sum_k T[t][k] O[o][k], canonical ascending-k chain
-    f32x16 sacc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
+    // ---- score tile: S[t][o] = sum_k T[t][k] O[o][k], ascending-k chain of 4-wide steps
+    f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
     {
-      // LDS operands four k-steps at a time, one group ahead of the MFMAs that use them
-      const float *ap = tb + j * RS + h;
-      float an[4], ac[4];
+      const float *ap = tb + j * RS + g;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) an[u] = ap[2 * u];
-#pragma unroll
-      for (int s0 = 0; s0 < KS; s0 += 4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) ac[u] = an[u];
-        if (s0 + 4 < KS) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) an[u] = ap[2 * (s0 + 4 + u)];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bop[s0 + u], sacc, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      for (int s = 0; s < KS; ++s) sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s], bop[s], sacc, 0, 0, 0);
     }
-    // ---- W in place: lane (j, h) register r <-> streamed row t = trow(r, h), owner row o = j
-    const int64_t *bl = m_lab + buf * kLabSlots * 32;
-    const PxMeta *bp = m_px + buf * kMaxSets * 32;
-    const int32_t *bi = m_inst + buf * 32;
+    // ---- W in place: lane (j, g) register r <-> streamed row t = 4 g + r, owner row o = j
+    const int64_t *bl = m_lab + buf * kLabSlots * 16;
+    const PxMeta *bp = m_px + buf * kMaxSets * 16;
+    const int32_t *bi = m_inst + buf * 16;
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      // (four registers = four consecutive streamed rows at a time: the scheduler must not hoist
-      //  the label / weight reads of all sixteen, that alone costs > 200 registers)
-      __builtin_amdgcn_sched_barrier(0);
+    for (int r = 0; r < 4; ++r) {
+      const int tr = 4 * g + r;
+      const int64_t t = b * 16 + tr;
+      float wv = 0.0f, sx = 0.0f;
+      bool own;
+      if constexpr (OWNER_PX) own = (int64_t)o_inst == t; else own = (int64_t)bi[tr] == o_row;
+      int64_t tl[kLabSlots];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * rg + e;
-        const int tr = e + 8 * rg + 4 * h;
-        const int64_t t = b * 32 + tr;
-        float wv = 0.0f, s = 0.0f;
-        bool own;
-        if constexpr (OWNER_PX) own = (int64_t)o_inst == t; else own = (int64_t)bi[tr] == o_row;
-        int64_t tl[kLabSlots];
+      for (int i = 0; i < kLabSlots; ++i) tl[i] = (i == 0 || i < a.ls.words || i >= kMaskWords) ? bl[i * 16 + tr] : 0;
 #pragma unroll
-        for (int i = 0; i < kLabSlots; ++i) tl[i] = (i == 0 || i < a.ls.words || i >= kMaskWords) ? bl[i * 32 + tr] : 0;
-#pragma unroll
-        for (int l = 0; l < kMaxSets; ++l)
-          if (l < L) {
-            if (l == 0 || a.ls.kappa[l] != a.ls.kappa[l - 1]) s = expf(sacc[r] * a.ls.kappa[l]);
-            const PxMeta pm = OWNER_PX ? o_px[l] : bp[l * 32 + tr];
-            const bool same = same_semantic(tl, o_lab, l, a.ls.setm[l]);
-            const float av = pm.plus_us ? (float)((int)same - (int)own) : (own ? 1.0f : 0.0f);
-            wv += s * (av * pm.A + (same ? 0.0f : pm.B));
-          }
-        sacc[r] = (o_valid && t < a.n_stream) ? wv : 0.0f;
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- second contraction: G[c][o] += sum_t T[t][c] W[t][o]; k-step r pairs the streamed rows
-    //      trow(r, 0) / trow(r, 1), exactly the rows the two half-waves hold in register r
-    {
-      float an[CG], ac[CG];
-      const float *ap0 = tb + (4 * h) * RS + cg0 * 32 + j;
-#pragma unroll
-      for (int ct = 0; ct < CG; ++ct) an[ct] = ap0[ct * 32];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-#pragma unroll
-        for (int ct = 0; ct < CG; ++ct) ac[ct] = an[ct];
-        if (r + 1 < 16) {
-          const float *ap = tb + (((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * h) * RS + cg0 * 32 + j;
-#pragma unroll
-          for (int ct = 0; ct < CG; ++ct) an[ct] = ap[ct * 32];
+      for (int l = 0; l < kMaxSets; ++l)
+        if (l < L) {
+          if (l == 0 || a.ls.kappa[l] != a.ls.kappa[l - 1]) sx = expf(sacc[r] * a.ls.kappa[l]);
+          const PxMeta pm = OWNER_PX ? o_px[l] : bp[l * 16 + tr];
+          const bool same = same_semantic(tl, o_lab, l, a.ls.setm[l]);
+          const float av = pm.plus_us ? (float)((int)same - (int)own) : (own ? 1.0f : 0.0f);
+          wv += sx * (av * pm.A + (same ? 0.0f : pm.B));
         }
-        __builtin_amdgcn_sched_barrier(0);
+      sacc[r] = (o_valid && t < a.n_stream) ? wv : 0.0f;
+    }
+    // ---- second contraction: G[c][o] += sum_t T[t][c] W[t][o]; k-step r takes the streamed rows
+    //      4 g + r, g = 0..3 -- the rows the four lane groups hold in register r
 #pragma unroll
-        for (int ct = 0; ct < CG; ++ct)
-          gacc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[ct], sacc[r], gacc[ct], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+    for (int r = 0; r < 4; ++r) {
+      const float *ap = tb + (4 * g + r) * RS + j;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+        gacc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[ct * 16], sacc[r], gacc[ct], 0, 0, 0);
     }
     if (b + 1 < b_end) store_block(buf ^ 1, b + 1);
   }
 
-  // ---- partial output: lane (j, h) holds G[c = ct*32 + 8 q + 4 h + e][o = j] in gacc[ct][4 q + e]
+  // ---- partial output: lane (j, g) holds G[c = 16 ct + 4 g + r][o = j] in gacc[ct][r]
   if (o_valid) {
     float *orow = a.out + ((int64_t)sp * a.n_owner + o_row) * c;
 #pragma unroll
-    for (int ct = 0; ct < CG; ++ct)
+    for (int ct = 0; ct < CT; ++ct) {
+      const int c0 = ct * 16 + 4 * g;
+      if constexpr (VEC4) {
+        if (c0 < c) *reinterpret_cast<float4 *>(orow + c0) = make_float4(gacc[ct][0], gacc[ct][1], gacc[ct][2], gacc[ct][3]);
+      } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c0 = (cg0 + ct) * 32 + 8 * q + 4 * h;
-        if constexpr (VEC4) {
-          if (c0 < c)
-            *reinterpret_cast<float4 *>(orow + c0) =
-                make_float4(gacc[ct][4 * q], gacc[ct][4 * q + 1], gacc[ct][4 * q + 2], gacc[ct][4 * q + 3]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (c0 + e < c) orow[c0 + e] = gacc[ct][4 * q + e];
-        }
+        for (int e = 0; e < 4; ++e)
+          if (c0 + e < c) orow[c0 + e] = gacc[ct][e];
       }
+    }
   }
 }
 
@@ -490,10 +449,12 @@ __global__ void loss_bwd_reduce_kernel(const float *__restrict__ part, int split
   }
 }
 
-static int bwd_split_for(int64_t n_owner, int64_t n_stream) {
-  const int64_t tiles = (n_owner + 127) / 128, blocks = (n_stream + 31) / 32;
+static int bwd_owner_rows(int c) { return c > 256 ? 64 : 128; }     // rows per workgroup (4 or 8 waves)
+
+static int bwd_split_for(int64_t n_owner, int64_t n_stream, int c) {
+  const int64_t tiles = (n_owner + bwd_owner_rows(c) - 1) / bwd_owner_rows(c), blocks = (n_stream + 15) / 16;
   int64_t split = 1;
-  while (tiles * split < 512 && split * 8 <= blocks) split *= 2;     // >= 8 streamed blocks per workgroup
+  while (tiles * split < 512 && split * 16 <= blocks) split *= 2;    // >= 16 streamed blocks per workgroup
   return (int)split;
 }
 
@@ -504,32 +465,31 @@ static int launch_loss_bwd(BwdArgs a, float *out, float *scratch, hipStream_t s)
     HSGK_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)a.n_owner * a.c, s));
     return 0;
   }
-  const int split = bwd_split_for(a.n_owner, a.n_stream);
-  const int64_t blocks = (a.n_stream + 31) / 32;
+  const int split = bwd_split_for(a.n_owner, a.n_stream, a.c);
+  const int64_t blocks = (a.n_stream + 15) / 16;
   a.split = split;
   a.blocks_per_split = (int)((blocks + split - 1) / split);
   a.out = split == 1 ? out : scratch;
-  const int ct = (a.c + 31) / 32;
+  const int ct = (a.c + 15) / 16;
   const bool vec4 = (a.c % 4) == 0;
-  auto go = [&](auto kern, int CT, int CG) -> int {
-    const size_t lds = (size_t)2 * 32 * (CT * 32 + 1) * 4 + (size_t)2 * 32 * (kLabSlots * 8 + kMaxSets * sizeof(PxMeta)) + 2 * 32 * 4;
+  auto go = [&](auto kern, int CT, int NW) -> int {
+    const size_t lds = (size_t)2 * 16 * (CT * 16 + 4) * 4 + (size_t)2 * 16 * (kLabSlots * 8 + kMaxSets * sizeof(PxMeta)) + 2 * 16 * 4;
     HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    for (int cg0 = 0; cg0 < CT && cg0 * 32 < a.c; cg0 += CG) {
-      hipLaunchKernelGGL(kern, dim3((unsigned)((a.n_owner + 127) / 128), split), dim3(256), lds, s, a, cg0);
-      HSGK_LAUNCH_CHECK();
-    }
+    const int ot = NW * 16;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((a.n_owner + ot - 1) / ot), split), dim3(NW * 64), lds, s, a);
+    HSGK_LAUNCH_CHECK();
     return 0;
   };
   int rc;
-#define HSGK_BWD_CASE(CTV, CGV)                                                                 \
-  rc = vec4 ? go(loss_bwd_kernel<CTV, CGV, OWNER_PX, true>, CTV, CGV)                           \
-            : go(loss_bwd_kernel<CTV, CGV, OWNER_PX, false>, CTV, CGV)
-  if (ct <= 1) HSGK_BWD_CASE(1, 1);
-  else if (ct <= 2) HSGK_BWD_CASE(2, 2);
-  else if (ct <= 4) HSGK_BWD_CASE(4, 4);
+#define HSGK_BWD_CASE(CTV, NWV)                                                                 \
+  rc = vec4 ? go(loss_bwd_kernel<CTV, NWV, OWNER_PX, true>, CTV, NWV)                           \
+            : go(loss_bwd_kernel<CTV, NWV, OWNER_PX, false>, CTV, NWV)
+  if (ct <= 2) HSGK_BWD_CASE(2, 8);
+  else if (ct <= 4) HSGK_BWD_CASE(4, 8);
   else if (ct <= 8) HSGK_BWD_CASE(8, 8);
-  else if (ct <= 12) HSGK_BWD_CASE(12, 6);
+  else if (ct <= 16) HSGK_BWD_CASE(16, 8);
+  else if (ct <= 24) HSGK_BWD_CASE(24, 4);
   else {
     set_error("segsort loss backward: embedding dimension %d > 384 is not supported", a.c);
     return -1;
@@ -538,8 +498,8 @@ static int launch_loss_bwd(BwdArgs a, float *out, float *scratch, hipStream_t s)
   if (rc) return rc;
   if (split > 1) {
     const int64_t total = a.n_owner * a.c;
-    const int64_t g = (total + 255) / 256;
-    hipLaunchKernelGGL(loss_bwd_reduce_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, scratch,
+    const int64_t gsz = (total + 255) / 256;
+    hipLaunchKernelGGL(loss_bwd_reduce_kernel, dim3((unsigned)(gsz > 4096 ? 4096 : gsz)), dim3(256), 0, s, scratch,
                        split, total, out);
     HSGK_LAUNCH_CHECK();
   }
@@ -606,8 +566,8 @@ int hsgk_segsort_loss_fwd(const float *emb, int64_t n, int c, const int64_t *ins
 size_t hsgk_segsort_loss_bwd_workspace_bytes(int64_t n, int c, int64_t P, int L) {
   Carver cv(nullptr);
   cv.take<PxMeta>((size_t)(L > 0 ? L : 1) * (size_t)(n > 0 ? n : 1));
-  const size_t a = (size_t)bwd_split_for(n, P) * (size_t)(n > 0 ? n : 1) * c;
-  const size_t b = (size_t)bwd_split_for(P, n) * (size_t)(P > 0 ? P : 1) * c;
+  const size_t a = (size_t)bwd_split_for(n, P, c) * (size_t)(n > 0 ? n : 1) * c;
+  const size_t b = (size_t)bwd_split_for(P, n, c) * (size_t)(P > 0 ? P : 1) * c;
   cv.take<float>(a > b ? a : b);
   return cv.off + 256;
 }
