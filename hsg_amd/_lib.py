@@ -55,6 +55,8 @@ _vp, _i64, _i32, _f32, _sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
 SIGNATURES = {
     'hsgk_version': (_i32, []),
     'hsgk_last_error': (ctypes.c_char_p, []),
+    'hsgk_host_grid_seed_map': (_i32, [_i32, _i32, _i32, _i32, _vp, _vp]),
+    'hsgk_host_location_features': (_i32, [_i32, _i32, _vp]),
     'hsgk_normalize_rows': (_i32, [_vp, _i64, _i32, _f32, _vp, _vp, _vp]),
     'hsgk_segment_by_kmeans_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32, _i32, _i64]),
     'hsgk_segment_by_kmeans': (_i32, [ctypes.POINTER(SegkmArgs), _vp]),

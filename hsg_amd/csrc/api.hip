@@ -4,7 +4,9 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -295,6 +297,55 @@ int hsgk_verify_collect(uint64_t *rows_compared, uint64_t *rows_differing) {
   HSGK_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_verify), zero, sizeof(zero)));
   if (rows_compared) *rows_compared = v[0];
   if (rows_differing) *rows_differing = v[1];
+  return 0;
+}
+
+// ---- host helpers: the two small tables of hsgk_segment_by_kmeans -----------------------------
+// torch.linspace(start, end, n) in float32 as ATen's CPU kernel evaluates it (step in float32; element
+// i = start + step * i below n / 2, end - step * (n - 1 - i) above, one rounding each): its bit pattern
+// is part of the reference's behaviour (hsg/utils/segsort/common.py:145-148, 175-187).
+static void linspace_f32(float start, float end, int n, std::vector<float> *out) {
+  out->resize((size_t)n);
+  if (n == 1) { (*out)[0] = start; return; }
+  const float step = (end - start) / (float)(n - 1);
+  for (int i = 0; i < n; ++i)
+    (*out)[i] = i < n / 2 ? (float)((double)start + (double)step * (double)i)
+                          : (float)((double)end - (double)step * (double)(n - 1 - i));
+}
+
+int hsgk_host_grid_seed_map(int ky, int kx, int H, int W, int32_t *seed_map, int32_t *num_clusters) {
+  HSGK_REQUIRE(ky >= 1 && kx >= 1 && H >= 1 && W >= 1 && seed_map && num_clusters, "bad arguments");
+  std::vector<float> fy, fx;
+  linspace_f32(0.0f, (float)(ky - 1), H, &fy);
+  linspace_f32(0.0f, (float)(kx - 1), W, &fx);
+  std::vector<long long> y((size_t)H), x((size_t)W);
+  long long ymax = 0;
+  for (int i = 0; i < H; ++i) { y[i] = (long long)rintf(fy[i]); ymax = y[i] > ymax ? y[i] : ymax; }   // round half to even
+  for (int i = 0; i < W; ++i) x[i] = (long long)rintf(fx[i]);
+  // y + (y.max() + 1) * x (common.py:150-151), then the rank among the distinct values (:341-342)
+  std::vector<long long> vals;
+  vals.reserve((size_t)H * W);
+  for (int i = 0; i < H; ++i)
+    for (int j = 0; j < W; ++j) vals.push_back(y[i] + (ymax + 1) * x[j]);
+  std::vector<long long> uniq(vals);
+  std::sort(uniq.begin(), uniq.end());
+  uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+  for (size_t p = 0; p < vals.size(); ++p)
+    seed_map[p] = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), vals[p]) - uniq.begin());
+  *num_clusters = (int32_t)uniq.size();
+  return 0;
+}
+
+int hsgk_host_location_features(int H, int W, float *loc) {
+  HSGK_REQUIRE(H >= 1 && W >= 1 && loc, "bad arguments");
+  std::vector<float> fy, fx;
+  linspace_f32(0.0f, 1.0f, H, &fy);
+  linspace_f32(0.0f, 1.0f, W, &fx);
+  for (int i = 0; i < H; ++i)
+    for (int j = 0; j < W; ++j) {
+      loc[((size_t)i * W + j) * 2 + 0] = fy[i] - 0.5f;       // (:316 / local_model.py:88-93)
+      loc[((size_t)i * W + j) * 2 + 1] = fx[j] - 0.5f;
+    }
   return 0;
 }
 

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void segreduce_chunk_kernel(
   uint32_t *rlist = reinterpret_cast<uint32_t *>(sums + rlds * DS);      // [HSGK_CHUNK]
   uint32_t *bits = rlist + HSGK_CHUNK;                                    // [kSegBitWords]
   int32_t *wpre = reinterpret_cast<int32_t *>(bits + kSegBitWords);       // [kSegBitWords]
-  int32_t *slots = wpre + kSegBitWords;                                   // [HSGK_CHUNK]
+  int16_t *slots = reinterpret_cast<int16_t *>(wpre + kSegBitWords);      // [HSGK_CHUNK]
   const int64_t row0 = (int64_t)c * HSGK_CHUNK;
   const int nrows = (int)((n - row0) < HSGK_CHUNK ? (n - row0) : HSGK_CHUNK);
   const int64_t *lab = labels + row0;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void segreduce_chunk_kernel(
         sl = wpre[o >> 5] + __popc(bits[o >> 5] & ((1u << (o & 31)) - 1u));
       }
     }
-    slots[r] = sl;
+    slots[r] = (int16_t)sl;
   }
 
   float *out = partial + (int64_t)c * rmax * d;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void segreduce_chunk_kernel(
     const int cur = (ndist - p0) < rlds ? (ndist - p0) : rlds;
     __syncthreads();
     for (int i = tid; i < cur * DS; i += 256) sums[i] = 0.0f;
-    chunk_accumulate<VEC, UNROLL, int32_t>(x + row0 * d, d, DS, slots, nrows, p0, cur, sums,
+    chunk_accumulate<VEC, UNROLL, int16_t>(x + row0 * d, d, DS, slots, nrows, p0, cur, sums,
                                            rlist, wcount);
     __syncthreads();
     for (int k = w; k < cur; k += 4)
@@ -349,17 +349,19 @@ int hsgk_segment_reduce(const float *x, int64_t n, int d, const int64_t *labels,
 
   const bool wide = d >= 256;
   const int DS = wide ? (d + 3) / 4 * 4 : d;
-  const size_t list_bytes = (size_t)HSGK_CHUNK * 4 * 2 + (size_t)kSegBitWords * 4 * 2;   // row list, slots, bitmap, prefix
+  const size_t list_bytes = (size_t)HSGK_CHUNK * (4 + 2) + (size_t)kSegBitWords * 4 * 2;   // row list, slots, bitmap, prefix
   // table rows per pass: two workgroups per CU when that still covers a useful
   // window, otherwise one workgroup with the whole LDS
   const int rl2 = (int)((76 * 1024 - list_bytes) / ((size_t)DS * 4));
   const int rl1 = (int)((150 * 1024 - list_bytes) / ((size_t)DS * 4));
-  int rlds = rl2 >= (rmax < 64 ? rmax : 64) ? rl2 : rl1;
+  // (chunks of image-major rows with sorted ids hold a few dozen distinct ids: 32 table rows per pass
+  //  are worth the second workgroup per CU; a chunk with more takes further passes over its rows)
+  int rlds = rl2 >= (rmax < 32 ? rmax : 32) ? rl2 : rl1;
   if (rlds > rmax) rlds = rmax;
   if (rlds > 1024) rlds = 1024;
   HSGK_REQUIRE(rlds >= 1, "row too long for the LDS segment table");
   if (nch > 0) {
-    auto kern = wide ? segreduce_chunk_kernel<4, 8> : segreduce_chunk_kernel<1, 16>;
+    auto kern = wide ? segreduce_chunk_kernel<4, 16> : segreduce_chunk_kernel<1, 16>;
     const size_t lds = (size_t)rlds * DS * 4 + list_bytes;
     HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(158 * 1024)));

@@ -89,6 +89,16 @@ typedef struct hsgk_segkm_meta {
 HSGK_API int hsgk_normalize_rows(const float *x, int64_t n, int d, float eps, float *out,
                                  float *norms, hsgk_stream_t stream);
 
+/* ---- host helpers (no GPU work): the two small tables hsgk_segment_by_kmeans reads, with the
+ * float32 bit patterns torch.linspace gives them in the reference ------------------------------
+ * hsgk_host_grid_seed_map: initialize_cluster_labels (common.py:129-153) made dense (:341-342):
+ *   seed_map[H*W] (HOST memory) and the number of seed clusters K.
+ * hsgk_host_location_features: generate_location_features(.., 'float') - 0.5 (common.py:156-189,
+ *   :313-316): loc[H*W*2] (HOST memory), (y, x) per pixel.  Copy both to the device.          */
+HSGK_API int hsgk_host_grid_seed_map(int ky, int kx, int H, int W, int32_t *seed_map_host,
+                                     int32_t *num_clusters);
+HSGK_API int hsgk_host_location_features(int H, int W, float *loc_host);
+
 /* ---- hsg/utils/segsort/common.py:270-408 segment_by_kmeans ---------------- */
 typedef struct hsgk_segkm_args {
   /* inputs */

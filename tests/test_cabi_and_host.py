@@ -81,3 +81,24 @@ def test_default_location_features_match_golden():
     n = int(key[1:])
     loc = sc.generate_location_features((n, 3), 'cpu', 'float').numpy()
     assert np.array_equal(loc[:, 0, 0], g[key])
+
+
+def test_host_helpers_match_torch_tables():
+  """The library's own host helpers (for non-Python hosts of the C ABI) give the seed map and the
+  location features the torch-based mirror computes -- the float32 linspace bits included."""
+  import ctypes
+  import numpy as np
+  import torch
+  from hsg_amd import _lib
+  from hsg_amd.utils.segsort import common as sc
+  L = _lib.lib()
+  for (ky, kx, H, W) in [(8, 8, 448, 448), (4, 4, 43, 28), (2, 4, 64, 64), (16, 16, 768, 768), (8, 16, 224, 224),
+                         (6, 6, 28, 28), (5, 7, 33, 47), (1, 1, 9, 5), (12, 24, 128, 256), (3, 9, 700, 31)]:
+    seed = np.empty((H * W,), np.int32)
+    K = ctypes.c_int32(0)
+    assert L.hsgk_host_grid_seed_map(ky, kx, H, W, seed.ctypes.data_as(ctypes.c_void_p), ctypes.byref(K)) == 0
+    want, wantK = sc._seed_map([ky, kx], H, W, torch.device('cpu'))
+    assert K.value == wantK and np.array_equal(seed, want.numpy()), (ky, kx, H, W)
+    loc = np.empty((H, W, 2), np.float32)
+    assert L.hsgk_host_location_features(H, W, loc.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert np.array_equal(loc.view(np.uint32), sc._default_loc(H, W, torch.device('cpu')).numpy().view(np.uint32))

@@ -120,3 +120,16 @@ def test_bench_spawns_its_ranks():
   r = _bench(['--gpus', '2', '--workload', 'cfg3', '--steps', '2', '--warmup', '1', '--cpu-images', '0'])
   assert r['n_gpus'] == 2 and r['config']['global_batch'] == 32
   assert 'error' not in r['prototype_exchange'] and r['prototype_exchange']['collectives_per_call'] == 2
+
+
+def test_torch_free_cpp_host_of_the_c_abi():
+  """examples/cabi_host.cpp: a C++ program that links libhsgk.so and nothing of torch -- host helpers for
+  the seed map / location features, hipMalloc'd buffers, its own stream -- runs segment_by_kmeans twice
+  and checks determinism, unit rows and dense ids itself (exit code 0)."""
+  exe = os.path.join(ROOT, 'examples', 'cabi_host')
+  assert os.path.exists(exe), 'examples/cabi_host is built by __graft_entry__.build()'
+  for argv in (['4', '256', '96', '80', '8', '8', '10'], ['3', '128', '28', '28', '4', '4', '5'],
+               ['2', '64', '33', '47', '5', '7', '3']):
+    p = subprocess.run([exe] + argv, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.stdout[-500:], p.stderr[-500:])
+    assert '-> OK' in p.stdout
