@@ -181,6 +181,8 @@ def main():
   rank = int(os.environ.get('RANK', '0'))
   world = int(os.environ.get('WORLD_SIZE', '1'))
   local = int(os.environ.get('LOCAL_RANK', '0'))
+  if 'HSGK_BENCH_DEVICE' in os.environ:            # testing aid: every rank on one device (a 1-GPU box)
+    local = int(os.environ['HSGK_BENCH_DEVICE'])
   dist = None
   if world > 1 or os.environ.get('HSGK_BENCH_FORCE_DIST') == '1':   # (the switch exercises the RCCL path on one GPU)
     import datetime

@@ -39,6 +39,12 @@ def _normalize(table):
   return ops.normalize_rows(table)
 
 
+def _local_prototypes(rows, ids, count):
+  """Normalised per-segment sums in one pass (libhsgk, mode 0): the single-rank path, where the
+  sums need not leave the kernel before they are normalised."""
+  return ops.segment_reduce(rows, ids, count, 0)
+
+
 # ---- small helpers -----------------------------------------------------------
 def _world(group):
   if dist.is_available() and dist.is_initialized():
@@ -190,17 +196,18 @@ def exchange_prototypes(embeddings, embeddings_with_loc, cluster_indices, batch_
   C = embeddings.shape[-1]
   D = embeddings_with_loc.shape[-1]
   n_local = local_tuples.shape[0]
-  local = torch.cat([
-      _segment_sums(embeddings.reshape(-1, C), local_ids, n_local),
-      _segment_sums(embeddings_with_loc.reshape(-1, D), local_ids, n_local)], 1)
   if world > 1:
+    local = torch.cat([
+        _segment_sums(embeddings.reshape(-1, C), local_ids, n_local),
+        _segment_sums(embeddings_with_loc.reshape(-1, D), local_ids, n_local)], 1)
     table = torch.zeros((P, C + D), dtype=local.dtype, device=dev)
     table = table.index_add(0, slot, local)
     table = _AllReduceSum.apply(table, group)
+    prototypes = _normalize(table[:, :C].contiguous())
+    prototypes_with_loc = _normalize(table[:, C:].contiguous())
   else:
-    table = local
-  prototypes = _normalize(table[:, :C].contiguous())
-  prototypes_with_loc = _normalize(table[:, C:].contiguous())
+    prototypes = _local_prototypes(embeddings.reshape(-1, C), local_ids, n_local)
+    prototypes_with_loc = _local_prototypes(embeddings_with_loc.reshape(-1, D), local_ids, n_local)
   return (prototypes, prototypes_with_loc, prototype_semantic_labels,
           prototype_instance_labels, prototype_batch_indices, updated_cluster_indices)
 

@@ -51,6 +51,7 @@ def _install_cpu_hooks(mu):
 
   mu._segment_sums = lambda rows, ids, count: _Sums.apply(rows, ids, count)
   mu._normalize = lambda t: t / t.norm(dim=1, keepdim=True).clamp_min(1e-12)
+  mu._local_prototypes = lambda rows, ids, count: mu._normalize(mu._segment_sums(rows, ids, count))
 
 
 def _worker(rank, world, port, result_dir):
@@ -132,7 +133,7 @@ def test_exchange_single_process_list_api(oracle):
   """Reference calling convention (lists, one tensor per GPU) without
   torch.distributed: the two 'GPUs' are concatenated on the anchor device."""
   from hsg_amd.models import utils as mu
-  saved = (mu._segment_sums, mu._normalize)
+  saved = (mu._segment_sums, mu._normalize, mu._local_prototypes)
   _install_cpu_hooks(mu)
   try:
     g = util.load('f8_exchange')
@@ -157,4 +158,4 @@ def test_exchange_single_process_list_api(oracle):
       assert int(mapping[0][a]) == max(bs) == int(g['mapping'][a])
     assert np.array_equal(mapping[0].numpy(), g['mapping'])
   finally:
-    mu._segment_sums, mu._normalize = saved
+    mu._segment_sums, mu._normalize, mu._local_prototypes = saved
