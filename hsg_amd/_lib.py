@@ -38,7 +38,8 @@ class SegkmArgs(ctypes.Structure):
       ('out_labels', ctypes.c_void_p), ('out_cluster', ctypes.c_void_p),
       ('out_batch', ctypes.c_void_p), ('meta', ctypes.c_void_p),
       ('out_norms', ctypes.c_void_p), ('out_rowmap', ctypes.c_void_p),
-      ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t)]
+      ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t),
+      ('seed_batch_stride', ctypes.c_int64)]
 
 
 class LossSet(ctypes.Structure):

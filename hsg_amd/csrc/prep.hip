@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void prep_kernel(
     const float *__restrict__ in, int C, int64_t HW, int ntiles,
     const float *__restrict__ loc, int64_t loc_sb, const int64_t *__restrict__ labels,
     int has_ignore, int64_t ignore, const int32_t *__restrict__ tile_off,
-    const int64_t *__restrict__ img_row0, const int32_t *__restrict__ seed_map,
+    const int64_t *__restrict__ img_row0, const int32_t *__restrict__ seed_map, int64_t seed_sb,
     float eps, float *__restrict__ emb, float *__restrict__ emb_loc,
     int64_t *__restrict__ labels_out, int32_t *__restrict__ klab,
     float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out,
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void prep_kernel(
     if (rowmap_out && pix < HW) rowmap_out[(int64_t)b * HW + pix] = row;
     if (keep) {
       labels_out[row] = lab;
-      klab[row] = seed_map[pix];
+      klab[row] = seed_map[(int64_t)b * seed_sb + pix];
       locv[2 * lane + 0] = loc[(int64_t)b * loc_sb + pix * 2 + 0];
       locv[2 * lane + 1] = loc[(int64_t)b * loc_sb + pix * 2 + 1];
     }
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(
     const float *__restrict__ in, int C, int64_t HW, int ntiles,
     const float *__restrict__ loc, int64_t loc_sb, const int64_t *__restrict__ labels,
     int has_ignore, int64_t ignore, const int32_t *__restrict__ tile_off,
-    const int64_t *__restrict__ img_row0, const int32_t *__restrict__ seed_map,
+    const int64_t *__restrict__ img_row0, const int32_t *__restrict__ seed_map, int64_t seed_sb,
     float eps, float *__restrict__ emb, float *__restrict__ emb_loc,
     int64_t *__restrict__ labels_out, int32_t *__restrict__ klab,
     float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out,
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(
     if (rowmap_out && pix < HW) rowmap_out[(int64_t)b * HW + pix] = row;
     if (keep) {
       labels_out[row] = lab;
-      klab[row] = seed_map[pix];
+      klab[row] = seed_map[(int64_t)b * seed_sb + pix];
       locv[2 * lane + 0] = loc[(int64_t)b * loc_sb + pix * 2 + 0];
       locv[2 * lane + 1] = loc[(int64_t)b * loc_sb + pix * 2 + 1];
     }
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     const float *__restrict__ in, int C, int64_t HW, int ntiles,
     const float *__restrict__ loc, int64_t loc_sb, const int64_t *__restrict__ labels,
     int has_ignore, int64_t ignore, const int32_t *__restrict__ tile_off,
-    const int64_t *__restrict__ img_row0, const int32_t *__restrict__ seed_map,
+    const int64_t *__restrict__ img_row0, const int32_t *__restrict__ seed_map, int64_t seed_sb,
     float eps, float *__restrict__ emb, float *__restrict__ emb_loc,
     int64_t *__restrict__ labels_out, int32_t *__restrict__ klab,
     float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out,
@@ -603,14 +603,14 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
       if (rowmap_out && pix < HW) rowmap_out[(int64_t)b * HW + pix] = row;
       if (keep) {
         labels_out[row] = lab;
-        klab[row] = seed_map[pix];
+        klab[row] = seed_map[(int64_t)b * seed_sb + pix];
         locv[2 * jl + 0] = loc[(int64_t)b * loc_sb + pix * 2 + 0];
         locv[2 * jl + 1] = loc[(int64_t)b * loc_sb + pix * 2 + 1];
       }
     }
     const unsigned long long mh = sh ? (m >> 32) : (m & 0xffffffffull);
     if (lane == 0) nrm1[0] = mh ? 1.0f : 0.0f;
-    if (m0on && (lane >> 5) == sh) seedl[lane & 31] = keep ? seed_map[pix] : -1;   // (fused first M-step)
+    if (m0on && (lane >> 5) == sh) seedl[lane & 31] = keep ? seed_map[(int64_t)b * seed_sb + pix] : -1;   // (fused first M-step)
   }
   __syncthreads();
   HSGK_TS(0);
@@ -859,7 +859,7 @@ int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTa
                                      (int)lds));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a.embeddings, a.C, HW, ntiles,
                      a.loc, a.loc_batch_stride, a.labels, a.has_ignore, a.ignore_index,
-                     tile_off, t.img_row0, a.seed_map, HSGK_EPS, a.out_embeddings,
+                     tile_off, t.img_row0, a.seed_map, a.seed_batch_stride, HSGK_EPS, a.out_embeddings,
                      a.out_embeddings_loc, a.out_labels, klab, a.out_norms, a.out_rowmap, xh, xt, m0v);
   HSGK_LAUNCH_CHECK();
   return 0;

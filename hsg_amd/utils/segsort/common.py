@@ -74,6 +74,34 @@ def _seed_map(num_clusters, H, W, device):
   return hit
 
 
+def _explicit_seeds(cluster_indices, B, H, W, device):
+  """Initial labels given by the caller (reference common.py:320-323, 341-345): every image's
+  map is made dense separately (`torch.unique(..., return_inverse=True)` per image) and the
+  number of clusters of an image is its number of distinct initial labels.  libhsgk runs the
+  batch with ONE cluster count, so all images must carry the same number of distinct labels
+  (an image with fewer would gain empty clusters whose zero centroids compete in the argmax,
+  which the reference's smaller table does not have)."""
+  ci = cluster_indices.detach().to(torch.int64)
+  if ci.dim() == 2:
+    ci = ci.unsqueeze(0)
+  if tuple(ci.shape[-2:]) != (H, W) or ci.shape[0] not in (1, B):
+    raise ValueError('cluster_indices must be [batch, height, width]')
+  ci = ci.to(device).expand(B, H, W).reshape(B, H * W)
+  lo = ci.min()
+  span = ci.max() - lo + 1
+  keys = (torch.arange(B, device=device).view(B, 1) * span + (ci - lo)).view(-1)
+  uniq, inv = torch.unique(keys, return_inverse=True)
+  first = torch.searchsorted(uniq, torch.arange(B, device=device) * span)          # first dense id of every image
+  counts = torch.diff(torch.cat([first, torch.tensor([uniq.shape[0]], device=device)]))
+  counts = counts.cpu().tolist()
+  if len(set(counts)) != 1:
+    raise NotImplementedError(
+        'cluster_indices with a different number of distinct labels per image (%s) are not supported'
+        % sorted(set(counts)))
+  dense = inv.view(B, H * W) - first.view(B, 1)
+  return dense.to(torch.int32).contiguous(), int(counts[0]), H * W
+
+
 def _default_loc(H, W, device):
   key = (H, W, str(device))
   with _cache_lock:
@@ -103,7 +131,7 @@ class _SegmentByKmeans(torch.autograd.Function):
   the three index outputs are not."""
 
   @staticmethod
-  def forward(ctx, x, lab, loc, loc_sb, seed_map, K, has_ignore, ign, iterations, batch_offset):
+  def forward(ctx, x, lab, loc, loc_sb, seed_map, K, has_ignore, ign, iterations, batch_offset, seed_sb):
     dev = x.device
     B, C, H, W = x.shape
     n_max = B * H * W
@@ -133,7 +161,7 @@ class _SegmentByKmeans(torch.autograd.Function):
           out_batch=out_batch.data_ptr(), meta=meta.data_ptr(),
           out_norms=norms.data_ptr() if norms is not None else None,
           out_rowmap=rowmap.data_ptr() if rowmap is not None else None,
-          workspace=ws.data_ptr(), workspace_bytes=ws_bytes)
+          workspace=ws.data_ptr(), workspace_bytes=ws_bytes, seed_batch_stride=seed_sb)
       _lib.check(L.hsgk_segment_by_kmeans(ctypes.byref(args), _lib.stream_ptr()))
       if lab is None:
         # no label map: every pixel is kept and neither data-dependent error can occur, so the
@@ -169,7 +197,7 @@ class _SegmentByKmeans(torch.autograd.Function):
           emb.data_ptr(), eloc.data_ptr(), norms.data_ptr(),
           rowmap.data_ptr() if rowmap is not None else None, B, C, H, W,
           ctypes.c_float(_lib.EPS), gx.data_ptr(), _lib.stream_ptr()))
-    return gx, None, None, None, None, None, None, None, None, None
+    return gx, None, None, None, None, None, None, None, None, None, None
 
 
 def segment_by_kmeans(embeddings,
@@ -196,14 +224,14 @@ def segment_by_kmeans(embeddings,
     raise ValueError('embeddings must be [batch, channels, height, width]')
   if embeddings.dtype != torch.float32:
     raise TypeError('embeddings must be float32')
-  if cluster_indices is not None:
-    raise NotImplementedError(
-        'explicit cluster_indices are not supported (no caller in the reference '
-        'passes them); seeds come from num_clusters')
   dev = embeddings.device
   B, C, H, W = embeddings.shape
   x = embeddings.contiguous()
-  seed_map, K = _seed_map(num_clusters, H, W, dev)
+  if cluster_indices is None:
+    seed_map, K = _seed_map(num_clusters, H, W, dev)
+    seed_sb = 0
+  else:
+    seed_map, K, seed_sb = _explicit_seeds(cluster_indices, B, H, W, dev)
 
   if local_features is None:
     loc, loc_sb = _default_loc(H, W, dev), 0
@@ -230,7 +258,7 @@ def segment_by_kmeans(embeddings,
   if batch_offset is None:
     batch_offset = _batch_offset(B, dev)
   return _SegmentByKmeans.apply(x, lab, loc, loc_sb, seed_map, K, has_ignore, ign,
-                                int(iterations), int(batch_offset))
+                                int(iterations), int(batch_offset), int(seed_sb))
 
 
 def kmeans_with_initial_labels(embeddings, initial_labels, max_label=None, iterations=10):

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HSGK_VERSION 100
+#define HSGK_VERSION 200
 #define HSGK_CHUNK 2048          /* rows per segment-sum chunk (order C2)      */
 #define HSGK_EPS 1e-12f          /* normalize_embedding eps (general/common.py:101) */
 
@@ -129,6 +129,9 @@ typedef struct hsgk_segkm_args {
   /* scratch */
   void *workspace;
   size_t workspace_bytes;
+  /* per-image seed maps (the `cluster_indices=` argument of the reference, common.py:320-323):
+   * seed label of pixel p of image b = seed_map[b * seed_batch_stride + p]; 0 = one map for all   */
+  int64_t seed_batch_stride;
 } hsgk_segkm_args;
 
 HSGK_API size_t hsgk_segment_by_kmeans_workspace_bytes(int B, int C, int H, int W, int K,

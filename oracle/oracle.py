@@ -180,8 +180,9 @@ def kmeans_with_initial_labels(embeddings, initial_labels, max_label=None,
 
 def segment_by_kmeans(embeddings, labels=None, num_clusters=(5, 5),
                       local_features=None, ignore_index=None, iterations=10,
-                      gpu_id=0, chunk=CHUNK):
-  """hsg/utils/segsort/common.py:270-408 (cluster_indices= kwarg never used).
+                      gpu_id=0, chunk=CHUNK, cluster_indices=None):
+  """hsg/utils/segsort/common.py:270-408.  cluster_indices [B,H,W]: the caller's initial labels
+  (:320-323), made dense per image (:341-345); default: the grid seeds of num_clusters.
 
   embeddings [B,C,H,W] f32; labels [B,H,W] i64 or None; local_features
   [H,W,2] or [B,H,W,2] f32 (REQUIRED here: the float32 bit patterns of
@@ -217,6 +218,9 @@ def segment_by_kmeans(embeddings, labels=None, num_clusters=(5, 5),
   off = 0
   for b in range(B):
     cnt = int(counts[b])
+    if cluster_indices is not None:
+      seeds = dense_relabel(_i64(cluster_indices)[b].reshape(-1))
+      K = int(seeds.max()) + 1
     if lab is not None and ignore_index is not None:
       keep = lab[b].reshape(-1) != int(ignore_index)
       init = seeds[keep]

@@ -52,6 +52,36 @@ def test_segment_by_kmeans_vs_golden_and_oracle(dev, oracle, case):
     assert np.array_equal(a, b), '%s: %d mismatching elements' % (name, int((a != b).sum()))
 
 
+def test_segment_by_kmeans_with_explicit_cluster_indices(dev, oracle):
+  """`cluster_indices=` (reference common.py:320-323): the caller's per-image initial labels (arbitrary
+  values, made dense per image) instead of the grid seeds -- golden from the reference, bit-exact vs the
+  oracle; maps with different label counts per image are rejected."""
+  import torch
+  from hsg_amd.utils.segsort import common as sc
+  g = util.load('f16_segkm_cluster_indices')
+  shape = tuple(int(v) for v in g['shape'])
+  seed = int(g['seed'])
+  x = synth.embeddings_nchw(seed, shape, 'mixture')
+  lab = synth.overseg_labels(int(g['label_seed']), shape[0], shape[2], shape[3], regions=5, ignore_rows=2,
+                             ignore_index=255)
+  ci = util.explicit_seed_maps(seed, shape[0], shape[2], shape[3])
+  out = sc.segment_by_kmeans(torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev), [9, 9],
+                             cluster_indices=torch.from_numpy(ci).to(dev), ignore_index=255,
+                             iterations=int(g['iters']))
+  emb, emb_loc, labels, cluster, batch = [t.cpu().numpy() for t in out]
+  assert np.array_equal(labels, g['labels']) and np.array_equal(batch, g['batch'])
+  assert np.array_equal(cluster, g['cluster'])
+  assert np.abs(emb[::util.ROW_STRIDE] - g['emb_rows']).max() <= FTOL
+  loc = util.loc_from_lin(g['ylin'], g['xlin'])
+  ref = oracle.segment_by_kmeans(x, lab, (9, 9), loc, 255, int(g['iters']), cluster_indices=ci)
+  for name, a, b in zip(('emb', 'emb_loc', 'labels', 'cluster', 'batch'), (emb, emb_loc, labels, cluster, batch), ref):
+    assert np.array_equal(a, b), name
+  bad = ci.copy()
+  bad[1][bad[1] == 40] = 3                          # image 1 now has five distinct labels, the others six
+  with pytest.raises(NotImplementedError):
+    sc.segment_by_kmeans(torch.from_numpy(x).to(dev), None, [9, 9], cluster_indices=torch.from_numpy(bad).to(dev))
+
+
 def test_explicit_local_features_match_default(dev):
   g = util.load('f4_segkm_ragged')
   x, lab, grid, ign, iters, loc = util.f4_inputs(g)

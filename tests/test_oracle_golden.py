@@ -225,3 +225,21 @@ def test_f13_dmon_affinity_graph(oracle):
   val = oracle.affinity_matrix_as_attention(x, pad, seg, 3, remove_self_loop=False, binarize=False)
   assert np.array_equal(val > 0, g['adj_val'] > 0)
   assert np.abs(val - g['adj_val']).max() <= 1e-4 * g['adj_val'].max()
+
+
+def test_segment_by_kmeans_with_explicit_cluster_indices(oracle):
+  """`cluster_indices=` (reference common.py:320-323): per-image initial labels instead of the grid seeds."""
+  g = util.load('f16_segkm_cluster_indices')
+  shape = tuple(int(v) for v in g['shape'])
+  seed = int(g['seed'])
+  x = synth.embeddings_nchw(seed, shape, 'mixture')
+  lab = synth.overseg_labels(int(g['label_seed']), shape[0], shape[2], shape[3], regions=5, ignore_rows=2,
+                             ignore_index=255)
+  ci = util.explicit_seed_maps(seed, shape[0], shape[2], shape[3])
+  loc = util.loc_from_lin(g['ylin'], g['xlin'])
+  emb, emb_loc, labels, cluster, batch = oracle.segment_by_kmeans(x, lab, (9, 9), loc, 255, int(g['iters']),
+                                                                  cluster_indices=ci)
+  assert np.array_equal(labels, g['labels']) and np.array_equal(batch, g['batch'])
+  assert np.array_equal(cluster, g['cluster'])
+  assert np.abs(emb[::util.ROW_STRIDE] - g['emb_rows']).max() <= 2e-6
+  assert np.abs(emb_loc[::util.ROW_STRIDE] - g['emb_loc_rows']).max() <= 2e-6

@@ -286,3 +286,15 @@ def segsort_inputs(seed, n=1500, C=24, B=3, K=9, M=60):
   return dict(emb=emb, emb_loc=emb_loc, cidx=cidx, sem=sem, inst=inst, bidx=bidx, protos=protos,
               psem=seg_sem, pbatch=pbatch, tags=tags, ptags=tags[pbatch], mem=mem, mem_lab=mem_lab,
               num_classes=np.int64(nc))
+
+
+def explicit_seed_maps(seed, B, H, W):
+  """Per-image initial label maps for `cluster_indices=`: diagonal stripes with a different phase and
+  arbitrary (non-dense, partly negative) label values per image, six distinct labels each."""
+  yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
+  maps = []
+  for b in range(B):
+    stripe = ((yy + 2 * xx + 5 * b) // 7) % 6
+    values = np.array([3, 40, -7, 12, 100 + b, 8], np.int64)           # image-specific, unsorted values
+    maps.append(values[stripe])
+  return np.stack(maps).astype(np.int64)

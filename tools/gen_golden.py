@@ -463,6 +463,22 @@ def f9():
     sg.gather = sg_gather
 
 
+# ---- F16 segment_by_kmeans with the caller's initial labels (cluster_indices=, common.py:320-323) ----
+def f16():
+  from tests import util as tutil
+  seed = synth.SEED_BASE + 97
+  shape, iters = (3, 32, 24, 30), 6
+  x = synth.embeddings_nchw(seed, shape, 'mixture')
+  lab = synth.overseg_labels(seed + 7, shape[0], shape[2], shape[3], regions=5, ignore_rows=2, ignore_index=255)
+  ci = tutil.explicit_seed_maps(seed, *shape[0:1], shape[2], shape[3])
+  out = ref_segment_by_kmeans(torch.from_numpy(x), torch.from_numpy(lab), [9, 9],
+                              cluster_indices=torch.from_numpy(ci), ignore_index=255, iterations=iters)
+  emb, emb_loc, labels, cidx, bidx = out
+  save('f16_segkm_cluster_indices', seed=seed, shape=np.array(shape), iters=iters, label_seed=seed + 7,
+       ylin=lin01(shape[2]), xlin=lin01(shape[3]), labels=labels.numpy(), cluster=cidx.numpy(), batch=bidx.numpy(),
+       emb_rows=emb.numpy()[::ROW_STRIDE].copy(), emb_loc_rows=emb_loc.numpy()[::ROW_STRIDE].copy())
+
+
 # ---- F14 one WHOLE training step around a stub backbone ----------------------------
 def f14():
   """tests/util.run_train_step with the reference's own modules on CPU: MultiviewResnetFcn's
@@ -537,6 +553,6 @@ def f15():
 
 if __name__ == '__main__':
   os.makedirs(OUT, exist_ok=True)
-  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13', 'f14', 'f15']
+  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13', 'f14', 'f15', 'f16']
   for w in which:
     globals()[w]()
