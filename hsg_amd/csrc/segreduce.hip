@@ -34,7 +34,7 @@ struct SegWin { int64_t lmin; int64_t lmax; int32_t ndist; int32_t slow; };
 template <int VEC, int UNROLL>
 __global__ __launch_bounds__(256) void segreduce_chunk_kernel(
     const float *__restrict__ x, int64_t n, int d, const int64_t *__restrict__ labels,
-    int64_t P, int rmax, int rlds, float *__restrict__ partial, SegWin *__restrict__ win,
+    int64_t P, int rmax, int rlds, int tab_floats, float *__restrict__ partial, SegWin *__restrict__ win,
     int64_t *__restrict__ seg_ids, int32_t *__restrict__ status) {
   extern __shared__ float sums[];   // [rlds][DS], the row list, the bitmap, its prefix, the slots
   __shared__ int wcount[4];
@@ -43,10 +43,12 @@ __global__ __launch_bounds__(256) void segreduce_chunk_kernel(
   const int c = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int DS = (d + VEC - 1) / VEC * VEC;
-  uint32_t *rlist = reinterpret_cast<uint32_t *>(sums + rlds * DS);      // [HSGK_CHUNK]
-  uint32_t *bits = rlist + HSGK_CHUNK;                                    // [kSegBitWords]
+  uint32_t *rlist = reinterpret_cast<uint32_t *>(sums + tab_floats);     // [HSGK_CHUNK]; tab_floats >= rlds * DS
+  int16_t *slots = reinterpret_cast<int16_t *>(rlist + HSGK_CHUNK);       // [HSGK_CHUNK]
+  // the presence bitmap and its prefix are only needed until the slots are known: they live in the
+  // (not yet zeroed) sum table, which keeps the workgroup at <= 78 KiB for 64 table rows of d = 258
+  uint32_t *bits = reinterpret_cast<uint32_t *>(sums);                    // [kSegBitWords]
   int32_t *wpre = reinterpret_cast<int32_t *>(bits + kSegBitWords);       // [kSegBitWords]
-  int16_t *slots = reinterpret_cast<int16_t *>(wpre + kSegBitWords);      // [HSGK_CHUNK]
   const int64_t row0 = (int64_t)c * HSGK_CHUNK;
   const int nrows = (int)((n - row0) < HSGK_CHUNK ? (n - row0) : HSGK_CHUNK);
   const int64_t *lab = labels + row0;
@@ -349,10 +351,10 @@ int hsgk_segment_reduce(const float *x, int64_t n, int d, const int64_t *labels,
 
   const bool wide = d >= 256;
   const int DS = wide ? (d + 3) / 4 * 4 : d;
-  const size_t list_bytes = (size_t)HSGK_CHUNK * (4 + 2) + (size_t)kSegBitWords * 4 * 2;   // row list, slots, bitmap, prefix
+  const size_t list_bytes = (size_t)HSGK_CHUNK * (4 + 2);      // row list, slots (bitmap + prefix alias the table)
   // table rows per pass: two workgroups per CU when that still covers a useful
   // window, otherwise one workgroup with the whole LDS
-  const int rl2 = (int)((76 * 1024 - list_bytes) / ((size_t)DS * 4));
+  const int rl2 = (int)((78 * 1024 - list_bytes) / ((size_t)DS * 4));
   const int rl1 = (int)((150 * 1024 - list_bytes) / ((size_t)DS * 4));
   // (chunks of image-major rows with sorted ids hold a few dozen distinct ids: 32 table rows per pass
   //  are worth the second workgroup per CU; a chunk with more takes further passes over its rows)
@@ -360,12 +362,14 @@ int hsgk_segment_reduce(const float *x, int64_t n, int d, const int64_t *labels,
   if (rlds > rmax) rlds = rmax;
   if (rlds > 1024) rlds = 1024;
   HSGK_REQUIRE(rlds >= 1, "row too long for the LDS segment table");
+  size_t tab_bytes = (size_t)rlds * DS * 4;
+  if (tab_bytes < (size_t)kSegBitWords * 8) tab_bytes = (size_t)kSegBitWords * 8;      // room for the bitmap + prefix
   if (nch > 0) {
     auto kern = wide ? segreduce_chunk_kernel<4, 16> : segreduce_chunk_kernel<1, 16>;
-    const size_t lds = (size_t)rlds * DS * 4 + list_bytes;
+    const size_t lds = tab_bytes + list_bytes;
     HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(158 * 1024)));
-    hipLaunchKernelGGL(kern, dim3(nch), dim3(256), lds, s, x, n, d, labels, P, rmax, rlds, partial,
+    hipLaunchKernelGGL(kern, dim3(nch), dim3(256), lds, s, x, n, d, labels, P, rmax, rlds, (int)(tab_bytes / 4), partial,
                        win, seg_ids, status);
     HSGK_LAUNCH_CHECK();
   }
