@@ -656,6 +656,23 @@ def test_small_maps_fused_and_per_kernel_routes_vs_oracle(dev, oracle, monkeypat
       assert np.array_equal(a, b), '%s: %d mismatching elements' % (name, int((a != b).sum()))
 
 
+@pytest.mark.parametrize('iters', [1, 2, 5])
+def test_small_maps_fused_route_with_first_mstep_from_prep(dev, oracle, monkeypatch, iters):
+  """The fused per-image Lloyd kernel starting from the sums the PREP kernel left for the seed labels
+  (HSGK_M0=1 forces that fusion also for narrow seed cells): its first iteration then skips the M-step."""
+  monkeypatch.setenv('HSGK_M0', '1')
+  monkeypatch.setenv('HSGK_SMALL', '1')
+  shape, grid = (3, 256, 24, 30), (2, 3)
+  B, C, H, W = shape
+  x = synth.embeddings_nchw(synth.SEED_BASE + 123, shape, 'iid')
+  lab = synth.overseg_labels(synth.SEED_BASE + 9, B, H, W, regions=3, ignore_rows=1)
+  loc = oracle.generate_location_features((H, W)) - np.float32(0.5)
+  got = _run_segkm(dev, x, lab, grid, 255, iters)
+  ref = oracle.segment_by_kmeans(x, lab, grid, loc, 255, iters)
+  for name, a, b in zip(('emb', 'emb_loc', 'labels', 'cluster', 'batch'), got, ref):
+    assert np.array_equal(a, b), '%s: %d mismatching elements' % (name, int((a != b).sum()))
+
+
 @pytest.mark.parametrize('m0', ['1', '0'])
 @pytest.mark.parametrize('shape,grid,iters', [((3, 256, 40, 56), (8, 8), 5), ((2, 128, 64, 96), (2, 3), 6),
                                               ((2, 64, 33, 47), (5, 7), 3)])
