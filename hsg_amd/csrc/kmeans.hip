@@ -1290,30 +1290,55 @@ int launch_assign_half(const float *x, const _Float16 *xm, const uint2 *xt, int 
 //   M  exact fixed-point sums (order C2x, sums_fx.hip): the rows whose label changed are added to
 //      / subtracted from an int64 [K][d] LDS table with ds_add_u64, the table is folded into the
 //      image's running sums in global memory (L2), and the same threads leave the unnormalised
-//      fp32 centroid in LDS;
-//   F  one lane per centroid walks the canonical norm chain, all threads divide -> cent (global);
+//      fp32 centroid in LDS (compact, above the engine's table planes: SmallLayout);
+//   F  one lane per centroid walks the canonical norm chain, all threads divide -> cent (global)
+//      and, from the same registers, the engine's fp16 hi / lo planes (no staging round trip);
 //   E  the fp16 filter engine (score_tiles_f16.h, hi + lo table planes) over the image's rows,
 //      ambiguous rows with their candidate sets into an LDS / global list;
 //   X  the exact fp32 chains of those candidates (exact_rescore16).
 // Same arithmetic, same labels as the per-kernel route (tests run both: HSGK_SMALL=0 / 1).
-// One CU per image bounds it: 0.29 ms instead of 0.58 for 16 x 256 x 14 x 14, 0.51 instead of
+// One CU per image bounds it: 0.24 ms instead of 0.58 for 16 x 256 x 14 x 14, 0.43 instead of
 // 0.66 for 48 x 256 x 28 x 28, slower than the per-kernel route from ~1500 rows per image on.
 // (Tried and dropped: the table as MFMA A operands in the registers of four 512-register waves,
 // rows straight from the fp16 copy as B operands, sums persistent in LDS -- every phase turned
 // latency-bound with one wave per SIMD, 0.95 ms for the 28 x 28 batch.)
 constexpr int kSmallRowsMax = 1024;       // rows per image the fused kernel accepts
 #ifdef HSGK_SMALL_TIMING                   // tools/probes/small_timing.py: cycles per phase, workgroup 0
-__device__ unsigned long long g_small_ts[8];
 #define HSGK_STS(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
     atomicAdd(&g_small_ts[i], now_ - sts_); sts_ = now_; } } while (0)
 #else
 #define HSGK_STS(i) do { } while (0)
 #endif
 
-__host__ __device__ inline size_t lloyd_small_lds_bytes(int d, int K, int NW) {
-  const size_t mstep = (size_t)K * d * 8 + 16 + (size_t)NW * 64 * 4 + (size_t)K * 4;
-  const size_t estep = half_lds_bytes<8, 2, 2, 2>(d) + (size_t)kSplitLdsList * 6 + 16;
-  return mstep > estep ? mstep : estep;
+// LDS map of the fused kernel (bytes; the whole 160 KiB of the CU, one workgroup per CU):
+//   [0, 8 K d)            int64 sums table                                   (M, flush)
+//   [8 K d + 16, ...)     per-wave changed-row lists                         (M)
+//   [fc0, fc0 + 4 K d)    unnormalised fp32 centroids, compact [K][d]        (flush -> F -> divide)
+//   [planes, fc0)         K norms right after the planes                     (F -> divide)
+//   [0, planes)           fp16 hi / lo table planes, then the row windows    (divide -> E)
+//   [tail0, 160 KiB)      LDS list of ambiguous rows                         (E -> X)
+// The fp32 centroids sit ABOVE the planes, so the divide step writes the planes straight from
+// them (no global round trip, nothing held in registers across a barrier).  Writing them while
+// the int64 table is still being read needs an order: the flush handles the table pairs whose
+// fp32 slot lies past the table first, then -- after a barrier -- the rest, whose fp32 slots
+// overwrite only pairs of the first batch (3 fc0 >= 16 K d, checked by small_layout_ok).
+struct SmallLayout { int planes, nrm0, fc0, tail0, total, p1; };
+__host__ __device__ inline SmallLayout small_layout(int d, int K) {
+  SmallLayout L;
+  L.total = 160 * 1024;
+  L.tail0 = (L.total - (kSplitLdsList * 6 + 16)) & ~15;
+  L.fc0 = (L.tail0 - 4 * K * d) & ~15;
+  L.planes = 2 * 64 * (half_main_cols(d) + 16 + 8) * 2;
+  L.nrm0 = L.planes;
+  const int over = 8 * K * d - L.fc0;                  // bytes of the table the fp32 array overlaps
+  L.p1 = over > 0 ? (over + 7) / 8 : 0;                // first table pair whose fp32 slot is past the table
+  return L;
+}
+__host__ __device__ inline bool small_layout_ok(int d, int K, int NW) {
+  const SmallLayout L = small_layout(d, K);
+  const int pairs = K * d / 2;
+  return ((K * d) & 1) == 0 && L.fc0 >= L.nrm0 + K * 4 && L.fc0 / 16 >= L.p1 && L.p1 <= pairs &&
+         (int)half_lds_bytes<8, 2, 2, 2>(d) <= L.tail0 && 8 * K * d + 16 + NW * 64 * 4 <= L.tail0;
 }
 
 template <int NW, int DEPTH, int NV>
@@ -1327,13 +1352,14 @@ __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
   const int64_t r0 = img_row0[b];
   const int n = (int)(img_row0[b + 1] - r0);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const SmallLayout L = small_layout(d, K);
   // phase M / F view of the LDS
   unsigned long long *tab = reinterpret_cast<unsigned long long *>(lds_raw);            // [K][d]
-  float *ftab = reinterpret_cast<float *>(lds_raw);                                     // fp32 value of slot i at [2 i]
   uint32_t *lists = reinterpret_cast<uint32_t *>(tab + (size_t)K * d + 2);              // [NW][64]
-  float *nrm = reinterpret_cast<float *>(lists + NW * 64);                              // [K]
+  float *fc = reinterpret_cast<float *>(lds_raw + L.fc0);                               // [K][d] fp32
+  float *nrm = reinterpret_cast<float *>(lds_raw + L.nrm0);                             // [K]
   // phase E / X view
-  unsigned char *etail = lds_raw + half_lds_bytes<8, 2, 2, 2>(d);
+  unsigned char *etail = lds_raw + L.tail0;
   int *qnp = reinterpret_cast<int *>(etail);                                            // [0] LDS-list length
   uint32_t *qcand = reinterpret_cast<uint32_t *>(etail + 16);                           // [kSplitLdsList]
   uint16_t *qpx = reinterpret_cast<uint16_t *>(qcand + kSplitLdsList);
@@ -1353,14 +1379,15 @@ __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
   unsigned long long sts_ = __builtin_readcyclecounter();
 #endif
 
+  auto zero_table = [&]() {
+    const int tot2 = (K * d + 1) / 2;
+    u64x2 *t2 = reinterpret_cast<u64x2 *>(tab);
+    for (int i = tid; i < tot2; i += NW * 64) t2[i] = u64x2{0ull, 0ull};
+  };
   for (int it = 0; it < iterations && n > 0; ++it) {
     // ---------------------------------------------------------------- M: exact sums of the changed rows
     const bool skip_m = it == 0 && first_sums_ready;
-    {
-      const int tot2 = (K * d + 1) / 2;
-      u64x2 *t2 = reinterpret_cast<u64x2 *>(tab);
-      for (int i = tid; i < tot2; i += NW * 64) t2[i] = u64x2{0ull, 0ull};
-    }
+    zero_table();
     __syncthreads();
     if (!skip_m) {
       for (int st = w; st * 64 < n; st += NW) {
@@ -1441,25 +1468,39 @@ __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
     __syncthreads();
     HSGK_STS(0);
     { int32_t *t = cur; cur = prev; prev = t; }      // the sums now hold `prev`; the E-step writes `cur`
-    // running sums += table; unnormalised fp32 centroid into the low word of the same slot.
-    // Eight independent L2 loads per thread in flight (a load-use loop would expose one L2 round
-    // trip per element: 32 of them per thread and iteration).
+    // running sums += table -> global (L2) and, as one fp32 rounding of the sum, the compact
+    // array above the planes.  Two slots per 16-byte access, twelve independent L2 loads per
+    // thread in flight; the pairs whose fp32 slot lies past the table go first (see SmallLayout).
     {
-      const int total = K * d;
-      for (int i0 = tid; i0 < total; i0 += 8 * NW * 64) {
-        long long g[8];
+      typedef long long i64x2 __attribute__((ext_vector_type(2), aligned(8)));
+      constexpr int FU = 12;
+      constexpr float kInvScale = 9.094947017729282e-13f;   // 2^-40, one rounding (finalize_fx_kernel)
+      const int pairs = (K * d) >> 1;
+      auto batch = [&](int pbeg, int pend) {
+        for (int p0 = pbeg + tid; p0 < pend; p0 += FU * NW * 64) {
+          i64x2 g[FU];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) g[u] = sq[min(i0 + u * NW * 64, total - 1)];
+          for (int u = 0; u < FU; ++u)
+            g[u] = *reinterpret_cast<const i64x2 *>(sq + 2 * (size_t)min(p0 + u * NW * 64, pend - 1));
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int i = i0 + u * NW * 64;
-          if (i < total) {
-            const long long tv = (long long)tab[i];
-            const long long v = g[u] + tv;
-            if (tv) sq[i] = v;
-            ftab[2 * i] = (float)v * 9.094947017729282e-13f;      // 2^-40, one rounding (finalize_fx_kernel)
+          for (int u = 0; u < FU; ++u) {
+            const int p = p0 + u * NW * 64;
+            if (p < pend) {
+              const u64x2 tv = *reinterpret_cast<const u64x2 *>(tab + 2 * (size_t)p);
+              const i64x2 v = {g[u].x + (long long)tv.x, g[u].y + (long long)tv.y};
+              if (tv.x | tv.y) *reinterpret_cast<i64x2 *>(sq + 2 * (size_t)p) = v;
+              *reinterpret_cast<float2 *>(fc + 2 * (size_t)p) = float2{(float)v.x * kInvScale, (float)v.y * kInvScale};
+            }
           }
         }
+      };
+      // (requesting the sums of both batches up front -- one L2 round trip instead of two -- costs
+      // 96 registers at this point of a kernel that has ~50 to spare: 150 spilled, slower)
+      batch(L.p1, pairs);
+      if (L.p1 > 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // (LDS order only)
+        batch(0, L.p1);
       }
     }
     __syncthreads();
@@ -1467,33 +1508,55 @@ __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
     // ---------------------------------------------------------------- F: norm chain, divide
     // one lane per centroid walks the canonical chain; its LDS reads are issued 16 at a time
     if (tid < K) {
-      const float *r = ftab + (size_t)2 * tid * d;
+      const float *r = fc + (size_t)tid * d;
       float ss = 0.0f;
       int i = 0;
       for (; i + 16 <= d; i += 16) {
         float v[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = r[2 * (i + u)];
+        for (int u = 0; u < 16; ++u) v[u] = r[i + u];
 #pragma unroll
         for (int u = 0; u < 16; ++u) ss = fmaf(v[u], v[u], ss);
       }
-      for (; i < d; ++i) ss = fmaf(r[2 * i], r[2 * i], ss);
+      for (; i < d; ++i) ss = fmaf(r[i], r[i], ss);
       float nv = sqrtf(ss);
       if (!(nv >= eps)) nv = eps;
       nrm[tid] = nv;
     }
+    if (tid == 0) qnp[0] = 0;
     __syncthreads();
-    for (int k = w; k < K; k += NW) {
-      const float nv = nrm[k];
-      for (int i = lane; i < d; i += 64) ct[(size_t)k * d + i] = ftab[2 * ((size_t)k * d + i)] / nv;
+    // divide: wave w owns the table rows w + NW*u, a lane the column pairs lane + 64*i (d is even:
+    // half_shape_ok) -> cent (global: the exact chains, the caller) and the engine's fp16 hi / lo
+    // planes (zero padded to 64 rows and to the plane row length), which no longer overlap `fc`
+    {
+      const int dp = d >> 1, RS2 = (half_main_cols(d) + 16 + 8) >> 1;
+      uint32_t *ch32 = reinterpret_cast<uint32_t *>(lds_raw);
+      uint32_t *cl32 = ch32 + 64 * RS2;
+      for (int k = w; k < 64; k += NW) {
+        const bool live = k < K;
+        const float nv = nrm[min(k, K - 1)];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {                           // 3 x 64 pairs >= RS2 (d <= 322)
+          const int pr = lane + 64 * i;
+          if (pr < RS2) {
+            uint32_t hi = 0u, lo = 0u;
+            if (live && pr < dp) {
+              const float2 f = *reinterpret_cast<const float2 *>(fc + (size_t)k * d + 2 * pr);
+              const float2 c = float2{f.x / nv, f.y / nv};
+              *reinterpret_cast<float2 *>(ct + (size_t)k * d + 2 * pr) = c;
+              f16_split2(c.x, c.y, hi, lo);
+            }
+            ch32[k * RS2 + pr] = hi;
+            cl32[k * RS2 + pr] = lo;
+          }
+        }
+      }
     }
-    if (tid == 0) qnp[0] = 0;                       // (past the table: not part of the M / F view)
-    __syncthreads();
     HSGK_STS(2);
     // ---------------------------------------------------------------- E: fp16 filter over the image's rows
     {
       HalfWideEpi<2, true> epi{K, n, b, r0, 0.0f, cur, qpx, qcand, qnp, gq, gc};
-      score_tiles_half<NW, DEPTH, HalfWideEpi<2, true>, 2, 2, 2>(xm, xt, d, ct, K, r0, n, lds_raw, epi, true);
+      score_tiles_half<NW, DEPTH, HalfWideEpi<2, true>, 2, 2, 2>(xm, xt, d, ct, K, r0, n, lds_raw, epi, false);
     }
     __syncthreads();
     HSGK_STS(3);
@@ -1523,17 +1586,16 @@ __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
 
 #ifdef HSGK_SMALL_TIMING
 extern "C" __attribute__((visibility("default"))) int hsgk_debug_small_timing(unsigned long long *out) {
-  unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long h[12], z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_small_ts), sizeof(h)) != hipSuccess) return -1;
-  for (int i = 0; i < 8; ++i) out[i] = h[i];
+  for (int i = 0; i < 12; ++i) out[i] = h[i];
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_small_ts), z, sizeof(z));
   return 0;
 }
 #endif
 
 bool lloyd_small_eligible(int d, int K, int64_t rows_per_image) {
-  return assign_half_eligible(d, K) && rows_per_image <= kSmallRowsMax && d <= 515 &&
-         lloyd_small_lds_bytes(d, K, 8) <= 160 * 1024;
+  return assign_half_eligible(d, K) && rows_per_image <= kSmallRowsMax && small_layout_ok(d, K, 8);
 }
 
 // lab_a: current labels (in / out), lab_b: the labels the sums hold (-1: row not added yet);
@@ -1544,7 +1606,7 @@ int launch_lloyd_small(const float *x, const _Float16 *xm, const uint2 *xt, int 
   if (B <= 0 || iterations <= 0) return 0;
   constexpr int NW = 8;
   const bool deep = ((d / 64) & 3) == 0;
-  const size_t lds = lloyd_small_lds_bytes(d, K, NW);
+  const size_t lds = (size_t)small_layout(d, K).total;
   HSGK_CHECK_HIP(hipMemsetAsync(qcount, 0, sizeof(int32_t) * B, s));
   auto go = [&](auto kern) -> int {
     HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),

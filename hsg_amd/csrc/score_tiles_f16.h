@@ -93,6 +93,47 @@ __host__ __device__ inline bool half_wide_shape_ok(int d) {
   return d >= 128 && d <= 450 && (nfull & 1) == 0 && d - nfull * 64 <= 2;
 }
 
+// The table planes written from registers (a caller that has just produced the table rows in
+// LDS / registers skips the global round trip of the engine's own staging and then passes
+// stage_table = false).  Same layout, same row ownership as the staging loop of
+// score_tiles_half: wave w owns table rows w + NW*u, lane l the column pairs l + 64*i;
+// cv[u][i] = the two fp32 values of that pair (anything where the row or pair is out of range).
+// d <= 322 (half_shape_ok): three pairs per lane cover a plane row.  The caller separates this
+// from the last read of whatever the plane region held before with a workgroup barrier.
+constexpr int kHalfRegPairs = 3;
+template <int NW, int MB = 2, int PLANES = 2>
+__device__ __forceinline__ void half_planes_from_regs(unsigned char *lds_raw, int d, int kvalid,
+                                                      const float2 (&cv)[32 * MB / NW][kHalfRegPairs]) {
+  constexpr int TR = 32 * MB;
+  const int DM = half_main_cols(d), RS = DM + 16 + 8, RS2 = RS >> 1, dp = d >> 1;
+  uint32_t *ch32 = reinterpret_cast<uint32_t *>(lds_raw);
+  uint32_t *cl32 = ch32 + (PLANES == 2 ? TR * RS2 : 0);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int u = 0; u < TR / NW; ++u) {
+    const int k = w + NW * u;
+    const bool live = k < kvalid;
+#pragma unroll
+    for (int i = 0; i < kHalfRegPairs; ++i) {
+      const int pr = lane + 64 * i;
+      if (pr < RS2) {
+        uint32_t hi = 0u, lo = 0u;
+        if (live && pr < dp) f16_split2(cv[u][i].x, cv[u][i].y, hi, lo);
+        ch32[k * RS2 + pr] = hi;
+        if constexpr (PLANES == 2) cl32[k * RS2 + pr] = lo;
+      }
+    }
+  }
+}
+
+#ifdef HSGK_SMALL_TIMING                   // tools/probes/small_timing.py: cycles per phase, workgroup 0
+__device__ unsigned long long g_small_ts[12];
+#define HSGK_ETS(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
+    atomicAdd(&g_small_ts[i], now_ - ets_); ets_ = now_; } } while (0)
+#else
+#define HSGK_ETS(i) do { } while (0)
+#endif
+
 // Epi(tile, acc, err): lane (j, h) holds acc[m][r] = approximate score of table row
 // m*32 + (r&3) + 8*(r>>2) + 4*h for row tile*NW*32 + w*32 + j of the pass, and err =
 // the measured rounding error of that row's copy.
@@ -123,58 +164,22 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int j = lane & 31, g = lane >> 5;
-
-  // ---- table block -> fp16 hi / lo planes (zero padded); a persistent caller
-  //      skips this while consecutive passes use the same table
-  if (stage_table) {
-    __syncthreads();                       // nobody still reads the previous table
-    // A wave converts whole table rows: lanes = column pairs (d is even, rows are 8-byte aligned:
-    // one 8-byte load, one packed hi and one packed lo dword per pair), four rows of loads in flight;
-    // the padding pairs of a row and the rows past kvalid are zeroed by the same lanes.  (The first
-    // version -- one element per thread with a division by d and 2-byte LDS stores -- took 11 us of
-    // the 29 us this kernel needs for a 256-row batch.)
-    uint32_t *ch32 = reinterpret_cast<uint32_t *>(chs);
-    uint32_t *cl32 = reinterpret_cast<uint32_t *>(cls);
-    const int RS2 = RS >> 1, dp = d >> 1;                     // dwords per table row, column pairs per row
-    constexpr int PPL = 4;                                    // pairs per lane and row (d <= 512)
-    for (int k0 = w; k0 < TR; k0 += 4 * NW) {
-      float2 v[4][PPL];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int k = min(k0 + u * NW, kvalid - 1);
-#pragma unroll
-        for (int i = 0; i < PPL; ++i)
-          v[u][i] = *reinterpret_cast<const float2 *>(table + (int64_t)k * d + 2 * min(lane + 64 * i, dp - 1));
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int k = k0 + u * NW;
-        if (k < TR) {
-          const bool live = k < kvalid;
-#pragma unroll
-          for (int i = 0; i < PPL; ++i) {
-            const int pr = lane + 64 * i;
-            if (pr < RS2) {
-              uint32_t hi = 0u, lo = 0u;
-              if (live && pr < dp) f16_split2(v[u][i].x, v[u][i].y, hi, lo);
-              ch32[k * RS2 + pr] = hi;
-              if constexpr (PLANES == 2) cl32[k * RS2 + pr] = lo;
-            }
-          }
-        }
-      }
-    }
-  }
+#ifdef HSGK_SMALL_TIMING
+  unsigned long long ets_ = __builtin_readcyclecounter();
+#endif
 
   const int nfull = DM / KC;
   const int tcol0 = DM;
   const bool has_tail = d > DM;                   // <= 2 tail columns (half_shape_ok), fed from xt
-  const int ntile = (nrows + TPX - 1) / TPX;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  // tiles of THIS wave: a wave whose 32 rows of the (partial) last tile all lie past nrows stops
+  // one tile early (no workgroup barrier below; with two waves per SIMD the other one then has
+  // the matrix pipe to itself)
+  const int ntile = max(0, (nrows - wu * 32 + TPX - 1) / TPX);
   const int nsteps = ntile * nfull;
 
   uint16_t *xw = xs + w * (NBUF * 32 * XSB);
   const int lpx = lane >> 4, lf = lane & 15;
-  const int wu = __builtin_amdgcn_readfirstlane(w);
 
   // ---- the row stream: explicit loads, explicit counted waits -----------------
   // Loads return in order, so "wait for the oldest of DEPTH sets" is s_waitcnt
@@ -301,25 +306,77 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
     else epi(tile, acc, __uint_as_float(tw.y));
   };
 
+  // DEPTH register sets rotate, each loaded DEPTH chunks (4 KiB per wave each) ahead
+  // of its use; nfull % DEPTH == 0 (half_shape_ok + the launcher's choice), so a tile
+  // always ends on the last set and there is ONE epilogue site.  The first sets are requested
+  // before the table is staged: they do not depend on it (measured neutral so far: the staging
+  // loads queue behind them).
+  static_assert(DEPTH == 2 || DEPTH == 4, "prefetch depth");
+  uint2 preA[LOADS], preB[LOADS], preC[DEPTH == 4 ? LOADS : 1], preD[DEPTH == 4 ? LOADS : 1];
+  if (nsteps > 0) {
+    load_next(preA);
+    load_next(preB);
+    if constexpr (DEPTH == 4) {
+      load_next(preC);
+      load_next(preD);
+    }
+  }
+
+  // ---- table block -> fp16 hi / lo planes (zero padded); a persistent caller
+  //      skips this while consecutive passes use the same table
+  if (stage_table) {
+    // nobody still reads the previous table.  A bare barrier: only LDS reads are ordered here
+    // (the caller has made the table itself visible), and __syncthreads() would also wait for the
+    // row loads requested above.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // A wave converts whole table rows: lanes = column pairs (d is even, rows are 8-byte aligned:
+    // one 8-byte load, one packed hi and one packed lo dword per pair), four rows of loads in flight;
+    // the padding pairs of a row and the rows past kvalid are zeroed by the same lanes.  (The first
+    // version -- one element per thread with a division by d and 2-byte LDS stores -- took 11 us of
+    // the 29 us this kernel needs for a 256-row batch.)
+    uint32_t *ch32 = reinterpret_cast<uint32_t *>(chs);
+    uint32_t *cl32 = reinterpret_cast<uint32_t *>(cls);
+    const int RS2 = RS >> 1, dp = d >> 1;                     // dwords per table row, column pairs per row
+    constexpr int PPL = 4;                                    // pairs per lane and row (d <= 512)
+    for (int k0 = w; k0 < TR; k0 += 4 * NW) {
+      float2 v[4][PPL];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = min(k0 + u * NW, kvalid - 1);
+#pragma unroll
+        for (int i = 0; i < PPL; ++i)
+          v[u][i] = *reinterpret_cast<const float2 *>(table + (int64_t)k * d + 2 * min(lane + 64 * i, dp - 1));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u * NW;
+        if (k < TR) {
+          const bool live = k < kvalid;
+#pragma unroll
+          for (int i = 0; i < PPL; ++i) {
+            const int pr = lane + 64 * i;
+            if (pr < RS2) {
+              uint32_t hi = 0u, lo = 0u;
+              if (live && pr < dp) f16_split2(v[u][i].x, v[u][i].y, hi, lo);
+              ch32[k * RS2 + pr] = hi;
+              if constexpr (PLANES == 2) cl32[k * RS2 + pr] = lo;
+            }
+          }
+        }
+      }
+    }
+  }
+
   // A visible full wait: the staging loads above are consumed under per-lane conditions,
   // so on paths where a consumer block is skipped the compiler's model keeps them
   // "pending" -- and would protect their registers (reused for the accumulators) with
   // vmcnt(0) waits inside the streaming loop, draining the prefetch queue.
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();                         // table planes visible to all waves
+  HSGK_ETS(5);
   zero_acc();
-  // DEPTH register sets rotate, each loaded DEPTH chunks (4 KiB per wave each) ahead
-  // of its use; nfull % DEPTH == 0 (half_shape_ok + the launcher's choice), so a tile
-  // always ends on the last set and there is ONE epilogue site.
-  static_assert(DEPTH == 2 || DEPTH == 4, "prefetch depth");
-  uint2 preA[LOADS], preB[LOADS], preC[DEPTH == 4 ? LOADS : 1], preD[DEPTH == 4 ? LOADS : 1];
-  if (nsteps <= 0) return;              // (uniform; callers pass nrows > 0)
-  load_next(preA);
-  load_next(preB);
-  if constexpr (DEPTH == 4) {
-    load_next(preC);
-    load_next(preD);
-  }
+  if (nsteps <= 0) return;              // (wave-uniform)
   uint2 tailv = {0u, 0u};
   u32x4 auxv = {0u, 0u, 0u, 0u};
 #define HSGK_HALF_STEP(BUF, PRE, QQ)                                          \
@@ -349,6 +406,7 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
     finish_tile(tile, tailv, auxv);
     zero_acc();
   }
+  HSGK_ETS(6);
   // drain the look-ahead sets; naming them keeps their registers reserved until here
   HSGK_VMWAIT8(0, preA);
   HSGK_VMWAIT8(0, preB);
@@ -356,6 +414,7 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
     HSGK_VMWAIT8(0, preC);
     HSGK_VMWAIT8(0, preD);
   }
+  HSGK_ETS(7);
 #undef HSGK_HALF_STEP
 #undef HSGK_VMWAIT8
 }

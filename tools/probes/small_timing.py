@@ -9,7 +9,7 @@ L = _lib.lib()
 dev = torch.device('cuda:0')
 for shape in ((48, 256, 28, 28), (16, 256, 14, 14), (48, 256, 56, 56)):
   x = torch.randn(shape, device=dev)
-  out = (ctypes.c_ulonglong * 8)()
+  out = (ctypes.c_ulonglong * 12)()
   for _ in range(2):
     sc.segment_by_kmeans(x, None, [8, 8], iterations=10)
   torch.cuda.synchronize()
@@ -17,8 +17,8 @@ for shape in ((48, 256, 28, 28), (16, 256, 14, 14), (48, 256, 56, 56)):
   sc.segment_by_kmeans(x, None, [8, 8], iterations=10)
   torch.cuda.synchronize()
   L.hsgk_debug_small_timing(out)
-  names = ['M update', 'flush + fp32', 'F chain + divide', 'E filter', 'X exact chains']
-  tot = sum(out)
+  names = ['M update', 'flush + fp32', 'F chain + divide', 'E filter', 'X exact chains', '  E: staging', '  E: tiles', '  E: drain']
+  tot = sum(out[:5])
   print(shape, 'total %.1f us (100 MHz counter) for 10 iterations' % (tot / 100.0))
   for nme, v in zip(names, out):
     print('   %-18s %7.1f us  %5.1f %%' % (nme, v / 100.0, 100.0 * v / max(tot, 1)))
