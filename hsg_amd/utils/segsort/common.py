@@ -139,36 +139,58 @@ class _SegmentByKmeans(torch.autograd.Function):
     xd = x.detach()
     table_cap = B * K if lab is None else max(B * K, min(B * K * 4096, _TABLE_CAP_MAX))
     L = _lib.lib()
-    with torch.cuda.device(dev):
-      out_emb = torch.empty((n_max, C), dtype=torch.float32, device=dev)
-      out_loc = torch.empty((n_max, C + 2), dtype=torch.float32, device=dev)
-      out_lab = torch.empty((n_max,), dtype=torch.int64, device=dev)
-      out_cluster = torch.empty((n_max,), dtype=torch.int64, device=dev)
-      out_batch = torch.empty((n_max,), dtype=torch.int64, device=dev)
-      meta = torch.empty((8,), dtype=torch.int64, device=dev)
-      norms = torch.empty((n_max, 2), dtype=torch.float32, device=dev) if want_grad else None
-      rowmap = (torch.empty((n_max,), dtype=torch.int64, device=dev)
-                if want_grad and has_ignore else None)
-      ws_bytes = L.hsgk_segment_by_kmeans_workspace_bytes(B, C, H, W, K, table_cap)
-      ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-      args = _lib.SegkmArgs(
-          embeddings=xd.data_ptr(), labels=lab.data_ptr() if lab is not None else None,
-          loc=loc.data_ptr(), loc_batch_stride=loc_sb, seed_map=seed_map.data_ptr(),
-          B=B, C=C, H=H, W=W, K=K, iterations=int(iterations), has_ignore=int(has_ignore),
-          ignore_index=ign, batch_offset=batch_offset, table_cap=table_cap,
-          out_embeddings=out_emb.data_ptr(), out_embeddings_loc=out_loc.data_ptr(),
-          out_labels=out_lab.data_ptr(), out_cluster=out_cluster.data_ptr(),
-          out_batch=out_batch.data_ptr(), meta=meta.data_ptr(),
-          out_norms=norms.data_ptr() if norms is not None else None,
-          out_rowmap=rowmap.data_ptr() if rowmap is not None else None,
-          workspace=ws.data_ptr(), workspace_bytes=ws_bytes, seed_batch_stride=seed_sb)
-      _lib.check(L.hsgk_segment_by_kmeans(ctypes.byref(args), _lib.stream_ptr()))
-      if lab is None:
-        # no label map: every pixel is kept and neither data-dependent error can occur, so the
-        # row count is known on the host and the call stays asynchronous (no host sync at all)
-        m = [n_max, 0, 0, 0, 0, 0, 0, 0]
-      else:
-        m = meta.cpu().tolist()        # the operator's single host sync
+
+    def run(lab, ign, table_cap):
+      with torch.cuda.device(dev):
+        out_emb = torch.empty((n_max, C), dtype=torch.float32, device=dev)
+        out_loc = torch.empty((n_max, C + 2), dtype=torch.float32, device=dev)
+        out_lab = torch.empty((n_max,), dtype=torch.int64, device=dev)
+        out_cluster = torch.empty((n_max,), dtype=torch.int64, device=dev)
+        out_batch = torch.empty((n_max,), dtype=torch.int64, device=dev)
+        meta = torch.empty((8,), dtype=torch.int64, device=dev)
+        norms = torch.empty((n_max, 2), dtype=torch.float32, device=dev) if want_grad else None
+        rowmap = (torch.empty((n_max,), dtype=torch.int64, device=dev)
+                  if want_grad and has_ignore else None)
+        ws_bytes = L.hsgk_segment_by_kmeans_workspace_bytes(B, C, H, W, K, table_cap)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        args = _lib.SegkmArgs(
+            embeddings=xd.data_ptr(), labels=lab.data_ptr() if lab is not None else None,
+            loc=loc.data_ptr(), loc_batch_stride=loc_sb, seed_map=seed_map.data_ptr(),
+            B=B, C=C, H=H, W=W, K=K, iterations=int(iterations), has_ignore=int(has_ignore),
+            ignore_index=ign, batch_offset=batch_offset, table_cap=table_cap,
+            out_embeddings=out_emb.data_ptr(), out_embeddings_loc=out_loc.data_ptr(),
+            out_labels=out_lab.data_ptr(), out_cluster=out_cluster.data_ptr(),
+            out_batch=out_batch.data_ptr(), meta=meta.data_ptr(),
+            out_norms=norms.data_ptr() if norms is not None else None,
+            out_rowmap=rowmap.data_ptr() if rowmap is not None else None,
+            workspace=ws.data_ptr(), workspace_bytes=ws_bytes, seed_batch_stride=seed_sb)
+        _lib.check(L.hsgk_segment_by_kmeans(ctypes.byref(args), _lib.stream_ptr()))
+        if lab is None:
+          # no label map: every pixel is kept and neither data-dependent error can occur, so the
+          # row count is known on the host and the call stays asynchronous (no host sync at all)
+          m = [n_max, 0, 0, 0, 0, 0, 0, 0]
+        else:
+          m = meta.cpu().tolist()        # the operator's single host sync
+      return m, (out_emb, out_loc, out_lab, out_cluster, out_batch, norms, rowmap)
+
+    m, outs = run(lab, ign, table_cap)
+    if m[5] == 2:
+      # The label values (or their number) do not fit the library's presence table.  The final
+      # ids only depend on the ORDER of the (image, cluster, label) triples (reference
+      # common.py:398-405: two sorted `unique`s), so the call is repeated on the ranks of the
+      # distinct label values -- a monotone map -- with a table sized for them, and the label
+      # output is mapped back.  (Rare: label values >= 2^24 or thousands of distinct values.)
+      uniq, inv = torch.unique(lab, return_inverse=True)
+      D = int(uniq.numel())
+      ign_rank = D
+      if has_ignore:
+        pos = int(torch.searchsorted(uniq, torch.tensor([ign], dtype=uniq.dtype, device=dev)))
+        if pos < D and int(uniq[pos]) == ign:
+          ign_rank = pos
+      m, outs = run(inv.view(B, H, W).contiguous(), ign_rank, max(table_cap, B * K * (D + 1)))
+      if m[5] == 0:
+        outs = outs[:2] + (uniq[outs[2].clamp_(0, D - 1)],) + outs[3:]
+    out_emb, out_loc, out_lab, out_cluster, out_batch, norms, rowmap = outs
     n, err = m[0], m[5]
     if err == 1:
       raise ValueError('segment_by_kmeans: negative labels are not supported')

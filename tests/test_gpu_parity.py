@@ -82,6 +82,33 @@ def test_segment_by_kmeans_with_explicit_cluster_indices(dev, oracle):
     sc.segment_by_kmeans(torch.from_numpy(x).to(dev), None, [9, 9], cluster_indices=torch.from_numpy(bad).to(dev))
 
 
+def test_segment_by_kmeans_huge_label_values_and_many_distinct_labels(dev, oracle):
+  """Label values past the library's presence table (>= 2^24, e.g. RGB-packed panoptic ids) and more
+  distinct values than it holds: the mirror repeats the call on the ranks of the distinct values (a
+  monotone map, so the reference's sorted `unique`s give the same ids) and maps the labels back."""
+  import torch
+  from hsg_amd.utils.segsort import common as sc
+  shape = (2, 128, 24, 40)
+  x = synth.embeddings_nchw(77, shape, 'mixture')
+  small = synth.overseg_labels(78, shape[0], shape[2], shape[3], regions=6, ignore_rows=2, ignore_index=255)
+  big = np.where(small == 255, 255, small.astype(np.int64) * 1000003 + (1 << 30))     # ignore value stays 255
+  a = _run_segkm(dev, x, small, (3, 4), 255, 4)
+  b = _run_segkm(dev, x, big, (3, 4), 255, 4)
+  assert np.array_equal(b[2], a[2].astype(np.int64) * 1000003 + (1 << 30))
+  for i in (0, 1, 3, 4):
+    assert np.array_equal(a[i], b[i])
+  loc = sc._default_loc(shape[2], shape[3], dev).cpu().numpy()     # the operator's own location features
+  ref = oracle.segment_by_kmeans(x, big, (3, 4), loc, 255, 4)
+  for name, u, v in zip(('emb', 'emb_loc', 'labels', 'cluster', 'batch'), b, ref):
+    assert np.array_equal(u, v), name
+  # every pixel its own label: far more distinct values than the table's 4096 per (image, cluster)
+  many = (np.arange(shape[0] * shape[2] * shape[3], dtype=np.int64).reshape(shape[0], shape[2], shape[3]) * 7919) + (1 << 26)
+  c = _run_segkm(dev, x, many, (3, 4), None, 2)
+  ref = oracle.segment_by_kmeans(x, many, (3, 4), loc, None, 2)
+  for name, u, v in zip(('emb', 'emb_loc', 'labels', 'cluster', 'batch'), c, ref):
+    assert np.array_equal(u, v), name
+
+
 def test_explicit_local_features_match_default(dev):
   g = util.load('f4_segkm_ragged')
   x, lab, grid, ign, iters, loc = util.f4_inputs(g)
