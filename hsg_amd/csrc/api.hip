@@ -188,10 +188,6 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
   // only (|x| <= 1 bounds the integer sums).  m0_ready: the prep kernel already summed the
   // rows under their seed labels (partials in k.m0, sumq zeroed before it ran).
   const bool fx = unit_rows && fx_enabled() && k.sumq != nullptr && k.max_chunks > 0;
-  if (fx && !m0_ready) {
-    HSGK_CHECK_HIP(hipMemsetAsync(k.klab_prev, 0xFF, sizeof(int32_t) * k.rows_cap, s));
-    HSGK_CHECK_HIP(hipMemsetAsync(k.sumq, 0, sizeof(long long) * (size_t)B * K * d, s));
-  }
   // Small feature maps (training resolution): one workgroup per image runs the whole loop in one
   // launch (kmeans.hip: lloyd_small_kernel).  HSGK_SMALL = 0 / 1 forces the per-kernel / the fused
   // route (read per call, so that the tests cover both); the verify switch keeps the per-kernel route.
@@ -208,6 +204,10 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
       return launch_lloyd_small(x, k.xh, k.xt, d, K, B, iterations, k.t, k.klab, k.klab_prev, k.sumq, k.cent,
                                 k.qrows, k.q1count, m0_ready, s);
     }
+  }
+  if (fx && !m0_ready) {     // (the fused kernel above needs neither)
+    HSGK_CHECK_HIP(hipMemsetAsync(k.klab_prev, 0xFF, sizeof(int32_t) * k.rows_cap, s));
+    HSGK_CHECK_HIP(hipMemsetAsync(k.sumq, 0, sizeof(long long) * (size_t)B * K * d, s));
   }
   // The working labels ping-pong between k.klab and k.klab_prev (every E-step rewrites all
   // rows): after the sums are brought up to date with `cur`, that buffer becomes `prev` and the
@@ -368,7 +368,7 @@ size_t hsgk_segment_by_kmeans_workspace_bytes(int B, int C, int H, int W, int K,
   carve_kmeans(cv, B, HW, C + 2, K, &k);
   carve_m0(cv, B, C, ntiles, K, &k);
   cv.take<int32_t>((size_t)table_cap * 2);
-  cv.take<int32_t>((size_t)table_cap / 2048 + 2);
+  cv.take<char>(relabel_scan_bytes(table_cap));
   return cv.off + 256;
 }
 
@@ -396,7 +396,7 @@ int hsgk_segment_by_kmeans(const hsgk_segkm_args *a, hsgk_stream_t stream) {
   carve_kmeans(cv, a->B, HW, D, a->K, &k);
   carve_m0(cv, a->B, a->C, ntiles, a->K, &k);
   int32_t *table = cv.take<int32_t>((size_t)a->table_cap * 2);
-  int32_t *scan_tmp = cv.take<int32_t>((size_t)a->table_cap / 2048 + 2);
+  int32_t *scan_tmp = reinterpret_cast<int32_t *>(cv.take<char>(relabel_scan_bytes(a->table_cap)));
 
   const bool compact = a->labels != nullptr && a->has_ignore;
   const bool want_half = assign_mode() == 2 && k.xh && a->iterations >= 1;

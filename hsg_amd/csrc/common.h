@@ -167,6 +167,7 @@ int launch_lloyd_small(const float *x, const _Float16 *xm, const uint2 *xt, int 
                        const ChunkTable &t, int32_t *lab_a, int32_t *lab_b, long long *sumq, float *cent,
                        void *qrows, int32_t *qcount, bool first_sums_ready, hipStream_t s);
 
+size_t relabel_scan_bytes(int64_t table_cap);      // scratch of the chained scans (scan_tmp of launch_relabel)
 int launch_relabel(const hsgk_segkm_args &a, const ChunkTable &t, int max_chunks,
                    const int32_t *klab, int32_t *table, int32_t *scan_tmp,
                    hipStream_t s);

@@ -1384,16 +1384,20 @@ __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
     u64x2 *t2 = reinterpret_cast<u64x2 *>(tab);
     for (int i = tid; i < tot2; i += NW * 64) t2[i] = u64x2{0ull, 0ull};
   };
+  if (tid == 0) __hip_atomic_store(gc, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (first append: after barriers)
   for (int it = 0; it < iterations && n > 0; ++it) {
     // ---------------------------------------------------------------- M: exact sums of the changed rows
     const bool skip_m = it == 0 && first_sums_ready;
+    // first iteration without prepared sums: no row has been added yet (previous label -1) and the
+    // running sums are zero -- neither buffer is read, so the caller does not have to initialise them
+    const bool fresh = it == 0 && !first_sums_ready;
     zero_table();
     __syncthreads();
     if (!skip_m) {
       for (int st = w; st * 64 < n; st += NW) {
         const int rb = st * 64, nr = min(64, n - rb);
         const int rr = min(lane, nr - 1);
-        int pl = prev[r0 + rb + rr];
+        int pl = fresh ? -1 : prev[r0 + rb + rr];
         const int cl = cur[r0 + rb + rr];
         if (lane >= nr) pl = cl;
         const bool ch = pl != cl;
@@ -1481,14 +1485,14 @@ __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
           i64x2 g[FU];
 #pragma unroll
           for (int u = 0; u < FU; ++u)
-            g[u] = *reinterpret_cast<const i64x2 *>(sq + 2 * (size_t)min(p0 + u * NW * 64, pend - 1));
+            g[u] = fresh ? i64x2{0, 0} : *reinterpret_cast<const i64x2 *>(sq + 2 * (size_t)min(p0 + u * NW * 64, pend - 1));
 #pragma unroll
           for (int u = 0; u < FU; ++u) {
             const int p = p0 + u * NW * 64;
             if (p < pend) {
               const u64x2 tv = *reinterpret_cast<const u64x2 *>(tab + 2 * (size_t)p);
               const i64x2 v = {g[u].x + (long long)tv.x, g[u].y + (long long)tv.y};
-              if (tv.x | tv.y) *reinterpret_cast<i64x2 *>(sq + 2 * (size_t)p) = v;
+              if ((tv.x | tv.y) || fresh) *reinterpret_cast<i64x2 *>(sq + 2 * (size_t)p) = v;
               *reinterpret_cast<float2 *>(fc + 2 * (size_t)p) = float2{(float)v.x * kInvScale, (float)v.y * kInvScale};
             }
           }
@@ -1598,8 +1602,9 @@ bool lloyd_small_eligible(int d, int K, int64_t rows_per_image) {
   return assign_half_eligible(d, K) && rows_per_image <= kSmallRowsMax && small_layout_ok(d, K, 8);
 }
 
-// lab_a: current labels (in / out), lab_b: the labels the sums hold (-1: row not added yet);
-// sumq / cent: [B][K][d]; qrows: >= one SplitEntry per row; qcount: >= B int32.
+// lab_a: current labels (in / out), lab_b: the labels the sums hold; sumq / cent: [B][K][d];
+// qrows: >= one SplitEntry per row; qcount: >= B int32.  first_sums_ready: sumq / lab_b are valid
+// (first M-step done elsewhere); otherwise neither needs initialising, nor does qcount.
 int launch_lloyd_small(const float *x, const _Float16 *xm, const uint2 *xt, int d, int K, int B, int iterations,
                        const ChunkTable &t, int32_t *lab_a, int32_t *lab_b, long long *sumq, float *cent,
                        void *qrows, int32_t *qcount, bool first_sums_ready, hipStream_t s) {
@@ -1607,7 +1612,6 @@ int launch_lloyd_small(const float *x, const _Float16 *xm, const uint2 *xt, int 
   constexpr int NW = 8;
   const bool deep = ((d / 64) & 3) == 0;
   const size_t lds = (size_t)small_layout(d, K).total;
-  HSGK_CHECK_HIP(hipMemsetAsync(qcount, 0, sizeof(int32_t) * B, s));
   auto go = [&](auto kern) -> int {
     HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -19,7 +19,7 @@ cp /tmp/prof_k/k_kernel_stats.csv $out/${tag}_bench_kernel_stats.csv
     rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d /tmp/prof_p -o p -- \
       python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-images 0 --no-exchange --no-extra > /dev/null 2>&1
     echo "## --pmc $pmc"
-    python $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/prof_p/p_counter_collection.csv hsgk init_meta_kernel,build_tables_kernel,count_valid_kernel,table_kernel,scan_reduce_kernel,scan_apply_kernel,scan_top_kernel,decide_kernel,sum_qcount_kernel
+    python $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/prof_p/p_counter_collection.csv hsgk init_meta_kernel,build_tables_kernel,count_valid_kernel,table_kernel,scan_chained_kernel,relabel_begin_kernel,relabel_ranked_kernel,sum_qcount_kernel
   done
 } > $out/${tag}_pmc.txt 2>&1
 # training-resolution workload (the fused per-image Lloyd kernel) and the other per-GPU configs
