@@ -194,15 +194,16 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
   {
     const char *se = getenv("HSGK_SMALL");
     const int64_t rows_per_image = B > 0 ? (int64_t)(k.rows_cap / (size_t)B) : 0;
-    const bool can = fx && half && iterations >= 1 && k.q1count && lloyd_small_eligible(d, K, rows_per_image) &&
+    const bool can = fx && half && iterations >= 1 && k.q1 && lloyd_small_eligible(d, K, B, rows_per_image) &&
                      !g_verify_on.load();
     const bool want = se ? se[0] == '1' : true;
     if (can && want) {
       if (m0_ready)
         if (int rc = launch_m0_reduce(k.m0, B, k.m0_wt, d, s)) return rc;
       ProfScope p(HSGK_PROF_ASSIGN, s);
+      // (k.q1, the first level's row queue of the per-kernel route, holds the fused kernel's counters)
       return launch_lloyd_small(x, k.xh, k.xt, d, K, B, iterations, k.t, k.klab, k.klab_prev, k.sumq, k.cent,
-                                k.qrows, k.q1count, m0_ready, s);
+                                k.qrows, k.q1, m0_ready, const_cast<hsgk_segkm_meta *>(meta), rows_per_image, s);
     }
   }
   if (fx && !m0_ready) {     // (the fused kernel above needs neither)

@@ -1346,11 +1346,18 @@ __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
     const float *__restrict__ x, const _Float16 *__restrict__ xm, const uint2 *__restrict__ xt, int d, int K,
     int iterations, const int64_t *__restrict__ img_row0, int32_t *__restrict__ lab_a,
     int32_t *__restrict__ lab_b, long long *__restrict__ sumq, float *__restrict__ cent,
-    SplitEntry *__restrict__ gqueue, int32_t *__restrict__ gcount, int first_sums_ready, float eps) {
+    SplitEntry *__restrict__ gqueue, int32_t *__restrict__ gcount, int first_sums_ready, float eps,
+    int G, unsigned int *__restrict__ bar, hsgk_segkm_meta *meta) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int b = blockIdx.x;
-  const int64_t r0 = img_row0[b];
-  const int n = (int)(img_row0[b + 1] - r0);
+  // G workgroups per image (co-resident: the launcher keeps B * G within the CU count): workgroup g
+  // owns a contiguous, 32-aligned share of the image's rows for the M, E and X phases; the
+  // image's running sums are shared through device-scope atomics and a per-image tick counter.
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  const int nimg = (int)(img_row0[b + 1] - img_row0[b]);
+  const int rpw = (((nimg + G - 1) / G) + 31) & ~31;
+  const int rs = min(nimg, g * rpw);
+  const int64_t r0 = img_row0[b] + rs;             // first row of THIS workgroup
+  const int n = min(nimg, rs + rpw) - rs;          // its rows (0 for a trailing workgroup: barriers only)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const SmallLayout L = small_layout(d, K);
   // phase M / F view of the LDS
@@ -1365,8 +1372,8 @@ __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
   uint16_t *qpx = reinterpret_cast<uint16_t *>(qcand + kSplitLdsList);
   long long *sq = sumq + (int64_t)b * K * d;
   float *ct = cent + (int64_t)b * K * d;
-  SplitEntry *gq = gqueue + r0;                   // this image's overflow region (<= n entries)
-  int32_t *gc = gcount + b;
+  SplitEntry *gq = gqueue + r0;                   // this workgroup's overflow region (<= n entries)
+  int32_t *gc = gcount + blockIdx.x;
   int32_t *cur = lab_a, *prev = lab_b;
   typedef float gvec_t __attribute__((ext_vector_type(4), aligned(4)));
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
@@ -1385,7 +1392,24 @@ __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
     for (int i = tid; i < tot2; i += NW * 64) t2[i] = u64x2{0ull, 0ull};
   };
   if (tid == 0) __hip_atomic_store(gc, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (first append: after barriers)
-  for (int it = 0; it < iterations && n > 0; ++it) {
+  // tick counter of the image: every workgroup ticks twice per iteration (sums added, sums read)
+  int &bar_dead = qnp[2];                        // a wait timed out: stop waiting (the call reports error 3);
+  if (tid == 0) bar_dead = 0;                    // (in the list header: no static LDS beside the 160 KiB array)
+  auto wait_ticks = [&](unsigned int target) {
+    if (tid == 0 && !bar_dead) {
+      unsigned int spins = 0;
+      while (__hip_atomic_load(bar + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 20)) {              // ~ a second: the workgroups are not co-resident
+          if (meta) meta->error = 3;
+          bar_dead = 1;
+          break;
+        }
+      }
+    }
+    __syncthreads();
+  };
+  for (int it = 0; it < iterations && nimg > 0; ++it) {
     // ---------------------------------------------------------------- M: exact sums of the changed rows
     const bool skip_m = it == 0 && first_sums_ready;
     // first iteration without prepared sums: no row has been added yet (previous label -1) and the
@@ -1472,6 +1496,41 @@ __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
     __syncthreads();
     HSGK_STS(0);
     { int32_t *t = cur; cur = prev; prev = t; }      // the sums now hold `prev`; the E-step writes `cur`
+    if (G > 1) {
+      // several workgroups per image: (a) nobody still reads the sums of the previous iteration,
+      // (b) this workgroup's deltas go to the image's running sums with device-scope atomics
+      // (performed at the memory side: the workgroups sit on different XCDs / L2s), (c) tick, wait
+      // for the others, (d) read the sums back with device-scope loads -> fp32 array, tick.
+      constexpr float kInvScale = 9.094947017729282e-13f;   // 2^-40, one rounding (finalize_fx_kernel)
+      const int total = K * d;
+      wait_ticks(2u * (unsigned)G * (unsigned)it);
+      HSGK_STS(8);
+      for (int i = tid; i < total; i += NW * 64) {
+        const unsigned long long tv = tab[i];
+        if (tv) (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(sq) + i, tv, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __builtin_amdgcn_s_waitcnt(0);               // the atomics above have been performed
+      __syncthreads();
+      HSGK_STS(9);
+      if (tid == 0) (void)__hip_atomic_fetch_add(bar + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      wait_ticks(2u * (unsigned)G * (unsigned)it + (unsigned)G);
+      HSGK_STS(10);
+      for (int i0 = tid; i0 < total; i0 += 16 * NW * 64) {      // (memory-side loads: 16 in flight per thread)
+        long long v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          v[u] = __hip_atomic_load(sq + min(i0 + u * NW * 64, total - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int i = i0 + u * NW * 64;
+          if (i < total) fc[i] = (float)v[u] * kInvScale;
+        }
+      }
+      __syncthreads();
+      HSGK_STS(11);
+      if (tid == 0) (void)__hip_atomic_fetch_add(bar + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else
     // running sums += table -> global (L2) and, as one fp32 rounding of the sum, the compact
     // array above the planes.  Two slots per 16-byte access, twelve independent L2 loads per
     // thread in flight; the pairs whose fp32 slot lies past the table go first (see SmallLayout).
@@ -1598,26 +1657,58 @@ extern "C" __attribute__((visibility("default"))) int hsgk_debug_small_timing(un
 }
 #endif
 
-bool lloyd_small_eligible(int d, int K, int64_t rows_per_image) {
-  return assign_half_eligible(d, K) && rows_per_image <= kSmallRowsMax && small_layout_ok(d, K, 8);
+// workgroups per image: one up to 512 rows; beyond that one per 256 rows (one engine tile each), as
+// many as keep all B * G workgroups co-resident (one workgroup per CU: they wait for each other).
+// Half of the CUs at most, so that two such calls on two streams still fit side by side (two
+// half-resident grids would wait for each other's CUs; a wait that times out reports error 3).
+static int small_cu_count() {
+  static const int n = [] {
+    int dev = 0, cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      cu = 0;
+    (void)hipGetLastError();
+    return cu;
+  }();
+  return n;
+}
+int lloyd_small_groups(int B, int64_t rows_per_image) {
+  const char *fe = getenv("HSGK_SMALL_GROUPS");        // tests: force the number of workgroups per image (read per call)
+  const int forced = fe ? atoi(fe) : 0;
+  const int gmax = std::max(1, std::min(8, B > 0 ? small_cu_count() / 2 / B : 1));
+  if (forced > 0) return std::min(forced, gmax);
+  if (rows_per_image <= 512) return 1;
+  return (int)std::min<int64_t>(gmax, (rows_per_image + 255) / 256);
+}
+
+bool lloyd_small_eligible(int d, int K, int B, int64_t rows_per_image) {
+  return assign_half_eligible(d, K) && small_layout_ok(d, K, 8) &&
+         rows_per_image <= (int64_t)kSmallRowsMax * lloyd_small_groups(B, rows_per_image);
 }
 
 // lab_a: current labels (in / out), lab_b: the labels the sums hold; sumq / cent: [B][K][d];
-// qrows: >= one SplitEntry per row; qcount: >= B int32.  first_sums_ready: sumq / lab_b are valid
-// (first M-step done elsewhere); otherwise neither needs initialising, nor does qcount.
+// qrows: >= one SplitEntry per row; counters: >= B * (G + 1) int32 (per-workgroup queue counts, then
+// the per-image tick counters).  first_sums_ready: sumq / lab_b are valid (first M-step done
+// elsewhere); otherwise neither needs initialising (one workgroup per image) or sumq is zeroed here.
 int launch_lloyd_small(const float *x, const _Float16 *xm, const uint2 *xt, int d, int K, int B, int iterations,
                        const ChunkTable &t, int32_t *lab_a, int32_t *lab_b, long long *sumq, float *cent,
-                       void *qrows, int32_t *qcount, bool first_sums_ready, hipStream_t s) {
+                       void *qrows, int32_t *counters, bool first_sums_ready, hsgk_segkm_meta *meta,
+                       int64_t rows_per_image, hipStream_t s) {
   if (B <= 0 || iterations <= 0) return 0;
   constexpr int NW = 8;
   const bool deep = ((d / 64) & 3) == 0;
   const size_t lds = (size_t)small_layout(d, K).total;
+  const int G = lloyd_small_groups(B, rows_per_image);
+  unsigned int *bar = reinterpret_cast<unsigned int *>(counters + (size_t)B * G);
+  if (G > 1) {
+    HSGK_CHECK_HIP(hipMemsetAsync(bar, 0, sizeof(unsigned int) * B, s));
+    if (!first_sums_ready) HSGK_CHECK_HIP(hipMemsetAsync(sumq, 0, sizeof(long long) * (size_t)B * K * d, s));
+  }
   auto go = [&](auto kern) -> int {
     HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(B), dim3(NW * 64), lds, s, x, xm, xt, d, K, iterations, t.img_row0, lab_a,
-                       lab_b, sumq, cent, reinterpret_cast<SplitEntry *>(qrows), qcount,
-                       first_sums_ready ? 1 : 0, HSGK_EPS);
+    hipLaunchKernelGGL(kern, dim3(B * G), dim3(NW * 64), lds, s, x, xm, xt, d, K, iterations, t.img_row0, lab_a,
+                       lab_b, sumq, cent, reinterpret_cast<SplitEntry *>(qrows), counters,
+                       first_sums_ready ? 1 : 0, HSGK_EPS, G, bar, meta);
     HSGK_LAUNCH_CHECK();
     return 0;
   };

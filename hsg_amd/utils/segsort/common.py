@@ -194,6 +194,9 @@ class _SegmentByKmeans(torch.autograd.Function):
     n, err = m[0], m[5]
     if err == 1:
       raise ValueError('segment_by_kmeans: negative labels are not supported')
+    if err == 3:
+      raise _lib.HsgkError('segment_by_kmeans: the cooperating workgroups of an image were not co-resident '
+                           '(inter-workgroup wait timed out); set HSGK_SMALL_GROUPS=1')
     if err == 2:
       raise _lib.HsgkError('segment_by_kmeans: label range too large for the relabel '
                            'table (label_max=%d)' % m[3])

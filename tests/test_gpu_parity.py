@@ -683,6 +683,33 @@ def test_small_maps_fused_and_per_kernel_routes_vs_oracle(dev, oracle, monkeypat
       assert np.array_equal(a, b), '%s: %d mismatching elements' % (name, int((a != b).sum()))
 
 
+@pytest.mark.parametrize('shape,grid,iters,m0,groups', [
+    ((2, 128, 56, 56), (4, 4), 15, '0', '0'),     # the reference's own training hyper-parameters (bashscripts/*/train.sh)
+    ((2, 128, 56, 56), (4, 4), 4, '0', '5'),
+    ((5, 256, 28, 28), (8, 8), 10, '0', '0'),
+    ((5, 256, 28, 28), (8, 8), 3, '0', '3'),
+    ((2, 256, 40, 50), (8, 8), 6, '0', '8'),      # 2000 rows per image, labels + ignore: ragged shares
+    ((3, 256, 24, 30), (2, 3), 3, '1', '2'),      # sums of the first M-step come from the prep kernel
+])
+def test_small_maps_several_workgroups_per_image_vs_oracle(dev, oracle, monkeypatch, shape, grid, iters, m0, groups):
+  """The fused Lloyd kernel with several co-operating workgroups per image (each owns a share of the rows;
+  the running sums are exchanged through device-scope atomics and a per-image tick counter):
+  HSGK_SMALL_GROUPS forces the number of workgroups per image ('0': the library's choice)."""
+  monkeypatch.setenv('HSGK_SMALL', '1')
+  monkeypatch.setenv('HSGK_M0', m0)
+  if groups != '0':
+    monkeypatch.setenv('HSGK_SMALL_GROUPS', groups)
+  B, C, H, W = shape
+  x = synth.embeddings_nchw(synth.SEED_BASE + 5 * C + W, shape, 'iid')
+  loc = oracle.generate_location_features((H, W)) - np.float32(0.5)
+  for lab, ign in ((synth.overseg_labels(synth.SEED_BASE + 11, B, H, W, regions=4, ignore_rows=3), 255), (None, None)):
+    got = _run_segkm(dev, x, lab, grid, ign, iters)
+    ref = oracle.segment_by_kmeans(x, lab, grid, loc, ign, iters)
+    for name, a, b in zip(('emb', 'emb_loc', 'labels', 'cluster', 'batch'), got, ref):
+      assert a.shape == b.shape, name
+      assert np.array_equal(a, b), '%s: %d mismatching elements' % (name, int((a != b).sum()))
+
+
 @pytest.mark.parametrize('iters', [1, 2, 5])
 def test_small_maps_fused_route_with_first_mstep_from_prep(dev, oracle, monkeypatch, iters):
   """The fused per-image Lloyd kernel starting from the sums the PREP kernel left for the seed labels

@@ -17,7 +17,7 @@ for shape in ((48, 256, 28, 28), (16, 256, 14, 14), (48, 256, 56, 56)):
   sc.segment_by_kmeans(x, None, [8, 8], iterations=10)
   torch.cuda.synchronize()
   L.hsgk_debug_small_timing(out)
-  names = ['M update', 'flush + fp32', 'F chain + divide', 'E filter', 'X exact chains', '  E: staging', '  E: tiles', '  E: drain']
+  names = ['M update', 'flush + fp32', 'F chain + divide', 'E filter', 'X exact chains', '  E: staging', '  E: tiles', '  E: drain', '  fold: wait readers', '  fold: atomics', '  fold: wait writers', '  fold: read sums']
   tot = sum(out[:5])
   print(shape, 'total %.1f us (100 MHz counter) for 10 iterations' % (tot / 100.0))
   for nme, v in zip(names, out):
