@@ -1657,10 +1657,11 @@ extern "C" __attribute__((visibility("default"))) int hsgk_debug_small_timing(un
 }
 #endif
 
-// workgroups per image: one up to 512 rows; beyond that one per 256 rows (one engine tile each), as
-// many as keep all B * G workgroups co-resident (one workgroup per CU: they wait for each other).
+// workgroups per image: one up to 512 rows; beyond that one per 256 rows (one engine tile each, at
+// most kSmallGroupsMax), as many as keep all B * G workgroups co-resident (one workgroup per CU: they wait for each other).
 // Half of the CUs at most, so that two such calls on two streams still fit side by side (two
 // half-resident grids would wait for each other's CUs; a wait that times out reports error 3).
+constexpr int kSmallGroupsMax = 16;
 static int small_cu_count() {
   static const int n = [] {
     int dev = 0, cu = 0;
@@ -1674,7 +1675,7 @@ static int small_cu_count() {
 int lloyd_small_groups(int B, int64_t rows_per_image) {
   const char *fe = getenv("HSGK_SMALL_GROUPS");        // tests: force the number of workgroups per image (read per call)
   const int forced = fe ? atoi(fe) : 0;
-  const int gmax = std::max(1, std::min(8, B > 0 ? small_cu_count() / 2 / B : 1));
+  const int gmax = std::max(1, std::min(kSmallGroupsMax, B > 0 ? small_cu_count() / 2 / B : 1));
   if (forced > 0) return std::min(forced, gmax);
   if (rows_per_image <= 512) return 1;
   return (int)std::min<int64_t>(gmax, (rows_per_image + 255) / 256);

@@ -7,18 +7,18 @@ from hsg_amd import _lib
 from hsg_amd.utils.segsort import common as sc
 L = _lib.lib()
 dev = torch.device('cuda:0')
-for shape in ((48, 256, 28, 28), (16, 256, 14, 14), (48, 256, 56, 56)):
+for shape, grid, iters in (((48, 256, 28, 28), [8, 8], 10), ((16, 256, 14, 14), [8, 8], 10), ((4, 128, 56, 56), [4, 4], 15)):
   x = torch.randn(shape, device=dev)
   out = (ctypes.c_ulonglong * 12)()
   for _ in range(2):
-    sc.segment_by_kmeans(x, None, [8, 8], iterations=10)
+    sc.segment_by_kmeans(x, None, grid, iterations=iters)
   torch.cuda.synchronize()
   L.hsgk_debug_small_timing(out)
-  sc.segment_by_kmeans(x, None, [8, 8], iterations=10)
+  sc.segment_by_kmeans(x, None, grid, iterations=iters)
   torch.cuda.synchronize()
   L.hsgk_debug_small_timing(out)
   names = ['M update', 'flush + fp32', 'F chain + divide', 'E filter', 'X exact chains', '  E: staging', '  E: tiles', '  E: drain', '  fold: wait readers', '  fold: atomics', '  fold: wait writers', '  fold: read sums']
   tot = sum(out[:5])
-  print(shape, 'total %.1f us (100 MHz counter) for 10 iterations' % (tot / 100.0))
+  print(shape, grid, 'total %.1f us (100 MHz counter) for %d iterations' % (tot / 100.0, iters))
   for nme, v in zip(names, out):
     print('   %-18s %7.1f us  %5.1f %%' % (nme, v / 100.0, 100.0 * v / max(tot, 1)))
