@@ -59,6 +59,9 @@ WORKLOADS = {
     # the reference's training resolution (input / 16): fixed-cost-bound small maps
     'train28': (6, 48, 256, 28, 28, (8, 8), 10),
     'train14': (7, 16, 256, 14, 14, (4, 4), 10),
+    # the reference's own training hyper-parameters (bashscripts/*/train.sh: 128 channels, 4 x 4 clusters,
+    # 15 iterations, 448^2 crops at output stride 8, a few images per GPU)
+    'reftrain': (8, 4, 128, 56, 56, (4, 4), 15),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 PMC_FILES = ('r02_pmc.txt', 'r01_pmc.txt')
