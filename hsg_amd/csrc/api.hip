@@ -175,7 +175,8 @@ static int assign_mode() {
 // otherwise a separate pass makes it when the iteration count pays for it.
 static int lloyd(const float *x, int d, int K, int B, int iterations,
                  const KmeansScratch &k, const hsgk_segkm_meta *meta, hipStream_t s,
-                 bool unit_rows = false, bool half_ready = false, bool m0_ready = false) {
+                 bool unit_rows = false, bool half_ready = false, bool m0_ready = false,
+                 bool host_reads_meta = true) {
   const bool half_any = unit_rows && assign_mode() == 2 && k.xh && (half_ready || iterations >= 3);
   const bool half = half_any && assign_half_eligible(d, K);
   const bool wide = half_any && !half && assign_half_wide_eligible(d, K);
@@ -203,7 +204,7 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
       ProfScope p(HSGK_PROF_ASSIGN, s);
       // (k.q1, the first level's row queue of the per-kernel route, holds the fused kernel's counters)
       return launch_lloyd_small(x, k.xh, k.xt, d, K, B, iterations, k.t, k.klab, k.klab_prev, k.sumq, k.cent,
-                                k.qrows, k.q1, m0_ready, const_cast<hsgk_segkm_meta *>(meta), rows_per_image, s);
+                                k.qrows, k.q1, m0_ready, const_cast<hsgk_segkm_meta *>(meta), rows_per_image, !host_reads_meta, s);
     }
   }
   if (fx && !m0_ready) {     // (the fused kernel above needs neither)
@@ -421,7 +422,7 @@ int hsgk_segment_by_kmeans(const hsgk_segkm_args *a, hsgk_stream_t stream) {
                              want_m0 ? &k.m0 : nullptr, &m0_ready)) return rc;
   }
   if (int rc = lloyd(a->out_embeddings_loc, D, a->K, a->B, a->iterations, k, a->meta, s,
-                     /*unit_rows=*/true, half_ready, m0_ready)) return rc;
+                     /*unit_rows=*/true, half_ready, m0_ready, /*host_reads_meta=*/a->labels != nullptr)) return rc;
   {
     ProfScope p(HSGK_PROF_RELABEL, s);
     if (int rc = launch_relabel(*a, k.t, k.max_chunks, k.klab, table, scan_tmp, s)) return rc;

@@ -1347,7 +1347,7 @@ __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
     int iterations, const int64_t *__restrict__ img_row0, int32_t *__restrict__ lab_a,
     int32_t *__restrict__ lab_b, long long *__restrict__ sumq, float *__restrict__ cent,
     SplitEntry *__restrict__ gqueue, int32_t *__restrict__ gcount, int first_sums_ready, float eps,
-    int G, unsigned int *__restrict__ bar, hsgk_segkm_meta *meta) {
+    int G, unsigned int *__restrict__ bar, hsgk_segkm_meta *meta, int trap_on_timeout) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   // G workgroups per image (co-resident: the launcher keeps B * G within the CU count): workgroup g
   // owns a contiguous, 32-aligned share of the image's rows for the M, E and X phases; the
@@ -1403,6 +1403,7 @@ __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
         if (++spins > (1u << 20)) {              // ~ a second: the workgroups are not co-resident
           if (meta) meta->error = 3;
           bar_dead = 1;
+          if (trap_on_timeout) __builtin_trap();   // nobody reads meta on the host: fail loudly
           break;
         }
       }
@@ -1688,12 +1689,13 @@ bool lloyd_small_eligible(int d, int K, int B, int64_t rows_per_image) {
 
 // lab_a: current labels (in / out), lab_b: the labels the sums hold; sumq / cent: [B][K][d];
 // qrows: >= one SplitEntry per row; counters: >= B * (G + 1) int32 (per-workgroup queue counts, then
-// the per-image tick counters).  first_sums_ready: sumq / lab_b are valid (first M-step done
+// the per-image tick counters).  trap_on_timeout: the caller does not read meta->error on the host (a
+// timed-out inter-workgroup wait then aborts the kernel instead of leaving wrong labels).  first_sums_ready: sumq / lab_b are valid (first M-step done
 // elsewhere); otherwise neither needs initialising (one workgroup per image) or sumq is zeroed here.
 int launch_lloyd_small(const float *x, const _Float16 *xm, const uint2 *xt, int d, int K, int B, int iterations,
                        const ChunkTable &t, int32_t *lab_a, int32_t *lab_b, long long *sumq, float *cent,
                        void *qrows, int32_t *counters, bool first_sums_ready, hsgk_segkm_meta *meta,
-                       int64_t rows_per_image, hipStream_t s) {
+                       int64_t rows_per_image, bool trap_on_timeout, hipStream_t s) {
   if (B <= 0 || iterations <= 0) return 0;
   constexpr int NW = 8;
   const bool deep = ((d / 64) & 3) == 0;
@@ -1709,7 +1711,7 @@ int launch_lloyd_small(const float *x, const _Float16 *xm, const uint2 *xt, int 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(B * G), dim3(NW * 64), lds, s, x, xm, xt, d, K, iterations, t.img_row0, lab_a,
                        lab_b, sumq, cent, reinterpret_cast<SplitEntry *>(qrows), counters,
-                       first_sums_ready ? 1 : 0, HSGK_EPS, G, bar, meta);
+                       first_sums_ready ? 1 : 0, HSGK_EPS, G, bar, meta, trap_on_timeout ? 1 : 0);
     HSGK_LAUNCH_CHECK();
     return 0;
   };

@@ -77,7 +77,10 @@ typedef struct hsgk_segkm_meta {
   int64_t label_min;     /* min / max of kept labels (0 / 0 when no labels)    */
   int64_t label_max;
   int64_t n_chunks;      /* chunks actually used                               */
-  int64_t error;         /* 0 ok; 1 negative label; 2 relabel table too small  */
+  int64_t error;         /* 0 ok; 1 negative label; 2 relabel table too small; 3 the co-operating
+                            workgroups of a small-map call were not co-resident (bounded wait timed
+                            out; without a label map -- nobody reads this on the host -- the kernel
+                            aborts instead)  */
   int64_t relabel_mode;  /* 0 direct table, 1 label-ranked table               */
   int64_t relabel_L;     /* effective label extent used by the table           */
 } hsgk_segkm_meta;
