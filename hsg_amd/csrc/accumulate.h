@@ -94,6 +94,31 @@ __device__ inline void chunk_accumulate(const float *__restrict__ xr, int d, int
       t[u] = xr[(int64_t)r * d + min(tcol + lane, d - 1)];
     }
   };
+  // The prefetched columns of the CURRENT label stay in registers while consecutive rows of the
+  // wave's list carry the same label (image-major rows: runs of tens to hundreds) and go back to
+  // the LDS table when it changes: a read-add-write through LDS per row is a ~150-cycle dependent
+  // chain, which bounded chunks with few distinct labels (one wave then owns >1000 rows).  Same
+  // additions in the same order.
+  int curl = -1;
+  lvec_t racc, racc2;
+  float rt = 0.0f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { racc[i] = 0.0f; racc2[i] = 0.0f; }
+  auto switch_to = [&](int l) {
+    if (curl >= 0) {
+      if (npass > 0) *reinterpret_cast<lvec_t *>(sums + curl * DS + lane * VEC) = racc;
+      if constexpr (TAILV != 0)
+        if (lane < nv2) *reinterpret_cast<lvec_t *>(sums + curl * DS + tail0 + lane * VEC) = racc2;
+      if (on) sums[curl * DS + tcol + lane] = rt;
+    }
+    curl = l;
+    if (l >= 0) {
+      if (npass > 0) racc = *reinterpret_cast<const lvec_t *>(sums + l * DS + lane * VEC);
+      if constexpr (TAILV != 0)
+        if (lane < nv2) racc2 = *reinterpret_cast<const lvec_t *>(sums + l * DS + tail0 + lane * VEC);
+      if (on) rt = sums[l * DS + tcol + lane];
+    }
+  };
   auto fold = [&](int b0, const gvec_t (&v)[UNROLL], const gvec_t (&v2)[TAILV ? UNROLL : 1],
                   const float (&t)[UNROLL]) {
 #pragma unroll
@@ -101,12 +126,10 @@ __device__ inline void chunk_accumulate(const float *__restrict__ xr, int d, int
       if (b0 + u < cnt) {
         const uint32_t e = mylist[b0 + u];
         const int r = (int)(e >> 10), l = (int)(e & 1023u);
+        if (l != curl) switch_to(l);
         if (npass > 0) {
-          lvec_t *dst = reinterpret_cast<lvec_t *>(sums + l * DS + lane * VEC);
-          lvec_t acc = *dst;
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[i] = acc[i] + v[u][i];
-          *dst = acc;
+          for (int i = 0; i < VEC; ++i) racc[i] = racc[i] + v[u][i];
         }
         for (int p = 1; p < npass; ++p) {                     // further full passes (wide rows)
           const gvec_t vv = *reinterpret_cast<const gvec_t *>(xr + (int64_t)r * d + p * PW + lane * VEC);
@@ -118,17 +141,11 @@ __device__ inline void chunk_accumulate(const float *__restrict__ xr, int d, int
         }
         if constexpr (TAILV != 0) {
           if (lane < nv2) {
-            lvec_t *dst = reinterpret_cast<lvec_t *>(sums + l * DS + tail0 + lane * VEC);
-            lvec_t acc = *dst;
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) acc[i] = acc[i] + v2[u][i];
-            *dst = acc;
+            for (int i = 0; i < VEC; ++i) racc2[i] = racc2[i] + v2[u][i];
           }
         }
-        if (on) {
-          float *dst = sums + l * DS + tcol + lane;
-          *dst = *dst + t[u];
-        }
+        if (on) rt = rt + t[u];
         if constexpr (TAILV == 0)
           for (int t0 = 64; t0 < tail; t0 += 64)              // wider tails, loaded in place (slow path)
             if (t0 + lane < tail) {
@@ -153,6 +170,7 @@ __device__ inline void chunk_accumulate(const float *__restrict__ xr, int d, int
       fold(b0 + UNROLL, vb, wb, tb);
       __builtin_amdgcn_sched_barrier(0);
     }
+    switch_to(-1);                                   // the last label's registers -> table
   }
 }
 

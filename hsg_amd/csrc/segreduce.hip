@@ -349,8 +349,11 @@ int hsgk_segment_reduce(const float *x, int64_t n, int d, const int64_t *labels,
   int64_t *seg_ids = cv.take<int64_t>((size_t)(nch > 0 ? nch : 1) * rmax);
   int32_t *counts = cv.take<int32_t>((size_t)P);
 
-  const bool wide = d >= 256;
-  const int DS = wide ? (d + 3) / 4 * 4 : d;
+  // floats per lane and row load: the first 64 * VEC columns of a row are prefetched 16 rows deep, further
+  // full passes are load-use (one exposed latency per row: d = 128 with one float per lane took 293 us for
+  // 12.5 K rows), so VEC grows with d (the sums do not depend on it: every column adds its rows in order)
+  const int vec = d >= 256 ? 4 : d >= 128 ? 2 : 1;
+  const int DS = (d + vec - 1) / vec * vec;
   const size_t list_bytes = (size_t)HSGK_CHUNK * (4 + 2);      // row list, slots (bitmap + prefix alias the table)
   // table rows per pass: two workgroups per CU when that still covers a useful
   // window, otherwise one workgroup with the whole LDS
@@ -365,7 +368,7 @@ int hsgk_segment_reduce(const float *x, int64_t n, int d, const int64_t *labels,
   size_t tab_bytes = (size_t)rlds * DS * 4;
   if (tab_bytes < (size_t)kSegBitWords * 8) tab_bytes = (size_t)kSegBitWords * 8;      // room for the bitmap + prefix
   if (nch > 0) {
-    auto kern = wide ? segreduce_chunk_kernel<4, 16> : segreduce_chunk_kernel<1, 16>;
+    auto kern = vec == 4 ? segreduce_chunk_kernel<4, 16> : vec == 2 ? segreduce_chunk_kernel<2, 16> : segreduce_chunk_kernel<1, 16>;
     const size_t lds = tab_bytes + list_bytes;
     HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(158 * 1024)));
