@@ -39,3 +39,28 @@ print('GPU kernel time per step: %.2f ms in %d launches' % (tot, sum(e.count for
 rows = sorted([e for e in ka if e.device_time_total], key=lambda e: -e.device_time_total)[:14]
 for e in rows:
   print('  %-70s %4d x  %8.1f us total per step' % (e.key[:70], e.count // 3, e.device_time_total / 3.0))
+
+# ---- launches and GPU time per phase of the step (record_function ranges around the calls of run_train_step)
+import contextlib
+from torch.profiler import record_function
+orig = dict(gen=emb_cls.generate_clusters, exch=mu.gather_clustering_and_update_prototypes,
+            maps=mu.gather_and_update_cluster_mappings, fwd=pred_mod.Hsg.forward)
+def wrap(name, fn):
+  def f(*a, **k):
+    with record_function('PHASE_' + name):
+      return fn(*a, **k)
+  return f
+emb_cls.generate_clusters = wrap('generate_clusters', orig['gen'])
+mu.gather_clustering_and_update_prototypes = wrap('exchange', orig['exch'])
+mu.gather_and_update_cluster_mappings = wrap('mappings', orig['maps'])
+pred_mod.Hsg.forward = wrap('losses_forward', orig['fwd'])
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+  out = util.run_train_step(mods, inp, dev)
+  torch.cuda.synchronize()
+evs = prof.events()
+phases = [e for e in evs if e.name.startswith('PHASE_')]
+kern = [e for e in evs if e.device_type == torch.autograd.DeviceType.CUDA]
+print('phases of one step (CPU wall of the call, kernels launched inside it):')
+for p in phases:
+  inside = [k for k in evs if k.device_type == torch.autograd.DeviceType.CPU and k.time_range.start >= p.time_range.start and k.time_range.end <= p.time_range.end and k.name.startswith(('hipLaunchKernel', 'hipExtModuleLaunchKernel', 'hipModuleLaunchKernel', 'hipMemcpy', 'hipMemset'))]
+  print('  %-22s %8.2f ms CPU, %4d launches / copies' % (p.name[6:], (p.time_range.end - p.time_range.start) / 1e3, len(inside)))
