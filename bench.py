@@ -122,8 +122,8 @@ def relaunch_as_ranks(n):
 def parse_args():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=3)
-  ap.add_argument('--warmup', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=10)
+  ap.add_argument('--warmup', type=int, default=3)
   ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
   ap.add_argument('--flavour', default='iid', choices=['iid', 'mixture'],
                   help='input distribution of the headline run (BASELINE.md: i.i.d. N(0,1))')
