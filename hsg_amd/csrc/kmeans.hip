@@ -1341,7 +1341,7 @@ __host__ __device__ inline bool small_layout_ok(int d, int K, int NW) {
          (int)half_lds_bytes<8, 2, 2, 2>(d) <= L.tail0 && 8 * K * d + 16 + NW * 64 * 4 <= L.tail0;
 }
 
-template <int NW, int DEPTH, int NV>
+template <int NW, int DEPTH, int NV, int MB>
 __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
     const float *__restrict__ x, const _Float16 *__restrict__ xm, const uint2 *__restrict__ xt, int d, int K,
     int iterations, const int64_t *__restrict__ img_row0, int32_t *__restrict__ lab_a,
@@ -1595,8 +1595,8 @@ __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
     {
       const int dp = d >> 1, RS2 = (half_main_cols(d) + 16 + 8) >> 1;
       uint32_t *ch32 = reinterpret_cast<uint32_t *>(lds_raw);
-      uint32_t *cl32 = ch32 + 64 * RS2;
-      for (int k = w; k < 64; k += NW) {
+      uint32_t *cl32 = ch32 + 32 * MB * RS2;                  // (MB = 1: a 32-row table for K <= 32, half the MFMAs)
+      for (int k = w; k < 32 * MB; k += NW) {
         const bool live = k < K;
         const float nv = nrm[min(k, K - 1)];
 #pragma unroll
@@ -1619,8 +1619,8 @@ __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
     HSGK_STS(2);
     // ---------------------------------------------------------------- E: fp16 filter over the image's rows
     {
-      HalfWideEpi<2, true> epi{K, n, b, r0, 0.0f, cur, qpx, qcand, qnp, gq, gc};
-      score_tiles_half<NW, DEPTH, HalfWideEpi<2, true>, 2, 2, 2>(xm, xt, d, ct, K, r0, n, lds_raw, epi, false);
+      HalfWideEpi<MB, true> epi{K, n, b, r0, 0.0f, cur, qpx, qcand, qnp, gq, gc};
+      score_tiles_half<NW, DEPTH, HalfWideEpi<MB, true>, MB, 2, 2>(xm, xt, d, ct, K, r0, n, lds_raw, epi, false);
     }
     __syncthreads();
     HSGK_STS(3);
@@ -1715,8 +1715,12 @@ int launch_lloyd_small(const float *x, const _Float16 *xm, const uint2 *xt, int 
     HSGK_LAUNCH_CHECK();
     return 0;
   };
-  if (d <= 259) return deep ? go(lloyd_small_kernel<NW, 4, 1>) : go(lloyd_small_kernel<NW, 2, 1>);
-  return deep ? go(lloyd_small_kernel<NW, 4, 2>) : go(lloyd_small_kernel<NW, 2, 2>);
+  if (K <= 32) {
+    if (d <= 259) return deep ? go(lloyd_small_kernel<NW, 4, 1, 1>) : go(lloyd_small_kernel<NW, 2, 1, 1>);
+    return deep ? go(lloyd_small_kernel<NW, 4, 2, 1>) : go(lloyd_small_kernel<NW, 2, 2, 1>);
+  }
+  if (d <= 259) return deep ? go(lloyd_small_kernel<NW, 4, 1, 2>) : go(lloyd_small_kernel<NW, 2, 1, 2>);
+  return deep ? go(lloyd_small_kernel<NW, 4, 2, 2>) : go(lloyd_small_kernel<NW, 2, 2, 2>);
 }
 
 int launch_assign_fast(const float *x, int d, const float *cent, int K, int B, const ChunkTable &t,
