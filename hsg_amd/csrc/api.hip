@@ -82,6 +82,7 @@ struct KmeansScratch {
   uint2 *xt;           // [rows] {packed fp16 tail columns of the copy, measured rounding error of the row}
   int32_t *q1;         // [B][q1cap] rows the first level left undecided
   int32_t *q1count;    // [B]
+  float *cent_multi;   // per-workgroup centroid copies of the multi-workgroup small-map route (or null)
   int64_t q1cap;
   size_t rows_cap;     // B * rows_per_image
   int max_chunks;
@@ -137,6 +138,9 @@ static void carve_kmeans(Carver &cv, int B, int64_t rows_per_img, int d, int K,
     k->q1 = cv.take<int32_t>((size_t)B * rows_per_img + 1);
     k->q1count = cv.take<int32_t>((size_t)B + 1);
   }
+  k->cent_multi = nullptr;
+  if (k->sumq && assign_half_eligible(d, K) && rows_per_img <= 16 * 1024)       // small maps only (lloyd_small_groups)
+    k->cent_multi = cv.take<float>(lloyd_small_cent_floats(d, K, B) + 1);
 }
 
 // segment_by_kmeans only: room for the first M-step's partial sums (prep.hip), when the
@@ -204,7 +208,7 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
       ProfScope p(HSGK_PROF_ASSIGN, s);
       // (k.q1, the first level's row queue of the per-kernel route, holds the fused kernel's counters)
       return launch_lloyd_small(x, k.xh, k.xt, d, K, B, iterations, k.t, k.klab, k.klab_prev, k.sumq, k.cent,
-                                k.qrows, k.q1, m0_ready, const_cast<hsgk_segkm_meta *>(meta), rows_per_image, !host_reads_meta, s);
+                                k.qrows, k.q1, m0_ready, const_cast<hsgk_segkm_meta *>(meta), rows_per_image, !host_reads_meta, k.cent_multi, s);
     }
   }
   if (fx && !m0_ready) {     // (the fused kernel above needs neither)

@@ -1347,7 +1347,8 @@ __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
     int iterations, const int64_t *__restrict__ img_row0, int32_t *__restrict__ lab_a,
     int32_t *__restrict__ lab_b, long long *__restrict__ sumq, float *__restrict__ cent,
     SplitEntry *__restrict__ gqueue, int32_t *__restrict__ gcount, int first_sums_ready, float eps,
-    int G, unsigned int *__restrict__ bar, hsgk_segkm_meta *meta, int trap_on_timeout) {
+    int G, unsigned int *__restrict__ bar, hsgk_segkm_meta *meta, int trap_on_timeout,
+    float *__restrict__ cent_multi) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   // G workgroups per image (co-resident: the launcher keeps B * G within the CU count): workgroup g
   // owns a contiguous, 32-aligned share of the image's rows for the M, E and X phases; the
@@ -1371,7 +1372,15 @@ __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
   uint32_t *qcand = reinterpret_cast<uint32_t *>(etail + 16);                           // [kSplitLdsList]
   uint16_t *qpx = reinterpret_cast<uint16_t *>(qcand + kSplitLdsList);
   long long *sq = sumq + (int64_t)b * K * d;
-  float *ct = cent + (int64_t)b * K * d;
+  // centroids in global memory (the exact chains read them from there).  With several workgroups
+  // per image every workgroup keeps ITS OWN copy: the same address written by workgroups on
+  // different XCDs sits dirty in several non-coherent L2s, and a late write-back of an OLDER
+  // iteration's line from one of them can land after a newer line was evicted elsewhere -- a
+  // re-fetch then returns stale centroids (seen once in ~600 calls with a second stream competing
+  // for the caches, never alone).
+  const int cslot = G > 1 ? (int)blockIdx.x : b;
+  const float *cbase = G > 1 ? cent_multi : cent;
+  float *ct = const_cast<float *>(cbase) + (int64_t)cslot * K * d;
   SplitEntry *gq = gqueue + r0;                   // this workgroup's overflow region (<= n entries)
   int32_t *gc = gcount + blockIdx.x;
   int32_t *cur = lab_a, *prev = lab_b;
@@ -1635,7 +1644,7 @@ __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
         SplitEntry ent{0, 0u, 0u};
         if (e < qn) ent = SplitEntry{(int32_t)(r0 + qpx[e]), qcand[e], 0u};
         else if (e < total) ent = gq[e - qn];
-        exact_rescore16(ent, e < total, b, x, d, cent, K, cur);
+        exact_rescore16(ent, e < total, cslot, x, d, cbase, K, cur);
       }
       __syncthreads();
       if (tid == 0 && gn) __hip_atomic_store(gc, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1682,6 +1691,11 @@ int lloyd_small_groups(int B, int64_t rows_per_image) {
   return (int)std::min<int64_t>(gmax, (rows_per_image + 255) / 256);
 }
 
+// floats of scratch for the per-workgroup centroid copies of the multi-workgroup route (B * G <= CUs / 2)
+size_t lloyd_small_cent_floats(int d, int K, int B) {
+  return ((size_t)small_cu_count() / 2 + (size_t)B) * K * d;
+}
+
 bool lloyd_small_eligible(int d, int K, int B, int64_t rows_per_image) {
   return assign_half_eligible(d, K) && small_layout_ok(d, K, 8) &&
          rows_per_image <= (int64_t)kSmallRowsMax * lloyd_small_groups(B, rows_per_image);
@@ -1695,12 +1709,12 @@ bool lloyd_small_eligible(int d, int K, int B, int64_t rows_per_image) {
 int launch_lloyd_small(const float *x, const _Float16 *xm, const uint2 *xt, int d, int K, int B, int iterations,
                        const ChunkTable &t, int32_t *lab_a, int32_t *lab_b, long long *sumq, float *cent,
                        void *qrows, int32_t *counters, bool first_sums_ready, hsgk_segkm_meta *meta,
-                       int64_t rows_per_image, bool trap_on_timeout, hipStream_t s) {
+                       int64_t rows_per_image, bool trap_on_timeout, float *cent_multi, hipStream_t s) {
   if (B <= 0 || iterations <= 0) return 0;
   constexpr int NW = 8;
   const bool deep = ((d / 64) & 3) == 0;
   const size_t lds = (size_t)small_layout(d, K).total;
-  const int G = lloyd_small_groups(B, rows_per_image);
+  const int G = cent_multi ? lloyd_small_groups(B, rows_per_image) : 1;   // (no scratch for private centroids: one workgroup per image)
   unsigned int *bar = reinterpret_cast<unsigned int *>(counters + (size_t)B * G);
   if (G > 1) {
     HSGK_CHECK_HIP(hipMemsetAsync(bar, 0, sizeof(unsigned int) * B, s));
@@ -1711,7 +1725,7 @@ int launch_lloyd_small(const float *x, const _Float16 *xm, const uint2 *xt, int 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(B * G), dim3(NW * 64), lds, s, x, xm, xt, d, K, iterations, t.img_row0, lab_a,
                        lab_b, sumq, cent, reinterpret_cast<SplitEntry *>(qrows), counters,
-                       first_sums_ready ? 1 : 0, HSGK_EPS, G, bar, meta, trap_on_timeout ? 1 : 0);
+                       first_sums_ready ? 1 : 0, HSGK_EPS, G, bar, meta, trap_on_timeout ? 1 : 0, cent_multi);
     HSGK_LAUNCH_CHECK();
     return 0;
   };

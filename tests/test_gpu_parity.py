@@ -710,6 +710,30 @@ def test_small_maps_several_workgroups_per_image_vs_oracle(dev, oracle, monkeypa
       assert np.array_equal(a, b), '%s: %d mismatching elements' % (name, int((a != b).sum()))
 
 
+def test_small_maps_two_streams_concurrently(dev):
+  """Two streams issuing multi-workgroup small-map calls at the same time: the co-residency cap keeps both
+  grids within the CUs (no timeout, no deadlock) and every result equals the single-stream one.  (A second
+  kernel competing for the caches is what exposed stale centroids when all workgroups of an image wrote ONE
+  global copy from different XCDs; tools/probes/two_stream_small.py runs thousands of pairs.)"""
+  import torch
+  from hsg_amd.utils.segsort import common as sc
+  shape, grid, iters = (20, 128, 40, 40), [4, 4], 8
+  g = torch.Generator(device=dev).manual_seed(5)
+  xs = [torch.randn(shape, device=dev, generator=g) for _ in range(2)]
+  ref = [[t.clone() for t in sc.segment_by_kmeans(x, None, grid, iterations=iters)] for x in xs]
+  torch.cuda.synchronize()
+  streams = [torch.cuda.Stream() for _ in range(2)]
+  for _ in range(150):
+    outs = []
+    for i, st in enumerate(streams):
+      with torch.cuda.stream(st):
+        outs.append(sc.segment_by_kmeans(xs[i], None, grid, iterations=iters))
+    torch.cuda.synchronize()
+    for o, r in zip(outs, ref):
+      for a, b in zip(o, r):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('iters', [1, 2, 5])
 def test_small_maps_fused_route_with_first_mstep_from_prep(dev, oracle, monkeypatch, iters):
   """The fused per-image Lloyd kernel starting from the sums the PREP kernel left for the seed labels
