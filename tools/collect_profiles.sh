@@ -27,6 +27,10 @@ rm -rf /tmp/prof_t
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_t -o t -- \
   python $GRAFT_REPO_ROOT/bench.py --workload train28 --steps 20 --warmup 3 --cpu-images 0 --no-exchange --no-extra > /dev/null 2>&1
 cp /tmp/prof_t/t_kernel_stats.csv $out/${tag}_train28_kernel_stats.csv
+rm -rf /tmp/prof_r
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r -o r -- \
+  python $GRAFT_REPO_ROOT/bench.py --workload reftrain --steps 20 --warmup 3 --cpu-images 0 --no-exchange --no-extra > /dev/null 2>&1
+cp /tmp/prof_r/r_kernel_stats.csv $out/${tag}_reftrain_kernel_stats.csv
 for wl in train28 train14 reftrain cfg3 cfg4 cfg5; do
   python $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 10 --warmup 3 --cpu-images 0 --no-extra 2>/dev/null | tail -1 > $out/${tag}_bench_${wl}.json
 done
