@@ -1408,7 +1408,7 @@ __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
     if (tid == 0 && !bar_dead) {
       unsigned int spins = 0;
       while (__hip_atomic_load(bar + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(2);                // (polling without it is not faster)
         if (++spins > (1u << 20)) {              // ~ a second: the workgroups are not co-resident
           if (meta) meta->error = 3;
           bar_dead = 1;
