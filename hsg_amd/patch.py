@@ -2,7 +2,7 @@
 libhsgk so that `pyscripts/train/train.py` and the inference scripts run unchanged.
 
 What is rebound (reference path -> hsg_amd implementation):
-  hsg.utils.segsort.common      segment_by_kmeans, kmeans_with_initial_labels,
+  hsg.utils.segsort.common      segment_by_kmeans, kmeans_with_initial_labels, kmeans,
                                 find_nearest_prototypes, calculate_prototypes_from_labels,
                                 prepare_prototype_labels, find_majority_label_index,
                                 initialize_cluster_labels, generate_location_features
@@ -53,7 +53,7 @@ def patch_reference(package='hsg'):
 
   done = []
   plan = [
-      ('utils.segsort.common', sc, ['segment_by_kmeans', 'kmeans_with_initial_labels',
+      ('utils.segsort.common', sc, ['segment_by_kmeans', 'kmeans_with_initial_labels', 'kmeans',
                                     'find_nearest_prototypes', 'calculate_prototypes_from_labels',
                                     'prepare_prototype_labels', 'find_majority_label_index',
                                     'initialize_cluster_labels', 'generate_location_features']),

@@ -307,6 +307,21 @@ def kmeans_with_initial_labels(embeddings, initial_labels, max_label=None, itera
   return lab
 
 
+def kmeans(embeddings, num_clusters, iterations=10):
+  """Grid-seeded Lloyd iterations over ONE `[batch, height, width, channels]` map (reference
+  common.py:100-126).  The reference pairs the `[height * width]` seed labels with the flattened
+  `[batch * height * width, channels]` embeddings, so it is only defined for batch = 1 (and, as written
+  there, calls `initialize_cluster_labels` without its `device` argument); this mirror follows that
+  contract with the device taken from `embeddings`.  Returns `[batch, height, width]` labels."""
+  _require_gpu(embeddings, 'embeddings')
+  shape = embeddings.shape
+  if len(shape) != 4 or shape[0] != 1:
+    raise ValueError('kmeans: embeddings must be [1, height, width, channels] (see the reference)')
+  labels = initialize_cluster_labels(num_clusters, [shape[1], shape[2]], embeddings.device)
+  labels = kmeans_with_initial_labels(embeddings.reshape(-1, shape[3]), labels.view(-1), iterations=iterations)
+  return labels.view(shape[0], shape[1], shape[2])
+
+
 def find_nearest_prototypes(embeddings, prototypes):
   """argmax_k <embedding, prototype_k> (reference common.py:44-64)."""
   _require_gpu(embeddings, 'embeddings')

@@ -109,6 +109,23 @@ def test_segment_by_kmeans_huge_label_values_and_many_distinct_labels(dev, oracl
     assert np.array_equal(u, v), name
 
 
+def test_kmeans_grid_seeded_single_map(dev, oracle):
+  """`kmeans` (reference common.py:100-126): one [1,H,W,C] map, grid seeds, Lloyd iterations -- equal to the
+  oracle's kmeans_with_initial_labels from the same seeds; other batch sizes are rejected (the reference
+  pairs H*W seed labels with B*H*W rows)."""
+  import torch
+  from hsg_amd.utils.segsort import common as sc
+  H, W, C = 24, 36, 130
+  x = synth.gaussish(4711, H * W * C).reshape(1, H, W, C)
+  x = (x / np.sqrt((x.astype(np.float64) ** 2).sum(-1, keepdims=True))).astype(np.float32)
+  got = sc.kmeans(torch.from_numpy(x).to(dev), [3, 4], iterations=6).cpu().numpy()
+  seeds = sc.initialize_cluster_labels([3, 4], [H, W], 'cpu').numpy().reshape(-1)
+  ref = oracle.kmeans_with_initial_labels(x.reshape(-1, C), seeds, int(seeds.max()) + 1, 6)
+  assert got.shape == (1, H, W) and np.array_equal(got.reshape(-1), ref)
+  with pytest.raises(ValueError):
+    sc.kmeans(torch.from_numpy(np.concatenate([x, x])).to(dev), [3, 4])
+
+
 def test_explicit_local_features_match_default(dev):
   g = util.load('f4_segkm_ragged')
   x, lab, grid, ign, iters, loc = util.f4_inputs(g)
