@@ -77,10 +77,10 @@ def _seed_map(num_clusters, H, W, device):
 def _explicit_seeds(cluster_indices, B, H, W, device):
   """Initial labels given by the caller (reference common.py:320-323, 341-345): every image's
   map is made dense separately (`torch.unique(..., return_inverse=True)` per image) and the
-  number of clusters of an image is its number of distinct initial labels.  libhsgk runs the
-  batch with ONE cluster count, so all images must carry the same number of distinct labels
-  (an image with fewer would gain empty clusters whose zero centroids compete in the argmax,
-  which the reference's smaller table does not have)."""
+  number of clusters of an image is its number of distinct initial labels.  libhsgk runs a
+  batch with ONE cluster count (an image with fewer would gain empty clusters whose zero centroids
+  compete in the argmax, which the reference's smaller table does not have): maps whose images
+  differ in that number come back with the list of counts and are run group by group."""
   ci = cluster_indices.detach().to(torch.int64)
   if ci.dim() == 2:
     ci = ci.unsqueeze(0)
@@ -94,12 +94,10 @@ def _explicit_seeds(cluster_indices, B, H, W, device):
   first = torch.searchsorted(uniq, torch.arange(B, device=device) * span)          # first dense id of every image
   counts = torch.diff(torch.cat([first, torch.tensor([uniq.shape[0]], device=device)]))
   counts = counts.cpu().tolist()
+  dense = (inv.view(B, H * W) - first.view(B, 1)).to(torch.int32).contiguous()
   if len(set(counts)) != 1:
-    raise NotImplementedError(
-        'cluster_indices with a different number of distinct labels per image (%s) are not supported'
-        % sorted(set(counts)))
-  dense = inv.view(B, H * W) - first.view(B, 1)
-  return dense.to(torch.int32).contiguous(), int(counts[0]), H * W
+    return dense, [int(c) for c in counts], H * W          # per-image counts: _segment_by_kmeans_grouped
+  return dense, int(counts[0]), H * W
 
 
 def _default_loc(H, W, device):
@@ -282,8 +280,49 @@ def segment_by_kmeans(embeddings,
   ign = int(ignore_index) if has_ignore else 0
   if batch_offset is None:
     batch_offset = _batch_offset(B, dev)
+  if isinstance(K, list):
+    return _segment_by_kmeans_grouped(x, lab, loc, loc_sb, seed_map, K, has_ignore, ign, iterations, batch_offset)
   return _SegmentByKmeans.apply(x, lab, loc, loc_sb, seed_map, K, has_ignore, ign,
                                 int(iterations), int(batch_offset), int(seed_sb))
+
+
+def _segment_by_kmeans_grouped(x, lab, loc, loc_sb, dense, counts, has_ignore, ign, iterations,
+                               batch_offset):
+  """`cluster_indices=` maps whose images carry different numbers of distinct labels: one library
+  call per group of images with the same count, then the reference's batch-wide bookkeeping on top
+  -- rows image by image in batch order, ids = rank of the segment inside its image + the number
+  of segments of the images before it (common.py:398-405: sorted `unique`s over (image, cluster,
+  label)).  A few host syncs (rare path; no reference caller passes such maps)."""
+  dev = x.device
+  B = x.shape[0]
+  HW = dense.shape[1]
+  per_image = [None] * B
+  for K in sorted(set(counts)):
+    idx = [b for b in range(B) if counts[b] == K]
+    it = torch.tensor(idx, dtype=torch.long, device=dev)
+    xs = x.index_select(0, it)
+    labs = lab.index_select(0, it).contiguous() if lab is not None else None
+    locs = loc if loc_sb == 0 else loc.index_select(0, it).contiguous()
+    seeds = dense.index_select(0, it).contiguous()
+    emb, eloc, labels, cluster, batch = _SegmentByKmeans.apply(
+        xs, labs, locs, loc_sb, seeds, K, has_ignore, ign, int(iterations), 0, HW)
+    bounds = torch.searchsorted(batch, torch.arange(len(idx) + 1, device=dev)).cpu().tolist()
+    for j, b in enumerate(idx):
+      s, e = bounds[j], bounds[j + 1]
+      per_image[b] = (emb[s:e], eloc[s:e], labels[s:e], cluster[s:e])
+  offset = 0
+  clusters, batches = [], []
+  for b in range(B):
+    c = per_image[b][3]
+    if c.numel():
+      lo, hi = int(c.min()), int(c.max())
+      clusters.append(c - lo + offset)
+      offset += hi - lo + 1
+    else:
+      clusters.append(c)
+    batches.append(torch.full_like(c, b + int(batch_offset)))
+  return (torch.cat([p[0] for p in per_image]), torch.cat([p[1] for p in per_image]),
+          torch.cat([p[2] for p in per_image]), torch.cat(clusters), torch.cat(batches))
 
 
 def kmeans_with_initial_labels(embeddings, initial_labels, max_label=None, iterations=10):

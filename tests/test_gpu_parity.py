@@ -55,7 +55,7 @@ def test_segment_by_kmeans_vs_golden_and_oracle(dev, oracle, case):
 def test_segment_by_kmeans_with_explicit_cluster_indices(dev, oracle):
   """`cluster_indices=` (reference common.py:320-323): the caller's per-image initial labels (arbitrary
   values, made dense per image) instead of the grid seeds -- golden from the reference, bit-exact vs the
-  oracle; maps with different label counts per image are rejected."""
+  oracle; maps with different label counts per image run group by group."""
   import torch
   from hsg_amd.utils.segsort import common as sc
   g = util.load('f16_segkm_cluster_indices')
@@ -76,10 +76,16 @@ def test_segment_by_kmeans_with_explicit_cluster_indices(dev, oracle):
   ref = oracle.segment_by_kmeans(x, lab, (9, 9), loc, 255, int(g['iters']), cluster_indices=ci)
   for name, a, b in zip(('emb', 'emb_loc', 'labels', 'cluster', 'batch'), (emb, emb_loc, labels, cluster, batch), ref):
     assert np.array_equal(a, b), name
-  bad = ci.copy()
-  bad[1][bad[1] == 40] = 3                          # image 1 now has five distinct labels, the others six
-  with pytest.raises(NotImplementedError):
-    sc.segment_by_kmeans(torch.from_numpy(x).to(dev), None, [9, 9], cluster_indices=torch.from_numpy(bad).to(dev))
+  # maps whose images carry DIFFERENT numbers of distinct labels: one library call per group of images
+  # with the same count, batch-wide ids on top -- bit-exact vs the oracle's per-image cluster counts
+  uneven = ci.copy()
+  uneven[1][uneven[1] == 40] = 3                    # image 1 now has five distinct labels, the others six
+  for l, ign in ((lab, 255), (None, None)):
+    out = sc.segment_by_kmeans(torch.from_numpy(x).to(dev), None if l is None else torch.from_numpy(l).to(dev), [9, 9],
+                               cluster_indices=torch.from_numpy(uneven).to(dev), ignore_index=ign, iterations=3)
+    ref = oracle.segment_by_kmeans(x, l, (9, 9), loc, ign, 3, cluster_indices=uneven)
+    for name, a, b in zip(('emb', 'emb_loc', 'labels', 'cluster', 'batch'), [t.cpu().numpy() for t in out], ref):
+      assert np.array_equal(a, b), name
 
 
 def test_segment_by_kmeans_huge_label_values_and_many_distinct_labels(dev, oracle):
