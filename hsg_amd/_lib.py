@@ -42,12 +42,28 @@ class SegkmArgs(ctypes.Structure):
       ('seed_batch_stride', ctypes.c_int64)]
 
 
+class ExchangeArgs(ctypes.Structure):
+  _fields_ = [
+      ('embeddings', ctypes.c_void_p), ('embeddings_loc', ctypes.c_void_p),
+      ('cluster', ctypes.c_void_p), ('batch', ctypes.c_void_p), ('semantic', ctypes.c_void_p),
+      ('instance', ctypes.c_void_p),
+      ('n', ctypes.c_int64), ('C', ctypes.c_int32), ('D', ctypes.c_int32),
+      ('cap_local', ctypes.c_int64), ('cap_total', ctypes.c_int64), ('pool_rows', ctypes.c_int64),
+      ('eps', ctypes.c_float),
+      ('table', ctypes.c_void_p), ('prototypes', ctypes.c_void_p), ('prototypes_loc', ctypes.c_void_p),
+      ('norms', ctypes.c_void_p),
+      ('proto_semantic', ctypes.c_void_p), ('proto_instance', ctypes.c_void_p), ('proto_batch', ctypes.c_void_p),
+      ('updated_cluster', ctypes.c_void_p), ('meta', ctypes.c_void_p),
+      ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t)]
+
+
 class LossSet(ctypes.Structure):
   _fields_ = [('sem', ctypes.c_void_p), ('psem', ctypes.c_void_p), ('kappa', ctypes.c_float),
               ('mode', ctypes.c_int32)]
 
 
 _lib = None
+ABI_VERSION = 300          # HSGK_VERSION the struct layouts / signatures below were written for
 
 _vp, _i64, _i32, _f32, _sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                               ctypes.c_float, ctypes.c_size_t)
@@ -97,6 +113,20 @@ SIGNATURES = {
     'hsgk_synth_gaussish': (_i32, [ctypes.c_uint64, ctypes.c_uint64, _i64, _vp, _vp]),
     'hsgk_synth_mixture': (_i32, [ctypes.c_uint64, ctypes.c_uint64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     'hsgk_assign_workspace_bytes': (_sz, [_i64, _i32, _i32]),
+    'hsgk_exchange_workspace_bytes': (_sz, [_i64, _i32, _i32, _i64, _i64, _i32, _i64]),
+    'hsgk_exchange_prototypes': (_i32, [ctypes.POINTER(ExchangeArgs), _vp, _i32, _i32, _vp]),
+    'hsgk_exchange_begin': (_i32, [ctypes.POINTER(ExchangeArgs), _vp, _i32, _i32, _vp]),
+    'hsgk_exchange_finish': (_i32, [ctypes.POINTER(ExchangeArgs), _i64, _vp, _i32, _vp]),
+    'hsgk_exchange_keys': (_i32, [ctypes.POINTER(ExchangeArgs), _i32, _vp]),
+    'hsgk_exchange_send_block': (_vp, [ctypes.POINTER(ExchangeArgs), _i32, ctypes.POINTER(ctypes.c_size_t)]),
+    'hsgk_exchange_recv_blocks': (_vp, [ctypes.POINTER(ExchangeArgs), _i32]),
+    'hsgk_exchange_merge': (_i32, [ctypes.POINTER(ExchangeArgs), _i32, _i32, _vp, _vp]),
+    'hsgk_exchange_sums': (_i32, [ctypes.POINTER(ExchangeArgs), _i32, _i32, _vp, _vp]),
+    'hsgk_comm_unique_id': (_i32, [_vp, _sz]),
+    'hsgk_comm_init_rank': (_i32, [ctypes.POINTER(ctypes.c_void_p), _i32, _i32, _vp, _sz]),
+    'hsgk_comm_destroy': (_i32, [_vp]),
+    'hsgk_comm_all_reduce_f32': (_i32, [_vp, _i64, _vp, _vp]),
+    'hsgk_comm_all_gather_bytes': (_i32, [_vp, _vp, _sz, _vp, _vp]),
     'hsgk_find_nearest_prototypes': (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
 }
 
@@ -120,6 +150,9 @@ def lib():
       fn = getattr(L, name)
       fn.restype = res
       fn.argtypes = args
+    if L.hsgk_version() != ABI_VERSION:
+      raise HsgkError('%s is version %d but hsg_amd/_lib.py binds version %d: rebuild it (`make -C hsg_amd/csrc`)'
+                      % (SO_PATH, L.hsgk_version(), ABI_VERSION))
     _lib = L
   return _lib
 

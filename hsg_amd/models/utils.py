@@ -1,48 +1,46 @@
 """Drop-in for the cross-GPU glue of `hsg.models.utils` (reference
-hsg/models/utils.py:41-240), re-designed for one process per GPU.
+hsg/models/utils.py:41-240), re-designed so that only TABLES cross the interconnect.
 
 The reference runs ONE process, gathers every pixel embedding of every GPU to
 an anchor GPU (`scatter_gather.gather`), computes the batch-wide prototype
-table there and copies it back (3x per iteration, train.py:190,219).  Here
-each rank reduces its own pixels to per-segment SUMS with libhsgk
-(segment_reduce, mode 2) and only the small segment table crosses xGMI:
+table there and copies it back (3x per iteration, train.py:190,219).  Here every
+device reduces its own pixels to per-segment SUMS with libhsgk (hsg_amd/csrc/exchange.hip:
+no sort over the pixel keys, both row sets summed in one fused pass) and only the small
+segment table travels:
 
-    keys      ONE fixed-capacity all_gather of the ranks' distinct
-              (image, cluster, sem, inst) tuples (row count in the buffer header)
-    sums      ONE RCCL all_reduce(sum) over the zero-padded [P_total, C + D] table
-    labels    decoded from the keys (identical on every rank)
+    keys      ONE fixed-capacity all_gather of the sources' sorted distinct
+              (image, cluster, sem, inst) tuples (row count in the block header)
+    sums      ONE all_reduce(sum) over the zero-padded [P_total, C + D] table
+    labels    decoded from the tuples (identical on every source)
 
-A segment normally lives on one rank (an image is never split), so the
-all_reduce only adds zeros to each row and the result is independent of the
-reduction order; if the same image id does occur on two ranks its rows merge,
-exactly as in the reference.  Payload ~ P_total * (2C+2) * 4 B (a few MB):
-latency-bound on xGMI, which is why it is ONE collective.
+in both multi-GPU modes:
 
-Every function accepts what the reference accepts -- a list with one tensor per
-GPU of this process -- and also a bare tensor (the natural form with one process
-per GPU); it returns the same structure it was given.  With
-`torch.distributed` initialised the exchange spans all ranks of `group`.
+  * one process per GPU (`torch.distributed` initialised): the two collectives run over the
+    process group (RCCL under the `nccl` backend), or in-stream on libhsgk's own RCCL
+    communicator (`use_library_comm`, the C entry hsgk_exchange_begin / _finish);
+  * ONE process driving several GPUs, the reference's DataParallel convention that
+    `pyscripts/train/train.py` uses (lists with one tensor per GPU): keys and sums are computed
+    on each tensor's OWN device, the tuple blocks and the sum tables (a few MB) are copied to the
+    anchor and merged / added there -- pixel rows never leave their device.
+
+A segment normally lives on one source (an image is never split), so the reduction only adds
+zeros to each row and the result is independent of its order; if the same image id does occur
+on two sources its rows merge, exactly as in the reference.
+
+The per-device work is behind a small backend interface (`keys` / `merge` / `sums` / `finish`,
+the phases of include/hsgk.h's exchange section); the CPU tests swap in an oracle-backed backend
+and run this very orchestration over `gloo`.
 """
+import ctypes
+import threading
+
 import torch
 import torch.distributed as dist
 
-from hsg_amd import ops
+from hsg_amd import _lib, ops
 
-
-# ---- hooks (replaced by the CPU gloo tests with oracle-backed versions) ------
-def _segment_sums(rows, ids, count):
-  """Raw per-segment sums [count, d] of the local rows (libhsgk, mode 2)."""
-  return ops.segment_reduce(rows, ids, count, 2)
-
-
-def _normalize(table):
-  return ops.normalize_rows(table)
-
-
-def _local_prototypes(rows, ids, count):
-  """Normalised per-segment sums in one pass (libhsgk, mode 0): the single-rank path, where the
-  sums need not leave the kernel before they are normalised."""
-  return ops.segment_reduce(rows, ids, count, 0)
+HDR = 8                      # int64 words in front of a tuple block (hsg_amd/csrc/exchange.hip kXHdr)
+ERR_NEGATIVE, ERR_CAPACITY, ERR_OVERFLOW, ERR_ROWS = 1, 2, 4, 8
 
 
 # ---- small helpers -----------------------------------------------------------
@@ -50,6 +48,12 @@ def _world(group):
   if dist.is_available() and dist.is_initialized():
     return dist.get_world_size(group)
   return 1
+
+
+def _rank(group):
+  if dist.is_available() and dist.is_initialized():
+    return dist.get_rank(group)
+  return 0
 
 
 def _as_list(v):
@@ -60,12 +64,36 @@ def _cat_to(tensors, device):
   return torch.cat([t.to(device) for t in tensors], 0)
 
 
-# Rows per rank of the fixed-size gather buffers, per call site.  Every rank starts from the
-# same value and grows it from the same gathered counts, so the sizes agree without a
-# collective of their own.
+def _pow2(v):
+  p = 1
+  while p < v:
+    p *= 2
+  return p
+
+
+# Rows per source of the fixed-size tuple / gather blocks, per (process group, call site).  Every
+# rank starts from the same value and grows it from the same gathered counts, so the sizes agree
+# without a collective of their own.
+_state_lock = threading.Lock()
 _capacity = {}
 _CAP_START = 4096
 collective_calls = 0        # incremented per collective issued (tests / bench read it)
+
+
+def _cap_get(group, tag, default=None):
+  with _state_lock:
+    return _capacity.get((id(group) if group is not None else None, tag), _CAP_START if default is None else default)
+
+
+def _cap_set(group, tag, value):
+  with _state_lock:
+    _capacity[(id(group) if group is not None else None, tag)] = value
+
+
+def _count_collective():
+  global collective_calls
+  with _state_lock:
+    collective_calls += 1
 
 
 def _all_gather_rows(t, group, tag):
@@ -74,7 +102,6 @@ def _all_gather_rows(t, group, tag):
   buffer whose first 8 bytes hold its row count.  If some rank has more rows than the
   capacity, every rank sees that in the same counts and repeats the gather with the next
   power of two (kept for later calls).  Returns (rows, counts)."""
-  global collective_calls
   world = _world(group)
   if world == 1:
     return t, [t.shape[0]]
@@ -84,9 +111,9 @@ def _all_gather_rows(t, group, tag):
   row_bytes = t.element_size()
   for s in row_shape:
     row_bytes *= s
-  key = (tag, row_bytes)
+  key = '%s/%d' % (tag, row_bytes)
   while True:
-    cap = _capacity.get(key, _CAP_START)
+    cap = _cap_get(group, key)
     send = torch.zeros((8 + cap * row_bytes,), dtype=torch.uint8, device=t.device)
     send[:8] = torch.tensor([n], dtype=torch.int64).view(torch.uint8).to(t.device, non_blocking=True)
     m = min(n, cap)
@@ -94,14 +121,12 @@ def _all_gather_rows(t, group, tag):
       send[8:8 + m * row_bytes] = t[:m].reshape(-1).view(torch.uint8)
     recv = torch.empty((world, 8 + cap * row_bytes), dtype=torch.uint8, device=t.device)
     dist.all_gather_into_tensor(recv.view(-1), send, group=group)
-    collective_calls += 1
+    _count_collective()
     counts = recv[:, :8].contiguous().view(torch.int64).view(-1).tolist()     # the one host read
     need = max(counts)
     if need <= cap:
       break
-    while cap < need:
-      cap *= 2
-    _capacity[key] = cap
+    _cap_set(group, key, _pow2(need))
   parts = [recv[r, 8:8 + c * row_bytes] for r, c in enumerate(counts) if c]
   if not parts:
     return t[:0], counts
@@ -109,107 +134,356 @@ def _all_gather_rows(t, group, tag):
   return flat.view(t.dtype).view((-1,) + row_shape), counts
 
 
-class _AllReduceSum(torch.autograd.Function):
-  """y = sum over ranks of x; dL/dx = sum over ranks of dL/dy (every rank's
-  loss sees the whole table)."""
+# ---- transports of the two collectives ----------------------------------------
+class _DistTransport:
+  """torch.distributed process group (RCCL under the `nccl` backend, gloo in the CPU tests and the
+  single-device dry runs)."""
+
+  def __init__(self, group):
+    self.group = group
+    self.world = _world(group)
+    self.rank = _rank(group)
+
+  def all_gather(self, send, recv):
+    dist.all_gather_into_tensor(recv.view(-1), send, group=self.group)
+    _count_collective()
+
+  def all_reduce(self, t):
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+    _count_collective()
+
+
+class _LibraryTransport:
+  """libhsgk's own RCCL communicator: both collectives are enqueued on the caller's current
+  stream between the kernels (no stream hop, no host sync)."""
+
+  def __init__(self, comm, rank, world):
+    self.comm, self.rank, self.world = comm, rank, world
+
+  def all_gather(self, send, recv):
+    _lib.check(_lib.lib().hsgk_comm_all_gather_bytes(
+        send.data_ptr(), recv.data_ptr(), send.numel() * send.element_size(), self.comm, _lib.stream_ptr()))
+    _count_collective()
+
+  def all_reduce(self, t):
+    assert t.dtype == torch.float32 and t.is_contiguous()
+    _lib.check(_lib.lib().hsgk_comm_all_reduce_f32(t.data_ptr(), t.numel(), self.comm, _lib.stream_ptr()))
+    _count_collective()
+
+
+_library_comms = {}
+use_library_comm = False     # one process per GPU: in-stream RCCL through libhsgk instead of the process group
+
+
+def library_transport(group=None):
+  """Creates (once per process group) libhsgk's RCCL communicator over the ranks of `group`: rank 0
+  draws the unique id, the process group carries its 128 bytes to the others."""
+  key = id(group) if group is not None else None
+  with _state_lock:
+    hit = _library_comms.get(key)
+  if hit is not None:
+    return hit
+  world, rank = _world(group), _rank(group)
+  L = _lib.lib()
+  ident = (ctypes.c_uint8 * 128)()
+  if rank == 0:
+    _lib.check(L.hsgk_comm_unique_id(ident, 128))
+  box = [bytes(ident)]
+  if world > 1:
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+  comm = ctypes.c_void_p()
+  buf = (ctypes.c_uint8 * 128).from_buffer_copy(box[0])
+  _lib.check(L.hsgk_comm_init_rank(ctypes.byref(comm), world, rank, buf, 128))
+  hit = _LibraryTransport(comm, rank, world)
+  with _state_lock:
+    _library_comms[key] = hit
+  return hit
+
+
+def _transport(group):
+  if _world(group) == 1:
+    return None
+  if use_library_comm:
+    return library_transport(group)
+  return _DistTransport(group)
+
+
+# ---- per-device backend: the phases of include/hsgk.h's exchange section -----
+class HsgkExchangeBackend:
+  """One source (device) of an exchange: keys -> [gather] -> merge -> sums -> [reduce] -> finish,
+  all enqueued on the device's current stream; `read_meta` is the only host read."""
+
+  def __init__(self, emb, emb_loc, c, b, sem, inst, cap_local, cap_total, world):
+    ops.require_gpu(emb, 'embeddings')
+    self.dev = emb.device
+    self.emb = emb.detach().reshape(-1, emb.shape[-1]).to(torch.float32).contiguous()
+    self.emb_loc = emb_loc.detach().reshape(-1, emb_loc.shape[-1]).to(torch.float32).contiguous()
+    self.keys_in = [t.detach().reshape(-1).to(device=self.dev, dtype=torch.int64).contiguous() for t in (c, b, sem, inst)]
+    n, C = self.emb.shape
+    D = self.emb_loc.shape[1]
+    if self.emb_loc.shape[0] != n or any(k.shape[0] != n for k in self.keys_in):
+      raise ValueError('embeddings, embeddings_with_loc and the index vectors disagree on the number of pixels')
+    self.n, self.C, self.D = n, C, D
+    self.cap, self.cap_total, self.world = int(cap_local), int(cap_total), int(world)
+    nch = (n + _lib.CHUNK - 1) // _lib.CHUNK
+    self.pool_rows = max(1, min(n, nch * min(self.cap_total, 256)))
+    L = _lib.lib()
+    with torch.cuda.device(self.dev):
+      wsb = L.hsgk_exchange_workspace_bytes(n, C, D, self.cap, self.cap_total, self.world, self.pool_rows)
+      self.ws = torch.empty((wsb,), dtype=torch.uint8, device=self.dev)
+      self.table = torch.empty((self.cap_total, C + D), dtype=torch.float32, device=self.dev)
+      self.upd = torch.empty((n,), dtype=torch.int64, device=self.dev)
+      self.plab = torch.empty((3, self.cap_total), dtype=torch.int64, device=self.dev)
+      self.meta = torch.empty((8,), dtype=torch.int64, device=self.dev)
+    self.args = _lib.ExchangeArgs(
+        embeddings=self.emb.data_ptr(), embeddings_loc=self.emb_loc.data_ptr(),
+        cluster=self.keys_in[0].data_ptr(), batch=self.keys_in[1].data_ptr(),
+        semantic=self.keys_in[2].data_ptr(), instance=self.keys_in[3].data_ptr(),
+        n=n, C=C, D=D, cap_local=self.cap, cap_total=self.cap_total, pool_rows=self.pool_rows, eps=_lib.EPS,
+        table=self.table.data_ptr(), prototypes=None, prototypes_loc=None, norms=None,
+        proto_semantic=self.plab[0].data_ptr(), proto_instance=self.plab[1].data_ptr(),
+        proto_batch=self.plab[2].data_ptr(), updated_cluster=self.upd.data_ptr(), meta=self.meta.data_ptr(),
+        workspace=self.ws.data_ptr(), workspace_bytes=wsb)
+
+  def _view(self, ptr, words):
+    off = ptr - self.ws.data_ptr()
+    return self.ws[off:off + 8 * words].view(torch.int64)
+
+  def keys(self):
+    L = _lib.lib()
+    with torch.cuda.device(self.dev):
+      _lib.check(L.hsgk_exchange_keys(ctypes.byref(self.args), self.world, _lib.stream_ptr()))
+    nbytes = ctypes.c_size_t(0)
+    ptr = L.hsgk_exchange_send_block(ctypes.byref(self.args), self.world, ctypes.byref(nbytes))
+    return self._view(ptr, HDR + 4 * self.cap)
+
+  def recv_blocks(self):
+    ptr = _lib.lib().hsgk_exchange_recv_blocks(ctypes.byref(self.args), self.world)
+    return self._view(ptr, self.world * (HDR + 4 * self.cap)).view(self.world, HDR + 4 * self.cap)
+
+  def merge(self, my_rank):
+    """-> slots int32 [world, cap] (my_rank < 0: every source's row is filled)."""
+    with torch.cuda.device(self.dev):
+      slots = torch.empty((self.world, self.cap), dtype=torch.int32, device=self.dev)
+      _lib.check(_lib.lib().hsgk_exchange_merge(ctypes.byref(self.args), my_rank, self.world,
+                                                 None if (self.world == 1 and my_rank == 0) else slots.data_ptr(),
+                                                 _lib.stream_ptr()))
+    self._slots = None if (self.world == 1 and my_rank == 0) else slots
+    return slots
+
+  def sums(self, my_rank, slots_row=None):
+    """ids + fused segment sums of both row sets into self.table (raw sums at the global rows)."""
+    if slots_row is None and self._slots is not None:
+      slots_row = self._slots[my_rank]
+    if slots_row is not None:
+      slots_row = slots_row.contiguous()
+    self._keep = slots_row
+    with torch.cuda.device(self.dev):
+      _lib.check(_lib.lib().hsgk_exchange_sums(ctypes.byref(self.args), max(my_rank, 0), self.world,
+                                                slots_row.data_ptr() if slots_row is not None else None,
+                                                _lib.stream_ptr()))
+
+  def read_meta(self):
+    m = self.meta.cpu().tolist()
+    return m[0], m[1], m[2], m[3]
+
+  def finish(self, table_rows):
+    """table_rows [rows, C + D] (raw, already reduced) -> prototypes, prototypes_with_loc, norms [rows, 2]."""
+    rows = table_rows.shape[0]
+    with torch.cuda.device(self.dev):
+      pa = torch.empty((rows, self.C), dtype=torch.float32, device=self.dev)
+      pb = torch.empty((rows, self.D), dtype=torch.float32, device=self.dev)
+      norms = torch.empty((rows, 2), dtype=torch.float32, device=self.dev)
+      if rows:
+        a = _lib.ExchangeArgs(C=self.C, D=self.D, cap_total=rows, eps=_lib.EPS, table=table_rows.data_ptr(),
+                              prototypes=pa.data_ptr(), prototypes_loc=pb.data_ptr(), norms=norms.data_ptr())
+        _lib.check(_lib.lib().hsgk_exchange_finish(ctypes.byref(a), rows, None, 1, _lib.stream_ptr()))
+    return pa, pb, norms
+
+  # backward pieces (mirror of finish and of the row -> segment map)
+  @staticmethod
+  def finish_bwd(g_pa, g_pb, pa, pb, norms):
+    """d(loss)/d(raw sums) [rows, C + D] from the gradients of the two normalised tables."""
+    rows, C = pa.shape
+    D = pb.shape[1]
+    dev = pa.device
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+      g = torch.zeros((rows, C + D), dtype=torch.float32, device=dev)
+      for gp, out, col, d, o in ((g_pa, pa, 0, C, 0), (g_pb, pb, 1, D, C)):
+        if gp is None or rows == 0:
+          continue
+        gseg = torch.empty((rows, d), dtype=torch.float32, device=dev)
+        aux = norms[:, col].contiguous()
+        _lib.check(L.hsgk_segment_reduce_bwd(gp.contiguous().data_ptr(), out.data_ptr(), aux.data_ptr(), None,
+                                             0, d, rows, 0, ctypes.c_float(_lib.EPS), gseg.data_ptr(), None,
+                                             _lib.stream_ptr()))
+        g[:, o:o + d] = gseg
+    return g
 
   @staticmethod
-  def forward(ctx, x, group):
-    global collective_calls
-    ctx.group = group
-    y = x.detach().clone()
-    dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
-    collective_calls += 1
-    return y
+  def rows_bwd(g_table, upd, C, D, need):
+    """gradient of the pixel rows: row i receives the gradient of its segment's sum."""
+    dev = upd.device
+    n, rows = upd.shape[0], g_table.shape[0]
+    L = _lib.lib()
+    outs = []
+    with torch.cuda.device(dev):
+      for want, d, o in ((need[0], C, 0), (need[1], D, C)):
+        if not want:
+          outs.append(None)
+          continue
+        gseg = g_table[:, o:o + d].contiguous()
+        gx = torch.empty((n, d), dtype=torch.float32, device=dev)
+        _lib.check(L.hsgk_segment_reduce_bwd(gseg.data_ptr(), gseg.data_ptr(), None, upd.data_ptr(), n, d, rows, 2,
+                                             ctypes.c_float(_lib.EPS), gseg.data_ptr(), gx.data_ptr(),
+                                             _lib.stream_ptr()))
+        outs.append(gx)
+    return outs
+
+
+backend_class = HsgkExchangeBackend       # the CPU tests install an oracle-backed class with the same methods
+
+
+def _raise_for(err):
+  if err & ERR_NEGATIVE:
+    raise ValueError('prototype exchange: negative cluster / batch / label values are not supported')
+  if err & ERR_OVERFLOW:
+    raise _lib.HsgkError('prototype exchange: (batch, cluster, semantic, instance) does not pack into 62 bits')
+  raise _lib.HsgkError('prototype exchange: device-side error %d' % err)
+
+
+class _Exchange(torch.autograd.Function):
+  """One process per GPU (or a single GPU): this rank's rows in, the batch-wide tables out."""
 
   @staticmethod
-  def backward(ctx, g):
-    g = g.contiguous().clone()
-    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
-    return g, None
+  def forward(ctx, emb, emb_loc, c, b, sem, inst, group, tag):
+    tr = _transport(group)
+    world = tr.world if tr is not None else 1
+    rank = tr.rank if tr is not None else 0
+    while True:
+      cap = _cap_get(group, tag)
+      be = backend_class(emb, emb_loc, c, b, sem, inst, cap, cap * world, world)
+      send = be.keys()
+      if tr is not None:
+        tr.all_gather(send, be.recv_blocks())
+      be.merge(rank)
+      be.sums(rank)
+      n_local, rows, err, need = be.read_meta()          # the exchange's one host read
+      if err & (ERR_CAPACITY | ERR_ROWS):
+        # some rank has more distinct tuples than the blocks hold: every rank sees the same
+        # counts in the gathered headers and regrows alike
+        _cap_set(group, tag, _pow2(max(need, 2 * cap)))
+        continue
+      if err:
+        _raise_for(err)
+      break
+    table = be.table[:rows]
+    if tr is not None and rows:
+      tr.all_reduce(table)
+    pa, pb, norms = be.finish(table)
+    psem, pinst, pbatch = be.plab[0, :rows], be.plab[1, :rows], be.plab[2, :rows]
+    ctx.save_for_backward(pa, pb, norms, be.upd)
+    ctx.tr, ctx.be_cls = tr, type(be)
+    ctx.mark_non_differentiable(psem, pinst, pbatch, be.upd)
+    return pa, pb, psem, pinst, pbatch, be.upd
 
-
-def _compose(tuples, rc, rl):
-  """(batch, cluster, semantic, instance) columns -> one sortable key."""
-  return ((tuples[:, 0] * rc + tuples[:, 1]) * rl + tuples[:, 2]) * rl + tuples[:, 3]
+  @staticmethod
+  def backward(ctx, g_pa, g_pb, _g2, _g3, _g4, _g5):
+    pa, pb, norms, upd = ctx.saved_tensors
+    g = ctx.be_cls.finish_bwd(g_pa, g_pb, pa, pb, norms)
+    if ctx.tr is not None and g.numel():
+      ctx.tr.all_reduce(g)              # every rank's loss sees the whole table
+    gx, gl = ctx.be_cls.rows_bwd(g, upd, pa.shape[1], pb.shape[1], ctx.needs_input_grad[:2])
+    return gx, gl, None, None, None, None, None, None
 
 
 # ---- hsg/models/utils.py:127-217 -----------------------------------------------
 def exchange_prototypes(embeddings, embeddings_with_loc, cluster_indices, batch_indices,
-                        semantic_labels, instance_labels, group=None):
+                        semantic_labels, instance_labels, group=None, tag='proto'):
   """Per-rank tensors in, batch-wide prototype tables out (same 6 results as
   the reference's gather_clustering_and_update_prototypes, un-listed).
 
-  Two collectives per call: one fixed-capacity all_gather of the ranks' distinct
+  Two collectives per call: one fixed-capacity all_gather of the ranks' sorted distinct
   (batch, cluster, semantic, instance) tuples and one all_reduce(sum) of the
   zero-padded [P_total, C + D] segment sums.  The reference's dense ids are the
   ranks of those tuples in lexicographic order (its two nested sorted
   `unique`s, utils.py:181-193), which does not depend on the radices used to
   pack them -- so each rank packs with its own maxima and no max-reduction is
   needed before the gather."""
-  dev = cluster_indices.device
-  c = cluster_indices.reshape(-1).long()
-  b = batch_indices.reshape(-1).long()
-  sem = semantic_labels.reshape(-1).long()
-  inst = instance_labels.reshape(-1).long()
-  world = _world(group)
-
-  if c.numel():
-    rc = c.max() + 1
-    rl = torch.maximum(inst.max(), sem.max()) + 1
-    keys = ((b * rc + c) * rl + sem) * rl + inst
-    local_keys, local_ids = torch.unique(keys, return_inverse=True)
-    rest, li = local_keys // rl, local_keys % rl
-    rest, ls = rest // rl, rest % rl
-    local_tuples = torch.stack([rest // rc, rest % rc, ls, li], 1)
-  else:
-    local_ids = torch.zeros((0,), dtype=torch.long, device=dev)
-    local_tuples = torch.zeros((0, 4), dtype=torch.long, device=dev)
-
-  if world > 1:
-    tuples, _ = _all_gather_rows(local_tuples, group, 'proto_keys')
-  else:
-    tuples = local_tuples
-  if tuples.shape[0]:
-    # utils.py:181-189: key order = (batch, cluster, semantic, instance)
-    divisor = tuples[:, 1].max() + 1
-    lab_div = tuples[:, 2:].max() + 1
-    if world > 1:
-      global_keys = torch.unique(_compose(tuples, divisor, lab_div))
-      slot = torch.searchsorted(global_keys, _compose(local_tuples, divisor, lab_div))
-    else:
-      global_keys = _compose(tuples, divisor, lab_div)        # already sorted and distinct
-      slot = None
-    updated_cluster_indices = slot[local_ids] if slot is not None else local_ids
-    # utils.py:193-197: labels of every prototype, decoded from the keys
-    prototype_instance_labels = global_keys % lab_div
-    prototype_semantic_labels = (global_keys // lab_div) % lab_div
-    prototype_batch_indices = (global_keys // (lab_div * lab_div)) // divisor
-  else:
-    global_keys = torch.zeros((0,), dtype=torch.long, device=dev)
-    slot = global_keys if world > 1 else None
-    updated_cluster_indices = local_ids
-    prototype_instance_labels = prototype_semantic_labels = prototype_batch_indices = global_keys
-  P = global_keys.shape[0]
-
-  # utils.py:199-202: segment sums -> (exchange) -> normalise
   C = embeddings.shape[-1]
   D = embeddings_with_loc.shape[-1]
-  n_local = local_tuples.shape[0]
-  if world > 1:
-    local = torch.cat([
-        _segment_sums(embeddings.reshape(-1, C), local_ids, n_local),
-        _segment_sums(embeddings_with_loc.reshape(-1, D), local_ids, n_local)], 1)
-    table = torch.zeros((P, C + D), dtype=local.dtype, device=dev)
-    table = table.index_add(0, slot, local)
-    table = _AllReduceSum.apply(table, group)
-    prototypes = _normalize(table[:, :C].contiguous())
-    prototypes_with_loc = _normalize(table[:, C:].contiguous())
-  else:
-    prototypes = _local_prototypes(embeddings.reshape(-1, C), local_ids, n_local)
-    prototypes_with_loc = _local_prototypes(embeddings_with_loc.reshape(-1, D), local_ids, n_local)
-  return (prototypes, prototypes_with_loc, prototype_semantic_labels,
-          prototype_instance_labels, prototype_batch_indices, updated_cluster_indices)
+  return _Exchange.apply(embeddings.reshape(-1, C), embeddings_with_loc.reshape(-1, D), cluster_indices,
+                         batch_indices, semantic_labels, instance_labels, group, tag)
+
+
+class _ExchangeList(torch.autograd.Function):
+  """ONE process driving several GPUs (lists of per-GPU tensors, train.py:190-223): keys and sums on
+  every tensor's own device; only tuple blocks and [P, C + D] tables move to the anchor."""
+
+  @staticmethod
+  def forward(ctx, ndev, anchor, tag, *tensors):
+    embs, locs = tensors[:ndev], tensors[ndev:2 * ndev]
+    cs, bs, sems, insts = (tensors[(2 + j) * ndev:(3 + j) * ndev] for j in range(4))
+    ai = _anchor_index(embs, anchor)
+    while True:
+      cap = _cap_get(None, tag)
+      # the anchor's workspace holds the `ndev` gathered tuple blocks and the merge; the others only their own
+      bes = [backend_class(embs[g], locs[g], cs[g], bs[g], sems[g], insts[g], cap, cap * ndev,
+                           ndev if g == ai else 1) for g in range(ndev)]
+      sends = [be.keys() for be in bes]
+      if ndev > 1:
+        recv = bes[ai].recv_blocks()
+        for g in range(ndev):
+          recv[g].copy_(sends[g], non_blocking=True)     # a tuple block: 8 + 4 cap words
+        slots = bes[ai].merge(-1)
+        for g in range(ndev):
+          bes[g].sums(-1, slots[g].to(embs[g].device, non_blocking=True))
+      else:
+        bes[0].merge(0)
+        bes[0].sums(0)
+      # one host read: the error bits of every device travel in its block header and are merged here
+      _n, rows, err, need = bes[ai].read_meta()
+      if err & (ERR_CAPACITY | ERR_ROWS):
+        _cap_set(None, tag, _pow2(max(need, 2 * cap)))
+        continue
+      if err:
+        _raise_for(err)
+      break
+    table = bes[ai].table[:rows]
+    for g in range(ndev):                                  # the tables, not the pixels, cross the links
+      if g != ai:
+        table += bes[g].table[:rows].to(anchor, non_blocking=True)
+    pa, pb, norms = bes[ai].finish(table)
+    plab = bes[ai].plab
+    upds = [be.upd for be in bes]
+    ctx.save_for_backward(pa, pb, norms, *upds)
+    ctx.ndev, ctx.be_cls = ndev, type(bes[0])
+    outs = (pa, pb, plab[0, :rows], plab[1, :rows], plab[2, :rows]) + tuple(upds)
+    ctx.mark_non_differentiable(*outs[2:])
+    return outs
+
+  @staticmethod
+  def backward(ctx, g_pa, g_pb, *_rest):
+    pa, pb, norms = ctx.saved_tensors[:3]
+    upds = ctx.saved_tensors[3:]
+    ndev = ctx.ndev
+    g = ctx.be_cls.finish_bwd(g_pa, g_pb, pa, pb, norms)
+    grads_e, grads_l = [], []
+    for k in range(ndev):
+      gd = g.to(upds[k].device)
+      ge, gl = ctx.be_cls.rows_bwd(gd, upds[k], pa.shape[1], pb.shape[1],
+                                   (ctx.needs_input_grad[3 + k], ctx.needs_input_grad[3 + ndev + k]))
+      grads_e.append(ge)
+      grads_l.append(gl)
+    return (None, None, None) + tuple(grads_e) + tuple(grads_l) + (None,) * (4 * ndev)
+
+
+def _anchor_index(tensors, anchor):
+  for i, t in enumerate(tensors):
+    if t.device == anchor:
+      return i
+  return 0
 
 
 def gather_clustering_and_update_prototypes(embeddings, embeddings_with_loc, cluster_indices,
@@ -223,18 +497,34 @@ def gather_clustering_and_update_prototypes(embeddings, embeddings_with_loc, clu
   sems, _ = _as_list(semantic_labels)
   insts, _ = _as_list(instance_labels)
   devices = [t.device for t in c_inds]
-  sections = [t.shape[0] for t in c_inds]
-  anchor = torch.device(anchor_device) if anchor_device is not None else devices[0]
-  if len(c_inds) > 1:            # several GPUs driven by this one process
+  if not listed or (len(c_inds) == 1 and _world(group) > 1):
+    res = exchange_prototypes(embs[0], embs_loc[0], c_inds[0], b_inds[0], sems[0], insts[0], group=group)
+    if not listed:
+      return res
+    return tuple([r] for r in res)
+  if _world(group) > 1:
+    # several GPUs per process AND several processes (not a reference configuration): the local
+    # tensors are joined on the anchor first, then the ranks exchange as usual
+    anchor = torch.device(anchor_device) if anchor_device is not None else devices[0]
+    sections = [t.shape[0] for t in c_inds]
     args = [_cat_to(v, anchor) for v in (embs, embs_loc, c_inds, b_inds, sems, insts)]
-  else:
-    args = [embs[0], embs_loc[0], c_inds[0], b_inds[0], sems[0], insts[0]]
-  protos, protos_loc, psem, pinst, pbatch, updated = exchange_prototypes(*args, group=group)
-  if not listed:
-    return protos, protos_loc, psem, pinst, pbatch, updated
-  updated = [u.to(d) for u, d in zip(torch.split(updated, sections), devices)]
+    protos, protos_loc, psem, pinst, pbatch, updated = exchange_prototypes(*args, group=group)
+    updated = [u.to(d) for u, d in zip(torch.split(updated, sections), devices)]
+    fan = lambda t: [t.to(d) for d in devices]
+    return fan(protos), fan(protos_loc), fan(psem), fan(pinst), fan(pbatch), updated
+  ndev = len(c_inds)
+  anchor = torch.device(anchor_device) if anchor_device is not None else devices[0]
+  if anchor.type == 'cuda' and anchor.index is None:
+    anchor = torch.device('cuda', torch.cuda.current_device())
+  if anchor not in devices:
+    anchor = devices[0]
+  C, D = embs[0].shape[-1], embs_loc[0].shape[-1]
+  outs = _ExchangeList.apply(ndev, anchor, 'proto_list',
+                             *[e.reshape(-1, C) for e in embs], *[e.reshape(-1, D) for e in embs_loc],
+                             *c_inds, *b_inds, *sems, *insts)
+  protos, protos_loc, psem, pinst, pbatch = outs[:5]
   fan = lambda t: [t.to(d) for d in devices]
-  return fan(protos), fan(protos_loc), fan(psem), fan(pinst), fan(pbatch), updated
+  return fan(protos), fan(protos_loc), fan(psem), fan(pinst), fan(pbatch), list(outs[5:])
 
 
 # ---- hsg/models/utils.py:41-74 ---------------------------------------------------

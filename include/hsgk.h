@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HSGK_VERSION 200
+#define HSGK_VERSION 300
 #define HSGK_CHUNK 2048          /* rows per segment-sum chunk (order C2)      */
 #define HSGK_EPS 1e-12f          /* normalize_embedding eps (general/common.py:101) */
 
@@ -259,6 +259,86 @@ HSGK_API int hsgk_segsort_loss_bwd(const float *emb, int64_t n, int c, const int
                                    const int32_t *use_same, const float *gscale, float *g_emb,
                                    float *g_proto, void *workspace, size_t workspace_bytes,
                                    hsgk_stream_t stream);
+
+/* ---- hsg/models/utils.py:127-217 gather_clustering_and_update_prototypes: the cross-GPU
+ *      prototype exchange (called three times per training iteration, pyscripts/train/train.py:190,219)
+ * Per-rank pixel rows in, batch-wide prototype tables out.  The reference ships every pixel
+ * embedding to one GPU; here a rank reduces its pixels to per-segment sums and only tables cross
+ * xGMI: ONE all_gather of the ranks' sorted distinct (batch, cluster, semantic, instance) tuples
+ * (fixed capacity, row count in the block header) and ONE all_reduce(sum) of the zero-padded
+ * [rows, C + D] sums, both RCCL calls on `stream` with the caller's ncclComm_t (`comm`, void*).
+ * No host read anywhere: counts and data-dependent errors come back in the device `meta` block.
+ *   embeddings [n,C], embeddings_loc [n,D] f32; cluster / batch / semantic / instance int64 [n], >= 0.
+ *   Dense id of a pixel = rank of its tuple among the distinct tuples of ALL ranks in lexicographic
+ *   order (the reference's two nested sorted `unique`s, utils.py:181-193) -> updated_cluster [n].
+ *   prototypes [rows,C], prototypes_loc [rows,D] = L2-normalised segment sums (order C2 per rank,
+ *   eps-clamped norm); norms [rows][2] (nullable) keeps the clamped norms for the backward pass;
+ *   proto_semantic / proto_instance / proto_batch [cap_total] decoded from the tuples (utils.py:193-197).
+ *   table [cap_total][C+D]: the raw sums (caller-owned so that it outlives the workspace between
+ *   begin and finish).
+ *   cap_local = tuple rows a rank may contribute, cap_total = rows of the tables; pool_rows = partial
+ *   rows of the chunk sums (sum over the chunks of 2048 rows of their distinct ids; chunks that find
+ *   the pool exhausted are summed by the slower per-segment scan, same order).
+ *   meta (device, int64[8]): [0] distinct local tuples, [1] distinct tuples over all ranks (= valid
+ *   table rows), [2] error bits: 1 negative component, 2 more tuples than cap_local (on any rank),
+ *   4 packed key overflows 2^62, 8 more rows than cap_total; [3] the largest tuple count of any rank
+ *   (what cap_local has to hold).  With an error the outputs are undefined.
+ * hsgk_exchange_prototypes = hsgk_exchange_begin + hsgk_exchange_finish(rows = cap_total): fully
+ * asynchronous.  A caller that needs the row count on the host anyway (to shape tensors) calls
+ * begin, reads meta, then finish with rows = meta[1] (the all_reduce then moves only the used rows).
+ * The phases are also exported for ONE process driving several GPUs (the reference's
+ * DataParallel mode: lists of per-GPU tensors): hsgk_exchange_keys on every device, the send
+ * blocks copied into the recv blocks of the anchor, hsgk_exchange_merge(my_rank = -1) there (slots
+ * for every source), hsgk_exchange_sums on every device, the tables added up on the anchor,
+ * hsgk_exchange_finish(comm = NULL).                                                            */
+typedef struct hsgk_exchange_args {
+  const float *embeddings;       /* [n,C]  */
+  const float *embeddings_loc;   /* [n,D]  */
+  const int64_t *cluster, *batch, *semantic, *instance;   /* [n] */
+  int64_t n;
+  int32_t C, D;
+  int64_t cap_local, cap_total, pool_rows;
+  float eps;
+  float *table;                  /* [cap_total][C+D] */
+  float *prototypes;             /* [rows][C] */
+  float *prototypes_loc;         /* [rows][D] */
+  float *norms;                  /* [rows][2] or NULL */
+  int64_t *proto_semantic, *proto_instance, *proto_batch;   /* [cap_total] */
+  int64_t *updated_cluster;      /* [n] */
+  int64_t *meta;                 /* device int64[8] */
+  void *workspace;
+  size_t workspace_bytes;
+} hsgk_exchange_args;
+HSGK_API size_t hsgk_exchange_workspace_bytes(int64_t n, int C, int D, int64_t cap_local,
+                                              int64_t cap_total, int world, int64_t pool_rows);
+HSGK_API int hsgk_exchange_prototypes(const hsgk_exchange_args *args, void *comm, int rank, int world,
+                                      hsgk_stream_t stream);
+HSGK_API int hsgk_exchange_begin(const hsgk_exchange_args *args, void *comm, int rank, int world,
+                                 hsgk_stream_t stream);
+HSGK_API int hsgk_exchange_finish(const hsgk_exchange_args *args, int64_t rows, void *comm, int world,
+                                  hsgk_stream_t stream);
+/* phases (see above).  send block = int64[8 + 4 cap_local]: [0] row count, [1] error bits, then the
+ * sorted tuples; recv blocks = `world` such blocks in rank order (both inside the workspace).
+ * merge: slots_out int32 [world][cap_local] (NULL: kept in the workspace) = table row of every
+ * source's tuple; sums: `slots` = this rank's row of that array (NULL: the workspace's).         */
+HSGK_API int hsgk_exchange_keys(const hsgk_exchange_args *args, int world, hsgk_stream_t stream);
+HSGK_API const int64_t *hsgk_exchange_send_block(const hsgk_exchange_args *args, int world, size_t *bytes);
+HSGK_API int64_t *hsgk_exchange_recv_blocks(const hsgk_exchange_args *args, int world);
+HSGK_API int hsgk_exchange_merge(const hsgk_exchange_args *args, int my_rank, int world,
+                                 int32_t *slots_out, hsgk_stream_t stream);
+HSGK_API int hsgk_exchange_sums(const hsgk_exchange_args *args, int my_rank, int world,
+                                const int32_t *slots, hsgk_stream_t stream);
+/* Communicator helpers (host): librccl is bound at run time -- the instance the process already
+ * loaded (torch's), else the system one -- so libhsgk.so has no link-time dependency on it.
+ * unique_id on rank 0, hand the bytes to every rank (any transport), init_rank on every rank with
+ * its device current.  all_reduce_f32 (in place) is the gradient's way back through the exchange. */
+#define HSGK_COMM_ID_BYTES 128
+HSGK_API int hsgk_comm_unique_id(void *id_out, size_t bytes);
+HSGK_API int hsgk_comm_init_rank(void **comm_out, int world, int rank, const void *id, size_t bytes);
+HSGK_API int hsgk_comm_destroy(void *comm);
+HSGK_API int hsgk_comm_all_reduce_f32(float *buf, int64_t count, void *comm, hsgk_stream_t stream);
+HSGK_API int hsgk_comm_all_gather_bytes(const void *send, void *recv, size_t bytes_per_rank, void *comm,
+                                        hsgk_stream_t stream);
 
 /* ---- hsg/models/embeddings/resnet_fcn_hsg.py:638-672 _hierarchical_grouping tail
  * fine_logits [B,KF,N], coarse_logits [B,KC,KF] (nullable).  fine_prob = softmax

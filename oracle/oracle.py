@@ -137,6 +137,40 @@ def calculate_prototypes_from_labels(embeddings, labels, max_label=None,
   return out
 
 
+
+def exchange_prototypes(parts):
+  """hsg/models/utils.py:127-217 gather_clustering_and_update_prototypes for a list of per-source
+  pixel sets (dicts with emb [n,C], emb_loc [n,D], cluster / batch / sem / inst [n]): the reference
+  concatenates the sources, makes (batch, cluster) dense, then `prepare_prototype_labels` on
+  (batch, sem, inst) x cluster -- i.e. dense id = rank of (batch, cluster, sem, inst) among the distinct
+  tuples in lexicographic order (:181-193) -- and normalises the per-id sums (:199-202).  Sums are
+  taken per SOURCE in order C2 and added in source order from +0.0f (the all-reduce of the product;
+  a segment normally lives on one source, so this only adds zeros).
+  Returns protos, protos_loc, psem, pinst, pbatch, [updated ids per source]."""
+  tup = [np.stack([_i64(p['batch']).reshape(-1), _i64(p['cluster']).reshape(-1),
+                   _i64(p['sem']).reshape(-1), _i64(p['inst']).reshape(-1)], 1) for p in parts]
+  allt = np.concatenate(tup, 0)
+  uniq, inv = np.unique(allt, axis=0, return_inverse=True)
+  inv = inv.reshape(-1).astype(np.int64)
+  P = uniq.shape[0]
+  C, D = parts[0]['emb'].shape[1], parts[0]['emb_loc'].shape[1]
+  ta, tb = np.zeros((P, C), np.float32), np.zeros((P, D), np.float32)
+  upd, o = [], 0
+  for p, t in zip(parts, tup):
+    ids = inv[o:o + t.shape[0]]
+    o += t.shape[0]
+    upd.append(ids)
+    for x, tab in ((p['emb'], ta), (p['emb_loc'], tb)):
+      x = _f32(x)
+      part = np.zeros((P, x.shape[1]), np.float32)
+      if x.shape[0]:
+        lib().orc_segment_sums(_p(x, _f32p), ctypes.c_int64(x.shape[0]), x.shape[1], _p(ids, _i64p),
+                               ctypes.c_int64(P), CHUNK, _p(part, _f32p))
+      tab += part
+  return (normalize_embedding(ta), normalize_embedding(tb), uniq[:, 2].copy(), uniq[:, 3].copy(),
+          uniq[:, 0].copy(), upd)
+
+
 def segment_mean(x, index, chunk=CHUNK):
   """hsg/utils/general/common.py:123-147."""
   x = _f32(x).reshape(-1, x.shape[-1])

@@ -28,30 +28,10 @@ def _free_port():
 
 
 def _install_cpu_hooks(mu):
-  from oracle import oracle as orc
-  import ctypes
-
-  class _Sums(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, rows, ids, count):
-      x = np.ascontiguousarray(rows.detach().numpy(), np.float32)
-      lab = np.ascontiguousarray(ids.numpy(), np.int64)
-      out = np.empty((count, x.shape[1]), np.float32)
-      orc.lib().orc_segment_sums(
-          x.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), ctypes.c_int64(x.shape[0]), x.shape[1],
-          lab.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), ctypes.c_int64(count), orc.CHUNK,
-          out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
-      ctx.save_for_backward(ids)
-      return torch.from_numpy(out)
-
-    @staticmethod
-    def backward(ctx, g):
-      (ids,) = ctx.saved_tensors
-      return g[ids], None, None
-
-  mu._segment_sums = lambda rows, ids, count: _Sums.apply(rows, ids, count)
-  mu._normalize = lambda t: t / t.norm(dim=1, keepdim=True).clamp_min(1e-12)
-  mu._local_prototypes = lambda rows, ids, count: mu._normalize(mu._segment_sums(rows, ids, count))
+  """The per-device kernels (libhsgk in production) are replaced by the oracle-backed backend of
+  tests/exchange_cpu_backend.py; the orchestration under test stays hsg_amd/models/utils.py."""
+  from tests.exchange_cpu_backend import CpuExchangeBackend
+  mu.backend_class = CpuExchangeBackend
 
 
 def _worker(rank, world, port, result_dir):
@@ -94,6 +74,20 @@ def _worker(rank, world, port, result_dir):
     m2 = mu.gather_and_update_cluster_mappings(upd if rank == 0 else empty,
                                                T('cluster') if rank == 0 else empty)
     assert m2.shape[0] == int(g['upd0'].max()) + 1
+    # the tuple blocks of the prototype exchange overflow too: 4 rows of capacity against 40 - 70 segments
+    # per rank -> every rank regrows from the gathered header counts and repeats; results unchanged
+    mu._capacity.clear()
+    saved_cap, mu._CAP_START = mu._CAP_START, 4
+    try:
+      before = mu.collective_calls
+      again = mu.gather_clustering_and_update_prototypes(
+          T('emb'), T('emb_loc'), T('cluster'), T('batch'), T('sem'), T('inst'))
+      assert mu.collective_calls - before > 2
+      assert np.array_equal(again[5].numpy(), g['upd%d' % rank]) and np.array_equal(again[2].numpy(), g['psem'])
+      assert np.abs(again[0].numpy() - g['protos']).max() <= 2e-6
+      assert mu._cap_get(None, 'proto') >= int(g['psem'].shape[0]) // 2
+    finally:
+      mu._CAP_START = saved_cap
     # capacity overflow: every rank regrows from the same counts and repeats the gather
     mu._capacity.clear()
     saved_cap, mu._CAP_START = mu._CAP_START, 4
@@ -130,10 +124,11 @@ def test_exchange_world2_gloo(tmp_path):
 
 
 def test_exchange_single_process_list_api(oracle):
-  """Reference calling convention (lists, one tensor per GPU) without
-  torch.distributed: the two 'GPUs' are concatenated on the anchor device."""
+  """Reference calling convention (lists, one tensor per GPU of ONE process, train.py:190) without
+  torch.distributed: keys and sums per 'device', only the tuple blocks and the sum tables are joined on
+  the anchor (no pixel row is moved: the backend objects never see another device's rows)."""
   from hsg_amd.models import utils as mu
-  saved = (mu._segment_sums, mu._normalize, mu._local_prototypes)
+  saved = mu.backend_class
   _install_cpu_hooks(mu)
   try:
     g = util.load('f8_exchange')
@@ -158,4 +153,4 @@ def test_exchange_single_process_list_api(oracle):
       assert int(mapping[0][a]) == max(bs) == int(g['mapping'][a])
     assert np.array_equal(mapping[0].numpy(), g['mapping'])
   finally:
-    mu._segment_sums, mu._normalize, mu._local_prototypes = saved
+    mu.backend_class = saved

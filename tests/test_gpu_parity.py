@@ -540,6 +540,162 @@ def test_exchange_list_api_on_gpu_vs_reference(dev):
   assert embs[0].grad is not None and embs[1].grad is not None
 
 
+def _exchange_case(seed, sizes, C, nimg, ncl, nsem, ninst, shuffle_ids=False):
+  """Per-source pixel sets with image-major rows (like segment_by_kmeans output) or arbitrary ids."""
+  parts = []
+  for g, n in enumerate(sizes):
+    e = synth.gaussish(seed + 10 * g, n * C).reshape(n, C).astype(np.float64)
+    e = (e / np.sqrt((e * e).sum(1, keepdims=True))).astype(np.float32)
+    l = synth.gaussish(seed + 10 * g + 1, n * 2).reshape(n, 2) * np.float32(0.3)
+    el = np.concatenate([e, l], 1).astype(np.float64)
+    el = (el / np.sqrt((el * el).sum(1, keepdims=True))).astype(np.float32)
+    img = np.sort((synth.hash_u64(seed + 10 * g + 2, n) % np.uint64(nimg)).astype(np.int64)) if n else np.zeros((0,), np.int64)
+    cl = (synth.hash_u64(seed + 10 * g + 3, n) % np.uint64(ncl)).astype(np.int64)
+    if shuffle_ids:
+      cl = cl * 977 + 13                                   # sparse, large ids
+    parts.append(dict(emb=e, emb_loc=el, cluster=cl, batch=img + (nimg * g if not shuffle_ids else 0),
+                      sem=(synth.hash_u64(seed + 10 * g + 4, n) % np.uint64(nsem)).astype(np.int64),
+                      inst=(synth.hash_u64(seed + 10 * g + 5, n) % np.uint64(ninst)).astype(np.int64)))
+  return parts
+
+
+@pytest.mark.parametrize('sizes,C,nimg,ncl,nsem,ninst,shuffle', [
+    ([5000], 256, 3, 64, 1, 1, False),            # one source, rows of 256 / 258 columns, several chunks
+    ([9000, 4100], 128, 2, 16, 3, 2, False),      # two sources, 130-column rows (scalar tail of 2)
+    ([2500, 0, 3000], 16, 2, 6, 4, 3, False),     # an empty source; rows shorter than a slice
+    ([6000, 6000], 64, 2, 40, 2, 2, True),        # the same images on both sources: segments MERGE; sparse ids
+    ([4097], 384, 1, 128, 1, 1, False),           # 384 / 386 columns: three slices + tail
+    ([3000], 200, 2, 9, 2, 1, False),             # 200 / 202 columns: remainder > 64 is its own slice
+])
+def test_exchange_list_mode_bit_exact_vs_oracle(dev, oracle, sizes, C, nimg, ncl, nsem, ninst, shuffle):
+  """hsg/models/utils.py:127-217 through the list API (one process, several 'GPUs' -- all tensors on the one
+  device of the box, each with its own backend / workspace): ids, labels exact and BOTH float tables
+  bit-identical to oracle.exchange_prototypes (same C2 sums per source, same C1 norm chain)."""
+  import torch
+  from hsg_amd.models import utils as mu
+  parts = _exchange_case(1234 + C, sizes, C, nimg, ncl, nsem, ninst, shuffle)
+  T = lambda k: [torch.from_numpy(p[k]).to(dev) for p in parts]
+  want = oracle.exchange_prototypes(parts)
+  got = mu.gather_clustering_and_update_prototypes(T('emb'), T('emb_loc'), T('cluster'), T('batch'), T('sem'),
+                                                   T('inst'), dev)
+  for j, name in ((2, 'psem'), (3, 'pinst'), (4, 'pbatch')):
+    assert np.array_equal(got[j][0].cpu().numpy(), want[j]), name
+  for g in range(len(sizes)):
+    assert np.array_equal(got[5][g].cpu().numpy(), want[5][g]), 'ids of source %d' % g
+  assert np.array_equal(got[0][0].cpu().numpy().view(np.uint32), want[0].view(np.uint32)), 'prototypes'
+  assert np.array_equal(got[1][-1].cpu().numpy().view(np.uint32), want[1].view(np.uint32)), 'prototypes_with_loc'
+  # a single tensor (one process per GPU, world 1) takes the same kernels through _Exchange
+  if len(sizes) == 1:
+    one = mu.gather_clustering_and_update_prototypes(*[T(k)[0] for k in ('emb', 'emb_loc', 'cluster', 'batch', 'sem', 'inst')])
+    assert np.array_equal(one[5].cpu().numpy(), want[5][0])
+    assert np.array_equal(one[0].cpu().numpy().view(np.uint32), want[0].view(np.uint32))
+    assert np.array_equal(one[1].cpu().numpy().view(np.uint32), want[1].view(np.uint32))
+
+
+def test_exchange_capacity_regrowth_and_errors(dev, oracle):
+  """The tuple blocks start too small (4 rows): the device reports the needed rows, the mirror regrows and
+  repeats; negative values raise like the reference's scatter would."""
+  import torch
+  from hsg_amd.models import utils as mu
+  parts = _exchange_case(77, [3000, 2000], 32, 2, 30, 2, 2)
+  T = lambda k: [torch.from_numpy(p[k]).to(dev) for p in parts]
+  want = oracle.exchange_prototypes(parts)
+  saved = mu._CAP_START
+  mu._capacity.clear()
+  mu._CAP_START = 4
+  try:
+    got = mu.gather_clustering_and_update_prototypes(T('emb'), T('emb_loc'), T('cluster'), T('batch'), T('sem'),
+                                                     T('inst'), dev)
+    assert mu._cap_get(None, 'proto_list') >= max(int(np.unique(np.stack([p[k] for k in ('batch', 'cluster', 'sem', 'inst')], 1), axis=0).shape[0]) for p in parts)
+  finally:
+    mu._CAP_START = saved
+    mu._capacity.clear()
+  assert np.array_equal(got[5][1].cpu().numpy(), want[5][1])
+  assert np.array_equal(got[0][0].cpu().numpy().view(np.uint32), want[0].view(np.uint32))
+  bad = T('sem')
+  bad[0][5] = -3
+  with pytest.raises(ValueError):
+    mu.gather_clustering_and_update_prototypes(T('emb'), T('emb_loc'), T('cluster'), T('batch'), bad, T('inst'), dev)
+
+
+def test_exchange_gradients_vs_torch(dev):
+  """backward through finish (normalise) and the row -> segment map, list mode, against torch autograd of the
+  same formula."""
+  import torch
+  from hsg_amd.models import utils as mu
+  parts = _exchange_case(99, [1500, 1100], 48, 2, 10, 2, 2)
+  T = lambda k: [torch.from_numpy(p[k]).to(dev) for p in parts]
+  embs = [t.requires_grad_(True) for t in T('emb')]
+  locs = [t.requires_grad_(True) for t in T('emb_loc')]
+  got = mu.gather_clustering_and_update_prototypes(embs, locs, T('cluster'), T('batch'), T('sem'), T('inst'), dev)
+  P = got[0][0].shape[0]
+  w1 = torch.from_numpy(synth.gaussish(5, P * 48).reshape(P, 48)).to(dev)
+  w2 = torch.from_numpy(synth.gaussish(6, P * 50).reshape(P, 50)).to(dev)
+  ((got[0][0] * w1).sum() + (got[1][1] * w2).sum()).backward()
+  e2 = [t.detach().clone().requires_grad_(True) for t in embs]
+  l2 = [t.detach().clone().requires_grad_(True) for t in locs]
+  ids = torch.cat(got[5])
+  sa = torch.zeros((P, 48), device=dev).index_add(0, ids, torch.cat(e2))
+  sb = torch.zeros((P, 50), device=dev).index_add(0, ids, torch.cat(l2))
+  pa = sa / sa.norm(dim=1, keepdim=True).clamp_min(1e-12)
+  pb = sb / sb.norm(dim=1, keepdim=True).clamp_min(1e-12)
+  ((pa * w1).sum() + (pb * w2).sum()).backward()
+  for a, b in zip(embs + locs, e2 + l2):
+    assert (a.grad - b.grad).abs().max().item() <= 2e-5 * max(b.grad.abs().max().item(), 1.0)
+
+
+def test_exchange_c_abi_composite_one_call(dev, oracle):
+  """hsgk_exchange_prototypes (begin + finish over the whole table capacity, no host read in between) through
+  ctypes, world 1: without a communicator, and with a ONE-rank RCCL communicator made by hsgk_comm_*; a
+  starved partial-row pool (chunks fall back to the per-segment scan) gives the same bits."""
+  import ctypes
+  import torch
+  from hsg_amd import _lib
+  parts = _exchange_case(4321, [7000], 128, 3, 20, 2, 2)
+  want = oracle.exchange_prototypes(parts)
+  p = parts[0]
+  L = _lib.lib()
+  n, C, D = p['emb'].shape[0], 128, 130
+  P = want[0].shape[0]
+  t = {k: torch.from_numpy(v).to(dev) for k, v in p.items()}
+  comm = ctypes.c_void_p()
+  ident = (ctypes.c_uint8 * 128)()
+  _lib.check(L.hsgk_comm_unique_id(ident, 128))
+  _lib.check(L.hsgk_comm_init_rank(ctypes.byref(comm), 1, 0, ident, 128))
+  try:
+    for use_comm, pool_rows in ((False, 4096), (True, 4096), (False, 40)):
+      cap = 512
+      wsb = L.hsgk_exchange_workspace_bytes(n, C, D, cap, cap, 1, pool_rows)
+      ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+      table = torch.empty((cap, C + D), device=dev)
+      pa, pb = torch.empty((cap, C), device=dev), torch.empty((cap, D), device=dev)
+      norms = torch.empty((cap, 2), device=dev)
+      plab = torch.empty((3, cap), dtype=torch.int64, device=dev)
+      upd = torch.empty((n,), dtype=torch.int64, device=dev)
+      meta = torch.empty((8,), dtype=torch.int64, device=dev)
+      a = _lib.ExchangeArgs(
+          embeddings=t['emb'].data_ptr(), embeddings_loc=t['emb_loc'].data_ptr(), cluster=t['cluster'].data_ptr(),
+          batch=t['batch'].data_ptr(), semantic=t['sem'].data_ptr(), instance=t['inst'].data_ptr(), n=n, C=C, D=D,
+          cap_local=cap, cap_total=cap, pool_rows=pool_rows, eps=_lib.EPS, table=table.data_ptr(),
+          prototypes=pa.data_ptr(), prototypes_loc=pb.data_ptr(), norms=norms.data_ptr(),
+          proto_semantic=plab[0].data_ptr(), proto_instance=plab[1].data_ptr(), proto_batch=plab[2].data_ptr(),
+          updated_cluster=upd.data_ptr(), meta=meta.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=wsb)
+      _lib.check(L.hsgk_exchange_prototypes(ctypes.byref(a), comm if use_comm else None, 0, 1, _lib.stream_ptr()))
+      m = meta.cpu().tolist()
+      assert m[0] == P and m[1] == P and m[2] == 0 and m[3] == P, m
+      assert np.array_equal(upd.cpu().numpy(), want[5][0])
+      assert np.array_equal(plab[0, :P].cpu().numpy(), want[2]) and np.array_equal(plab[2, :P].cpu().numpy(), want[4])
+      assert np.array_equal(pa[:P].cpu().numpy().view(np.uint32), want[0].view(np.uint32)), (use_comm, pool_rows)
+      assert np.array_equal(pb[:P].cpu().numpy().view(np.uint32), want[1].view(np.uint32)), (use_comm, pool_rows)
+      assert float(pa[P:].abs().max()) == 0.0          # unused table rows: zero sums -> zero rows
+    # the in-place all_reduce helper on the one-rank communicator is the identity
+    buf = torch.arange(1000, dtype=torch.float32, device=dev)
+    _lib.check(L.hsgk_comm_all_reduce_f32(buf.data_ptr(), 1000, comm, _lib.stream_ptr()))
+    assert torch.equal(buf.cpu(), torch.arange(1000, dtype=torch.float32))
+  finally:
+    _lib.check(L.hsgk_comm_destroy(comm))
+
+
 @pytest.mark.parametrize('B,HW,C,K', [(2, 4096, 32, 8), (1, 5000, 256, 64), (3, 2500, 128, 37),
                                       (1, 300, 64, 64), (2, 3000, 384, 128), (1, 4000, 256, 100), (1, 3000, 256, 200),
                                       (2, 2500, 256, 256)])

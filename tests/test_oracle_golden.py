@@ -243,3 +243,14 @@ def test_segment_by_kmeans_with_explicit_cluster_indices(oracle):
   assert np.array_equal(cluster, g['cluster'])
   assert np.abs(emb[::util.ROW_STRIDE] - g['emb_rows']).max() <= 2e-6
   assert np.abs(emb_loc[::util.ROW_STRIDE] - g['emb_loc_rows']).max() <= 2e-6
+
+
+def test_exchange_restatement_vs_reference_golden(oracle):
+  """f8: oracle.exchange_prototypes (the checker of the GPU exchange) against the reference's own
+  gather_clustering_and_update_prototypes outputs for the two-'GPU' fixture."""
+  g = util.load('f8_exchange')
+  parts = util.exchange_inputs(int(g['seed']))
+  pa, pb, psem, pinst, pbatch, upd = oracle.exchange_prototypes(parts)
+  assert np.array_equal(psem, g['psem']) and np.array_equal(pinst, g['pinst']) and np.array_equal(pbatch, g['pbatch'])
+  assert np.array_equal(upd[0], g['upd0']) and np.array_equal(upd[1], g['upd1'])
+  assert np.abs(pa - g['protos']).max() <= 2e-6 and np.abs(pb - g['protos_loc']).max() <= 2e-6
