@@ -111,12 +111,12 @@ def free_port():
   return port
 
 
-def relaunch_as_ranks(n):
+def relaunch_as_ranks(n, env=None):
   """`python bench.py --gpus N` outside torchrun: start N ranks of this script on this node."""
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
          '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
          os.path.abspath(__file__)] + sys.argv[1:]
-  return subprocess.call(cmd)
+  return subprocess.call(cmd, env=env)
 
 
 def parse_args():
@@ -132,6 +132,9 @@ def parse_args():
   ap.add_argument('--no-exchange', action='store_true',
                   help='skip the prototype-table exchange measurement')
   ap.add_argument('--no-extra', action='store_true', help='skip the mixture / labelled side runs')
+  ap.add_argument('--dry-ranks', type=int, default=0,
+                  help='N ranks on ONE device (gloo transport on device tensors; RCCL refuses several ranks per '
+                       'device): exercises the rank bookkeeping, not the interconnect -- the value is not a benchmark')
   ap.add_argument('--cpu-images', type=int, default=4,
                   help='images of the workload shape timed on the host CPU (0 = skip)')
   return ap.parse_args()
@@ -177,6 +180,11 @@ def cpu_baseline(torch, x_cpu, grid, iters, shape_note):
 
 def main():
   args = parse_args()
+  if args.dry_ranks > 1 and 'WORLD_SIZE' not in os.environ:
+    env = dict(os.environ)
+    env['HSGK_BENCH_DEVICE'] = env.get('HSGK_BENCH_DEVICE', '0')
+    env['HSGK_BENCH_BACKEND'] = 'gloo'
+    sys.exit(relaunch_as_ranks(args.dry_ranks, env))
   if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
     sys.exit(relaunch_as_ranks(args.gpus))
 
@@ -195,8 +203,12 @@ def main():
     os.environ.setdefault('RANK', '0')
     os.environ.setdefault('WORLD_SIZE', '1')
     torch.cuda.set_device(local)
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local),
-                            timeout=datetime.timedelta(seconds=300))
+    backend = os.environ.get('HSGK_BENCH_BACKEND', 'nccl')
+    if backend == 'nccl':
+      dist.init_process_group('nccl', device_id=torch.device('cuda', local),
+                              timeout=datetime.timedelta(seconds=300))
+    else:
+      dist.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
   dev = torch.device('cuda', local)
   torch.cuda.set_device(dev)
 
@@ -265,10 +277,13 @@ def main():
   # the segment keys and ONE RCCL all_reduce over xGMI when N > 1; hsg_amd/models/utils.py).
   # Not part of `value` (BASELINE.md metric = the segment_by_kmeans call); timed on its own
   # with the same fences, max over ranks.
-  exch = None
-  if not args.no_exchange:
-    try:        # never let the side measurement take the headline line down with it
-      from hsg_amd.models import utils as model_utils
+  exch, exch_lib = None, None
+  backend_name = (dist.get_backend() if dist is not None else None)
+
+  def measure_exchange(library_comm):
+    from hsg_amd.models import utils as model_utils
+    model_utils.use_library_comm = library_comm
+    try:
       emb, emb_loc, lab, cidx, bidx = out
       zeros = torch.zeros_like(lab)
       times, ncoll, res = [], 0, None
@@ -285,14 +300,21 @@ def main():
       if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
       tl = tt.tolist()
-      exch = {'ms': round(statistics.median(tl) * 1e3, 3), 'runs_ms': [round(t * 1e3, 3) for t in tl],
+      return {'ms': round(statistics.median(tl) * 1e3, 3), 'runs_ms': [round(t * 1e3, 3) for t in tl],
               'segments_total': int(res[0].shape[0]), 'collectives_per_call': int(ncoll),
-              'payload_MB': round(res[0].shape[0] * (2 * C + 2) * 4 / 1e6, 2)}
-      del res, emb, emb_loc, lab, cidx, bidx, zeros
+              'payload_MB': round(res[0].shape[0] * (2 * C + 2) * 4 / 1e6, 2),
+              'transport': ('libhsgk RCCL communicator, in-stream' if library_comm else
+                            'torch.distributed (%s)' % backend_name) if world > 1 else 'none (one rank)'}
+    finally:
+      model_utils.use_library_comm = False
+
+  if not args.no_exchange:
+    try:        # never let the side measurement take the headline line down with it
+      exch = measure_exchange(False)
     except Exception as e:                      # noqa: BLE001
       exch = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
-  del out
-
+  if not (world > 1 and backend_name == 'nccl'):
+    out = None                                  # (kept for the in-stream variant at the end otherwise)
   if dist is not None:
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -395,10 +417,12 @@ def main():
     nb = min(args.cpu_images, B)
     cpu = cpu_baseline(torch, x[:nb].cpu(), grid, iters, '%dx%dx%d each' % (C, H, W))
 
-  if rank == 0:
+  def emit(instream):
+    if rank != 0:
+      return
     print(json.dumps({
         'metric': 'pixel-embeddings clustered/sec', 'value': round(value, 1),
-        'unit': 'pixels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'unit': 'pixels/s', 'n_gpus': 1 if args.dry_ranks > 1 else world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s: segment_by_kmeans %dx%dx%dx%d per GPU, K=%dx%d, %d Lloyd '
@@ -408,8 +432,31 @@ def main():
                    'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world,
                    'phase_ms_per_step': phases},
         'exchange_ms': exch.get('ms') if exch else None, 'prototype_exchange': exch,
+        'prototype_exchange_instream': instream, 'dist_backend': backend_name,
+        'rccl_ranks': world if backend_name == 'nccl' else 0, 'dry_ranks': args.dry_ranks if args.dry_ranks > 1 else 0,
         'roofline': roofline, 'roofline_mstep': roofline_mstep, 'roofline_prep': roofline_prep,
-        'roofline_iteration': roofline_iteration, 'cpu_baseline': cpu, 'extra_runs': extra}))
+        'roofline_iteration': roofline_iteration, 'cpu_baseline': cpu, 'extra_runs': extra}), flush=True)
+
+  # The same exchange with both collectives IN-STREAM on libhsgk's own RCCL communicator (the C entry points
+  # hsgk_exchange_* / hsgk_comm_*): only with real RCCL ranks.  It runs last, under a watchdog that prints the
+  # line without it and ends the process if a collective should hang, so the headline line never depends on it.
+  instream = None
+  if world > 1 and backend_name == 'nccl' and not args.no_exchange and exch and 'error' not in exch:
+    import threading
+    done = threading.Event()
+
+    def watchdog():
+      if not done.wait(120.0):
+        emit({'error': 'timeout: no result within 120 s'})
+        os._exit(0)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+      instream = measure_exchange(True)
+    except Exception as e:                      # noqa: BLE001
+      instream = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
+    done.set()
+  emit(instream)
   if dist is not None:
     dist.destroy_process_group()
 

@@ -67,18 +67,21 @@ def test_bench_line_single_rank_process_group():
   assert r['exchange_ms'] > 0
 
 
-def _nccl_worker(rank, world, port, result_dir):
+def _dist_worker(rank, world, port, result_dir, backend, same_device, library_comm):
   import torch
   import torch.distributed as dist
   sys.path.insert(0, ROOT)
   os.environ['MASTER_ADDR'] = '127.0.0.1'
   os.environ['MASTER_PORT'] = str(port)
   os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-  torch.cuda.set_device(rank)
-  dev = torch.device('cuda', rank)
-  dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+  index = 0 if same_device else rank
+  torch.cuda.set_device(index)
+  dev = torch.device('cuda', index)
+  kw = {'device_id': dev} if backend == 'nccl' else {}
+  dist.init_process_group(backend, rank=rank, world_size=world, **kw)
   try:
     from hsg_amd.models import utils as mu
+    mu.use_library_comm = library_comm
     g = util.load('f8_exchange')
     part = util.exchange_inputs(int(g['seed']))[rank]
     T = lambda k: torch.from_numpy(part[k]).to(dev)
@@ -93,8 +96,24 @@ def _nccl_worker(rank, world, port, result_dir):
     assert np.array_equal(upd.cpu().numpy(), g['upd%d' % rank])
     assert np.abs(protos.detach().cpu().numpy() - g['protos']).max() <= FTOL
     assert np.abs(protos_loc.detach().cpu().numpy() - g['protos_loc']).max() <= FTOL
+    # the oracle's restatement (per-source C2 sums, added in source order) bit for bit
+    from oracle import oracle as orc
+    want = orc.exchange_prototypes(util.exchange_inputs(int(g['seed'])))
+    assert np.array_equal(protos.detach().cpu().numpy().view(np.uint32), want[0].view(np.uint32))
+    assert np.array_equal(protos_loc.detach().cpu().numpy().view(np.uint32), want[1].view(np.uint32))
     protos.sum().backward()
-    assert emb.grad is not None and torch.isfinite(emb.grad).all()
+    assert emb.grad is not None and torch.isfinite(emb.grad).all() and float(emb.grad.abs().sum()) > 0
+    # too small tuple blocks: every rank regrows from the gathered header counts and repeats
+    mu._capacity.clear()
+    saved, mu._CAP_START = mu._CAP_START, 8
+    try:
+      again = mu.gather_clustering_and_update_prototypes(
+          T('emb'), T('emb_loc'), T('cluster'), T('batch'), T('sem'), T('inst'))
+      assert np.array_equal(again[5].cpu().numpy(), g['upd%d' % rank])
+      assert np.array_equal(again[0].cpu().numpy().view(np.uint32), want[0].view(np.uint32))
+    finally:
+      mu._CAP_START = saved
+    mu.use_library_comm = False
     img = mu.gather_and_reorder_image_indices(T('image_id'))
     assert np.array_equal(img.cpu().numpy(), g['img%d' % rank])
     mapping = mu.gather_and_update_cluster_mappings(upd, T('cluster'))
@@ -104,22 +123,49 @@ def _nccl_worker(rank, world, port, result_dir):
     dist.destroy_process_group()
 
 
-def test_exchange_world2_rccl(tmp_path):
+def test_exchange_world2_on_one_device(tmp_path):
+  """Two ranks sharing the box's ONE GPU: the libhsgk phases (keys -> merge over two gathered blocks ->
+  sums into the global table rows -> finish) with world = 2 on hardware, the two collectives over gloo on
+  device tensors (RCCL refuses several ranks per device: profiles/r03_rccl_same_device_probe.txt), against
+  the reference's golden outputs and bit for bit against the oracle."""
+  import torch.multiprocessing as mp
+  mp.spawn(_dist_worker, args=(2, _free_port(), str(tmp_path), 'gloo', True, False), nprocs=2, join=True)
+  assert (tmp_path / 'ok0').exists() and (tmp_path / 'ok1').exists()
+
+
+@pytest.mark.parametrize('library_comm', [False, True])
+def test_exchange_world2_rccl(tmp_path, library_comm):
+  """The same over RCCL between two GPUs: through the process group, and in-stream on libhsgk's own
+  communicator (hsgk_comm_*: unique id from rank 0, carried by the process group)."""
   import torch
   if torch.cuda.device_count() < 2:
-    pytest.skip('needs two GPUs (the 8-GPU node of the driver); the world-2 logic runs on gloo in the CPU suite')
+    pytest.skip('true peer-to-peer: needs two GPUs (the 8-GPU node of the driver)')
   import torch.multiprocessing as mp
-  mp.spawn(_nccl_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+  mp.spawn(_dist_worker, args=(2, _free_port(), str(tmp_path), 'nccl', False, library_comm), nprocs=2, join=True)
   assert (tmp_path / 'ok0').exists() and (tmp_path / 'ok1').exists()
+
+
+def test_bench_dry_ranks_on_one_device():
+  """bench.py --dry-ranks 2: two ranks on the one GPU (gloo transport), every rank its own shard of the
+  global batch (B * rank image offsets), max-over-ranks timing, the exchange with world = 2."""
+  r = _bench(['--dry-ranks', '2', '--workload', 'cfg1', '--steps', '2', '--warmup', '1', '--cpu-images', '0'])
+  assert r['dry_ranks'] == 2 and r['dist_backend'] == 'gloo' and r['rccl_ranks'] == 0
+  assert r['config']['global_batch'] == 8 and r['config']['parallelism'] == 'dp2'
+  px = r['prototype_exchange']
+  assert 'error' not in px, px
+  assert px['collectives_per_call'] == 2 and px['segments_total'] == 2 * 4 * 8       # 2 ranks x 4 images x 8 clusters
+  one = _bench(['--workload', 'cfg1', '--steps', '2', '--warmup', '1', '--cpu-images', '0', '--no-extra'])
+  assert one['prototype_exchange']['segments_total'] == 4 * 8
 
 
 def test_bench_spawns_its_ranks():
   import torch
   if torch.cuda.device_count() < 2:
-    pytest.skip('needs two GPUs')
+    pytest.skip('true peer-to-peer: needs two GPUs')
   r = _bench(['--gpus', '2', '--workload', 'cfg3', '--steps', '2', '--warmup', '1', '--cpu-images', '0'])
-  assert r['n_gpus'] == 2 and r['config']['global_batch'] == 32
+  assert r['n_gpus'] == 2 and r['config']['global_batch'] == 32 and r['rccl_ranks'] == 2
   assert 'error' not in r['prototype_exchange'] and r['prototype_exchange']['collectives_per_call'] == 2
+  assert 'error' not in r['prototype_exchange_instream'], r['prototype_exchange_instream']
 
 
 def test_torch_free_cpp_host_of_the_c_abi():
