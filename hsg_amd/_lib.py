@@ -39,7 +39,7 @@ class SegkmArgs(ctypes.Structure):
       ('out_batch', ctypes.c_void_p), ('meta', ctypes.c_void_p),
       ('out_norms', ctypes.c_void_p), ('out_rowmap', ctypes.c_void_p),
       ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t),
-      ('seed_batch_stride', ctypes.c_int64)]
+      ('seed_batch_stride', ctypes.c_int64), ('flags', ctypes.c_int32)]
 
 
 class ExchangeArgs(ctypes.Structure):
@@ -72,6 +72,7 @@ _vp, _i64, _i32, _f32, _sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
 SIGNATURES = {
     'hsgk_version': (_i32, []),
     'hsgk_last_error': (ctypes.c_char_p, []),
+    'hsgk_small_map_groups': (_i32, [_i32, _i32, _i32, _i32, _i32]),
     'hsgk_host_grid_seed_map': (_i32, [_i32, _i32, _i32, _i32, _vp, _vp]),
     'hsgk_host_location_features': (_i32, [_i32, _i32, _vp]),
     'hsgk_normalize_rows': (_i32, [_vp, _i64, _i32, _f32, _vp, _vp, _vp]),

@@ -180,7 +180,7 @@ static int assign_mode() {
 static int lloyd(const float *x, int d, int K, int B, int iterations,
                  const KmeansScratch &k, const hsgk_segkm_meta *meta, hipStream_t s,
                  bool unit_rows = false, bool half_ready = false, bool m0_ready = false,
-                 bool host_reads_meta = true) {
+                 bool single_group = false) {
   const bool half_any = unit_rows && assign_mode() == 2 && k.xh && (half_ready || iterations >= 3);
   const bool half = half_any && assign_half_eligible(d, K);
   const bool wide = half_any && !half && assign_half_wide_eligible(d, K);
@@ -208,7 +208,7 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
       ProfScope p(HSGK_PROF_ASSIGN, s);
       // (k.q1, the first level's row queue of the per-kernel route, holds the fused kernel's counters)
       return launch_lloyd_small(x, k.xh, k.xt, d, K, B, iterations, k.t, k.klab, k.klab_prev, k.sumq, k.cent,
-                                k.qrows, k.q1, m0_ready, const_cast<hsgk_segkm_meta *>(meta), rows_per_image, !host_reads_meta, k.cent_multi, s);
+                                k.qrows, k.q1, m0_ready, const_cast<hsgk_segkm_meta *>(meta), rows_per_image, single_group, k.cent_multi, s);
     }
   }
   if (fx && !m0_ready) {     // (the fused kernel above needs neither)
@@ -270,6 +270,18 @@ using namespace hsgk;
 extern "C" {
 
 int hsgk_version(void) { return HSGK_VERSION; }
+
+int hsgk_small_map_groups(int B, int C, int H, int W, int K) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0) return 0;
+  const char *se = getenv("HSGK_SMALL");
+  if (se && se[0] == '0') return 0;
+  const int d = C + 2;
+  const int64_t rows = (int64_t)H * W;
+  if (!(sums_fx_eligible(d) && K <= 1023 && assign_half_eligible(d, K) && rows <= 16 * 1024 &&
+        lloyd_small_eligible(d, K, B, rows)))
+    return 0;
+  return lloyd_small_groups(B, rows);
+}
 const char *hsgk_last_error(void) { return g_err; }
 
 void hsgk_profile_enable(int on) { g_prof_on.store(on ? 1 : 0); }
@@ -426,7 +438,7 @@ int hsgk_segment_by_kmeans(const hsgk_segkm_args *a, hsgk_stream_t stream) {
                              want_m0 ? &k.m0 : nullptr, &m0_ready)) return rc;
   }
   if (int rc = lloyd(a->out_embeddings_loc, D, a->K, a->B, a->iterations, k, a->meta, s,
-                     /*unit_rows=*/true, half_ready, m0_ready, /*host_reads_meta=*/a->labels != nullptr)) return rc;
+                     /*unit_rows=*/true, half_ready, m0_ready, /*single_group=*/(a->flags & HSGK_SEGKM_ONE_GROUP) != 0)) return rc;
   {
     ProfScope p(HSGK_PROF_RELABEL, s);
     if (int rc = launch_relabel(*a, k.t, k.max_chunks, k.klab, table, scan_tmp, s)) return rc;

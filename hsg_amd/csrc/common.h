@@ -166,7 +166,8 @@ bool lloyd_small_eligible(int d, int K, int B, int64_t rows_per_image);
 int launch_lloyd_small(const float *x, const _Float16 *xm, const uint2 *xt, int d, int K, int B, int iterations,
                        const ChunkTable &t, int32_t *lab_a, int32_t *lab_b, long long *sumq, float *cent,
                        void *qrows, int32_t *counters, bool first_sums_ready, hsgk_segkm_meta *meta,
-                       int64_t rows_per_image, bool trap_on_timeout, float *cent_multi, hipStream_t s);
+                       int64_t rows_per_image, bool single_group, float *cent_multi, hipStream_t s);
+int lloyd_small_groups(int B, int64_t rows_per_image);
 size_t lloyd_small_cent_floats(int d, int K, int B);
 
 size_t relabel_scan_bytes(int64_t table_cap);      // scratch of the chained scans (scan_tmp of launch_relabel)

@@ -13,6 +13,8 @@
 //      exactly what v_mfma_f32_32x32x2_f32 computes (k-ordered fmaf chain) --
 //      argmax takes the first maximal index.
 #include "common.h"
+#include <atomic>
+
 #include "accumulate.h"
 #include "score_tiles.h"
 #include "score_tiles_bf16.h"
@@ -1347,8 +1349,7 @@ __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
     int iterations, const int64_t *__restrict__ img_row0, int32_t *__restrict__ lab_a,
     int32_t *__restrict__ lab_b, long long *__restrict__ sumq, float *__restrict__ cent,
     SplitEntry *__restrict__ gqueue, int32_t *__restrict__ gcount, int first_sums_ready, float eps,
-    int G, unsigned int *__restrict__ bar, hsgk_segkm_meta *meta, int trap_on_timeout,
-    float *__restrict__ cent_multi) {
+    int G, unsigned int *__restrict__ bar, hsgk_segkm_meta *meta, float *__restrict__ cent_multi) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   // G workgroups per image (co-resident: the launcher keeps B * G within the CU count): workgroup g
   // owns a contiguous, 32-aligned share of the image's rows for the M, E and X phases; the
@@ -1404,16 +1405,27 @@ __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
   // tick counter of the image: every workgroup ticks twice per iteration (sums added, sums read)
   int &bar_dead = qnp[2];                        // a wait timed out: stop waiting (the call reports error 3);
   if (tid == 0) bar_dead = 0;                    // (in the list header: no static LDS beside the 160 KiB array)
+  // The grid is launched co-operatively (hipLaunchCooperativeKernel: the runtime only accepts a grid
+  // that fits the device at once), so the other shares of the image are running or will start as soon as
+  // kernels of OTHER streams release their CUs: the wait is bounded by wall-clock time (10 s of the 100 MHz
+  // real-time counter, far beyond any kernel a training step runs beside this one), not by a spin count a
+  // profiler or a busy neighbour could exhaust.  On a time-out the call reports error 3 in its meta block
+  // (the labels are then not valid); the mirror re-runs such a call with one workgroup per image or raises
+  // it through the deferred-error path -- the kernel never traps.
   auto wait_ticks = [&](unsigned int target) {
     if (tid == 0 && !bar_dead) {
+      unsigned long long t0 = 0;
       unsigned int spins = 0;
       while (__hip_atomic_load(bar + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(2);                // (polling without it is not faster)
-        if (++spins > (1u << 20)) {              // ~ a second: the workgroups are not co-resident
-          if (meta) meta->error = 3;
-          bar_dead = 1;
-          if (trap_on_timeout) __builtin_trap();   // nobody reads meta on the host: fail loudly
-          break;
+        if ((++spins & 1023u) == 0) {
+          const unsigned long long now = wall_clock64();
+          if (t0 == 0) t0 = now;
+          if (now - t0 > 1000000000ull) {
+            if (meta) meta->error = 3;
+            bar_dead = 1;
+            break;
+          }
         }
       }
     }
@@ -1672,15 +1684,43 @@ extern "C" __attribute__((visibility("default"))) int hsgk_debug_small_timing(un
 // Half of the CUs at most, so that two such calls on two streams still fit side by side (two
 // half-resident grids would wait for each other's CUs; a wait that times out reports error 3).
 constexpr int kSmallGroupsMax = 16;
-static int small_cu_count() {
-  static const int n = [] {
-    int dev = 0, cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-      cu = 0;
-    (void)hipGetLastError();
-    return cu;
-  }();
-  return n;
+static int small_cu_count() {              // of the CURRENT device (cached per device: one thread per GPU calls in)
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) { (void)hipGetLastError(); return 0; }
+  if (dev < 64) { const int c = cache[dev].load(std::memory_order_relaxed); if (c > 0) return c; }
+  int cu = 0;
+  if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 0;
+  (void)hipGetLastError();
+  if (dev < 64 && cu > 0) cache[dev].store(cu, std::memory_order_relaxed);
+  return cu;
+}
+// HSGK_SMALL_COOP=1: hipLaunchCooperativeKernel for the multi-workgroup grids.  The default is a plain launch
+// behind the SAME admission test the co-operative API applies (occupancy x CUs >= grid, queried once per
+// kernel and device): the co-operative path costs ~30 us per call on this runtime (reftrain 0.294 -> 0.328 ms,
+// train28 0.382 -> 0.412 ms, tools/probes/coop_ab.sh) and guards against nothing else -- a neighbour stream that
+// holds CUs only DELAYS the remaining workgroups, which the wall-clock bounded waits tolerate.  Read per call.
+static bool small_coop_enabled() {
+  const char *e = getenv("HSGK_SMALL_COOP");
+  return e && e[0] == '1';
+}
+// workgroups of `kern` (512 threads, `lds` bytes) the current device holds at once
+static int small_resident_capacity(const void *kern, size_t lds) {
+  struct Slot { std::atomic<const void *> k{nullptr}; std::atomic<int> cap{0}; };
+  static Slot slots[64][8];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 0; }
+  for (auto &sl : slots[dev])
+    if (sl.k.load(std::memory_order_acquire) == kern) return sl.cap.load(std::memory_order_relaxed);
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 8 * 64, lds) != hipSuccess) nb = 0;
+  (void)hipGetLastError();
+  const int cap = nb * small_cu_count();
+  for (auto &sl : slots[dev]) {
+    const void *expect = nullptr;
+    if (sl.k.compare_exchange_strong(expect, kern)) { sl.cap.store(cap, std::memory_order_relaxed); break; }
+  }
+  return cap;
 }
 int lloyd_small_groups(int B, int64_t rows_per_image) {
   const char *fe = getenv("HSGK_SMALL_GROUPS");        // tests: force the number of workgroups per image (read per call)
@@ -1703,29 +1743,51 @@ bool lloyd_small_eligible(int d, int K, int B, int64_t rows_per_image) {
 
 // lab_a: current labels (in / out), lab_b: the labels the sums hold; sumq / cent: [B][K][d];
 // qrows: >= one SplitEntry per row; counters: >= B * (G + 1) int32 (per-workgroup queue counts, then
-// the per-image tick counters).  trap_on_timeout: the caller does not read meta->error on the host (a
-// timed-out inter-workgroup wait then aborts the kernel instead of leaving wrong labels).  first_sums_ready: sumq / lab_b are valid (first M-step done
+// the per-image tick counters).  single_group: one workgroup per image whatever the map size (no
+// inter-workgroup wait at all).  first_sums_ready: sumq / lab_b are valid (first M-step done
 // elsewhere); otherwise neither needs initialising (one workgroup per image) or sumq is zeroed here.
 int launch_lloyd_small(const float *x, const _Float16 *xm, const uint2 *xt, int d, int K, int B, int iterations,
                        const ChunkTable &t, int32_t *lab_a, int32_t *lab_b, long long *sumq, float *cent,
                        void *qrows, int32_t *counters, bool first_sums_ready, hsgk_segkm_meta *meta,
-                       int64_t rows_per_image, bool trap_on_timeout, float *cent_multi, hipStream_t s) {
+                       int64_t rows_per_image, bool single_group, float *cent_multi, hipStream_t s) {
   if (B <= 0 || iterations <= 0) return 0;
   constexpr int NW = 8;
   const bool deep = ((d / 64) & 3) == 0;
   const size_t lds = (size_t)small_layout(d, K).total;
-  const int G = cent_multi ? lloyd_small_groups(B, rows_per_image) : 1;   // (no scratch for private centroids: one workgroup per image)
-  unsigned int *bar = reinterpret_cast<unsigned int *>(counters + (size_t)B * G);
-  if (G > 1) {
-    HSGK_CHECK_HIP(hipMemsetAsync(bar, 0, sizeof(unsigned int) * B, s));
-    if (!first_sums_ready) HSGK_CHECK_HIP(hipMemsetAsync(sumq, 0, sizeof(long long) * (size_t)B * K * d, s));
-  }
+  int G = (cent_multi && !single_group) ? lloyd_small_groups(B, rows_per_image) : 1;   // (no scratch for private centroids: one workgroup per image)
   auto go = [&](auto kern) -> int {
     HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // co-operating workgroups must all be resident: admitted only within HALF of what the device holds of
+    // this kernel (a second such call on another stream still fits beside it); otherwise one workgroup per
+    // image, which waits for nobody.  (rows_per_image <= kSmallRowsMax whenever the route was chosen with G = 1
+    // in mind; a larger map that loses its groups here is handled by the caller's eligibility test.)
+    if (G > 1 && 2 * B * G > small_resident_capacity(reinterpret_cast<const void *>(kern), lds) &&
+        rows_per_image <= kSmallRowsMax)
+      G = 1;
+    unsigned int *bar = reinterpret_cast<unsigned int *>(counters + (size_t)B * G);
+    if (G > 1) {
+      HSGK_CHECK_HIP(hipMemsetAsync(bar, 0, sizeof(unsigned int) * B, s));
+      if (!first_sums_ready) HSGK_CHECK_HIP(hipMemsetAsync(sumq, 0, sizeof(long long) * (size_t)B * K * d, s));
+    }
+    if (G > 1 && small_coop_enabled()) {
+      // several workgroups per image wait for each other: a co-operative launch (the runtime rejects a grid
+      // that cannot be resident at once -- hipErrorCooperativeLaunchTooLarge -- instead of letting it hang)
+      const int64_t *img_row0 = t.img_row0;
+      SplitEntry *gq = reinterpret_cast<SplitEntry *>(qrows);
+      int fsr = first_sums_ready ? 1 : 0, g = G;
+      float eps = HSGK_EPS;
+      void *kargs[] = {(void *)&x, (void *)&xm, (void *)&xt, (void *)&d, (void *)&K, (void *)&iterations,
+                       (void *)&img_row0, (void *)&lab_a, (void *)&lab_b, (void *)&sumq, (void *)&cent, (void *)&gq,
+                       (void *)&counters, (void *)&fsr, (void *)&eps, (void *)&g, (void *)&bar, (void *)&meta,
+                       (void *)&cent_multi};
+      HSGK_CHECK_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(kern), dim3(B * G), dim3(NW * 64),
+                                                kargs, (unsigned int)lds, s));
+      return 0;
+    }
     hipLaunchKernelGGL(kern, dim3(B * G), dim3(NW * 64), lds, s, x, xm, xt, d, K, iterations, t.img_row0, lab_a,
                        lab_b, sumq, cent, reinterpret_cast<SplitEntry *>(qrows), counters,
-                       first_sums_ready ? 1 : 0, HSGK_EPS, G, bar, meta, trap_on_timeout ? 1 : 0, cent_multi);
+                       first_sums_ready ? 1 : 0, HSGK_EPS, G, bar, meta, cent_multi);
     HSGK_LAUNCH_CHECK();
     return 0;
   };

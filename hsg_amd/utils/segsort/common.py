@@ -138,7 +138,7 @@ class _SegmentByKmeans(torch.autograd.Function):
     table_cap = B * K if lab is None else max(B * K, min(B * K * 4096, _TABLE_CAP_MAX))
     L = _lib.lib()
 
-    def run(lab, ign, table_cap):
+    def run(lab, ign, table_cap, flags=0):
       with torch.cuda.device(dev):
         out_emb = torch.empty((n_max, C), dtype=torch.float32, device=dev)
         out_loc = torch.empty((n_max, C + 2), dtype=torch.float32, device=dev)
@@ -161,17 +161,28 @@ class _SegmentByKmeans(torch.autograd.Function):
             out_batch=out_batch.data_ptr(), meta=meta.data_ptr(),
             out_norms=norms.data_ptr() if norms is not None else None,
             out_rowmap=rowmap.data_ptr() if rowmap is not None else None,
-            workspace=ws.data_ptr(), workspace_bytes=ws_bytes, seed_batch_stride=seed_sb)
+            workspace=ws.data_ptr(), workspace_bytes=ws_bytes, seed_batch_stride=seed_sb, flags=flags)
         _lib.check(L.hsgk_segment_by_kmeans(ctypes.byref(args), _lib.stream_ptr()))
         if lab is None:
           # no label map: every pixel is kept and neither data-dependent error can occur, so the
           # row count is known on the host and the call stays asynchronous (no host sync at all)
           m = [n_max, 0, 0, 0, 0, 0, 0, 0]
+          if flags == 0 and L.hsgk_small_map_groups(B, C, H, W, K) > 1:
+            # several co-operating workgroups per image: a wait that timed out (error 3) is the one
+            # data-independent failure of this path -- it travels to pinned host memory behind the
+            # kernels and is raised by a later libhsgk call (or at once with HSGK_SYNC_ERRORS=1)
+            _lib.defer_status(meta.view(torch.int32)[10:11],
+                              'segment_by_kmeans: the co-operating workgroups of an image waited 10 s for each '
+                              'other (labels invalid); set HSGK_SMALL_GROUPS=1')
         else:
           m = meta.cpu().tolist()        # the operator's single host sync
       return m, (out_emb, out_loc, out_lab, out_cluster, out_batch, norms, rowmap)
 
     m, outs = run(lab, ign, table_cap)
+    if m[5] == 3:
+      # the co-operating workgroups of an image timed out waiting for each other (another stream kept the
+      # CUs for > 10 s): repeat with ONE workgroup per image, which waits for nobody
+      m, outs = run(lab, ign, table_cap, flags=1)
     if m[5] == 2:
       # The label values (or their number) do not fit the library's presence table.  The final
       # ids only depend on the ORDER of the (image, cluster, label) triples (reference

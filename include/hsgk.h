@@ -78,9 +78,8 @@ typedef struct hsgk_segkm_meta {
   int64_t label_max;
   int64_t n_chunks;      /* chunks actually used                               */
   int64_t error;         /* 0 ok; 1 negative label; 2 relabel table too small; 3 the co-operating
-                            workgroups of a small-map call were not co-resident (bounded wait timed
-                            out; without a label map -- nobody reads this on the host -- the kernel
-                            aborts instead)  */
+                            workgroups of a small-map call waited 10 s for each other (the labels
+                            are then not valid: repeat the call with HSGK_SEGKM_ONE_GROUP)  */
   int64_t relabel_mode;  /* 0 direct table, 1 label-ranked table               */
   int64_t relabel_L;     /* effective label extent used by the table           */
 } hsgk_segkm_meta;
@@ -135,7 +134,14 @@ typedef struct hsgk_segkm_args {
   /* per-image seed maps (the `cluster_indices=` argument of the reference, common.py:320-323):
    * seed label of pixel p of image b = seed_map[b * seed_batch_stride + p]; 0 = one map for all   */
   int64_t seed_batch_stride;
+  int32_t flags;               /* HSGK_SEGKM_* */
 } hsgk_segkm_args;
+/* small feature maps (training resolution) run the whole Lloyd loop of an image in one launch; maps of
+ * more than 512 rows are shared by several co-operating workgroups (co-operative launch).  ONE_GROUP keeps
+ * one workgroup per image (no inter-workgroup wait).  hsgk_small_map_groups: the workgroups per image the
+ * call would use on the current device (0: the shape does not take the one-launch route).          */
+#define HSGK_SEGKM_ONE_GROUP 1
+HSGK_API int hsgk_small_map_groups(int B, int C, int H, int W, int K);
 
 HSGK_API size_t hsgk_segment_by_kmeans_workspace_bytes(int B, int C, int H, int W, int K,
                                               int64_t table_cap);

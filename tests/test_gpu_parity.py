@@ -913,6 +913,87 @@ def test_small_maps_two_streams_concurrently(dev):
         assert torch.equal(a, b)
 
 
+def test_small_maps_beside_a_saturating_stream(dev):
+  """The multi-workgroup small-map route (co-operative launch, wall-clock bounded waits) while a SECOND stream
+  keeps every CU busy with long streaming kernels (a backbone / collective stand-in): the reference's own
+  training shape, with and without labels -- no error 3, no hang, every result bit-identical to the quiet run."""
+  import torch
+  from hsg_amd import _lib
+  from hsg_amd.utils.segsort import common as sc
+  shape, grid, iters = (4, 128, 56, 56), [4, 4], 15
+  assert _lib.lib().hsgk_small_map_groups(4, 128, 56, 56, 16) > 1
+  g = torch.Generator(device=dev).manual_seed(11)
+  x = torch.randn(shape, device=dev, generator=g)
+  lab = torch.from_numpy(synth.overseg_labels(synth.SEED_BASE + 3, 4, 56, 56, regions=5, ignore_rows=2)).to(dev)
+  ref = [[t.clone() for t in sc.segment_by_kmeans(x, None, grid, iterations=iters)],
+         [t.clone() for t in sc.segment_by_kmeans(x, lab, grid, ignore_index=255, iterations=iters)]]
+  torch.cuda.synchronize()
+  big = torch.empty((1 << 30,), dtype=torch.float32, device=dev)            # 4 GiB: ~2.5 ms per pass, all CUs
+  side = torch.cuda.Stream()
+  for rnd in range(6):
+    with torch.cuda.stream(side):
+      for _ in range(40):
+        big.mul_(1.0001)
+    outs = []
+    for _ in range(10):
+      outs.append(sc.segment_by_kmeans(x, None, grid, iterations=iters))
+      outs.append(sc.segment_by_kmeans(x, lab, grid, ignore_index=255, iterations=iters))
+    torch.cuda.synchronize()
+    _lib.poll_deferred(wait=True)                                               # a timed-out wait would raise here
+    for i, o in enumerate(outs):
+      for a, b in zip(o, ref[i % 2]):
+        assert torch.equal(a, b)
+
+
+def test_boundary_is_thread_safe_one_thread_per_stream(dev, oracle):
+  """The reference calls the operators from ONE PYTHON THREAD PER GPU (lib/nn/parallel/data_parallel.py:104-105).
+  Two threads, each on its own stream (its own device when the box has two), run segment_by_kmeans, the
+  prototype exchange, segment_reduce and the loss concurrently: every result equals the serial one."""
+  import threading
+  import torch
+  from hsg_amd.models import utils as mu
+  from hsg_amd.utils.segsort import common as sc
+  from hsg_amd.utils.segsort.loss import SegSortLoss
+  ndev = min(2, torch.cuda.device_count())
+  devs = [torch.device('cuda', i % ndev) for i in range(2)]
+  shapes = [((3, 128, 40, 56), [2, 4]), ((2, 256, 33, 47), [3, 3])]
+
+  def work(i, reps, out):
+    d = devs[i]
+    torch.cuda.set_device(d)
+    st = torch.cuda.Stream(device=d)
+    shape, grid = shapes[i]
+    x = torch.from_numpy(synth.embeddings_nchw(synth.SEED_BASE + 40 + i, shape, 'mixture')).to(d)
+    lab = torch.from_numpy(synth.overseg_labels(synth.SEED_BASE + 50 + i, shape[0], shape[2], shape[3],
+                                                regions=5, ignore_rows=2)).to(d)
+    res = []
+    with torch.cuda.stream(st):
+      for _ in range(reps):
+        emb, eloc, labels, cidx, bidx = sc.segment_by_kmeans(x, lab, grid, ignore_index=255, iterations=6)
+        protos, protos_loc, psem, pinst, pbatch, upd = mu.gather_clustering_and_update_prototypes(
+            emb, eloc, cidx, bidx, labels, torch.zeros_like(labels))
+        means = sc.calculate_prototypes_from_labels(emb, upd, protos.shape[0])
+        loss = SegSortLoss(16, 'segsort+')(emb, labels, upd, protos, psem)
+        res.append([t.detach().cpu() for t in (emb, eloc, labels, cidx, protos, protos_loc, upd, means, loss)])
+      st.synchronize()
+    out[i] = res
+
+  serial = [None, None]
+  for i in range(2):
+    work(i, 1, serial)
+  conc = [None, None]
+  threads = [threading.Thread(target=work, args=(i, 12, conc)) for i in range(2)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join()
+  for i in range(2):
+    assert conc[i] is not None and len(conc[i]) == 12, 'thread %d died' % i
+    for rep in conc[i]:
+      for a, b in zip(rep, serial[i][0]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('iters', [1, 2, 5])
 def test_small_maps_fused_route_with_first_mstep_from_prep(dev, oracle, monkeypatch, iters):
   """The fused per-image Lloyd kernel starting from the sums the PREP kernel left for the seed labels
