@@ -1760,11 +1760,12 @@ int launch_lloyd_small(const float *x, const _Float16 *xm, const uint2 *xt, int 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // co-operating workgroups must all be resident: admitted only within HALF of what the device holds of
     // this kernel (a second such call on another stream still fits beside it); otherwise one workgroup per
-    // image, which waits for nobody.  (rows_per_image <= kSmallRowsMax whenever the route was chosen with G = 1
-    // in mind; a larger map that loses its groups here is handled by the caller's eligibility test.)
-    if (G > 1 && 2 * B * G > small_resident_capacity(reinterpret_cast<const void *>(kern), lds) &&
-        rows_per_image <= kSmallRowsMax)
+    // image, which waits for nobody (maps beyond its row limit are refused: lloyd_small_groups sizes G from
+    // the same CU count, so that only happens if the kernel's occupancy is not what it was built for).
+    if (G > 1 && 2 * B * G > small_resident_capacity(reinterpret_cast<const void *>(kern), lds)) {
+      HSGK_REQUIRE(rows_per_image <= kSmallRowsMax, "co-operating workgroups would not be co-resident");
       G = 1;
+    }
     unsigned int *bar = reinterpret_cast<unsigned int *>(counters + (size_t)B * G);
     if (G > 1) {
       HSGK_CHECK_HIP(hipMemsetAsync(bar, 0, sizeof(unsigned int) * B, s));
