@@ -344,7 +344,8 @@ def main():
     res = {'bound': 'hbm', 'kernel': kernel, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
            'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
            'traffic': int(moved) if moved_source.startswith('profiles/') else None,
-           'bytes_source': moved_source, 'avg_launch_ms': round(ms / n, 4), 'launches': int(n),
+           'bytes_source': moved_source, 'traffic_measured_in_this_run': False,
+           'avg_launch_ms': round(ms / n, 4), 'launches': int(n),
            'algorithmic_bytes_per_launch': int(algorithmic),
            'algorithmic_achieved': round(alg, 1), 'algorithmic_frac': round(alg / HBM_PEAK_GBS, 4)}
     res.update(extra)

@@ -94,10 +94,10 @@ SIGNATURES = {
     'hsgk_segment_reduce': (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
     'hsgk_segment_reduce_bwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _f32, _vp, _vp, _vp]),
     'hsgk_segsort_loss_workspace_bytes': (_sz, [_i64, _i32, _i64, _i32]),
-    'hsgk_segsort_loss_fwd': (_i32, [_vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp,
+    'hsgk_segsort_loss_fwd': (_i32, [_vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _sz, _vp]),
     'hsgk_segsort_loss_bwd_workspace_bytes': (_sz, [_i64, _i32, _i64, _i32]),
-    'hsgk_segsort_loss_bwd': (_i32, [_vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp,
+    'hsgk_segsort_loss_bwd': (_i32, [_vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _vp, _vp, _sz, _vp]),
     'hsgk_lloyd_requeued_rows': (_i32, [_i32, _i64, _i32, _i32, _vp, _sz, _vp, _vp]),
     'hsgk_hier_assign': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),

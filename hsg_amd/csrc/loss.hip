@@ -44,6 +44,11 @@ struct LossSets {
   int setm[kMaxSets];       // set mode (multi-hot labels as class bit masks)
   int words;                // words per label of set 0 (1 unless set mode with > 63 classes; then L == 1)
   int L;
+  // optional grouping: prototype p takes part in pixel i's sums (numerator and denominator) only when
+  // pgroup[p] == qgroup[i] -- per-image prototype tables in one launch (predictions/segsort.py:224-244),
+  // prototypes without a valid class masked out instead of compacted (:181-196).  Both null: no grouping.
+  const int64_t *qgroup;    // [n]
+  const int64_t *pgroup;    // [P]
 };
 
 // slot of (set l, word w) in a row's label words
@@ -89,6 +94,8 @@ struct LossFwdEpi {
     const bool valid = px < nrows;
     const int64_t row = crow0 + (valid ? px : 0);
     const int64_t ij = inst[row];
+    const bool grouped = ls.qgroup != nullptr;
+    const int64_t gj = grouped ? ls.qgroup[row] : 0;
     int64_t sj[kLabSlots];
     float own[kMaxSets], same[kMaxSets], diff[kMaxSets];
 #pragma unroll
@@ -103,7 +110,7 @@ struct LossFwdEpi {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t p = kb0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (p < P) {
+        if (p < P && (!grouped || ls.pgroup[p] == gj)) {
           float s = 0.0f;
           int64_t pj[kLabSlots];
 #pragma unroll
@@ -231,7 +238,10 @@ __global__ void loss_bwd_prep_kernel(const float *__restrict__ num, const float 
     const int64_t i = (int64_t)l * N + r;
     const float gs = gscale[i] * ls.kappa[l];
     const float inv_num = 1.0f / num[i], inv_den = 1.0f / den[i];
-    meta[i] = PxMeta{gs * (inv_den - inv_num), gs * inv_den, (ls.plus[l] && use_same[i]) ? 1 : 0, 0};
+    // a pixel without upstream gradient (masked out by the caller: its own prototype may be outside its
+    // group, num = 0) contributes exactly nothing
+    meta[i] = gs == 0.0f ? PxMeta{0.0f, 0.0f, 0, 0}
+                         : PxMeta{gs * (inv_den - inv_num), gs * inv_den, (ls.plus[l] && use_same[i]) ? 1 : 0, 0};
   }
 }
 
@@ -272,6 +282,7 @@ __global__ __launch_bounds__(NW * 64) void loss_bwd_kernel(BwdArgs a) {
   int64_t *m_lab = reinterpret_cast<int64_t *>(mbase);       // [2][kLabSlots][16]
   PxMeta *m_px = reinterpret_cast<PxMeta *>(m_lab + 2 * kLabSlots * 16);  // [2][kMaxSets][16]
   int32_t *m_inst = reinterpret_cast<int32_t *>(m_px + 2 * kMaxSets * 16);  // [2][16]
+  int64_t *m_grp = reinterpret_cast<int64_t *>(m_inst + 2 * 16);            // [2][16] group of the streamed rows
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
@@ -306,6 +317,8 @@ __global__ __launch_bounds__(NW * 64) void loss_bwd_kernel(BwdArgs a) {
     }
   }
   if constexpr (OWNER_PX) o_inst = (int32_t)a.inst[o_ld];
+  const bool grouped = a.ls.qgroup != nullptr;
+  const int64_t o_grp = grouped ? (OWNER_PX ? a.ls.qgroup[o_ld] : a.ls.pgroup[o_ld]) : 0;
 
   f32x4 gacc[CT];
 #pragma unroll
@@ -364,6 +377,8 @@ __global__ __launch_bounds__(NW * 64) void loss_bwd_kernel(BwdArgs a) {
       }
       if constexpr (!OWNER_PX)
         if (l == 0) m_inst[buf * 16 + row] = t < a.n_stream ? (int32_t)a.inst[t] : -1;
+      if (l == 0 && grouped)
+        m_grp[buf * 16 + row] = t < a.n_stream ? (OWNER_PX ? a.ls.pgroup[t] : a.ls.qgroup[t]) : 0;
     }
   };
 
@@ -388,11 +403,13 @@ __global__ __launch_bounds__(NW * 64) void loss_bwd_kernel(BwdArgs a) {
     const int64_t *bl = m_lab + buf * kLabSlots * 16;
     const PxMeta *bp = m_px + buf * kMaxSets * 16;
     const int32_t *bi = m_inst + buf * 16;
+    const int64_t *bg = m_grp + buf * 16;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int tr = 4 * g + r;
       const int64_t t = b * 16 + tr;
       float wv = 0.0f, sx = 0.0f;
+      const bool in_group = !grouped || bg[tr] == o_grp;
       bool own;
       if constexpr (OWNER_PX) own = (int64_t)o_inst == t; else own = (int64_t)bi[tr] == o_row;
       int64_t tl[kLabSlots];
@@ -407,7 +424,7 @@ __global__ __launch_bounds__(NW * 64) void loss_bwd_kernel(BwdArgs a) {
           const float av = pm.plus_us ? (float)((int)same - (int)own) : (own ? 1.0f : 0.0f);
           wv += sx * (av * pm.A + (same ? 0.0f : pm.B));
         }
-      sacc[r] = (o_valid && t < a.n_stream) ? wv : 0.0f;
+      sacc[r] = (o_valid && t < a.n_stream && in_group) ? wv : 0.0f;
     }
     // ---- second contraction: G[c][o] += sum_t T[t][c] W[t][o]; k-step r takes the streamed rows
     //      4 g + r, g = 0..3 -- the rows the four lane groups hold in register r
@@ -473,7 +490,8 @@ static int launch_loss_bwd(BwdArgs a, float *out, float *scratch, hipStream_t s)
   const int ct = (a.c + 15) / 16;
   const bool vec4 = (a.c % 4) == 0;
   auto go = [&](auto kern, int CT, int NW) -> int {
-    const size_t lds = (size_t)2 * 16 * (CT * 16 + 4) * 4 + (size_t)2 * 16 * (kLabSlots * 8 + kMaxSets * sizeof(PxMeta)) + 2 * 16 * 4;
+    const size_t lds = (size_t)2 * 16 * (CT * 16 + 4) * 4 + (size_t)2 * 16 * (kLabSlots * 8 + kMaxSets * sizeof(PxMeta)) + 2 * 16 * 4 +
+                       2 * 16 * 8;
     HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int ot = NW * 16;
@@ -506,9 +524,12 @@ static int launch_loss_bwd(BwdArgs a, float *out, float *scratch, hipStream_t s)
   return 0;
 }
 
-static int make_sets(int L, const hsgk_loss_set *sets, LossSets *ls) {
+static int make_sets(int L, const hsgk_loss_set *sets, const int64_t *qgroup, const int64_t *pgroup, LossSets *ls) {
   HSGK_REQUIRE(L >= 1 && L <= kMaxSets && sets != nullptr, "1..3 label sets");
+  HSGK_REQUIRE((qgroup == nullptr) == (pgroup == nullptr), "pixel and prototype groups come together");
   ls->L = L;
+  ls->qgroup = qgroup;
+  ls->pgroup = pgroup;
   ls->words = 1;
   if ((sets[0].mode >> 1) & 1) {
     const int wds = sets[0].mode >> 8;               // words per class mask (0 = 1)
@@ -541,12 +562,13 @@ size_t hsgk_segsort_loss_workspace_bytes(int64_t n, int c, int64_t P, int L) {
 }
 
 int hsgk_segsort_loss_fwd(const float *emb, int64_t n, int c, const int64_t *inst, const float *proto,
-                          int64_t P, int L, const hsgk_loss_set *sets, float *nll, float *num, float *den,
+                          int64_t P, int L, const hsgk_loss_set *sets, const int64_t *pixel_group,
+                          const int64_t *proto_group, float *nll, float *num, float *den,
                           int32_t *use_same, void *workspace, size_t workspace_bytes,
                           hsgk_stream_t stream) {
   HSGK_REQUIRE(n >= 0 && c >= 1 && P >= 1, "bad shape");
   LossSets ls;
-  if (int rc = make_sets(L, sets, &ls)) return rc;
+  if (int rc = make_sets(L, sets, pixel_group, proto_group, &ls)) return rc;
   HSGK_REQUIRE(workspace_bytes >= hsgk_segsort_loss_workspace_bytes(n, c, P, L), "workspace too small");
   if (n == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -573,12 +595,13 @@ size_t hsgk_segsort_loss_bwd_workspace_bytes(int64_t n, int c, int64_t P, int L)
 }
 
 int hsgk_segsort_loss_bwd(const float *emb, int64_t n, int c, const int64_t *inst, const float *proto,
-                          int64_t P, int L, const hsgk_loss_set *sets, const float *num, const float *den,
+                          int64_t P, int L, const hsgk_loss_set *sets, const int64_t *pixel_group,
+                          const int64_t *proto_group, const float *num, const float *den,
                           const int32_t *use_same, const float *gscale, float *g_emb, float *g_proto,
                           void *workspace, size_t workspace_bytes, hsgk_stream_t stream) {
   HSGK_REQUIRE(n >= 0 && c >= 1 && P >= 1, "bad shape");
   LossSets ls;
-  if (int rc = make_sets(L, sets, &ls)) return rc;
+  if (int rc = make_sets(L, sets, pixel_group, proto_group, &ls)) return rc;
   HSGK_REQUIRE(workspace_bytes >= hsgk_segsort_loss_bwd_workspace_bytes(n, c, P, L), "workspace too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
   (void)hipGetLastError();

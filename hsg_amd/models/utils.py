@@ -357,8 +357,8 @@ class _Exchange(torch.autograd.Function):
   """One process per GPU (or a single GPU): this rank's rows in, the batch-wide tables out."""
 
   @staticmethod
-  def forward(ctx, emb, emb_loc, c, b, sem, inst, group, tag):
-    tr = _transport(group)
+  def forward(ctx, emb, emb_loc, c, b, sem, inst, group, tag, local=False):
+    tr = None if local else _transport(group)
     world = tr.world if tr is not None else 1
     rank = tr.rank if tr is not None else 0
     while True:
@@ -395,12 +395,12 @@ class _Exchange(torch.autograd.Function):
     if ctx.tr is not None and g.numel():
       ctx.tr.all_reduce(g)              # every rank's loss sees the whole table
     gx, gl = ctx.be_cls.rows_bwd(g, upd, pa.shape[1], pb.shape[1], ctx.needs_input_grad[:2])
-    return gx, gl, None, None, None, None, None, None
+    return gx, gl, None, None, None, None, None, None, None
 
 
 # ---- hsg/models/utils.py:127-217 -----------------------------------------------
 def exchange_prototypes(embeddings, embeddings_with_loc, cluster_indices, batch_indices,
-                        semantic_labels, instance_labels, group=None, tag='proto'):
+                        semantic_labels, instance_labels, group=None, tag='proto', local=False):
   """Per-rank tensors in, batch-wide prototype tables out (same 6 results as
   the reference's gather_clustering_and_update_prototypes, un-listed).
 
@@ -410,11 +410,12 @@ def exchange_prototypes(embeddings, embeddings_with_loc, cluster_indices, batch_
   ranks of those tuples in lexicographic order (its two nested sorted
   `unique`s, utils.py:181-193), which does not depend on the radices used to
   pack them -- so each rank packs with its own maxima and no max-reduction is
-  needed before the gather."""
+  needed before the gather.  `local`: this rank's rows only, no collective (the per-GPU prototype tables
+  of predictions/segsort.py:224-244)."""
   C = embeddings.shape[-1]
   D = embeddings_with_loc.shape[-1]
   return _Exchange.apply(embeddings.reshape(-1, C), embeddings_with_loc.reshape(-1, D), cluster_indices,
-                         batch_indices, semantic_labels, instance_labels, group, tag)
+                         batch_indices, semantic_labels, instance_labels, group, tag, bool(local))
 
 
 class _ExchangeList(torch.autograd.Function):

@@ -10,14 +10,18 @@ What is rebound (reference path -> hsg_amd implementation):
   hsg.utils.segsort.loss        SegSortLoss, SetSegSortLoss
   hsg.utils.segsort.eval        top_k_ranking
   hsg.utils.graph.common / loss affinity_matrix_as_attention; DMonLoss, HierarchicalDMonLoss
+  hsg.utils.segsort.others      load_memory_banks (the .npy prototype bank)
   hsg.models.utils              gather_and_reorder_image_indices, gather_and_update_cluster_mappings,
-                                gather_clustering_and_update_prototypes, gather_and_update_datas
+                                gather_clustering_and_update_prototypes, gather_and_update_datas,
+                                gather_multiset_labels_per_batch_by_nearest_neighbor
   hsg.models.embeddings.resnet_fcn_hsg   ResnetFcn / MultiviewResnetFcn: generate_clusters,
                                 _calculate_kmeans_prototypes, _hierarchical_grouping,
                                 _collect_nd_coarser_prototype,
                                 _collect_pixel_hierarchical_clustering_indices
   hsg.models.embeddings.transformer_clusters   TransformerClustering.forward (tail on libhsgk)
   hsg.models.predictions.hsg    Hsg._construct_loss, Hsg.losses (three losses, one E P^T pass)
+  hsg.models.predictions.segsort   Segsort.predictions (ONE top-k launch instead of the 10-chunk retrieval loop,
+                                pyscripts/inference/inference.py:70,92), Segsort.losses (batched), _construct_loss
 
 Modules that import the op library under an alias (`import hsg.utils.segsort.common as
 segsort_common`) hold a reference to the module object, so rebinding the module's attributes
@@ -38,6 +42,8 @@ def patch_reference(package='hsg'):
   from hsg_amd.models.embeddings import resnet_fcn_hsg as emb_mirror
   from hsg_amd.models.embeddings import transformer_clusters as tc_mirror
   from hsg_amd.models.predictions import hsg as pred_mirror
+  from hsg_amd.models.predictions import segsort as segsort_mirror
+  from hsg_amd.utils.segsort import others as so
   from hsg_amd.utils.general import common as gc
   from hsg_amd.utils.graph import common as graph_c
   from hsg_amd.utils.graph import loss as graph_l
@@ -62,8 +68,10 @@ def patch_reference(package='hsg'):
       ('utils.segsort.eval', se, ['top_k_ranking']),
       ('utils.graph.common', graph_c, ['affinity_matrix_as_attention']),
       ('utils.graph.loss', graph_l, ['DMonLoss', 'HierarchicalDMonLoss', 'dmon_pool_loss']),
+      ('utils.segsort.others', so, ['load_memory_banks']),
       ('models.utils', mu, ['gather_and_reorder_image_indices', 'gather_and_update_cluster_mappings',
-                            'gather_clustering_and_update_prototypes', 'gather_and_update_datas']),
+                            'gather_clustering_and_update_prototypes', 'gather_and_update_datas',
+                            'gather_multiset_labels_per_batch_by_nearest_neighbor']),
   ]
   for name, source, attrs in plan:
     m = mod(name)
@@ -93,4 +101,11 @@ def patch_reference(package='hsg'):
     m.Hsg._construct_loss = pred_mirror._construct_loss
     m.Hsg.losses = pred_mirror.losses
     done += [m.__name__ + '.Hsg._construct_loss', m.__name__ + '.Hsg.losses']
+  m = mod('models.predictions.segsort')
+  if m is not None and hasattr(m, 'Segsort'):
+    for name in ('predictions', 'losses', '_construct_loss'):
+      setattr(m.Segsort, name, getattr(segsort_mirror.Segsort, name))
+      done.append('%s.Segsort.%s' % (m.__name__, name))
+    for name in ('_prototype_table', '_semantic_losses', '_image_similarity_loss'):   # helpers of the mirror's losses
+      setattr(m.Segsort, name, getattr(segsort_mirror.Segsort, name))
   return done

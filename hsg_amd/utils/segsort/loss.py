@@ -33,9 +33,10 @@ class _SegSortNLL(torch.autograd.Function):
   over the same embeddings / own-prototype indices / prototype table: [L, n]."""
 
   @staticmethod
-  def forward(ctx, embeddings, instance_labels, prototypes, kappas, modes, *labels):
+  def forward(ctx, embeddings, instance_labels, prototypes, kappas, modes, groups, *labels):
     L = len(kappas)
     sems, psems = labels[:L], labels[L:]
+    qg, pg = groups if groups is not None else (None, None)
     emb = embeddings.detach().contiguous()
     proto = prototypes.detach().contiguous()
     n, c = emb.shape
@@ -52,10 +53,12 @@ class _SegSortNLL(torch.autograd.Function):
       sets = _make_sets(sems, psems, kappas, modes)
       _lib.check(lib.hsgk_segsort_loss_fwd(
           emb.data_ptr(), n, c, instance_labels.data_ptr(), proto.data_ptr(), P, L, sets,
+          qg.data_ptr() if qg is not None else None, pg.data_ptr() if pg is not None else None,
           nll.data_ptr(), num.data_ptr(), den.data_ptr(), use_same.data_ptr(), ws.data_ptr(), wsb,
           _lib.stream_ptr()))
     ctx.save_for_backward(emb, proto, instance_labels, num, den, use_same, *labels)
     ctx.cfg = (tuple(float(k) for k in kappas), tuple(int(m) for m in modes))
+    ctx.groups = (qg, pg)
     return nll
 
   @staticmethod
@@ -63,6 +66,7 @@ class _SegSortNLL(torch.autograd.Function):
     emb, proto, inst, num, den, use_same = ctx.saved_tensors[:6]
     labels = ctx.saved_tensors[6:]
     kappas, modes = ctx.cfg
+    qg, pg = ctx.groups
     L = len(kappas)
     n, c = emb.shape
     P = proto.shape[0]
@@ -81,16 +85,18 @@ class _SegSortNLL(torch.autograd.Function):
         ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
         sets = _make_sets(labels[:L], labels[L:], kappas, modes)
         _lib.check(lib.hsgk_segsort_loss_bwd(
-            emb.data_ptr(), n, c, inst.data_ptr(), proto.data_ptr(), P, L, sets, num.data_ptr(),
+            emb.data_ptr(), n, c, inst.data_ptr(), proto.data_ptr(), P, L, sets,
+            qg.data_ptr() if qg is not None else None, pg.data_ptr() if pg is not None else None, num.data_ptr(),
             den.data_ptr(), use_same.data_ptr(), gscale.data_ptr(),
             g_emb.data_ptr() if want_e else None, g_proto.data_ptr() if want_p else None,
             ws.data_ptr(), wsb, _lib.stream_ptr()))
-    return (g_emb, None, g_proto, None, None) + (None,) * len(labels)
+    return (g_emb, None, g_proto, None, None, None) + (None,) * len(labels)
 
 
-def _nll_sets(embeddings, instance_labels, prototypes, label_sets):
+def _nll_sets(embeddings, instance_labels, prototypes, label_sets, groups=None):
   """label_sets: list of (semantic_labels [n], prototype_semantic_labels [P], concentration,
-  mode) with mode bit 0 = 'segsort+', bit 1 = class-mask labels -> nll [L, n]."""
+  mode) with mode bit 0 = 'segsort+', bit 1 = class-mask labels -> nll [L, n].  groups = (pixel_groups [n],
+  prototype_groups [P]): a prototype only takes part in the sums of the pixels of its own group."""
   ops.require_gpu(embeddings, 'embeddings')
   if not 1 <= len(label_sets) <= MAX_LABEL_SETS:
     raise ValueError('1..%d label sets per pass' % MAX_LABEL_SETS)
@@ -106,8 +112,26 @@ def _nll_sets(embeddings, instance_labels, prototypes, label_sets):
       raise ValueError('label vectors do not match the embeddings / prototypes')
     sems.append(a)
     psems.append(b)
+  if groups is not None:
+    qg = groups[0].reshape(-1).to(torch.int64).contiguous()
+    pg = groups[1].reshape(-1).to(torch.int64).contiguous()
+    if qg.shape[0] != emb.shape[0] or pg.shape[0] != proto.shape[0]:
+      raise ValueError('group vectors do not match the embeddings / prototypes')
+    groups = (qg, pg)
   return _SegSortNLL.apply(emb, inst, proto, tuple(ls[2] for ls in label_sets),
-                           tuple(ls[3] for ls in label_sets), *sems, *psems)
+                           tuple(ls[3] for ls in label_sets), groups, *sems, *psems)
+
+
+def segsort_nll(embeddings, semantic_labels, instance_labels, prototypes, prototype_semantic_labels,
+                concentration, group_mode='segsort+', pixel_groups=None, prototype_groups=None):
+  """Per-pixel negative log-likelihood [num_pixels] of SegSortLoss (reference loss.py:15-82) with an
+  optional restriction of every pixel to the prototypes of its own group (not in the reference: it
+  compacts / loops instead, predictions/segsort.py:181-196, 224-244).  A pixel whose group holds none of
+  its prototypes yields inf / nan -- mask it with `torch.where` before reducing."""
+  groups = None if pixel_groups is None else (pixel_groups, prototype_groups)
+  return _nll_sets(embeddings, instance_labels, prototypes,
+                   [(semantic_labels, prototype_semantic_labels, float(concentration),
+                     1 if group_mode == 'segsort+' else 0)], groups)[0]
 
 
 def segsort_losses(embeddings, instance_labels, prototypes, label_sets, reduction='mean'):

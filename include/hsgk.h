@@ -243,7 +243,12 @@ HSGK_API int hsgk_segment_reduce_bwd(const float *gout, const float *out, const 
  * state num[L][n], den[L][n], use_same[L][n]; no [n,P] matrix exists.
  * bwd takes gscale[L][n] = dLoss/dnll and writes g_emb [n,c] and / or g_proto [P,c]
  * (either may be null): the score tiles are recomputed and contracted in place, memory
- * stays O(n c + P c).  c <= 384 for bwd.                                             */
+ * stays O(n c + P c).  c <= 384 for bwd.
+ * pixel_group int64 [n] / proto_group int64 [P] (both null: none): prototype p takes part in pixel
+ * i's sums only when proto_group[p] == pixel_group[i] -- the per-image prototype tables of
+ * hsg/models/predictions/segsort.py:224-244 in ONE launch, and prototypes without a valid class
+ * masked out instead of compacted (:181-196).  A pixel whose gscale is 0 contributes nothing to
+ * either gradient (even if its own prototype lies outside its group).                          */
 #define HSGK_LOSS_MAX_SETS 3
 #define HSGK_LOSS_MASK_WORDS 4   /* set mode: <= 4 x 63 = 252 classes */
 typedef struct hsgk_loss_set {
@@ -255,13 +260,15 @@ typedef struct hsgk_loss_set {
 HSGK_API size_t hsgk_segsort_loss_workspace_bytes(int64_t n, int c, int64_t P, int L);
 HSGK_API int hsgk_segsort_loss_fwd(const float *emb, int64_t n, int c, const int64_t *inst,
                                    const float *proto, int64_t P, int L,
-                                   const hsgk_loss_set *sets, float *nll, float *num, float *den,
+                                   const hsgk_loss_set *sets, const int64_t *pixel_group,
+                                   const int64_t *proto_group, float *nll, float *num, float *den,
                                    int32_t *use_same, void *workspace, size_t workspace_bytes,
                                    hsgk_stream_t stream);
 HSGK_API size_t hsgk_segsort_loss_bwd_workspace_bytes(int64_t n, int c, int64_t P, int L);
 HSGK_API int hsgk_segsort_loss_bwd(const float *emb, int64_t n, int c, const int64_t *inst,
                                    const float *proto, int64_t P, int L,
-                                   const hsgk_loss_set *sets, const float *num, const float *den,
+                                   const hsgk_loss_set *sets, const int64_t *pixel_group,
+                                   const int64_t *proto_group, const float *num, const float *den,
                                    const int32_t *use_same, const float *gscale, float *g_emb,
                                    float *g_proto, void *workspace, size_t workspace_bytes,
                                    hsgk_stream_t stream);

@@ -540,6 +540,52 @@ def test_exchange_list_api_on_gpu_vs_reference(dev):
   assert embs[0].grad is not None and embs[1].grad is not None
 
 
+def test_grouped_loss_equals_per_group_tables(dev, oracle):
+  """pixel / prototype groups of the loss kernels (include/hsgk.h): the grouped call == one plain call per group
+  on the compacted rows (forward per-pixel nll vs the oracle, both gradients vs the plain GPU calls); a pixel
+  with zero upstream gradient whose own prototype lies outside its group contributes nothing."""
+  import torch
+  from hsg_amd.utils.segsort import loss as sl
+  n, c, P, ngroups = 3000, 64, 90, 4
+  e = oracle.normalize_embedding(synth.gaussish(71, n * c).reshape(n, c))
+  pr = oracle.normalize_embedding(synth.gaussish(72, P * c).reshape(P, c))
+  pg = np.sort((synth.hash_u64(73, P) % np.uint64(ngroups)).astype(np.int64))
+  psem = (synth.hash_u64(74, P) % np.uint64(5)).astype(np.int64)
+  inst = (synth.hash_u64(75, n) % np.uint64(P)).astype(np.int64)
+  qg = pg[inst].copy()
+  sem = psem[inst].copy()
+  sem[::7] = (sem[::7] + 1) % 5
+  T = lambda a: torch.from_numpy(a).to(dev)
+  et, pt = T(e).requires_grad_(True), T(pr).requires_grad_(True)
+  nll = sl.segsort_nll(et, T(sem), T(inst), pt, T(psem), 12.0, 'segsort+', pixel_groups=T(qg), prototype_groups=T(pg))
+  w = T(synth.gaussish(76, n).astype(np.float32))
+  (nll * w).sum().backward()
+  want = np.zeros(n, np.float32)
+  ge, gp = torch.zeros_like(et), torch.zeros_like(pt)
+  for g in range(ngroups):
+    pi, qi = np.nonzero(pg == g)[0], np.nonzero(qg == g)[0]
+    remap = -np.ones(P, np.int64)
+    remap[pi] = np.arange(len(pi))
+    want[qi] = oracle.segsort_nll(e[qi], sem[qi], remap[inst[qi]], pr[pi], psem[pi], 12.0, 'segsort+').reshape(-1)
+    e2, p2 = T(e[qi]).requires_grad_(True), T(pr[pi]).requires_grad_(True)
+    part = sl.segsort_nll(e2, T(sem[qi]), T(remap[inst[qi]]), p2, T(psem[pi]), 12.0, 'segsort+')
+    (part * w[T(qi)]).sum().backward()
+    ge[T(qi)] += e2.grad
+    gp[T(pi)] += p2.grad
+  assert np.abs(nll.detach().cpu().numpy() - want).max() <= 1e-4
+  assert (et.grad - ge).abs().max().item() <= 2e-5 * max(ge.abs().max().item(), 1.0)
+  assert (pt.grad - gp).abs().max().item() <= 2e-5 * max(gp.abs().max().item(), 1.0)
+  # own prototype outside the pixel's group: inf / nan forward, masked by the caller, no gradient at all
+  qg2 = qg.copy()
+  qg2[:50] = ngroups + 3
+  e3 = T(e).requires_grad_(True)
+  nll2 = sl.segsort_nll(e3, T(sem), T(inst), T(pr), T(psem), 12.0, 'segsort+', pixel_groups=T(qg2), prototype_groups=T(pg))
+  keep = torch.ones(n, dtype=torch.bool, device=dev)
+  keep[:50] = False
+  torch.where(keep, nll2, torch.zeros_like(nll2)).sum().backward()
+  assert torch.isfinite(e3.grad).all() and float(e3.grad[:50].abs().max()) == 0.0
+
+
 def _exchange_case(seed, sizes, C, nimg, ncl, nsem, ninst, shuffle_ids=False):
   """Per-source pixel sets with image-major rows (like segment_by_kmeans output) or arbitrary ids."""
   parts = []
