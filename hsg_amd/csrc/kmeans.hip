@@ -1083,6 +1083,202 @@ __global__ __launch_bounds__(NW * 64) void assign_half_wide2_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// 128 < K <= 256 in ONE pass: the hi plane of all 256 centroids (143 KB at d = 258) stays in LDS with four
+// single-buffered row windows (four waves, one per SIMD, eight accumulator sets each: 161.8 KB), so the fp16
+// rows are streamed ONCE per E-step instead of once per table half, no 16-byte state record per row is
+// written and read back, and there is one epilogue per row tile.  (profiles/r03_cfg4_*: the two-half kernel
+// ran at 0.725 ms per launch with the matrix pipe 21 % busy, the LDS 19 %, the vector ALU 41 % -- phases in
+// series, twice.)  Undecided rows go to the workgroup's OWN slice of the exact queue (it starts at the
+// workgroup's first row: a workgroup never has more entries than rows) through an LDS counter -- no global
+// atomic per entry, no staging list in LDS (there is no room for one); the exact pass walks the slices.
+struct SegQueue { int32_t *count; int64_t *row0; };     // per filter workgroup: entries, first row (= slice start)
+
+template <int MB>
+struct HalfWide1Epi {
+  int K, nrows;
+  int64_t crow0;
+  float errc_max;
+  int32_t *klab;
+  int *qn;               // LDS counter of the workgroup (over all its passes)
+  SplitEntry *slice;     // the workgroup's slice of the exact queue
+  __device__ inline void operator()(int tile, const f32x16 (&sacc)[MB], float err) const {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int TPX = (int)(blockDim.x >> 1);
+    // Scores carry their row WITHIN the 32-row table block in the low 4 mantissa bits (register index r: one
+    // v_and_or with an inline constant; a perturbation of at most 15 ulp <= 1.8e-6 that the gap accounts for),
+    // so the running top-2 of a block needs no index bookkeeping: b1 = max, b2 = med3(b1, b2, v) -- three
+    // vector instructions per score.  Blocks entirely below K are unmasked, entirely above skipped (uniform).
+    float bm1[MB];
+    float t1 = -INFINITY, t2 = -INFINITY;
+    int tm = 0;
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      float b1 = -INFINITY, b2 = -INFINITY;
+      if (m * 32 < K) {
+        if ((m + 1) * 32 <= K) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = __uint_as_float((__float_as_uint(sacc[m][r]) & ~15u) | (uint32_t)r);
+            b2 = __builtin_amdgcn_fmed3f(b1, b2, v);
+            b1 = fmaxf(b1, v);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float v = __uint_as_float((__float_as_uint(sacc[m][r]) & ~15u) | (uint32_t)r);
+            v = k < K ? v : -INFINITY;
+            b2 = __builtin_amdgcn_fmed3f(b1, b2, v);
+            b1 = fmaxf(b1, v);
+          }
+        }
+      }
+      bm1[m] = b1;
+      // merge into the lane's running top-2 (strict >: the lower block wins a tie)
+      const bool up = b1 > t1;
+      t2 = up ? fmaxf(t1, b2) : fmaxf(t2, b1);
+      tm = up ? m : tm;
+      t1 = up ? b1 : t1;
+    }
+    const uint32_t tg = __float_as_uint(t1) & 15u;
+    int ti = tm * 32 + (int)(tg & 3u) + 8 * (int)(tg >> 2) + 4 * h;
+    {
+      const float o1 = __shfl_xor(t1, 32), o2 = __shfl_xor(t2, 32);
+      const int oi = __shfl_xor(ti, 32);
+      if (o1 > t1 || (o1 == t1 && oi < ti)) { t2 = fmaxf(t1, o2); t1 = o1; ti = oi; }
+      else { t2 = fmaxf(o1, t2); }
+    }
+    const int px = tile * TPX + w * 32 + j;
+    const bool valid = px < nrows;
+    const float gap = half_wide_gap(err, errc_max) + 4.0e-6f;      // + 2 x the tag perturbation
+    const bool amb = valid && !(t1 - t2 > gap);                    // ambiguous (or NaN)
+    if (h == 0 && valid) klab[crow0 + px] = ti;                    // provisional for ambiguous rows
+    if (!__any(amb)) return;
+    // candidates of this lane's half, merged with the partner half (<= 7, else "all"); only table blocks
+    // whose maximum reaches some ambiguous row's threshold are scanned
+    const float thr = amb ? t1 - gap - 2.0e-6f : INFINITY;
+    unsigned long long list = 0;
+    int cnt = 0;
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      if (!__any(bm1[m] >= thr)) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool hit = k < (uint32_t)K && sacc[m][r] >= thr;      // NaN scores never hit
+        list = hit ? ((list << 8) | k) : list;
+        cnt += hit ? 1 : 0;
+      }
+    }
+    const unsigned long long olist = __shfl_xor(list, 32);
+    const int ocnt = __shfl_xor(cnt, 32);
+    const int tot = cnt + ocnt;
+    uint32_t cand = 255u << 24, cand_hi = 0u;
+    if (tot <= 7 && tot >= 1 && t1 == t1) {
+      const unsigned long long all = (list & ((1ull << (8 * cnt)) - 1ull)) | (olist << (8 * cnt));
+      cand = (uint32_t)(all & 0xFFFFFFull) | ((uint32_t)tot << 24);
+      cand_hi = (uint32_t)(all >> 24);
+    }
+    if (h == 0 && amb) slice[atomicAdd(qn, 1)] = SplitEntry{(int32_t)(crow0 + px), cand, cand_hi};
+  }
+};
+
+template <int NW, int DEPTH, int MB, int NFULL>
+__global__ __launch_bounds__(NW * 64) void assign_half_wide1_kernel(
+    const _Float16 *__restrict__ xm, const uint2 *__restrict__ xt, int d,
+    const float *__restrict__ cent, const float *__restrict__ errc, int K,
+    const int64_t *__restrict__ img_row0, int B, int32_t *__restrict__ klab,
+    SplitEntry *__restrict__ gqueue, SegQueue seg, const hsgk_segkm_meta *__restrict__ meta) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int TPX = NW * 32;
+  int *qnp = reinterpret_cast<int *>(lds_raw + half_lds_bytes<NW, MB, 1, 1>(d));
+  const int64_t N = meta->n_rows;
+  const int64_t per = (N + (int64_t)gridDim.x * TPX - 1) / ((int64_t)gridDim.x * TPX) * TPX;
+  int64_t r = (int64_t)blockIdx.x * per;
+  const int64_t r_end = min(N, r + per);
+  if (threadIdx.x == 0) { seg.count[blockIdx.x] = 0; seg.row0[blockIdx.x] = r < r_end ? r : 0; qnp[0] = 0; }
+  if (r >= r_end) return;
+  const int64_t slice0 = r;
+  int b = image_of_row(img_row0, B, r);
+  int staged_img = -1;
+  float errc_max = 0.0f;
+  while (r < r_end) {
+    while (img_row0[b + 1] <= r) ++b;
+    const int64_t seg_end = min(r_end, img_row0[b + 1]);
+    const int nrows = (int)min(seg_end - r, (int64_t)1 << 24);
+    const int64_t crow0 = r;
+    if (b != staged_img) {                                     // largest table rounding error of this image
+      float m = 0.0f;
+      for (int k = threadIdx.x & 63; k < K; k += 64) m = fmaxf(m, errc[(int64_t)b * K + k]);
+      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+      errc_max = m;
+    }
+    HalfWide1Epi<MB> epi{K, nrows, crow0, errc_max, klab, qnp, gqueue + slice0};
+    score_tiles_half<NW, DEPTH, HalfWide1Epi<MB>, MB, 1, 1>(
+        xm, xt, d, cent + (int64_t)b * K * d, K, crow0, nrows, lds_raw, epi, b != staged_img);
+    staged_img = b;
+    r += nrows;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) seg.count[blockIdx.x] = qnp[0];
+}
+
+// exact pass over the per-workgroup slices of the queue (nseg <= 1024)
+__global__ __launch_bounds__(256) void assign_requeue_seg_kernel(
+    const float *__restrict__ x, int d, const float *__restrict__ cent, int K,
+    int32_t *__restrict__ klab, const SplitEntry *__restrict__ gqueue, SegQueue seg, int nseg,
+    const int64_t *__restrict__ img_row0, int B) {
+  __shared__ int pre[1025];
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // exclusive prefix of the segment counts (four per thread)
+  int c[4], tot = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int sidx = tid * 4 + i; c[i] = sidx < nseg ? seg.count[sidx] : 0; tot += c[i]; }
+  int inc = tot;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(inc, off);
+    if (lane >= off) inc += o;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int base = inc - tot;
+  for (int i = 0; i < w; ++i) base += wsum[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { pre[tid * 4 + i] = base; base += c[i]; }
+  if (tid == 255) pre[1024] = base;
+  __syncthreads();
+  const int total = pre[1024];
+  const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+  const int grp = lane >> 2;
+  for (int e0 = wave * 16; e0 < total; e0 += nwaves * 16) {
+    const int e = e0 + grp;
+    SplitEntry ent{0, 0u, 0u};
+    if (e < total) {
+      int lo = 0, hi = 1024;                       // last segment with pre[seg] <= e
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (pre[mid] <= e) lo = mid; else hi = mid;
+      }
+      ent = gqueue[seg.row0[lo] + (e - pre[lo])];
+    }
+    int img = 0;
+    {
+      int hi = B;
+      while (hi - img > 1) {
+        const int mid = (img + hi) >> 1;
+        if (img_row0[mid] <= (int64_t)ent.row) img = mid; else hi = mid;
+      }
+    }
+    exact_rescore16(ent, e < total, img, x, d, cent, K, klab);
+  }
+}
+
+static bool wide1_fits(int d) { return (d / 64 == 4 || d / 64 == 2) && half_lds_bytes<4, 8, 1, 1>(d) + 32 <= 160 * 1024; }
+
 bool assign_half_wide2_eligible(int d, int K) {
   return K > 128 && K <= 256 && half_wide_shape_ok(d) &&
          half_lds_bytes<8, 4, 1, 1>(d) + (size_t)kSplitLdsList * 6 <= 160 * 1024;
@@ -1103,10 +1299,31 @@ int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt
   }();
   const int64_t max_tiles = ((int64_t)max_chunks * HSGK_CHUNK + TPX - 1) / TPX;
   const int grid = (int)(max_tiles < n_cu ? max_tiles : n_cu);
-  HSGK_CHECK_HIP(hipMemsetAsync(qcount, 0, sizeof(int32_t), s));
   hipLaunchKernelGGL(centroid_half_err_kernel, dim3((unsigned)(((int64_t)B * K + 3) / 4)), dim3(256), 0, s,
                      cent, d, (int64_t)B * K, errc);
   HSGK_LAUNCH_CHECK();
+  const char *two = getenv("HSGK_WIDE2");               // "two": the two-half kernel (A/B; read per call)
+  if (wide1_fits(d) && !(two && two[0] == 't') && grid <= 1024 &&
+      (int64_t)max_chunks * HSGK_CHUNK * 16 >= (int64_t)grid * 16) {
+    // one pass over the rows, all 256 centroids resident (see assign_half_wide1_kernel); the per-workgroup
+    // entry counts and slice starts live at the head of the (otherwise unused) state records
+    constexpr int NW1 = 4, MB1 = 8, TPX1 = NW1 * 32;
+    const int64_t tiles1 = ((int64_t)max_chunks * HSGK_CHUNK + TPX1 - 1) / TPX1;
+    const int grid1 = (int)(tiles1 < n_cu ? tiles1 : n_cu);
+    SegQueue seg{reinterpret_cast<int32_t *>(state), reinterpret_cast<int64_t *>(static_cast<char *>(state) + 4096)};
+    auto kern = d / 64 == 4 ? assign_half_wide1_kernel<NW1, 4, MB1, 4> : assign_half_wide1_kernel<NW1, 2, MB1, 2>;
+    const size_t lds = half_lds_bytes<NW1, MB1, 1, 1>(d) + 32;
+    HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid1), dim3(NW1 * 64), lds, s, xm, xt, d, cent, errc, K, t.img_row0, B, klab,
+                       reinterpret_cast<SplitEntry *>(qrows), seg, meta);
+    HSGK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(assign_requeue_seg_kernel, dim3(2048), dim3(256), 0, s, x, d, cent, K, klab,
+                       reinterpret_cast<const SplitEntry *>(qrows), seg, grid1, t.img_row0, B);
+    HSGK_LAUNCH_CHECK();
+    return 0;
+  }
+  HSGK_CHECK_HIP(hipMemsetAsync(qcount, 0, sizeof(int32_t), s));
   {
     const bool deep = ((d / 64) & 3) == 0;
     auto kern = deep ? assign_half_wide2_kernel<NW, 4, MB> : assign_half_wide2_kernel<NW, 2, MB>;

@@ -143,7 +143,12 @@ __device__ unsigned long long g_small_ts[12];
 // order -- and saves LDS for the wide variants).
 // AUX: a 16-byte per-row record aux[row] (state left by an earlier pass over the same rows)
 // is prefetched with the tail and handed to Epi(tile, acc, err, aux).
-template <int NW, int DEPTH, class Epi, int MB = 2, int PLANES = 2, int NBUF = 2, bool AUX = false>
+// ZERO_C: the first MFMA of a tile takes the constant 0 as its C operand instead of a zeroed accumulator: no
+// 16 MB accumulator writes per tile and no loop-carried accumulator values (with eight accumulator sets the
+// loop phis cost a register-to-register copy of all 128 of them per tile).  It needs the number of 64-column
+// chunks of a row at compile time (NFULL_CT = d / 64; 0 = taken from d at run time, ZERO_C then unavailable).
+template <int NW, int DEPTH, class Epi, int MB = 2, int PLANES = 2, int NBUF = 2, bool AUX = false, bool ZERO_C = false,
+          int NFULL_CT = 0>
 __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm,
                                                  const uint2 *__restrict__ xt, int d,
                                                  const float *__restrict__ table, int kvalid,
@@ -168,7 +173,8 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
   unsigned long long ets_ = __builtin_readcyclecounter();
 #endif
 
-  const int nfull = DM / KC;
+  static_assert(!ZERO_C || NFULL_CT > 0, "ZERO_C needs the chunk count at compile time");
+  const int nfull = NFULL_CT > 0 ? NFULL_CT : DM / KC;
   const int tcol0 = DM;
   const bool has_tail = d > DM;                   // <= 2 tail columns (half_shape_ok), fed from xt
   const int wu = __builtin_amdgcn_readfirstlane(w);
@@ -247,10 +253,11 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
       for (int m = 0; m < MB; ++m) o.al[m] = *reinterpret_cast<const f16x8 *>(lp + m * 32 * RS);
     }
   };
-  auto mfma_ops = [&](const Ops &o) {
+  auto mfma_ops = [&](const Ops &o, bool first = false) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < MB; ++m)
-      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.ah[m], o.b, acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.ah[m], o.b, first ? zero : acc[m], 0, 0, 0);
     if constexpr (PLANES == 2) {
 #pragma unroll
       for (int m = 0; m < MB; ++m)
@@ -263,7 +270,7 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
     load_table_ops(col0, o);
     mfma_ops(o);
   };
-  auto compute_chunk = [&](int buf, int q) {
+  auto compute_chunk = [&](int buf, int q, bool first = false) {
     const uint16_t *bp = xw + (buf % NBUF) * (32 * XSB) + j * XSB + 8 * g;
     Ops o0, o1;
     o0.b = *reinterpret_cast<const f16x8 *>(bp);
@@ -271,7 +278,7 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
     __builtin_amdgcn_sched_barrier(0);
     o1.b = *reinterpret_cast<const f16x8 *>(bp + 16);
     load_table_ops(q * KC + 16, o1);
-    mfma_ops(o0);
+    mfma_ops(o0, first);
     __builtin_amdgcn_sched_barrier(0);
     o0.b = *reinterpret_cast<const f16x8 *>(bp + 32);
     load_table_ops(q * KC + 32, o0);
@@ -375,36 +382,52 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();                         // table planes visible to all waves
   HSGK_ETS(5);
-  zero_acc();
+  if constexpr (!ZERO_C) zero_acc();
   if (nsteps <= 0) return;              // (wave-uniform)
   uint2 tailv = {0u, 0u};
   u32x4 auxv = {0u, 0u, 0u, 0u};
-#define HSGK_HALF_STEP(BUF, PRE, QQ)                                          \
+#define HSGK_HALF_STEP(BUF, PRE, QQ, FIRST)                                   \
   HSGK_VMWAIT8(8 * (DEPTH - 1), PRE);                                         \
   store_chunk(BUF, PRE);                                                      \
   __builtin_amdgcn_sched_barrier(0);                                          \
   load_next(PRE);                                                             \
   __builtin_amdgcn_sched_barrier(0);                                          \
-  compute_chunk(BUF, QQ);                                                     \
+  compute_chunk(BUF, QQ, FIRST);                                              \
   __builtin_amdgcn_sched_barrier(0);
   for (int tile = 0; tile < ntile; ++tile) {
     load_tail(tile, tailv);
     if constexpr (AUX) load_aux(tile, auxv);
-    for (int q = 0; q < nfull; q += DEPTH) {
-      if constexpr (DEPTH == 4) {
-        HSGK_HALF_STEP(0, preA, q)
-        HSGK_HALF_STEP(1, preB, q + 1)
-        HSGK_HALF_STEP(0, preC, q + 2)
-        HSGK_HALF_STEP(1, preD, q + 3)
-      } else {
-        HSGK_HALF_STEP(0, preA, q)
-        HSGK_HALF_STEP(1, preB, q + 1)
+    if constexpr (NFULL_CT > 0) {
+#pragma unroll
+      for (int q = 0; q < NFULL_CT; q += DEPTH) {
+        const bool first = ZERO_C && q == 0;          // (folds after unrolling)
+        if constexpr (DEPTH == 4) {
+          HSGK_HALF_STEP(0, preA, q, first)
+          HSGK_HALF_STEP(1, preB, q + 1, false)
+          HSGK_HALF_STEP(0, preC, q + 2, false)
+          HSGK_HALF_STEP(1, preD, q + 3, false)
+        } else {
+          HSGK_HALF_STEP(0, preA, q, first)
+          HSGK_HALF_STEP(1, preB, q + 1, false)
+        }
+      }
+    } else {
+      for (int q = 0; q < nfull; q += DEPTH) {
+        if constexpr (DEPTH == 4) {
+          HSGK_HALF_STEP(0, preA, q, false)
+          HSGK_HALF_STEP(1, preB, q + 1, false)
+          HSGK_HALF_STEP(0, preC, q + 2, false)
+          HSGK_HALF_STEP(1, preD, q + 3, false)
+        } else {
+          HSGK_HALF_STEP(0, preA, q, false)
+          HSGK_HALF_STEP(1, preB, q + 1, false)
+        }
       }
     }
     // the tail (and aux) loads were issued before this tile's nfull >= DEPTH chunk sets
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(tailv), "+v"(auxv) : "n"(8 * DEPTH));
     finish_tile(tile, tailv, auxv);
-    zero_acc();
+    if constexpr (!ZERO_C) zero_acc();
   }
   HSGK_ETS(6);
   // drain the look-ahead sets; naming them keeps their registers reserved until here
