@@ -53,6 +53,27 @@ __device__ inline void bf16_split2(float a, float b, uint32_t &hi, uint32_t &lo)
   lo = __builtin_bit_cast(uint32_t, l);
 }
 
+// fp16 variant of the split with SCALED residuals: x = xh + 2^-11 xl', xh = fp16(x), xl' = fp16((x - xh) 2^11)
+// (fp16 carries 11 significant bits, so the two terms hold 22 -- bf16's two hold 16; the scaling keeps the
+// residual in fp16's normal range).  Same three MFMAs per 16 columns, but the cross terms go to a second
+// accumulator that is folded in with 2^-11 at the end of a tile:
+//     acc  += ch * xh          acc2 += cl' * xh + ch * xl'          score = acc + 2^-11 acc2
+// Error against the fp32 chain for |x|, |c| <= 1: dropped cl xl <= 2^-22, residual rounding 2 * 2^-22,
+// MFMA accumulation 17 * 2^-22 (fp32 accumulate, measured per instruction) -- about 5e-6 in the worst case,
+// the size of the fp32 chain's own rounding (gamma_258 = 1.5e-5); values must stay below fp16's 65504.
+// Used where a TOLERANCE is the contract (the loss: exp(kappa s) amplifies a score error kappa-fold, and its
+// backward divides by differences of those sums), not for the E-step filters, whose bounds are built on bf16.
+__device__ inline void f16s_split2(float a, float b, uint32_t &hi, uint32_t &lo) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {a, b};
+  const f16x2 h = __builtin_convertvector(v, f16x2);
+  const f32x2 r = (v - __builtin_convertvector(h, f32x2)) * 2048.0f;
+  const f16x2 l = __builtin_convertvector(r, f16x2);
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+
 template <int NW>
 __host__ __device__ constexpr size_t split_lds_bytes(int d) {
   return (size_t)2 * 64 * (((d + 15) / 16) * 16 + 8) * 2 + (size_t)NW * 2 * 2 * 32 * 40 * 2 + 16;
@@ -67,7 +88,7 @@ __host__ __device__ constexpr size_t split_lds_bytes(int d) {
 // rl_lds[NW][2][32] (tile parity), loaded two tiles ahead: an id fetched from global
 // right before its use would drain the whole prefetch queue (loads return in order).
 // Epi may read the ids of tile t from the slot t & 1 inside its call.
-template <int NW, int DEPTH, class Epi, bool ROWS = false>
+template <int NW, int DEPTH, class Epi, bool ROWS = false, bool F16S = false>
 __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, int d,
                                          const float *__restrict__ table, int kvalid,
                                          int64_t crow0, int nrows, unsigned char *lds_raw,
@@ -88,6 +109,9 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int j = lane & 31, g = lane >> 5;
+  auto split2 = [](float a, float b, uint32_t &hi, uint32_t &lo) {
+    if constexpr (F16S) f16s_split2(a, b, hi, lo); else bf16_split2(a, b, hi, lo);
+  };
 
   // ---- table block -> bf16 hi / lo planes (zero padded); a persistent caller
   //      skips this while consecutive chunks use the same table
@@ -111,7 +135,7 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
         if (f < total) {
           const int k = f / half, col = 2 * (f - k * half);
           uint32_t hi, lo;
-          bf16_split2(v[u].x, v[u].y, hi, lo);
+          split2(v[u].x, v[u].y, hi, lo);
           *reinterpret_cast<uint32_t *>(chs + k * RS + col) = hi;
           *reinterpret_cast<uint32_t *>(cls + k * RS + col) = lo;
         }
@@ -168,27 +192,40 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
     for (int i = 0; i < LOADS; ++i) {
       const int px = lpx + 4 * i;
       uint32_t hi, lo;
-      bf16_split2(pre[i].x, pre[i].y, hi, lo);
+      split2(pre[i].x, pre[i].y, hi, lo);
       *reinterpret_cast<uint32_t *>(hp + px * XSB + 2 * lf2) = hi;
       *reinterpret_cast<uint32_t *>(lp + px * XSB + 2 * lf2) = lo;
     }
   };
 
   f32x16 acc[2];
+  f32x16 acc2[F16S ? 2 : 1];                    // cross terms of the scaled fp16 split
   auto zero_acc = [&]() {
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) {
+        acc[m][r] = 0.0f;
+        if constexpr (F16S) acc2[m][r] = 0.0f;
+      }
   };
   auto kblock = [&](const bf16x8 &bh, const bf16x8 &bl, int col0) {
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(chs + (m * 32 + j) * RS + col0 + 8 * g);
       const bf16x8 al = *reinterpret_cast<const bf16x8 *>(cls + (m * 32 + j) * RS + col0 + 8 * g);
-      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[m], 0, 0, 0);
-      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[m], 0, 0, 0);
-      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[m], 0, 0, 0);
+      if constexpr (F16S) {
+        typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+        const h16x8 fah = __builtin_bit_cast(h16x8, ah), fal = __builtin_bit_cast(h16x8, al);
+        const h16x8 fbh = __builtin_bit_cast(h16x8, bh), fbl = __builtin_bit_cast(h16x8, bl);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fbh, acc[m], 0, 0, 0);
+        acc2[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal, fbh, acc2[m], 0, 0, 0);
+        acc2[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fbl, acc2[m], 0, 0, 0);
+      } else {
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[m], 0, 0, 0);
+      }
     }
   };
   auto compute_chunk = [&](int buf, int q) {
@@ -215,7 +252,7 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
       const int ca = c0 + 2 * p;
       const float a = (j < n && ca < d) ? src[min(ca, d - 1)] : 0.0f;
       const float b = (j < n && ca + 1 < d) ? src[min(ca + 1, d - 1)] : 0.0f;
-      bf16_split2(a, b, hw[p], lw[p]);
+      split2(a, b, hw[p], lw[p]);
     }
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     u32x4 hv = {hw[0], hw[1], hw[2], hw[3]}, lv = {lw[0], lw[1], lw[2], lw[3]};
@@ -235,7 +272,7 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
   auto finish_tile = [&](int tile, const float2 &tv) {
     if (two_tail) {
       uint32_t hi, lo;
-      bf16_split2(tv.x, tv.y, hi, lo);
+      split2(tv.x, tv.y, hi, lo);
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
       const u32x4 hv = {g == 0 ? hi : 0u, 0u, 0u, 0u}, lv = {g == 0 ? lo : 0u, 0u, 0u, 0u};
       kblock(__builtin_bit_cast(bf16x8, hv), __builtin_bit_cast(bf16x8, lv), tcol0);
@@ -245,6 +282,12 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
         tail_operands(tile, kb, bh, bl);
         kblock(bh, bl, tcol0 + 16 * kb);
       }
+    }
+    if constexpr (F16S) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = fmaf(acc2[m][r], 0.00048828125f, acc[m][r]);
     }
     epi(tile, acc);
   };

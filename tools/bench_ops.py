@@ -58,6 +58,31 @@ def main():
     SegSortLoss(16, 'segsort+')(e, s1, c1, p, psem).backward()
   res['segsort_loss_fwd_bwd_ms'] = timeit(fwd_bwd)
   res['segsort_loss_fwd_tflops'] = round(2.0 * 256 * P * n1 / (res['segsort_loss_fwd_ms'] * 1e-3) / 1e12, 1)
+  # the loss where the reference runs it (predictions/hsg.py:105,130,149) and at one benchmark image against a
+  # whole batch's table: (N, C, P); forward on the bf16x3 engine (default) and on the fp32 engine
+  rows = {}
+  for n_, c_, P_ in ((9408, 128, 1536), (37632, 256, 3072), (200704, 256, 3072)):
+    pr = torch.nn.functional.normalize(torch.randn((P_, c_), device=dev, generator=gen), dim=1)
+    ins = torch.randint(0, P_, (n_,), device=dev, generator=gen)
+    ee = torch.nn.functional.normalize(pr[ins] + 0.35 * torch.randn((n_, c_), device=dev, generator=gen), dim=1)
+    ps = torch.arange(P_, device=dev) % 21
+    se = ps[ins]
+    row = {}
+    for eng in ('split', 'fp32'):
+      os.environ['HSGK_LOSS'] = eng
+      ms = timeit(lambda: SegSortLoss(16, 'segsort+')(ee, se, ins, pr, ps))
+      row['fwd_ms_' + eng] = ms
+      row['fwd_tflops_equiv_' + eng] = round(2.0 * c_ * P_ * n_ / (ms * 1e-3) / 1e12, 1)
+    os.environ.pop('HSGK_LOSS', None)
+
+    def fb():
+      a = ee.detach().requires_grad_(True)
+      b = pr.detach().requires_grad_(True)
+      SegSortLoss(16, 'segsort+')(a, se, ins, b, ps).backward()
+    row['fwd_bwd_ms'] = timeit(fb)
+    row['bwd_tflops'] = round(8.0 * c_ * P_ * n_ / ((row['fwd_bwd_ms'] - row['fwd_ms_split']) * 1e-3) / 1e12, 1)
+    rows['N%d_C%d_P%d' % (n_, c_, P_)] = row
+  res['segsort_loss_scale'] = rows
   res['top_k_ranking_k20_ms'] = timeit(lambda: ev.top_k_ranking(e1, s1, protos, psem, 20))
   res['prototype_table_4img_ms'] = timeit(lambda: sc.calculate_prototypes_from_labels(emb, cidx))
   zeros = torch.zeros_like(lab)
