@@ -491,9 +491,12 @@ __device__ inline XSlice slice_of(int w, const float *xa, int da, const float *x
 static int slices_of_host(int d) { return slices_count(d); }
 
 // U rows in flight per wave and buffer (two buffers)
+// slot_first / slot_step: partial row of the list's first run and the distance between consecutive runs' rows
+// (0 / 1 for the whole sorted list; rg / RG when the runs of a chunk are dealt out to RG groups of waves)
 template <bool TAIL, int V, int U>
 __device__ inline void stream_runs(const XSlice sl, int64_t row0, const uint16_t *__restrict__ srow, int nvalid,
-                                   float *__restrict__ prow /* partial row 0 of this chunk */, int T) {
+                                   float *__restrict__ prow /* partial row 0 of this chunk */, int T,
+                                   int slot_first = 0, int slot_step = 1) {
   typedef float fv __attribute__((ext_vector_type(V), aligned(4)));
   const int lane = threadIdx.x & 63;
   const int ml = lane < sl.nmain ? lane : (sl.nmain > 0 ? sl.nmain - 1 : 0);
@@ -516,7 +519,7 @@ __device__ inline void stream_runs(const XSlice sl, int64_t row0, const uint16_t
 #pragma unroll
   for (int i = 0; i < V; ++i) acc[i] = 0.0f;
   float tacc = 0.0f;
-  int slot = -1;
+  int slot = slot_first - slot_step;
   auto flush = [&]() {
     float *dst = prow + (int64_t)slot * T + sl.out0;
     if (has_main && lane < sl.nmain) *reinterpret_cast<fv *>(dst + sl.col0 + V * lane) = acc;
@@ -528,8 +531,8 @@ __device__ inline void stream_runs(const XSlice sl, int64_t row0, const uint16_t
       if (e0 + u < nvalid) {
         const int start = __builtin_amdgcn_readfirstlane((int)(srow[e0 + u] >> 15));
         if (start) {
-          if (slot >= 0) flush();
-          ++slot;
+          if (slot >= slot_first) flush();
+          slot += slot_step;
 #pragma unroll
           for (int i = 0; i < V; ++i) acc[i] = 0.0f;
           tacc = 0.0f;
@@ -552,14 +555,21 @@ __device__ inline void stream_runs(const XSlice sl, int64_t row0, const uint16_t
     fold(e0 + U, vb, tb);
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (slot >= 0) flush();
+  if (slot >= slot_first) flush();
 }
 
-// blockDim = 64 * (slices(da) + slices(db)); one workgroup per chunk
+// blockDim = 64 * (slices(da) + slices(db)) * RG; one workgroup per chunk.  RG > 1 (small inputs: a few chunks
+// on 256 CUs, where one wave per column slice walking all 2048 rows of a chunk is a chain of ~130 exposed
+// memory round trips): the chunk's RUNS are dealt out to RG groups of waves (run s to group s % RG), every
+// group streams only its runs' rows -- a run is still summed by one wave in row order (order C2 unchanged).
+// Dynamic LDS: RG lists of 2048 entries (none for RG = 1).
 __global__ void xk_sums_chunk_kernel(const float *__restrict__ xa, int da, const float *__restrict__ xb, int db,
                                      const int64_t *__restrict__ ids, int64_t n, int64_t P,
                                      float *__restrict__ pool, int64_t *__restrict__ pool_ids, int pool_rows,
-                                     XChunk *__restrict__ chunks, int32_t *__restrict__ seg_range, XCtrl *ctrl) {
+                                     XChunk *__restrict__ chunks, int32_t *__restrict__ seg_range, XCtrl *ctrl,
+                                     int RG) {
+  extern __shared__ uint16_t glist[];             // [RG][HSGK_CHUNK] (RG > 1)
+  __shared__ int gcount[8];
   __shared__ unsigned long long skey[HSGK_CHUNK];
   __shared__ uint16_t srow[HSGK_CHUNK];
   __shared__ long long red[2][16];
@@ -663,14 +673,39 @@ __global__ void xk_sums_chunk_kernel(const float *__restrict__ xa, int da, const
   if (base < 0) return;
   if (tid == 0) chunks[c] = XChunk{base, ndist, 0, 0, lo, hi};
   __syncthreads();
-  const XSlice sl = slice_of(w, xa, da, xb, db);
+  const int nsl = nw / RG;                          // column slices
+  const int rg = w / nsl;
+  const uint16_t *list = srow;
+  int nlist = nvalid;
+  if (RG > 1) {
+    if (w % nsl == 0) {                             // the first wave of a group compacts the group's entries
+      uint16_t *mine = glist + rg * HSGK_CHUNK;
+      int runs_before = 0, pos = 0;
+      for (int e0 = 0; e0 < nvalid; e0 += 64) {
+        const int e = e0 + lane;
+        const uint16_t ent = e < nvalid ? srow[e] : 0;
+        const unsigned long long sm = __ballot(e < nvalid && (ent >> 15));
+        const int run = runs_before + __popcll(sm & ((2ull << lane) - 1ull)) - 1;
+        const bool take = e < nvalid && (run % RG) == rg;
+        const unsigned long long tm = __ballot(take);
+        if (take) mine[pos + __popcll(tm & ((1ull << lane) - 1ull))] = ent;
+        pos += __popcll(tm);
+        runs_before += __popcll(sm);
+      }
+      if (lane == 0) gcount[rg] = pos;
+    }
+    __syncthreads();
+    list = glist + rg * HSGK_CHUNK;
+    nlist = gcount[rg];
+  }
+  const XSlice sl = slice_of(w % nsl, xa, da, xb, db);
   float *prow = pool + (int64_t)base * T;
   if (sl.vec == 4) {
-    if (sl.ntail > 0) stream_runs<true, 4, 8>(sl, row0, srow, nvalid, prow, T);
-    else stream_runs<false, 4, 8>(sl, row0, srow, nvalid, prow, T);
+    if (sl.ntail > 0) stream_runs<true, 4, 8>(sl, row0, list, nlist, prow, T, rg, RG);
+    else stream_runs<false, 4, 8>(sl, row0, list, nlist, prow, T, rg, RG);
   } else {
-    if (sl.ntail > 0) stream_runs<true, 2, 16>(sl, row0, srow, nvalid, prow, T);
-    else stream_runs<false, 2, 16>(sl, row0, srow, nvalid, prow, T);
+    if (sl.ntail > 0) stream_runs<true, 2, 16>(sl, row0, list, nlist, prow, T, rg, RG);
+    else stream_runs<false, 2, 16>(sl, row0, list, nlist, prow, T, rg, RG);
   }
 }
 
@@ -1014,9 +1049,12 @@ static int launch_ids_and_sums(const hsgk_exchange_args *a, const XWs &w, const 
   if (w.nch > 0) {
     const int nw = slices_of_host(a->C) + slices_of_host(a->D);
     HSGK_REQUIRE(nw <= 16, "rows too long");
-    hipLaunchKernelGGL(xk_sums_chunk_kernel, dim3((unsigned)w.nch), dim3(64 * nw), 0, s, a->embeddings, a->C,
+    int rg = 1;                                     // run groups per chunk: small inputs only (see the kernel)
+    if (w.nch <= 512) rg = nw <= 2 ? 8 : nw <= 4 ? 4 : nw <= 8 ? 2 : 1;
+    hipLaunchKernelGGL(xk_sums_chunk_kernel, dim3((unsigned)w.nch), dim3(64 * nw * rg),
+                       rg > 1 ? (size_t)rg * HSGK_CHUNK * 2 : 0, s, a->embeddings, a->C,
                        a->embeddings_loc, a->D, a->updated_cluster, a->n, a->cap_total, w.pool, w.pool_ids,
-                       (int)a->pool_rows, w.chunks, w.seg_range, w.ctrl);
+                       (int)a->pool_rows, w.chunks, w.seg_range, w.ctrl, rg);
     HSGK_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(xk_sums_final_kernel, dim3((unsigned)a->cap_total), dim3(256), 0, s, w.pool, w.pool_ids, w.chunks,

@@ -568,6 +568,17 @@ def gather_and_update_cluster_mappings(cluster_indices_1, cluster_indices_2,
   anchor = torch.device(anchor_device) if anchor_device is not None else devices[0]
   a = _cat_to(c1, anchor).long() if len(c1) > 1 else c1[0].long()
   b = _cat_to(c2, anchor).long() if len(c2) > 1 else c2[0].long()
+  if _world(group) == 1:
+    # one process: mapping[i] = the LARGEST partner of index i -- what the reference's duplicate-index
+    # assignment leaves behind on sorted pairs (utils.py:112-121) -- is one scatter-max
+    if a.numel():
+      size = int(a.max()) + 1                    # (the reference reads this maximum on the host too)
+      mapping = torch.zeros((size,), dtype=torch.long, device=a.device).scatter_reduce(0, a, b, 'amax', include_self=True)
+    else:
+      mapping = torch.zeros((0,), dtype=torch.long, device=a.device)
+    if not listed:
+      return mapping
+    return [mapping.to(d) for d in devices]
   if a.numel():
     local_max = b.max() + 1
     pk = torch.unique(a * local_max + b)
