@@ -6,6 +6,8 @@
 // Canonical arithmetic: every sum of squares is one fmaf
 // chain in ascending channel order starting from +0.0f; sqrtf and '/' are the
 // correctly rounded IEEE operations (hipcc default, no fast-math).
+#include <algorithm>
+
 #include "common.h"
 
 namespace hsgk {
@@ -872,6 +874,276 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
   HSGK_TS(7);
 }
 
+// --------------------------------------------------------------------------
+// Persistent, software-pipelined form of prep_fast32_kernel (HSGK_PREP=pipe; C <= 256): a workgroup walks
+// half tiles h = blockIdx.x, + gridDim.x, ... with TWO LDS tiles.  Per iteration: the plane loads and the
+// bookkeeping loads of half tile i + 1 are issued, half tile i is computed from its LDS tile (chains, divide),
+// then ONE full wait -- by then only those loads and the row stores of half tile i - 1 are outstanding, and
+// both have had a whole compute phase to complete -- the prefetched registers go to the other LDS tile, and
+// only then are the 85 KB of row stores of half tile i issued.  (The round-2 pipelined variant consumed the
+// prefetch AFTER the stores: loads and stores share the vmcnt counter and complete out of order against each
+// other, so that wait drained the stores it had just issued: 11.3 ms against 7.6.)  Same arithmetic, same
+// outputs as prep_fast32_kernel.
+__global__ __launch_bounds__(256) void prep_pipe32_kernel(
+    const float *__restrict__ in, int C, int64_t HW, int ntiles, int B,
+    const float *__restrict__ loc, int64_t loc_sb, const int64_t *__restrict__ labels,
+    int has_ignore, int64_t ignore, const int32_t *__restrict__ tile_off,
+    const int64_t *__restrict__ img_row0, const int32_t *__restrict__ seed_map, int64_t seed_sb,
+    float eps, float *__restrict__ emb, float *__restrict__ emb_loc,
+    int64_t *__restrict__ labels_out, int32_t *__restrict__ klab,
+    float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out,
+    _Float16 *__restrict__ xh, uint2 *__restrict__ xt, PrepM0 m0) {
+  const bool m0on = m0.part != nullptr;
+  // workgroup barrier that orders LDS traffic only: __syncthreads() would also wait for the global loads in flight
+  // (the prefetch of the next half tile) and the stores of the previous one
+  auto lds_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); };
+  extern __shared__ float lds[];
+  const int D = C + 2;
+  const int NQ = C >> 2;
+  // per buffer: tile [32][C], nrm1 [32], nrm2 [32], locv [64], rowi [32] i64, seedl [32], flags [4]
+  const int buf_floats = 32 * C + 32 + 32 + 64 + 64 + 32 + 4;
+  int *m0l = reinterpret_cast<int *>(lds + 2 * buf_floats);                        // [4]
+  unsigned long long *mtab = reinterpret_cast<unsigned long long *>(m0l + 4);       // [2][D]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int jl = lane & 31, sub = lane >> 5;
+  const int sw = jl & 15;
+  const int64_t total = (int64_t)B * 2 * ntiles;
+
+  // registers of the prefetched half tile
+  float4 v1[8];
+  int64_t pf_lab = 0, pf_base = 0;
+  int pf_seed = -1;
+  float pf_ly = 0.0f, pf_lx = 0.0f;
+  auto issue = [&](int64_t h) {                     // h < total (uniform)
+    const int b = (int)(h / (2 * ntiles));
+    const int r2 = (int)(h - (int64_t)b * 2 * ntiles);
+    const int t = r2 >> 1, sh = r2 & 1;
+    const int64_t q0 = (int64_t)t * kTilePix + 32 * sh;
+    const bool pix_ok = q0 + jl < HW;
+    const float *src = in + (int64_t)b * C * HW + (pix_ok ? q0 + jl : HW - 1);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = min(2 * w + sub + 8 * u, NQ - 1);
+      v1[u].x = src[(int64_t)(4 * q + 0) * HW];
+      v1[u].y = src[(int64_t)(4 * q + 1) * HW];
+      v1[u].z = src[(int64_t)(4 * q + 2) * HW];
+      v1[u].w = src[(int64_t)(4 * q + 3) * HW];
+    }
+    if (w == 0) {                                   // bookkeeping loads: all independent of each other
+      const int64_t pix = min((int64_t)t * kTilePix + lane, HW - 1);
+      pf_lab = labels ? labels[(int64_t)b * HW + pix] : 0;
+      pf_seed = seed_map[(int64_t)b * seed_sb + pix];
+      pf_ly = loc[(int64_t)b * loc_sb + pix * 2 + 0];
+      pf_lx = loc[(int64_t)b * loc_sb + pix * 2 + 1];
+      pf_base = img_row0[b] + (tile_off ? (int64_t)tile_off[(int64_t)b * ntiles + t] : (int64_t)t * kTilePix);
+    }
+  };
+  // prefetched registers -> LDS buffer `bf` (tile + bookkeeping); returns nothing, flags[0] = any kept pixel
+  auto commit = [&](int64_t h, int bf) {
+    float *tile = lds + bf * buf_floats;
+    float *locv = tile + 32 * C + 64;
+    int64_t *rowi = reinterpret_cast<int64_t *>(locv + 64);
+    int *seedl = reinterpret_cast<int *>(rowi + 32);
+    int *flags = seedl + 32;
+    const int b = (int)(h / (2 * ntiles));
+    const int r2 = (int)(h - (int64_t)b * 2 * ntiles);
+    const int t = r2 >> 1, sh = r2 & 1;
+    const int64_t p0 = (int64_t)t * kTilePix;
+    const bool pix_ok = p0 + 32 * sh + jl < HW;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = 2 * w + sub + 8 * u;
+      if (q < NQ)
+        *reinterpret_cast<float4 *>(tile + jl * C + ((q ^ sw) << 2)) = pix_ok ? v1[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (w == 0) {
+      const int64_t pix = p0 + lane;
+      const bool keep = pix < HW && !(has_ignore && pf_lab == ignore);
+      const unsigned long long m = __ballot(keep);
+      const int rank = __popcll(m & ((1ull << lane) - 1ull));
+      const int64_t row = keep ? pf_base + rank : -1;
+      if ((lane >> 5) == sh) {
+        rowi[lane & 31] = row;
+        if (rowmap_out && pix < HW) rowmap_out[(int64_t)b * HW + pix] = row;
+        if (keep) {
+          labels_out[row] = pf_lab;
+          klab[row] = pf_seed;
+          locv[2 * (lane & 31) + 0] = pf_ly;
+          locv[2 * (lane & 31) + 1] = pf_lx;
+        }
+        seedl[lane & 31] = keep ? pf_seed : -1;
+      }
+      const unsigned long long mh = sh ? (m >> 32) : (m & 0xffffffffull);
+      if (lane == 0) flags[0] = mh ? 1 : 0;
+    }
+  };
+
+  int64_t h = blockIdx.x;
+  if (h >= total) return;
+  issue(h);
+  __builtin_amdgcn_s_waitcnt(0);
+  commit(h, 0);
+  __syncthreads();
+  for (int it = 0; h < total; ++it, h += gridDim.x) {
+    const int bf = it & 1;
+    const int64_t hn = h + gridDim.x;
+    const bool more = hn < total;
+    if (more) issue(hn);                            // in flight during the phases below
+    float *tile = lds + bf * buf_floats;
+    float *nrm1 = tile + 32 * C;
+    float *nrm2 = nrm1 + 32;
+    float *locv = nrm2 + 32;
+    int64_t *rowi = reinterpret_cast<int64_t *>(locv + 64);
+    int *seedl = reinterpret_cast<int *>(rowi + 32);
+    int *flags = seedl + 32;
+    const int b = (int)(h / (2 * ntiles));
+    const int r2 = (int)(h - (int64_t)b * 2 * ntiles);
+    const bool live = flags[0] != 0;                // (uniform: written before the last barrier)
+    if (live) {
+      // phase 2a: C1 chain (wave 0, lanes 0..31); meanwhile the M-step slots
+      if (w == 0 && sub == 0) {
+        const float *r = tile + jl * C;
+        float ss = 0.0f;
+        for (int q = 0; q < NQ; ++q) {
+          const float4 v = *reinterpret_cast<const float4 *>(r + ((q ^ sw) << 2));
+          ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss); ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss);
+        }
+        float n1 = sqrtf(ss);
+        if (!(n1 >= eps)) n1 = eps;
+        nrm1[jl] = n1;
+      } else if (m0on && w == 1) {
+        const int sl = lane < 32 ? seedl[lane] : -1;
+        const unsigned long long mk = __ballot(sl >= 0);
+        int L0 = -1, L1 = -1;
+        if (mk) {
+          L0 = __builtin_amdgcn_readlane(sl, __builtin_ctzll(mk));
+          const unsigned long long m1 = __ballot(sl >= 0 && sl != L0);
+          if (m1) L1 = __builtin_amdgcn_readlane(sl, __builtin_ctzll(m1));
+        }
+        if (lane == 0) { m0l[0] = L0; m0l[1] = L1; }
+      } else if (m0on && w >= 2) {
+        for (int i = tid - 128; i < 2 * D; i += 128) mtab[i] = 0ull;
+      }
+      lds_barrier();
+      {                                             // phase 2b
+        const float n1 = nrm1[jl];
+        float *r = tile + jl * C;
+        for (int q = 2 * w + sub; q < NQ; q += 8) {
+          float4 *pv = reinterpret_cast<float4 *>(r + ((q ^ sw) << 2));
+          float4 v = *pv;
+          v.x = v.x / n1; v.y = v.y / n1; v.z = v.z / n1; v.w = v.w / n1;
+          *pv = v;
+        }
+      }
+      lds_barrier();
+      if (w == 0 && sub == 0) {                     // phase 2c
+        const float *r = tile + jl * C;
+        float ss = 0.0f;
+        for (int q = 0; q < NQ; ++q) {
+          const float4 v = *reinterpret_cast<const float4 *>(r + ((q ^ sw) << 2));
+          ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss); ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss);
+        }
+        const float ly = locv[2 * jl], lx = locv[2 * jl + 1];
+        ss = fmaf(ly, ly, ss);
+        ss = fmaf(lx, lx, ss);
+        float n2 = sqrtf(ss);
+        if (!(n2 >= eps)) n2 = eps;
+        nrm2[jl] = n2;
+      }
+    }
+    // the ONE full wait of the iteration: loads of the next half tile (and the stores of the previous one),
+    // then the prefetched registers go to the other LDS tile BEFORE this half tile's stores are issued
+    __builtin_amdgcn_s_waitcnt(0);
+    if (more) commit(hn, bf ^ 1);
+    lds_barrier();
+    if (live) {
+      // phase 3 (as in prep_fast32_kernel)
+      long long cur[4] = {0, 0, 0, 0}, tcur[2] = {0, 0};
+      int cslot = -1;
+      unsigned long long *cg = nullptr;
+      auto m0_flush = [&]() {
+        if (cslot == 0 || cslot == 1) {
+          unsigned long long *t = mtab + cslot * D;
+          if (lane < NQ)
+            for (int i = 0; i < 4; ++i) atomicAdd(t + 4 * lane + i, (unsigned long long)cur[i]);
+          if (lane == 0) { atomicAdd(t + C, (unsigned long long)tcur[0]); atomicAdd(t + C + 1, (unsigned long long)tcur[1]); }
+        } else if (cslot == 2) {
+          if (lane < NQ)
+            for (int i = 0; i < 4; ++i) atomicAdd(cg + 4 * lane + i, (unsigned long long)cur[i]);
+          if (lane == 0) { atomicAdd(cg + C, (unsigned long long)tcur[0]); atomicAdd(cg + C + 1, (unsigned long long)tcur[1]); }
+        }
+        cur[0] = cur[1] = cur[2] = cur[3] = 0; tcur[0] = tcur[1] = 0;
+      };
+      for (int j = w; j < 32; j += 4) {
+        const int64_t row = rowi[j];
+        if (row < 0) continue;
+        const float n2 = nrm2[j];
+        if (norms_out && lane == 0) { norms_out[2 * row] = nrm1[j]; norms_out[2 * row + 1] = n2; }
+        const float *r = tile + j * C;
+        float *eo = emb + row * C;
+        float *lo = emb_loc + row * D;
+        _Float16 *ho = xh ? xh + row * C : nullptr;
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const int sj = j & 15;
+        float e2 = 0.0f;
+        if (m0on) {
+          const int L = __builtin_amdgcn_readfirstlane(seedl[j]);
+          const int L0 = __builtin_amdgcn_readfirstlane(m0l[0]), L1 = __builtin_amdgcn_readfirstlane(m0l[1]);
+          const int slot = L < 0 ? -1 : L == L0 ? 0 : L == L1 ? 1 : L < m0.K ? 2 : -1;
+          unsigned long long *g = slot == 2 ? m0.sumq + ((int64_t)b * m0.K + L) * D : nullptr;
+          if (slot != cslot || g != cg) { m0_flush(); cslot = slot; cg = g; }
+        }
+        for (int q = lane; q < NQ; q += 64) {
+          const float4 v = *reinterpret_cast<const float4 *>(r + ((q ^ sj) << 2));
+          *reinterpret_cast<float4 *>(eo + 4 * q) = v;
+          float2 a, c2;
+          a.x = v.x / n2; a.y = v.y / n2; c2.x = v.z / n2; c2.y = v.w / n2;
+          *reinterpret_cast<float2 *>(lo + 4 * q) = a;
+          *reinterpret_cast<float2 *>(lo + 4 * q + 2) = c2;
+          if (m0on) {
+            cur[0] += to_fixed(a.x); cur[1] += to_fixed(a.y); cur[2] += to_fixed(c2.x); cur[3] += to_fixed(c2.y);
+          }
+          if (ho) {
+            const h4 hv = {(_Float16)a.x, (_Float16)a.y, (_Float16)c2.x, (_Float16)c2.y};
+            *reinterpret_cast<h4 *>(ho + 4 * q) = hv;
+            const float e0 = a.x - (float)hv[0], e1 = a.y - (float)hv[1];
+            const float e2b = c2.x - (float)hv[2], e3 = c2.y - (float)hv[3];
+            e2 = fmaf(e0, e0, e2); e2 = fmaf(e1, e1, e2); e2 = fmaf(e2b, e2b, e2); e2 = fmaf(e3, e3, e2);
+          }
+        }
+        if (ho)
+          for (int off = 32; off > 0; off >>= 1) e2 += __shfl_xor(e2, off);
+        if (lane == 0) {
+          float2 lv;
+          lv.x = locv[2 * j] / n2;
+          lv.y = locv[2 * j + 1] / n2;
+          *reinterpret_cast<float2 *>(lo + C) = lv;
+          if (m0on) { tcur[0] += to_fixed(lv.x); tcur[1] += to_fixed(lv.y); }
+          if (ho) {
+            const h2 hv = {(_Float16)lv.x, (_Float16)lv.y};
+            const float e0 = lv.x - (float)hv[0], e1 = lv.y - (float)hv[1];
+            e2 = fmaf(e0, e0, e2); e2 = fmaf(e1, e1, e2);
+            xt[row] = make_uint2(__builtin_bit_cast(uint32_t, hv), __float_as_uint(sqrtf(e2) * 1.0001f));
+          }
+        }
+      }
+      if (m0on) {
+        m0_flush();
+        lds_barrier();
+        const int64_t e0 = ((int64_t)b * 2 * ntiles + r2) * 2;
+        for (int sidx = 0; sidx < 2; ++sidx) {
+          if (m0l[sidx] < 0) continue;
+          if (tid == 0) m0.lab[e0 + sidx] = m0l[sidx];
+          unsigned long long *dst = m0.part + (e0 + sidx) * D;
+          for (int i = tid; i < D; i += 256) dst[i] = mtab[sidx * D + i];
+        }
+      }
+    }
+    lds_barrier();                                // mtab / m0l / this LDS tile free for the next rounds
+  }
+}
+
 #ifdef HSGK_PREP_TIMING
 extern "C" __attribute__((visibility("default"))) int hsgk_debug_prep_timing(unsigned long long *out) {
   unsigned long long h[8];
@@ -917,6 +1189,29 @@ int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTa
     }
   }
   if (fast && wrote_half) *wrote_half = xh != nullptr;      // both fast kernels write the fp16 copy
+  {
+    const char *pe = getenv("HSGK_PREP");            // "pipe": the persistent two-tile kernel (A/B; read per call)
+    if (fast && tile32 && a.C <= 256 && pe && pe[0] == 'p') {
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      (void)hipGetLastError();
+      const size_t bufb = ((size_t)32 * a.C + 32 + 32 + 64 + 64 + 32 + 4) * 4;
+      const size_t lds2 = 2 * bufb + 16 + (size_t)2 * (a.C + 2) * 8;
+      const int per_cu = lds2 <= 78 * 1024 ? 2 : 1;
+      const char *ge = getenv("HSGK_PREP_WGS");      // workgroups per CU override (tuning)
+      const int wpc = ge ? atoi(ge) : per_cu;
+      const int64_t total = (int64_t)a.B * 2 * ntiles;
+      const int g = (int)std::min<int64_t>(total, (int64_t)cus * (wpc > 0 ? wpc : per_cu));
+      HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(prep_pipe32_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      hipLaunchKernelGGL(prep_pipe32_kernel, dim3(g), dim3(256), lds2, s, a.embeddings, a.C, HW, ntiles, a.B,
+                         a.loc, a.loc_batch_stride, a.labels, a.has_ignore, a.ignore_index,
+                         tile_off, t.img_row0, a.seed_map, a.seed_batch_stride, HSGK_EPS, a.out_embeddings,
+                         a.out_embeddings_loc, a.out_labels, klab, a.out_norms, a.out_rowmap, xh, xt, m0v);
+      HSGK_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));

@@ -653,6 +653,22 @@ def test_grouped_loss_equals_per_group_tables(dev, oracle):
   assert torch.isfinite(e3.grad).all() and float(e3.grad[:50].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('shape,grid,labelled', [((3, 256, 40, 56), (4, 4), True), ((2, 128, 65, 33), (2, 3), False)])
+def test_pipelined_prep_variant_is_bit_identical(dev, oracle, monkeypatch, shape, grid, labelled):
+  """HSGK_PREP=pipe: the persistent two-LDS-tile form of the prep kernel (kept for the A/B of DESIGN.md
+  section 5b: it is slower) produces the same five outputs as the oracle."""
+  monkeypatch.setenv('HSGK_PREP', 'pipe')
+  B, C, H, W = shape
+  x = synth.embeddings_nchw(synth.SEED_BASE + 321 + C, shape, 'mixture')
+  lab = synth.overseg_labels(synth.SEED_BASE + 17, B, H, W, regions=5, ignore_rows=2) if labelled else None
+  ign = 255 if labelled else None
+  loc = oracle.generate_location_features((H, W)) - np.float32(0.5)
+  got = _run_segkm(dev, x, lab, grid, ign, 4)
+  ref = oracle.segment_by_kmeans(x, lab, grid, loc, ign, 4)
+  for name, a, b in zip(('emb', 'emb_loc', 'labels', 'cluster', 'batch'), got, ref):
+    assert a.shape == b.shape and np.array_equal(a, b), name
+
+
 def _exchange_case(seed, sizes, C, nimg, ncl, nsem, ninst, shuffle_ids=False):
   """Per-source pixel sets with image-major rows (like segment_by_kmeans output) or arbitrary ids."""
   parts = []
