@@ -1225,6 +1225,349 @@ __global__ __launch_bounds__(NW * 64) void assign_half_wide1_kernel(
   if (threadIdx.x == 0) seg.count[blockIdx.x] = qnp[0];
 }
 
+// ---------------------------------------------------------------------------
+// The same one-pass K <= 256 filter with TWO waves per SIMD: eight waves in four PAIRS.  A pair shares one row
+// window (32 rows x 64 columns; each wave loads and stores 16 of its rows) and splits the table: wave `hf` of a
+// pair scores the tile against table blocks 4 hf .. 4 hf + 3 (four accumulator sets, 64 registers instead of
+// 128), so the LDS budget is that of the four-wave kernel (table 143 KB + four windows) while every SIMD has a
+// second wave to issue from when one waits for its LDS operands, its accumulators or the row stream.  The two
+// table halves of a row meet in the epilogue through the pair's (then idle) window: top-2 of the partner's half,
+// the merged decision and threshold, the partner's candidate list.  Workgroup barriers order the shared window
+// (two per 64-column chunk) and the three exchanges of the epilogue.
+template <int DEPTH>
+__global__ __launch_bounds__(512) void assign_half_pair_kernel(
+    const _Float16 *__restrict__ xm, const uint2 *__restrict__ xt, int d,
+    const float *__restrict__ cent, const float *__restrict__ errc, int K,
+    const int64_t *__restrict__ img_row0, int B, int32_t *__restrict__ klab,
+    SplitEntry *__restrict__ gqueue, SegQueue seg, const hsgk_segkm_meta *__restrict__ meta) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int NP = 4, NW = 8, TPX = NP * 32, KC = 64, XSB = 72, MBW = 4, TR = 256;
+  const int DM = half_main_cols(d);
+  const int RS = DM + 16 + 8;
+  uint16_t *chs = reinterpret_cast<uint16_t *>(lds_raw);                 // [256][RS] hi plane of the table
+  uint16_t *xs = chs + TR * RS;                                          // [NP][32][XSB] one window per pair
+  int *qnp = reinterpret_cast<int *>(xs + NP * 32 * XSB);               // [0] queue length of the workgroup
+  int *pcnt = qnp + 4;                                                   // [NP][2] arrival counters of the pairs' waves
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int j = lane & 31, g = lane >> 5;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const int p = wu >> 1, hf = wu & 1;
+  uint16_t *xw = xs + p * (32 * XSB);
+  // epilogue exchange area of the pair = its window (idle between a tile's last chunk and the next store)
+  float *ex_f = reinterpret_cast<float *>(xw);                           // [0..31] t1, [32..63] t2 of the partner half
+  int *ex_i = reinterpret_cast<int *>(xw) + 64;                          // [0..31] ti
+  float *ex_thr = reinterpret_cast<float *>(xw) + 96;                    // [0..31] threshold of the row (inf: decided)
+  unsigned long long *ex_list = reinterpret_cast<unsigned long long *>(reinterpret_cast<int *>(xw) + 128);   // [32]
+  int *ex_cnt = reinterpret_cast<int *>(xw) + 192;                       // [0..31]
+  int *ex_any = reinterpret_cast<int *>(xw) + 224;                       // [0] any ambiguous row in this pair's tile
+
+  const int64_t N = meta->n_rows;
+  const int64_t per = (N + (int64_t)gridDim.x * TPX - 1) / ((int64_t)gridDim.x * TPX) * TPX;
+  int64_t r = (int64_t)blockIdx.x * per;
+  const int64_t r_end = min(N, r + per);
+  if (tid == 0) { seg.count[blockIdx.x] = 0; seg.row0[blockIdx.x] = r < r_end ? r : 0; qnp[0] = 0; }
+  if (tid < 2 * NP) pcnt[tid] = 0;
+  if (r >= r_end) return;
+  // Pair-local synchronisation instead of workgroup barriers: a wave publishes its arrival count and polls its
+  // partner's (LDS executes a wave's operations in order, so everything the wave wrote or read before the count
+  // is done when the partner sees it).  The four pairs then run out of phase -- pairs 2 and 3 start half a tile
+  // late -- and a SIMD, which hosts one wave of two different pairs, overlaps the matrix phase of one with the
+  // vector-heavy epilogue of the other (with workgroup barriers all eight waves moved in lockstep: 0.60 ms per
+  // launch against 0.63 for the four-wave kernel).
+  int epoch = 0;
+  int *cnt_mine = pcnt + 2 * p + hf, *cnt_other = pcnt + 2 * p + (1 - hf);
+  auto psync = [&]() {
+    ++epoch;
+    if (lane == 0) __hip_atomic_store(cnt_mine, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(cnt_other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch)
+      asm volatile("s_nop 3");
+    asm volatile("" ::: "memory");
+  };
+  SplitEntry *slice = gqueue + r;
+  int b = image_of_row(img_row0, B, r);
+  int staged_img = -1;
+  float errc_max = 0.0f;
+  const int nfull = DM / KC;
+  const bool has_tail = d > DM;
+  auto bar = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); };
+
+  while (r < r_end) {
+    while (img_row0[b + 1] <= r) ++b;
+    const int64_t seg_end = min(r_end, img_row0[b + 1]);
+    const int nrows = (int)min(seg_end - r, (int64_t)1 << 24);
+    const int64_t crow0 = r;
+    if (b != staged_img) {
+      float m = 0.0f;
+      for (int k = lane; k < K; k += 64) m = fmaxf(m, errc[(int64_t)b * K + k]);
+      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+      errc_max = m;
+      // ---- table -> fp16 hi plane (rows >= K and the padding zeroed); every wave converts whole rows
+      bar();                                           // nobody still reads the previous table / windows
+      const float *table = cent + (int64_t)b * K * d;
+      uint32_t *ch32 = reinterpret_cast<uint32_t *>(chs);
+      const int RS2 = RS >> 1, dp = d >> 1;
+      constexpr int PPL = 4;
+      for (int k0 = w; k0 < TR; k0 += 4 * NW) {
+        float2 v[4][PPL];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = min(k0 + u * NW, K - 1);
+#pragma unroll
+          for (int i = 0; i < PPL; ++i)
+            v[u][i] = *reinterpret_cast<const float2 *>(table + (int64_t)k * d + 2 * min(lane + 64 * i, dp - 1));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = k0 + u * NW;
+          if (k < TR) {
+            const bool live = k < K;
+#pragma unroll
+            for (int i = 0; i < PPL; ++i) {
+              const int pr = lane + 64 * i;
+              if (pr < RS2) {
+                uint32_t hi = 0u, lo = 0u;
+                if (live && pr < dp) f16_split2(v[u][i].x, v[u][i].y, hi, lo);
+                ch32[k * RS2 + pr] = hi;
+              }
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      staged_img = b;
+    }
+
+    // ---- the row stream of THIS wave: rows 16 hf .. 16 hf + 15 of the pair's 32-row tile, asm loads with
+    //      counted waits (see score_tiles_f16.h); the fp16 copy has kHalfSlackRows readable rows past the end
+    const int ntile = (nrows + TPX - 1) / TPX;         // (all pairs run all tiles: they share the barriers)
+    const int lpx = lane >> 4, lf = lane & 15;
+    const uint32_t voff = (uint32_t)(lpx * DM + 4 * lf) * 2u;
+    const char *wbase = reinterpret_cast<const char *>(xm + (crow0 + p * 32 + 16 * hf) * DM);
+    const int64_t tile_bytes = (int64_t)TPX * DM * 2, grp_bytes = (int64_t)4 * DM * 2;
+    int ld_tile = 0, ld_q = 0;
+    constexpr int LOADS = 4;
+    auto load_next = [&](uint2 (&pre)[LOADS]) {
+      const char *tb = wbase + ld_tile * tile_bytes + ld_q * (KC * 2);
+#pragma unroll
+      for (int i = 0; i < LOADS; ++i)
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(pre[i]) : "v"(voff), "s"(tb + i * grp_bytes));
+      const bool wrap = ld_q + 1 == nfull;
+      ld_q = wrap ? 0 : ld_q + 1;
+      ld_tile += wrap ? 1 : 0;
+    };
+#define HSGK_VMWAIT4(N, P) \
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(P[0]), "+v"(P[1]), "+v"(P[2]), "+v"(P[3]) : "n"(N))
+    auto store_chunk = [&](const uint2 (&pre)[LOADS]) {
+#pragma unroll
+      for (int i = 0; i < LOADS; ++i)
+        *reinterpret_cast<uint2 *>(xw + (16 * hf + lpx + 4 * i) * XSB + 4 * lf) = pre[i];
+    };
+    f32x16 acc[MBW];
+    auto zero_acc = [&]() {
+#pragma unroll
+      for (int m = 0; m < MBW; ++m)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) acc[m][rr] = 0.0f;
+    };
+    struct Ops { f16x8 b; f16x8 ah[MBW]; };
+    const uint16_t *hp0 = chs + (4 * hf * 32 + j) * RS + 8 * g;          // this wave's table blocks
+    auto load_ops = [&](const uint16_t *bp, int col0, Ops &o) {
+      o.b = *reinterpret_cast<const f16x8 *>(bp);
+#pragma unroll
+      for (int m = 0; m < MBW; ++m) o.ah[m] = *reinterpret_cast<const f16x8 *>(hp0 + m * 32 * RS + col0);
+    };
+    auto mfma_ops = [&](const Ops &o) {
+#if defined(HSGK_PAIR_DEBUG) && HSGK_PAIR_DEBUG >= 2          // probes: no matrix work
+#pragma unroll
+      for (int m = 0; m < MBW; ++m) acc[m][0] += (float)o.ah[m][0] * (float)o.b[0];
+#else
+#pragma unroll
+      for (int m = 0; m < MBW; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.ah[m], o.b, acc[m], 0, 0, 0);
+#endif
+    };
+    auto compute_chunk = [&](int q) {
+      const uint16_t *bp = xw + j * XSB + 8 * g;
+      Ops o0, o1;
+      load_ops(bp, q * KC, o0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_ops(bp + 16, q * KC + 16, o1);
+      mfma_ops(o0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_ops(bp + 32, q * KC + 32, o0);
+      mfma_ops(o1);
+      __builtin_amdgcn_sched_barrier(0);
+      load_ops(bp + 48, q * KC + 48, o1);
+      mfma_ops(o0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_ops(o1);
+    };
+    const uint32_t toff = (uint32_t)(p * 32 + j) * 8u;
+    auto load_tail = [&](int tile, uint2 &v) {
+      const char *tb = reinterpret_cast<const char *>(xt + crow0 + (int64_t)tile * TPX);
+      asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(toff), "s"(tb));
+    };
+    uint2 preA[LOADS], preB[LOADS], preC[DEPTH == 4 ? LOADS : 1], preD[DEPTH == 4 ? LOADS : 1];
+    if (p >= 2) __builtin_amdgcn_s_sleep(127);          // half a tile (~8 K cycles) behind pairs 0 and 1
+    load_next(preA);
+    load_next(preB);
+    if constexpr (DEPTH == 4) { load_next(preC); load_next(preD); }
+    zero_acc();
+    uint2 tailv = {0u, 0u};
+#define HSGK_PAIR_STEP(PRE, QQ)                                               \
+  HSGK_VMWAIT4(LOADS * (DEPTH - 1), PRE);                                     \
+  psync();                                 /* the window is free: the partner has read the previous chunk */ \
+  store_chunk(PRE);                                                           \
+  __builtin_amdgcn_sched_barrier(0);                                          \
+  load_next(PRE);                                                             \
+  __builtin_amdgcn_sched_barrier(0);                                          \
+  psync();                                 /* the window is complete */       \
+  compute_chunk(QQ);                                                          \
+  __builtin_amdgcn_sched_barrier(0);
+    for (int tile = 0; tile < ntile; ++tile) {
+      load_tail(tile, tailv);
+      for (int q = 0; q < nfull; q += DEPTH) {
+        if constexpr (DEPTH == 4) {
+          HSGK_PAIR_STEP(preA, q)
+          HSGK_PAIR_STEP(preB, q + 1)
+          HSGK_PAIR_STEP(preC, q + 2)
+          HSGK_PAIR_STEP(preD, q + 3)
+        } else {
+          HSGK_PAIR_STEP(preA, q)
+          HSGK_PAIR_STEP(preB, q + 1)
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(%1)" : "+v"(tailv) : "n"(LOADS * DEPTH));
+      if (has_tail) {                                  // the two location columns: k = 0, 1 of one more k-block
+        const u32x4 tv = {g == 0 ? tailv.x : 0u, 0u, 0u, 0u};
+        Ops o;
+        o.b = __builtin_bit_cast(f16x8, tv);
+#pragma unroll
+        for (int m = 0; m < MBW; ++m) o.ah[m] = *reinterpret_cast<const f16x8 *>(hp0 + m * 32 * RS + DM);
+        mfma_ops(o);
+      }
+      const float err = __uint_as_float(tailv.y);
+#if defined(HSGK_PAIR_DEBUG) && HSGK_PAIR_DEBUG >= 1          // probes: no epilogue
+      if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.678f) klab[crow0] = 1;
+      psync();
+      zero_acc();
+      continue;
+#endif
+      // ---------------- epilogue: this wave's half of the table, then the pair
+      const int h = g;
+      float bm1[MBW];
+      float t1 = -INFINITY, t2 = -INFINITY;
+      int tm = 0;
+#pragma unroll
+      for (int m = 0; m < MBW; ++m) {
+        const int mg = 4 * hf + m;                     // global table block
+        float b1 = -INFINITY, b2 = -INFINITY;
+        if (mg * 32 < K) {
+          if ((mg + 1) * 32 <= K) {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+              const float v = __uint_as_float((__float_as_uint(acc[m][rr]) & ~15u) | (uint32_t)rr);
+              b2 = __builtin_amdgcn_fmed3f(b1, b2, v);
+              b1 = fmaxf(b1, v);
+            }
+          } else {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+              const int k = mg * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+              float v = __uint_as_float((__float_as_uint(acc[m][rr]) & ~15u) | (uint32_t)rr);
+              v = k < K ? v : -INFINITY;
+              b2 = __builtin_amdgcn_fmed3f(b1, b2, v);
+              b1 = fmaxf(b1, v);
+            }
+          }
+        }
+        bm1[m] = b1;
+        const bool up = b1 > t1;
+        t2 = up ? fmaxf(t1, b2) : fmaxf(t2, b1);
+        tm = up ? mg : tm;
+        t1 = up ? b1 : t1;
+      }
+      const uint32_t tg = __float_as_uint(t1) & 15u;
+      int ti = tm * 32 + (int)(tg & 3u) + 8 * (int)(tg >> 2) + 4 * h;
+      {
+        const float o1 = __shfl_xor(t1, 32), o2 = __shfl_xor(t2, 32);
+        const int oi = __shfl_xor(ti, 32);
+        if (o1 > t1 || (o1 == t1 && oi < ti)) { t2 = fmaxf(t1, o2); t1 = o1; ti = oi; }
+        else { t2 = fmaxf(o1, t2); }
+      }
+      psync();                                         // the partner's window reads of the last chunk are done
+      if (hf == 1 && h == 0) { ex_f[j] = t1; ex_f[32 + j] = t2; ex_i[j] = ti; }
+      psync();
+      const int px = tile * TPX + p * 32 + j;
+      const bool valid = px < nrows;
+      const float gap = half_wide_gap(err, errc_max) + 4.0e-6f;
+      bool amb = false;
+      float thr = INFINITY;
+      if (hf == 0) {
+        const float o1 = ex_f[j], o2 = ex_f[32 + j];
+        const int oi = ex_i[j];
+        if (o1 > t1 || (o1 == t1 && oi < ti)) { t2 = fmaxf(t1, o2); t1 = o1; ti = oi; }
+        else { t2 = fmaxf(o1, t2); }
+        amb = valid && !(t1 - t2 > gap);
+        if (h == 0 && valid) klab[crow0 + px] = ti;
+        thr = amb ? t1 - gap - 2.0e-6f : INFINITY;
+        const bool any = __any(amb);
+        if (h == 0) ex_thr[j] = thr;
+        if (lane == 0) ex_any[0] = any ? 1 : 0;
+      }
+      psync();
+      const bool any = ex_any[0] != 0;                 // (pair-uniform; the barriers below are unconditional)
+      unsigned long long list = 0;
+      int cnt = 0;
+      if (any) {
+        thr = ex_thr[j];
+#pragma unroll
+        for (int m = 0; m < MBW; ++m) {
+          if (!__any(bm1[m] >= thr)) continue;
+          const int mg = 4 * hf + m;
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) {
+            const uint32_t k = mg * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+            const bool hit = k < (uint32_t)K && acc[m][rr] >= thr;
+            list = hit ? ((list << 8) | k) : list;
+            cnt += hit ? 1 : 0;
+          }
+        }
+        const unsigned long long olist = __shfl_xor(list, 32);
+        const int ocnt = __shfl_xor(cnt, 32);
+        // this wave's half of the row: own lane half first, then the partner lane half (<= 7 kept)
+        const int tot = cnt + ocnt;
+        if (tot <= 7) list = (list & ((1ull << (8 * cnt)) - 1ull)) | (cnt < 8 ? (olist << (8 * cnt)) : 0ull);
+        cnt = tot;
+      }
+      if (any && hf == 1 && h == 0) { ex_list[j] = list; ex_cnt[j] = cnt; }
+      psync();
+      if (any && hf == 0 && h == 0 && amb) {
+        const unsigned long long plist = ex_list[j];
+        const int pcnt = ex_cnt[j];
+        const int tot = cnt + pcnt;
+        uint32_t cand = 255u << 24, cand_hi = 0u;
+        if (tot <= 7 && tot >= 1 && t1 == t1) {
+          const unsigned long long all = (list & ((1ull << (8 * cnt)) - 1ull)) | (plist << (8 * cnt));
+          cand = (uint32_t)(all & 0xFFFFFFull) | ((uint32_t)tot << 24);
+          cand_hi = (uint32_t)(all >> 24);
+        }
+        slice[atomicAdd(qnp, 1)] = SplitEntry{(int32_t)(crow0 + px), cand, cand_hi};
+      }
+      zero_acc();
+      // (the next tile's first HSGK_PAIR_STEP starts with a barrier: the exchange area is read before it is overwritten)
+    }
+    HSGK_VMWAIT4(0, preA);
+    HSGK_VMWAIT4(0, preB);
+    if constexpr (DEPTH == 4) { HSGK_VMWAIT4(0, preC); HSGK_VMWAIT4(0, preD); }
+#undef HSGK_PAIR_STEP
+#undef HSGK_VMWAIT4
+    r += nrows;
+  }
+  __syncthreads();
+  if (tid == 0) seg.count[blockIdx.x] = qnp[0];
+}
+
 // exact pass over the per-workgroup slices of the queue (nseg <= 1024)
 __global__ __launch_bounds__(256) void assign_requeue_seg_kernel(
     const float *__restrict__ x, int d, const float *__restrict__ cent, int K,
@@ -1277,7 +1620,7 @@ __global__ __launch_bounds__(256) void assign_requeue_seg_kernel(
   }
 }
 
-static bool wide1_fits(int d) { return (d / 64 == 4 || d / 64 == 2) && half_lds_bytes<4, 8, 1, 1>(d) + 32 <= 160 * 1024; }
+static bool wide1_fits(int d) { return (d / 64 == 4 || d / 64 == 2) && half_lds_bytes<4, 8, 1, 1>(d) + 64 <= 160 * 1024; }
 
 bool assign_half_wide2_eligible(int d, int K) {
   return K > 128 && K <= 256 && half_wide_shape_ok(d) &&
@@ -1311,12 +1654,20 @@ int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt
     const int64_t tiles1 = ((int64_t)max_chunks * HSGK_CHUNK + TPX1 - 1) / TPX1;
     const int grid1 = (int)(tiles1 < n_cu ? tiles1 : n_cu);
     SegQueue seg{reinterpret_cast<int32_t *>(state), reinterpret_cast<int64_t *>(static_cast<char *>(state) + 4096)};
-    auto kern = d / 64 == 4 ? assign_half_wide1_kernel<NW1, 4, MB1, 4> : assign_half_wide1_kernel<NW1, 2, MB1, 2>;
-    const size_t lds = half_lds_bytes<NW1, MB1, 1, 1>(d) + 32;
-    HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid1), dim3(NW1 * 64), lds, s, xm, xt, d, cent, errc, K, t.img_row0, B, klab,
-                       reinterpret_cast<SplitEntry *>(qrows), seg, meta);
+    const size_t lds = half_lds_bytes<NW1, MB1, 1, 1>(d) + 64;
+    if (two && two[0] == 'o') {                       // "one": the four-wave kernel (one wave per SIMD)
+      auto kern = d / 64 == 4 ? assign_half_wide1_kernel<NW1, 4, MB1, 4> : assign_half_wide1_kernel<NW1, 2, MB1, 2>;
+      HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, dim3(grid1), dim3(NW1 * 64), lds, s, xm, xt, d, cent, errc, K, t.img_row0, B, klab,
+                         reinterpret_cast<SplitEntry *>(qrows), seg, meta);
+    } else {                                          // eight waves in pairs (two per SIMD), same LDS budget
+      auto kern = d / 64 == 4 ? assign_half_pair_kernel<4> : assign_half_pair_kernel<2>;
+      HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, dim3(grid1), dim3(512), lds, s, xm, xt, d, cent, errc, K, t.img_row0, B, klab,
+                         reinterpret_cast<SplitEntry *>(qrows), seg, meta);
+    }
     HSGK_LAUNCH_CHECK();
     hipLaunchKernelGGL(assign_requeue_seg_kernel, dim3(2048), dim3(256), 0, s, x, d, cent, K, klab,
                        reinterpret_cast<const SplitEntry *>(qrows), seg, grid1, t.img_row0, B);
