@@ -718,36 +718,62 @@ struct HalfWideEpi {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int TPX = (int)(blockDim.x >> 1);
-    float b1 = -INFINITY, b2 = -INFINITY;
-    int bi = 0;
+    // Tagged top-2 (see HalfWide1Epi): a score carries its row within the 32-row table block in its low 4
+    // mantissa bits (<= 1.8e-6, added to the gap), so a block's running top-2 is max + med3 without index
+    // bookkeeping; blocks entirely below K are unmasked, above skipped; the candidate scan only visits blocks
+    // whose maximum reaches an ambiguous row's threshold.
+    float bm1[MB];
+    float t1 = -INFINITY, t2 = -INFINITY;
+    int tm = 0;
 #pragma unroll
-    for (int m = 0; m < MB; ++m)
+    for (int m = 0; m < MB; ++m) {
+      float b1 = -INFINITY, b2 = -INFINITY;
+      if (m * 32 < K) {
+        if ((m + 1) * 32 <= K) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float v = k < K ? sacc[m][r] : -INFINITY;
-        b2 = fmaxf(b2, fminf(b1, v));
-        bi = v > b1 ? k : bi;
-        b1 = fmaxf(b1, v);
+          for (int r = 0; r < 16; ++r) {
+            const float v = __uint_as_float((__float_as_uint(sacc[m][r]) & ~15u) | (uint32_t)r);
+            b2 = __builtin_amdgcn_fmed3f(b1, b2, v);
+            b1 = fmaxf(b1, v);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float v = __uint_as_float((__float_as_uint(sacc[m][r]) & ~15u) | (uint32_t)r);
+            v = k < K ? v : -INFINITY;
+            b2 = __builtin_amdgcn_fmed3f(b1, b2, v);
+            b1 = fmaxf(b1, v);
+          }
+        }
       }
-    const float o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
-    const int oi = __shfl_xor(bi, 32);
-    float t1, t2;
-    int ti;
-    if (o1 > b1 || (o1 == b1 && oi < bi)) { t1 = o1; ti = oi; t2 = fmaxf(b1, o2); }
-    else { t1 = b1; ti = bi; t2 = fmaxf(o1, b2); }
+      bm1[m] = b1;
+      const bool up = b1 > t1;
+      t2 = up ? fmaxf(t1, b2) : fmaxf(t2, b1);
+      tm = up ? m : tm;
+      t1 = up ? b1 : t1;
+    }
+    const uint32_t tg = __float_as_uint(t1) & 15u;
+    int ti = tm * 32 + (int)(tg & 3u) + 8 * (int)(tg >> 2) + 4 * h;
+    {
+      const float o1 = __shfl_xor(t1, 32), o2 = __shfl_xor(t2, 32);
+      const int oi = __shfl_xor(ti, 32);
+      if (o1 > t1 || (o1 == t1 && oi < ti)) { t2 = fmaxf(t1, o2); t1 = o1; ti = oi; }
+      else { t2 = fmaxf(o1, t2); }
+    }
     const int px = tile * TPX + w * 32 + j;
     const bool valid = px < nrows;
-    const float gap = HILO ? half_gap(err) : half_wide_gap(err, errc_max);   // (hi + lo table planes: no table error term)
+    const float gap = (HILO ? half_gap(err) : half_wide_gap(err, errc_max)) + 4.0e-6f;   // (hi + lo table planes: no table error term)
     const bool amb = valid && !(t1 - t2 > gap);               // ambiguous (or NaN)
     if (h == 0 && valid) klab[crow0 + px] = ti;               // provisional for ambiguous rows
     if (!__any(amb)) return;
     // candidates of this lane's half, merged with the partner half (<= 7, else "all")
-    const float thr = t1 - gap;
+    const float thr = amb ? t1 - gap - 2.0e-6f : INFINITY;
     unsigned long long list = 0;
     int cnt = 0;
 #pragma unroll
-    for (int m = 0; m < MB; ++m)
+    for (int m = 0; m < MB; ++m) {
+      if (!__any(bm1[m] >= thr)) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const uint32_t k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -755,6 +781,7 @@ struct HalfWideEpi {
         list = hit ? ((list << 8) | k) : list;
         cnt += hit ? 1 : 0;
       }
+    }
     const unsigned long long olist = __shfl_xor(list, 32);
     const int ocnt = __shfl_xor(cnt, 32);
     const int tot = cnt + ocnt;
