@@ -67,7 +67,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 PMC_FILES = ('r03_cfg2_pmc.txt', 'r02_pmc.txt', 'r01_pmc.txt')
 
 
-def pmc_traffic(kernels):
+def pmc_traffic(kernels, files=None):
   """HBM bytes per launch of the given kernels from the committed rocprofv3 counter passes
   (profiles/rNN_pmc.txt, collected by tools/collect_profiles.sh with one --pmc pass per
   counter group), corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE (KB)
@@ -75,7 +75,7 @@ def pmc_traffic(kernels):
   matches the expected bytes of the prep and label writes within 2 %).  Calibration on these
   very access patterns: 2 x FETCH_SIZE of assign_half_kernel = 5.07 GB for 5.05 GB streamed,
   of the M-step's full pass 10.2 GB for 9.98 GB.  (None, None) when no file has them."""
-  for fname in PMC_FILES:
+  for fname in (files or PMC_FILES):
     path = os.path.join(ROOT, 'profiles', fname)
     try:
       lines = open(path).read().splitlines()
@@ -361,10 +361,20 @@ def main():
     tr, src = pmc_traffic(['assign_half_kernel', 'assign_split_rows_kernel', 'assign_requeue_rows_kernel'])
     if tr:
       e_moved, e_src = tr, src + ': 2 x FETCH_SIZE + WRITE_SIZE summed over the group (gfx950 correction of MI355X_MICROARCH.md)'
+  # the other per-GPU configs at their default batch: counters of profiles/r03_<workload>_pmc.txt (same passes)
+  group = {'cfg3': ['assign_half_kernel', 'assign_requeue_rows_kernel'],
+           'cfg4': ['assign_half_pair_kernel', 'assign_requeue_seg_kernel', 'centroid_half_err_kernel'],
+           'cfg5': ['assign_half_wide_kernel', 'assign_requeue_rows_kernel', 'centroid_half_err_kernel']}.get(args.workload)
+  e_kernel = None
+  if group and args.flavour == 'iid' and not args.labels and B == WORKLOADS[args.workload][1]:
+    tr, src = pmc_traffic(group, ['r03_%s_pmc.txt' % args.workload])
+    if tr:
+      e_moved, e_src = tr, src + ': 2 x FETCH_SIZE + WRITE_SIZE summed over the group (gfx950 correction of MI355X_MICROARCH.md)'
+      e_kernel = 'E-step launch group (dominant by time): ' + ' + '.join(group)
   roofline = rl(
       'E-step launch group (dominant by time): assign_half_kernel (fp16 filter over the fp16 row '
       'copy) + assign_split_rows_kernel (bf16x3 on the undecided rows) + assign_requeue_rows_kernel '
-      '(exact fp32 chains)' if half_ok else 'E-step launch group (dominant by time)',
+      '(exact fp32 chains)' if half_ok and not e_kernel else (e_kernel or 'E-step launch group (dominant by time)'),
       e_alg, e_moved, e_src, a_ms, a_n,
       mfma_tflops=round(2.0 * D * K * npx / (a_ms / max(a_n, 1) * 1e-3) / 1e12, 2) if a_n else None)
 

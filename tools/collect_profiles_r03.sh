@@ -12,7 +12,7 @@ rm -rf /tmp/prof_k
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k -o k -- $B --steps 3 --warmup 1 --cpu-images 0 --no-exchange --no-extra > /dev/null 2>&1
 cp /tmp/prof_k/k_kernel_stats.csv $out/${tag}_bench_kernel_stats.csv
 skip=init_meta_kernel,build_tables_kernel,count_valid_kernel,table_kernel,scan_chained_kernel,relabel_begin_kernel,relabel_ranked_kernel,sum_qcount_kernel
-for wl in cfg2 cfg4; do
+for wl in cfg2 cfg3 cfg4 cfg5; do
   {
     echo "# rocprofv3 --kernel-trace --pmc <counters>, one pass per line, python bench.py --workload $wl --steps 2 --warmup 1 --cpu-images 0 --no-exchange --no-extra; means per dispatch"
     for pmc in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES"; do
@@ -23,8 +23,10 @@ for wl in cfg2 cfg4; do
     done
   } > $out/${tag}_${wl}_pmc.txt 2>&1
 done
-rm -rf /tmp/prof_k; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k -o k -- $B --workload cfg4 --steps 5 --warmup 2 --cpu-images 0 --no-exchange --no-extra > /dev/null 2>&1
-cp /tmp/prof_k/k_kernel_stats.csv $out/${tag}_cfg4_kernel_stats.csv
+for wl in cfg3 cfg4 cfg5; do
+  rm -rf /tmp/prof_k; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k -o k -- $B --workload $wl --steps 5 --warmup 2 --cpu-images 0 --no-exchange --no-extra > /dev/null 2>&1
+  cp /tmp/prof_k/k_kernel_stats.csv $out/${tag}_${wl}_kernel_stats.csv
+done
 # the prototype exchange on the cfg2 output and the loss at N = 200704, C = 256, P = 3072 (both engines)
 rm -rf /tmp/prof_k; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k -o k -- python $GRAFT_REPO_ROOT/tools/probes/exchange_run.py cfg2 > $out/${tag}_exchange_cfg2.txt 2>&1
 cp /tmp/prof_k/k_kernel_stats.csv $out/${tag}_exchange_kernel_stats.csv
