@@ -161,6 +161,8 @@ def lib():
 def check(rc):
   if rc != 0:
     raise HsgkError('libhsgk error %d: %s' % (rc, lib().hsgk_last_error().decode()))
+  if _deferred:                            # (cheap: a list check; completed flags are looked at by every libhsgk call)
+    poll_deferred()
 
 
 PROF_KINDS = ('prep', 'accumulate', 'finalize', 'assign', 'relabel')
@@ -215,8 +217,8 @@ def defer_status(status_dev, message):
 
 
 def poll_deferred(wait=False):
-  """Raises the first recorded device-side error whose kernels have finished (all of them
-  with wait=True, which synchronises)."""
+  """Raises the recorded device-side errors whose kernels have finished (all of them with
+  wait=True, which synchronises) as ONE HsgkError carrying every message."""
   with _deferred_lock:
     pending, done = [], []
     for item in _deferred:
@@ -224,9 +226,24 @@ def poll_deferred(wait=False):
         item[0].synchronize()
       (done if item[0].query() else pending).append(item)
     _deferred[:] = pending
-  for _ev, host, message in done:
-    if int(host[0]) != 0:
-      raise HsgkError(message)
+  failed = [message for _ev, host, message in done if int(host[0]) != 0]
+  if failed:
+    raise HsgkError('; '.join(dict.fromkeys(failed)))
+
+
+def _flush_deferred_at_exit():
+  """An error flagged by the last calls of a run still surfaces (as a message: raising here would be lost)."""
+  try:
+    poll_deferred(wait=True)
+  except HsgkError as e:
+    import sys
+    sys.stderr.write('hsg_amd: device-side error reported at exit: %s\n' % e)
+  except Exception:                       # noqa: BLE001  (interpreter shutting down: the runtime may be gone)
+    pass
+
+
+import atexit   # noqa: E402
+atexit.register(_flush_deferred_at_exit)
 
 
 def stream_ptr():

@@ -96,7 +96,7 @@ def _count_collective():
     collective_calls += 1
 
 
-def _all_gather_rows(t, group, tag):
+def _all_gather_rows(t, group, tag, cap_start=None):
   """Concatenation over ranks (rank order) of tensors whose first dimension differs per
   rank, in ONE collective and ONE host read: every rank contributes a fixed-capacity byte
   buffer whose first 8 bytes hold its row count.  If some rank has more rows than the
@@ -113,7 +113,7 @@ def _all_gather_rows(t, group, tag):
     row_bytes *= s
   key = '%s/%d' % (tag, row_bytes)
   while True:
-    cap = _cap_get(group, key)
+    cap = _cap_get(group, key, cap_start)       # (cap_start: whole tensors as rows -- every rank passes the same hint)
     send = torch.zeros((8 + cap * row_bytes,), dtype=torch.uint8, device=t.device)
     send[:8] = torch.tensor([n], dtype=torch.int64).view(torch.uint8).to(t.device, non_blocking=True)
     m = min(n, cap)
@@ -612,7 +612,7 @@ def gather_and_update_datas(datas, anchor_device=None, group=None):
   anchor = torch.device(anchor_device) if anchor_device is not None else devices[0]
   local = _cat_to(items, anchor) if len(items) > 1 else items[0]
   flat = local.reshape(local.shape[0], -1)
-  gathered, _ = _all_gather_rows(flat, group, 'datas')
+  gathered, _ = _all_gather_rows(flat, group, 'datas', cap_start=_pow2(max(int(flat.shape[0]), 16)))
   out = gathered.reshape((gathered.shape[0],) + tuple(local.shape[1:]))
   if not listed:
     return out

@@ -89,6 +89,11 @@ def _explicit_seeds(cluster_indices, B, H, W, device):
   ci = ci.to(device).expand(B, H, W).reshape(B, H * W)
   lo = ci.min()
   span = ci.max() - lo + 1
+  if int(span) * B >= (1 << 62):
+    # (batch * span + value would overflow int64 and merge seeds across images: rank-compress the values first)
+    ci = torch.unique(ci, return_inverse=True)[1].view(B, H * W)
+    lo = ci.min()
+    span = ci.max() - lo + 1
   keys = (torch.arange(B, device=device).view(B, 1) * span + (ci - lo)).view(-1)
   uniq, inv = torch.unique(keys, return_inverse=True)
   first = torch.searchsorted(uniq, torch.arange(B, device=device) * span)          # first dense id of every image
@@ -189,6 +194,10 @@ class _SegmentByKmeans(torch.autograd.Function):
       # common.py:398-405: two sorted `unique`s), so the call is repeated on the ranks of the
       # distinct label values -- a monotone map -- with a table sized for them, and the label
       # output is mapped back.  (Rare: label values >= 2^24 or thousands of distinct values.)
+      kept = lab[lab != ign] if has_ignore else lab
+      if kept.numel() and int(kept.min()) < 0:
+        # (the rank compression below would hide negative labels from the library's own check)
+        raise ValueError('segment_by_kmeans: negative labels are not supported')
       uniq, inv = torch.unique(lab, return_inverse=True)
       D = int(uniq.numel())
       ign_rank = D
