@@ -98,8 +98,49 @@ int main(int argc, char **argv) {
     cmax = c0[i] > cmax ? c0[i] : cmax;
     diff += c0[i] != c1[i];
   }
+  // ---- the batch-wide prototype table of that output through the C ABI's exchange (one process, no
+  //      communicator: hsg/models/utils.py:127-217; with an ncclComm_t the same call spans the ranks)
+  const int64_t cap = (int64_t)B * K + 64, pool_rows = 256 * ((N + HSGK_CHUNK - 1) / HSGK_CHUNK);
+  hsgk_exchange_args xa = {};
+  float *table, *protos, *protos_loc, *pnorms;
+  int64_t *plab, *ids, *xmeta;
+  CHECK_HIP(hipMalloc(&table, sizeof(float) * cap * (C + D)));
+  CHECK_HIP(hipMalloc(&protos, sizeof(float) * cap * C));
+  CHECK_HIP(hipMalloc(&protos_loc, sizeof(float) * cap * D));
+  CHECK_HIP(hipMalloc(&pnorms, sizeof(float) * cap * 2));
+  CHECK_HIP(hipMalloc(&plab, sizeof(int64_t) * cap * 3));
+  CHECK_HIP(hipMalloc(&ids, sizeof(int64_t) * N));
+  CHECK_HIP(hipMalloc(&xmeta, sizeof(int64_t) * 8));
+  xa.embeddings = emb; xa.embeddings_loc = eloc; xa.cluster = cluster[0]; xa.batch = batch;
+  xa.semantic = labels; xa.instance = labels;                       // (no label map: all zero)
+  xa.n = N; xa.C = C; xa.D = D; xa.cap_local = cap; xa.cap_total = cap; xa.pool_rows = pool_rows; xa.eps = HSGK_EPS;
+  xa.table = table; xa.prototypes = protos; xa.prototypes_loc = protos_loc; xa.norms = pnorms;
+  xa.proto_semantic = plab; xa.proto_instance = plab + cap; xa.proto_batch = plab + 2 * cap;
+  xa.updated_cluster = ids; xa.meta = xmeta;
+  xa.workspace_bytes = hsgk_exchange_workspace_bytes(N, C, D, cap, cap, 1, pool_rows);
+  CHECK_HIP(hipMalloc(&xa.workspace, xa.workspace_bytes));
+  float xms = 0.f;
+  for (int run = 0; run < 2; ++run) {
+    CHECK_HIP(hipEventRecord(e0, stream));
+    CHECK_HSGK(hsgk_exchange_prototypes(&xa, nullptr, 0, 1, stream));
+    CHECK_HIP(hipEventRecord(e1, stream));
+    CHECK_HIP(hipEventSynchronize(e1));
+    CHECK_HIP(hipEventElapsedTime(&xms, e0, e1));
+  }
+  int64_t xm[8];
+  CHECK_HIP(hipMemcpy(xm, xmeta, sizeof(xm), hipMemcpyDeviceToHost));
+  CHECK_HIP(hipMemcpy(c1.data(), ids, sizeof(int64_t) * N, hipMemcpyDeviceToHost));
+  int64_t idiff = 0;
+  for (int64_t i = 0; i < N; ++i) idiff += c0[i] != c1[i];          // the ids were dense and sorted already
+  std::vector<float> prow((size_t)C);
+  CHECK_HIP(hipMemcpy(prow.data(), protos + (size_t)(xm[1] / 2) * C, sizeof(float) * C, hipMemcpyDeviceToHost));
+  double pn = 0.0;
+  for (int i = 0; i < C; ++i) pn += (double)prow[i] * prow[i];
+  const bool xok = xm[2] == 0 && xm[1] == m.n_segments && idiff == 0 && fabs(pn - 1.0) < 1e-5;
+  printf("exchange: %lld prototypes, %.3f ms, ids unchanged: %s, |prototype| = %.7f -> %s\n", (long long)xm[1], xms,
+         idiff == 0 ? "yes" : "NO", sqrt(pn), xok ? "ok" : "FAILED");
   const bool ok = m.error == 0 && m.n_rows == N && diff == 0 && fabs(nrm - 1.0) < 1e-5 && cmax < (int64_t)B * K &&
-                  m.n_segments == cmax + 1;
+                  m.n_segments == cmax + 1 && xok;
   printf("%dx%dx%dx%d grid %dx%d (K=%d) it=%d: %.3f ms per call (first %.3f), %.1f Mpixel/s, rows %lld, segments %lld, "
          "cluster-id checksum %016llx, second call identical: %s, |row| = %.7f  -> %s\n",
          B, C, H, W, ky, kx, K, iters, ms[1], ms[0], N / (ms[1] * 1e3), (long long)m.n_rows, (long long)m.n_segments,
