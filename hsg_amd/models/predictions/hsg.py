@@ -39,6 +39,45 @@ def _is_segsort(mod):
           and hasattr(mod, 'concentration') and hasattr(mod, 'group_mode'))
 
 
+_HIERARCHY_LEVELS = ('coarse', 'fine')
+
+
+def _dmon_terms(self, datas):
+  """Spectral (DMon) clustering objective + collapse regulariser of both hierarchy levels (reference :163-186):
+  every level's grouping logits are scored against the same k-NN graph inputs (node prototypes, padding
+  masks, node -> image indices)."""
+  graph = (datas['nd_prototype'], datas['nd_prototype_padding_mask'], datas['nd_prototype_batch_index'])
+  total = None
+  for level in _HIERARCHY_LEVELS:
+    cut, collapse = self.dmon_loss(datas[level + 'hrchy_nd_prototype_grouping_logit'], *graph)
+    total = cut + collapse if total is None else total + cut + collapse
+  return total
+
+
+def _centroid_rows(centroids):
+  """[images, channels, groups] -> unit rows [images * groups, channels]."""
+  return common_utils.normalize_embedding(centroids.permute(0, 2, 1).reshape(-1, centroids.shape[1]))
+
+
+def _centroid_contrast_terms(self, datas, targets):
+  """Group centroids of this GPU's images against the batch-wide target centroids (reference :188-227): the
+  label of a centroid is its row in the target table, and this GPU's images are a contiguous range of that
+  table -- found ONCE for both levels (the reference, and the round-2 mirror, re-derived it per level with
+  its own host read)."""
+  image_indices = torch.gather(targets['image_index'], 0, datas['cluster_batch_index'])
+  first, last = torch.stack([image_indices.min(), image_indices.max()]).tolist()      # the block's one host read
+  total = None
+  for level in _HIERARCHY_LEVELS:
+    target = targets[level + 'hrchy_nd_prototype_grouping_centroid']
+    images, groups = target.shape[0], target.shape[2]
+    target_labels = torch.arange(images * groups, dtype=torch.long, device=target.device)
+    own_labels = target_labels[first * groups:(last + 1) * groups]
+    loss = self.centroid_cont_loss(_centroid_rows(datas[level + 'hrchy_nd_prototype_grouping_centroid']),
+                                   own_labels, own_labels, _centroid_rows(target), target_labels)
+    total = loss if total is None else total + loss
+  return total
+
+
 def losses(self, datas, targets={}):
   """:78-227: (img_sim_loss, hrchy_group_loss, clustering_loss, img_sim_acc)."""
   img_sim_loss = None
@@ -90,41 +129,13 @@ def losses(self, datas, targets={}):
   if 'coarse' in values:
     hrchy_group_loss = values['coarse'] if hrchy_group_loss is None else hrchy_group_loss + values['coarse']
 
-  if self.dmon_loss is not None:                                                        # :163-186
-    nd_prototypes = datas['nd_prototype']
-    nd_prototype_batch_indices = datas['nd_prototype_batch_index']
-    nd_prototype_padding_masks = datas['nd_prototype_padding_mask']
-    dmon_losses, collapse_losses = [], []
-    for nd_logits in [datas['coarsehrchy_nd_prototype_grouping_logit'],
-                      datas['finehrchy_nd_prototype_grouping_logit']]:
-      dmon_loss, reg_loss = self.dmon_loss(nd_logits, nd_prototypes, nd_prototype_padding_masks,
-                                           nd_prototype_batch_indices)
-      dmon_losses.append(dmon_loss)
-      collapse_losses.append(reg_loss)
-    clustering_loss = sum(dmon_losses) + sum(collapse_losses)
-    clustering_loss = clustering_loss * self.dmon_loss_weight
-
-  if self.centroid_cont_loss is not None:                                               # :188-227
-    centroid_cont_losses = []
-    for prefix in ['coarse', 'fine']:
-      nd_target_centroids = targets[prefix + 'hrchy_nd_prototype_grouping_centroid']
-      target_shape = nd_target_centroids.shape
-      nd_target_centroids = nd_target_centroids.permute(0, 2, 1).contiguous().flatten(0, 1)
-      norm_target_centroids = common_utils.normalize_embedding(nd_target_centroids)
-      nd_target_centroid_labels = torch.arange(
-          nd_target_centroids.shape[0], dtype=torch.long,
-          device=nd_target_centroids.device).view(target_shape[0], target_shape[2])
-      nd_centroids = datas[prefix + 'hrchy_nd_prototype_grouping_centroid']
-      nd_centroids = nd_centroids.permute(0, 2, 1).contiguous().flatten(0, 1)
-      norm_centroids = common_utils.normalize_embedding(nd_centroids)
-      image_indices = torch.gather(targets['image_index'], 0, datas['cluster_batch_index'])
-      lo_hi = torch.stack([image_indices.min(), image_indices.max() + 1]).tolist()
-      nd_centroid_labels = nd_target_centroid_labels[lo_hi[0]:lo_hi[1]]
-      centroid_cont_losses.append(self.centroid_cont_loss(
-          norm_centroids, nd_centroid_labels.view(-1), nd_centroid_labels.view(-1),
-          norm_target_centroids, nd_target_centroid_labels.view(-1)))
-    cont = sum(centroid_cont_losses) * self.centroid_cont_loss_weight
-    clustering_loss = cont if clustering_loss is None else clustering_loss + cont
+  terms = []
+  if self.dmon_loss is not None:
+    terms.append(_dmon_terms(self, datas) * self.dmon_loss_weight)
+  if self.centroid_cont_loss is not None:
+    terms.append(_centroid_contrast_terms(self, datas, targets) * self.centroid_cont_loss_weight)
+  if terms:
+    clustering_loss = terms[0] if len(terms) == 1 else terms[0] + terms[1]
 
   return img_sim_loss, hrchy_group_loss, clustering_loss, img_sim_acc
 
