@@ -511,8 +511,8 @@ __device__ inline void stream_runs(const XSlice sl, int64_t row0, const uint16_t
     for (int u = 0; u < U; ++u) {
       const int e = e0 + u < nvalid ? e0 + u : nvalid - 1;
       const int r = __builtin_amdgcn_readfirstlane((int)(srow[e] & 2047));
-      v[u] = *reinterpret_cast<const fv *>(xm + (int64_t)r * sl.d);
-      if constexpr (TAIL) t[u] = xt[(int64_t)r * sl.d];
+      v[u] = __builtin_nontemporal_load(reinterpret_cast<const fv *>(xm + (int64_t)r * sl.d));
+      if constexpr (TAIL) t[u] = __builtin_nontemporal_load(xt + (int64_t)r * sl.d);
     }
   };
   fv acc;
