@@ -214,7 +214,7 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
     const char *tb = wbase + ld_tile * tile_bytes + ld_q * (KC * 2);
 #pragma unroll
     for (int i = 0; i < LOADS; ++i)
-      asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(pre[i]) : "v"(voff), "s"(tb + i * grp_bytes));
+      asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=v"(pre[i]) : "v"(voff), "s"(tb + i * grp_bytes));
     const bool wrap = ld_q + 1 == nfull;
     ld_q = wrap ? 0 : ld_q + 1;
     ld_tile += wrap ? 1 : 0;
