@@ -174,6 +174,11 @@ size_t relabel_scan_bytes(int64_t table_cap);      // scratch of the chained sca
 int launch_relabel(const hsgk_segkm_args &a, const ChunkTable &t, int max_chunks,
                    const int32_t *klab, int32_t *table, int32_t *scan_tmp,
                    hipStream_t s);
+// exchange.hip: segment sums of one or two row sets by ids in [0, P), order C2 (sorted runs per chunk, column slices)
+int launch_sorted_sums(const float *xa, int da, const float *xb, int db, const int64_t *ids, int64_t n, int64_t P,
+                       void *chunks, int32_t *seg_range, int64_t *pool_ids, float *pool, int64_t pool_rows,
+                       int32_t *pool_used, float *table, int32_t *status, hipStream_t s);
+size_t sorted_sums_chunk_bytes();
 int launch_i64_to_i32(const int64_t *in, int64_t n, int32_t *out, hipStream_t s);
 int launch_i32_to_i64(const int32_t *in, int64_t n, int64_t *out, hipStream_t s);
 int launch_flat_table(int64_t n, ChunkTable t, int max_chunks, hsgk_segkm_meta *meta,

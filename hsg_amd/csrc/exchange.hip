@@ -461,6 +461,7 @@ struct XSlice { const float *x; int d; int col0; int nmain; int vec; int tcol0; 
 // 128) is a slice of its own.
 __host__ __device__ inline bool slices_wide(int d) { return d >= 256 && (d % 256) <= 64; }
 __host__ __device__ inline int slices_count(int d) {
+  if (d <= 0) return 0;
   if (slices_wide(d)) return d / 256;
   const int f = d / 128, rem = d % 128;
   return f + ((rem > 64 || (rem > 0 && f == 0)) ? 1 : 0);
@@ -566,8 +567,8 @@ __device__ inline void stream_runs(const XSlice sl, int64_t row0, const uint16_t
 __global__ void xk_sums_chunk_kernel(const float *__restrict__ xa, int da, const float *__restrict__ xb, int db,
                                      const int64_t *__restrict__ ids, int64_t n, int64_t P,
                                      float *__restrict__ pool, int64_t *__restrict__ pool_ids, int pool_rows,
-                                     XChunk *__restrict__ chunks, int32_t *__restrict__ seg_range, XCtrl *ctrl,
-                                     int RG) {
+                                     XChunk *__restrict__ chunks, int32_t *__restrict__ seg_range, int32_t *pool_used,
+                                     int RG, int32_t *__restrict__ status) {
   extern __shared__ uint16_t glist[];             // [RG][HSGK_CHUNK] (RG > 1)
   __shared__ int gcount[8];
   __shared__ unsigned long long skey[HSGK_CHUNK];
@@ -583,10 +584,12 @@ __global__ void xk_sums_chunk_kernel(const float *__restrict__ xa, int da, const
 
   // id range of the chunk's valid rows
   long long lo = INT64_MAX, hi = INT64_MIN;
+  bool bad = false;
   for (int r = tid; r < nrows; r += nt) {
     const long long l = ids[row0 + r];
-    if (l >= 0 && l < P) { lo = l < lo ? l : lo; hi = l > hi ? l : hi; }
+    if (l >= 0 && l < P) { lo = l < lo ? l : lo; hi = l > hi ? l : hi; } else bad = true;
   }
+  if (status && __ballot(bad) && lane == 0) atomicOr(status, 2);        // (such rows are skipped)
   for (int off = 32; off > 0; off >>= 1) {
     const long long olo = __shfl_xor(lo, off), ohi = __shfl_xor(hi, off);
     lo = olo < lo ? olo : lo;
@@ -644,8 +647,8 @@ __global__ void xk_sums_chunk_kernel(const float *__restrict__ xa, int da, const
   if (tid == 0) {
     int nd = 0, nv = 0;
     for (int i = 0; i < nw; ++i) { nd += wcnt[i]; nv += (int)red[0][i]; }
-    int base = atomicAdd(&ctrl->pool_used, nd);
-    if (base + nd > pool_rows) { atomicSub(&ctrl->pool_used, nd); base = -1; }
+    int base = atomicAdd(pool_used, nd);
+    if (base + nd > pool_rows) { atomicSub(pool_used, nd); base = -1; }
     sh_base = base; sh_ndist = nd; sh_nvalid = nv;
   }
   __syncthreads();
@@ -1035,6 +1038,34 @@ static int launch_merge(const int64_t *recv, int world, int my_rank, int64_t cap
   return 0;
 }
 
+// Segment sums of one or two row sets by int64 ids in [0, P), canonical order C2, into table [P][da + db]
+// (db = 0: one row set).  Scratch: chunks [nch], seg_range [P][2], pool_ids [pool_rows], pool [pool_rows][da + db],
+// pool_used (zeroed by the caller).  status (nullable): bit 1 set when an id lies outside [0, P).
+int launch_sorted_sums(const float *xa, int da, const float *xb, int db, const int64_t *ids, int64_t n, int64_t P,
+                       void *chunks_v, int32_t *seg_range, int64_t *pool_ids, float *pool, int64_t pool_rows,
+                       int32_t *pool_used, float *table, int32_t *status, hipStream_t s) {
+  XChunk *chunks = static_cast<XChunk *>(chunks_v);
+  const int nch = (int)((n + HSGK_CHUNK - 1) / HSGK_CHUNK);
+  if (P <= 0) return 0;
+  hipLaunchKernelGGL(xk_seg_range_init_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, seg_range, P);
+  HSGK_LAUNCH_CHECK();
+  if (nch > 0) {
+    const int nw = slices_of_host(da) + (db > 0 ? slices_of_host(db) : 0);
+    HSGK_REQUIRE(nw >= 1 && nw <= 16, "rows too long");
+    int rg = 1;                                     // run groups per chunk: small inputs only (see the kernel)
+    if (nch <= 512) rg = nw <= 2 ? 8 : nw <= 4 ? 4 : nw <= 8 ? 2 : 1;
+    hipLaunchKernelGGL(xk_sums_chunk_kernel, dim3((unsigned)nch), dim3(64 * nw * rg),
+                       rg > 1 ? (size_t)rg * HSGK_CHUNK * 2 : 0, s, xa, da, xb, db, ids, n, P, pool, pool_ids,
+                       (int)pool_rows, chunks, seg_range, pool_used, rg, status);
+    HSGK_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(xk_sums_final_kernel, dim3((unsigned)P), dim3(256), 0, s, pool, pool_ids, chunks, seg_range, xa, da,
+                     xb, db, ids, n, table);
+  HSGK_LAUNCH_CHECK();
+  return 0;
+}
+size_t sorted_sums_chunk_bytes() { return sizeof(XChunk); }
+
 static int launch_ids_and_sums(const hsgk_exchange_args *a, const XWs &w, const int32_t *gslot_mine, hipStream_t s) {
   const int T = a->C + a->D;
   {
@@ -1043,23 +1074,10 @@ static int launch_ids_and_sums(const hsgk_exchange_args *a, const XWs &w, const 
                        w.rank_of_slot, gslot_mine, a->updated_cluster, w.ctrl, a->meta);
     HSGK_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(xk_seg_range_init_kernel, dim3((unsigned)((a->cap_total + 255) / 256)), dim3(256), 0, s,
-                     w.seg_range, a->cap_total);
-  HSGK_LAUNCH_CHECK();
-  if (w.nch > 0) {
-    const int nw = slices_of_host(a->C) + slices_of_host(a->D);
-    HSGK_REQUIRE(nw <= 16, "rows too long");
-    int rg = 1;                                     // run groups per chunk: small inputs only (see the kernel)
-    if (w.nch <= 512) rg = nw <= 2 ? 8 : nw <= 4 ? 4 : nw <= 8 ? 2 : 1;
-    hipLaunchKernelGGL(xk_sums_chunk_kernel, dim3((unsigned)w.nch), dim3(64 * nw * rg),
-                       rg > 1 ? (size_t)rg * HSGK_CHUNK * 2 : 0, s, a->embeddings, a->C,
-                       a->embeddings_loc, a->D, a->updated_cluster, a->n, a->cap_total, w.pool, w.pool_ids,
-                       (int)a->pool_rows, w.chunks, w.seg_range, w.ctrl, rg);
-    HSGK_LAUNCH_CHECK();
-  }
-  hipLaunchKernelGGL(xk_sums_final_kernel, dim3((unsigned)a->cap_total), dim3(256), 0, s, w.pool, w.pool_ids, w.chunks,
-                     w.seg_range, a->embeddings, a->C, a->embeddings_loc, a->D, a->updated_cluster, a->n, a->table);
-  HSGK_LAUNCH_CHECK();
+  if (int rc = launch_sorted_sums(a->embeddings, a->C, a->embeddings_loc, a->D, a->updated_cluster, a->n, a->cap_total,
+                                  w.chunks, w.seg_range, w.pool_ids, w.pool, a->pool_rows, &w.ctrl->pool_used, a->table,
+                                  nullptr, s))
+    return rc;
   (void)T;
   return 0;
 }

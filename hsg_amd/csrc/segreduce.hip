@@ -313,9 +313,49 @@ __global__ __launch_bounds__(256) void segreduce_bwd_rows_kernel(
   }
 }
 
+// raw sums -> the mode's output: 0 L2-normalised (C1 norm chain, eps clamp; aux = norm), 1 mean (aux = count,
+// 0 -> 1), 2 raw.  One workgroup per segment.
+__global__ __launch_bounds__(256) void segreduce_epilogue_kernel(const float *__restrict__ sums, int d, int mode, float eps,
+                                                                 const int32_t *__restrict__ counts,
+                                                                 float *__restrict__ out, float *__restrict__ aux) {
+  extern __shared__ float row[];             // [d + 1]
+  const int64_t k = blockIdx.x;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < d; i += 256) row[i] = sums[k * d + i];
+  __syncthreads();
+  if (tid == 0) {
+    float a = 1.0f;
+    if (mode == 0) {
+      float ss = 0.0f;
+      for (int i = 0; i < d; ++i) ss = fmaf(row[i], row[i], ss);
+      a = sqrtf(ss);
+      if (!(a >= eps)) a = eps;
+    } else if (mode == 1) {
+      a = (float)counts[k];
+      if (a == 0.0f) a = 1.0f;
+    }
+    row[d] = a;
+    if (aux) aux[k] = a;
+  }
+  __syncthreads();
+  const float a = row[d];
+  for (int i = tid; i < d; i += 256) out[k * d + i] = row[i] / a;
+}
+
 }  // namespace hsgk
 
 using namespace hsgk;
+
+// Round 3: rows of up to 1024 columns take the sorted-run kernels of exchange.hip (one row set: the rows of a chunk
+// stably sorted by id, a wave per column slice, runs summed in registers -- no LDS table, any ids; 5.3 TB/s against
+// 3.7 for the LDS-table kernel below, same order C2, same bits).  Wider rows keep the LDS-table kernels.
+static bool seg_sorted_path(int d) { return d <= 1024; }
+static int64_t seg_pool_rows(int64_t n, int64_t P) {
+  const int64_t nch = (n + HSGK_CHUNK - 1) / HSGK_CHUNK;
+  int64_t r = nch * (P < 256 ? P : 256);
+  if (r > n) r = n;
+  return r < 1 ? 1 : r;
+}
 
 static int seg_rmax(int64_t P) { return (int)(P < kSegRmax ? (P < 1 ? 1 : P) : kSegRmax); }
 
@@ -323,6 +363,18 @@ extern "C" {
 
 size_t hsgk_segment_reduce_workspace_bytes(int64_t n, int d, int64_t P) {
   const int64_t nch = (n + HSGK_CHUNK - 1) / HSGK_CHUNK;
+  if (seg_sorted_path(d)) {
+    Carver cv(nullptr);
+    const int64_t pr = seg_pool_rows(n, P);
+    cv.take<char>((size_t)(nch > 0 ? nch : 1) * sorted_sums_chunk_bytes());
+    cv.take<int32_t>((size_t)2 * (P > 0 ? P : 1));
+    cv.take<int64_t>((size_t)pr);
+    cv.take<float>((size_t)pr * d);
+    cv.take<int32_t>(64);
+    cv.take<int32_t>((size_t)(P > 0 ? P : 1));
+    cv.take<float>((size_t)(P > 0 ? P : 1) * d);
+    return cv.off + 256;
+  }
   Carver cv(nullptr);
   cv.take<float>((size_t)(nch > 0 ? nch : 1) * seg_rmax(P) * d);
   cv.take<SegWin>((size_t)(nch > 0 ? nch : 1));
@@ -341,6 +393,37 @@ int hsgk_segment_reduce(const float *x, int64_t n, int d, const int64_t *labels,
   (void)hipGetLastError();
   HSGK_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), s));
   if (P == 0) return 0;
+  if (seg_sorted_path(d)) {
+    const int64_t nchl = (n + HSGK_CHUNK - 1) / HSGK_CHUNK;
+    const int64_t pr = seg_pool_rows(n, P);
+    Carver cv(workspace);
+    char *chunks = cv.take<char>((size_t)(nchl > 0 ? nchl : 1) * sorted_sums_chunk_bytes());
+    int32_t *seg_range = cv.take<int32_t>((size_t)2 * P);
+    int64_t *pool_ids = cv.take<int64_t>((size_t)pr);
+    float *pool = cv.take<float>((size_t)pr * d);
+    int32_t *pool_used = cv.take<int32_t>(64);
+    int32_t *counts = cv.take<int32_t>((size_t)P);
+    float *sums = cv.take<float>((size_t)P * d);
+    HSGK_CHECK_HIP(hipMemsetAsync(pool_used, 0, sizeof(int32_t), s));
+    float *table = mode == 2 ? out : sums;
+    if (int rc = launch_sorted_sums(x, d, nullptr, 0, labels, n, P, chunks, seg_range, pool_ids, pool, pr, pool_used,
+                                    table, status, s))
+      return rc;
+    if (mode == 1) {
+      HSGK_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)P * 4, s));
+      if (n > 0) {
+        int64_t g = (n + 255) / 256;
+        hipLaunchKernelGGL(count_labels_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, s, labels, n, P, counts);
+        HSGK_LAUNCH_CHECK();
+      }
+    }
+    if (mode != 2) {
+      hipLaunchKernelGGL(segreduce_epilogue_kernel, dim3((unsigned)P), dim3(256), (size_t)(d + 1) * 4, s, sums, d, mode, eps,
+                         counts, out, aux);
+      HSGK_LAUNCH_CHECK();
+    }
+    return 0;
+  }
   const int nch = (int)((n + HSGK_CHUNK - 1) / HSGK_CHUNK);
   const int rmax = seg_rmax(P);
   Carver cv(workspace);

@@ -218,7 +218,8 @@ def test_prototypes_and_segment_mean_vs_golden_and_oracle(dev, oracle):
 
 
 @pytest.mark.parametrize('n,d,P', [(1, 3, 1), (2047, 34, 7), (2049, 258, 64), (30000, 130, 700),
-                                   (9000, 258, 300), (5000, 66, 1000)])
+                                   (9000, 258, 300), (5000, 66, 1000), (6000, 386, 128), (4100, 1000, 50),
+                                   (3000, 1100, 20)])          # (d > 1024: the LDS-table kernels)
 def test_segment_reduce_sorted_ids_vs_oracle(dev, oracle, n, d, P):
   """Large P with image-major style (monotone, locally clustered) ids."""
   import torch
