@@ -362,7 +362,7 @@ def main():
     if tr:
       e_moved, e_src = tr, src + ': 2 x FETCH_SIZE + WRITE_SIZE summed over the group (gfx950 correction of MI355X_MICROARCH.md)'
   # the other per-GPU configs at their default batch: counters of profiles/r03_<workload>_pmc.txt (same passes)
-  group = {'cfg3': ['assign_half_kernel', 'assign_requeue_rows_kernel'],
+  group = {'cfg3': ['assign_half_wide_kernel', 'assign_requeue_rows_kernel'],
            'cfg4': ['assign_half_pair_kernel', 'assign_requeue_seg_kernel', 'centroid_half_err_kernel'],
            'cfg5': ['assign_half_wide_kernel', 'assign_requeue_rows_kernel', 'centroid_half_err_kernel']}.get(args.workload)
   e_kernel = None
