@@ -569,8 +569,9 @@ __global__ __launch_bounds__(NW * 64) void loss_bwd_kernel(BwdArgs a) {
   }
   for (int64_t b = b_begin; b < b_end; ++b) {
     const int buf = (int)((b - b_begin) & 1);
-    if (b + 1 < b_end) load_block(b + 1);          // in flight during the MFMAs below
     __syncthreads();                                // buffer `buf` is complete
+    if (b + 1 < b_end) load_block(b + 1);          // in flight during the MFMAs below (issued after the
+                                                    // barrier, whose vmcnt(0) wait would expose their latency)
     const float *tb = tbuf + buf * (16 * RS);
 
     // ---- score tile: S[t][o] = sum_k T[t][k] O[o][k], ascending-k chain of 4-wide steps
@@ -636,6 +637,229 @@ __global__ __launch_bounds__(NW * 64) void loss_bwd_kernel(BwdArgs a) {
   }
 }
 
+
+// ---- fast backward tile: PLAIN labels (one int64 per row and set), c = 64 M channels ------------------------
+// Same two contractions and the same W expression as loss_bwd_kernel; what changes is how the operands reach
+// the MFMAs and what the epilogue costs (rocprofv3 + ISA of the generic kernel at C = 256: every pair of MFMAs
+// waited on its own ds_read2_b32 -- 128 exposed LDS round trips per block -- the label words of the next block
+// were fetched from global memory between the MFMAs and the barrier, and the generic W epilogue compiled to
+// ~140 instructions per score with scratch traffic: the MFMA pipe was 54 % busy):
+//   * score contraction: the order of k inside a contraction is free, so k-step (q, i) takes channel
+//     16 q + 4 g + i from lane group g: one ds_read_b128 feeds four MFMAs, the owner operand is loaded from
+//     global as float4, and two accumulators break the 64-deep dependent chain;
+//   * second contraction: MFMA row i of channel tile (m, v) is channel 64 m + 4 i + v, so lane (j, g) reads
+//     float4 T[4 g + r][64 m + 4 j ..] -- again one ds_read_b128 per four MFMAs -- and ends up holding 16
+//     contiguous output channels per m;
+//   * the next block's label / weight words are prefetched into registers with its rows;
+//   * L is a template parameter; the label words come from LDS through a shared-memory pointer.
+template <int M, int L, bool OWNER_PX>
+__global__ __launch_bounds__(512, 2) void loss_bwd_fast_kernel(BwdArgs a) {
+  constexpr int CP = 64 * M, RS = CP + 4, NT = 512, OT = 128;
+  constexpr int F4 = 4 * CP;                  // float4 per staged 16-row block
+  constexpr int L4 = (F4 + NT - 1) / NT;
+  constexpr int QS = CP / 16;
+  constexpr int kMetaBytes = 3 * 16 * 8 + 16 * 8 + 3 * 16 * 16 + 16 * 4;     // labels, group, weights, instance
+  extern __shared__ __attribute__((aligned(16))) float lds_fast[];
+  float *tbuf = lds_fast;                                                       // [2][16][RS]
+  unsigned char *mbase = reinterpret_cast<unsigned char *>(lds_fast + 2 * 16 * RS);
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int c = a.c;
+  const int64_t o_row = (int64_t)blockIdx.x * OT + w * 16 + j;
+  const bool o_valid = o_row < a.n_owner;
+  const int64_t o_ld = o_valid ? o_row : a.n_owner - 1;
+  const int sp = blockIdx.y;
+  const int64_t nblocks = (a.n_stream + 15) / 16;
+  const int64_t b_begin = (int64_t)sp * a.blocks_per_split;
+  const int64_t b_end = min(nblocks, b_begin + a.blocks_per_split);
+  const bool grouped = a.ls.qgroup != nullptr;
+
+  // owner rows: B operand of the score contraction, lane (j, g) holds O[o][16 q + 4 g + i] in bop[4 q + i]
+  float bop[4 * QS];
+  {
+    const float *orow = a.owner + o_ld * c + 4 * g;
+#pragma unroll
+    for (int q = 0; q < QS; ++q) {
+      const float4 v = *reinterpret_cast<const float4 *>(orow + 16 * q);
+      bop[4 * q] = v.x; bop[4 * q + 1] = v.y; bop[4 * q + 2] = v.z; bop[4 * q + 3] = v.w;
+    }
+  }
+  int64_t o_lab[L];
+  float o_A[L], o_B[L];
+  int o_pu[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    o_lab[l] = (OWNER_PX ? (l == 0 ? a.ls.sem[0] : l == 1 ? a.ls.sem[1] : a.ls.sem[2])
+                         : (l == 0 ? a.ls.psem[0] : l == 1 ? a.ls.psem[1] : a.ls.psem[2]))[o_ld];
+    o_A[l] = o_B[l] = 0.0f;
+    o_pu[l] = 0;
+    if constexpr (OWNER_PX) {
+      const PxMeta pm = a.meta[(int64_t)l * a.N + o_ld];
+      o_A[l] = pm.A; o_B[l] = pm.B; o_pu[l] = pm.plus_us;
+    }
+  }
+  const int o_own = OWNER_PX ? (int)a.inst[o_ld] : (int)o_row;     // the streamed row / instance that is "own"
+  const int64_t o_grp = grouped ? (OWNER_PX ? a.ls.qgroup[o_ld] : a.ls.pgroup[o_ld]) : 0;
+  const float k0 = a.ls.kappa[0], k1 = a.ls.kappa[L > 1 ? 1 : 0], k2 = a.ls.kappa[L > 2 ? 2 : 0];
+  const bool e1 = L > 1 && k1 != k0, e2 = L > 2 && k2 != k1;
+
+  f32x4 gacc[4 * M];
+#pragma unroll
+  for (int i = 0; i < 4 * M; ++i) gacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // label / weight words of the streamed block: thread (ml, mrow) = (tid >> 4, tid & 15), tid < 64; ml < L holds
+  // set ml of row mrow, ml == 3 the row's group and instance
+  const int ml = tid >> 4, mrow = tid & 15;
+  const int64_t *lab_src = nullptr;
+  if (ml == 0) lab_src = OWNER_PX ? a.ls.psem[0] : a.ls.sem[0];
+  else if (ml == 1 && L > 1) lab_src = OWNER_PX ? a.ls.psem[1] : a.ls.sem[1];
+  else if (ml == 2 && L > 2) lab_src = OWNER_PX ? a.ls.psem[2] : a.ls.sem[2];
+  else if (ml == 3 && grouped) lab_src = OWNER_PX ? a.ls.pgroup : a.ls.qgroup;
+  float4 pre[L4];
+  int64_t lab_pre = 0;
+  float4 px_pre = make_float4(0.f, 0.f, 0.f, 0.f);
+  int inst_pre = -1;
+  auto load_block = [&](int64_t b) {
+#pragma unroll
+    for (int u = 0; u < L4; ++u) {
+      const int f = tid + NT * u;
+      const int row = f / (CP / 4), c4 = (f - row * (CP / 4)) * 4;
+      const int64_t t = b * 16 + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < F4 && t < a.n_stream) v = *reinterpret_cast<const float4 *>(a.stream + t * c + c4);
+      pre[u] = v;
+    }
+    if (tid < 64) {
+      const int64_t t = b * 16 + mrow;
+      const bool ok = t < a.n_stream;
+      lab_pre = (ok && lab_src) ? lab_src[t] : 0;
+      if constexpr (!OWNER_PX) {
+        px_pre = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && ml < L) px_pre = *reinterpret_cast<const float4 *>(a.meta + (int64_t)ml * a.N + t);
+        inst_pre = (ok && ml == 3) ? (int)a.inst[t] : -1;
+      }
+    }
+  };
+  auto store_block = [&](int buf) {
+    float *dst = tbuf + buf * (16 * RS);
+#pragma unroll
+    for (int u = 0; u < L4; ++u) {
+      const int f = tid + NT * u;
+      const int row = f / (CP / 4), c4 = (f - row * (CP / 4)) * 4;
+      if (f < F4) *reinterpret_cast<float4 *>(dst + row * RS + c4) = pre[u];
+    }
+    if (tid < 64) {
+      unsigned char *mb = mbase + buf * kMetaBytes;
+      if (ml < 3) {
+        reinterpret_cast<int64_t *>(mb)[ml * 16 + mrow] = lab_pre;
+        if constexpr (!OWNER_PX) reinterpret_cast<float4 *>(mb + 512)[ml * 16 + mrow] = px_pre;
+      } else {
+        reinterpret_cast<int64_t *>(mb + 384)[mrow] = lab_pre;
+        if constexpr (!OWNER_PX) reinterpret_cast<int *>(mb + 1280)[mrow] = inst_pre;
+      }
+    }
+  };
+
+  if (b_begin < b_end) {
+    load_block(b_begin);
+    store_block(0);
+  }
+  for (int64_t b = b_begin; b < b_end; ++b) {
+    const int buf = (int)((b - b_begin) & 1);
+    __syncthreads();                                // buffer `buf` is complete
+    if (b + 1 < b_end) load_block(b + 1);          // in flight during the MFMAs below
+    const float *tb = tbuf + buf * (16 * RS);
+
+    // ---- score tile S[t][o]: lane (j, g) register r <-> streamed row 4 g + r, owner row j
+    f32x4 sacc;
+    {
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+      const float *ap = tb + j * RS + 4 * g;
+#pragma unroll
+      for (int q = 0; q < QS; ++q) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(ap + 16 * q);
+        s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bop[4 * q], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bop[4 * q + 1], s1, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bop[4 * q + 2], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bop[4 * q + 3], s1, 0, 0, 0);
+      }
+      sacc = s0 + s1;
+    }
+    // ---- W in place
+    {
+      const unsigned char *mb = mbase + buf * kMetaBytes;
+      const int64_t *bl = reinterpret_cast<const int64_t *>(mb);
+      const int64_t *bg = reinterpret_cast<const int64_t *>(mb + 384);
+      const PxMeta *bp = reinterpret_cast<const PxMeta *>(mb + 512);
+      const int *bi = reinterpret_cast<const int *>(mb + 1280);
+      const int t0 = (int)(b * 16);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tr = 4 * g + r;
+        const float sc = sacc[r];
+        float x[3];
+        x[0] = expf(sc * k0);
+        x[1] = e1 ? expf(sc * k1) : x[0];
+        x[2] = e2 ? expf(sc * k2) : x[1];
+        bool own;
+        if constexpr (OWNER_PX) own = o_own == t0 + tr; else own = bi[tr] == o_own;
+        float wv = 0.0f;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+          const bool same = bl[l * 16 + tr] == o_lab[l];
+          float A = o_A[l], B = o_B[l];
+          int pu = o_pu[l];
+          if constexpr (!OWNER_PX) {
+            const PxMeta pm = bp[l * 16 + tr];
+            A = pm.A; B = pm.B; pu = pm.plus_us;
+          }
+          const float av = pu ? (float)((int)same - (int)own) : (own ? 1.0f : 0.0f);
+          wv += x[l] * (av * A + (same ? 0.0f : B));
+        }
+        bool live = o_valid && (int64_t)(t0 + tr) < a.n_stream;
+        if (grouped) live = live && bg[tr] == o_grp;
+        sacc[r] = live ? wv : 0.0f;
+      }
+    }
+    // ---- second contraction: G[ch][o] += sum_t T[t][ch] W[t][o], k-step r = streamed rows 4 g + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float *tp = tb + (4 * g + r) * RS + 4 * j;
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const float4 t4 = *reinterpret_cast<const float4 *>(tp + 64 * m);
+        gacc[4 * m] = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.x, sacc[r], gacc[4 * m], 0, 0, 0);
+        gacc[4 * m + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.y, sacc[r], gacc[4 * m + 1], 0, 0, 0);
+        gacc[4 * m + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.z, sacc[r], gacc[4 * m + 2], 0, 0, 0);
+        gacc[4 * m + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.w, sacc[r], gacc[4 * m + 3], 0, 0, 0);
+      }
+    }
+    if (b + 1 < b_end) store_block(buf ^ 1);
+  }
+
+  // ---- partial output: gacc[4 m + v][e] of lane (j, g) is G[channel 64 m + 16 g + 4 e + v][o = j]
+  if (o_valid) {
+    float *orow = a.out + ((int64_t)sp * a.n_owner + o_row) * c + 16 * g;
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        *reinterpret_cast<float4 *>(orow + 64 * m + 4 * e) =
+            make_float4(gacc[4 * m][e], gacc[4 * m + 1][e], gacc[4 * m + 2][e], gacc[4 * m + 3][e]);
+  }
+}
+
+static bool loss_bwd_fast_ok(const BwdArgs &a) {
+  const char *e = getenv("HSGK_LOSS_BWD");             // "generic": the general tile for every shape
+  if (e && e[0] == 'g') return false;
+  if (a.c != 64 && a.c != 128 && a.c != 256) return false;
+  if (a.ls.words != 1 || a.n_stream >= (int64_t)1 << 31 || a.n_owner >= (int64_t)1 << 31) return false;
+  for (int l = 0; l < a.ls.L; ++l)
+    if (a.ls.setm[l]) return false;
+  return true;
+}
+
 // out[i] = sum over splits (split order) of part[s][i]
 __global__ void loss_bwd_reduce_kernel(const float *__restrict__ part, int split, int64_t total,
                                        float *__restrict__ out) {
@@ -668,6 +892,37 @@ static int launch_loss_bwd(BwdArgs a, float *out, float *scratch, hipStream_t s)
   a.split = split;
   a.blocks_per_split = (int)((blocks + split - 1) / split);
   a.out = split == 1 ? out : scratch;
+  auto finish_split = [&]() -> int {
+    if (split > 1) {
+      const int64_t total = a.n_owner * a.c;
+      const int64_t gsz = (total + 255) / 256;
+      hipLaunchKernelGGL(loss_bwd_reduce_kernel, dim3((unsigned)(gsz > 4096 ? 4096 : gsz)), dim3(256), 0, s, scratch,
+                         split, total, out);
+      HSGK_LAUNCH_CHECK();
+    }
+    return 0;
+  };
+  if (loss_bwd_fast_ok(a)) {
+    auto gof = [&](auto kern, int M) -> int {
+      const size_t lds = (size_t)2 * 16 * (64 * M + 4) * 4 + 2 * (3 * 16 * 8 + 16 * 8 + 3 * 16 * 16 + 16 * 4);
+      HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, dim3((unsigned)((a.n_owner + 127) / 128), split), dim3(512), lds, s, a);
+      HSGK_LAUNCH_CHECK();
+      return 0;
+    };
+    int rcf;
+#define HSGK_BWD_FAST(MV)                                                                           \
+  rcf = a.ls.L == 1   ? gof(loss_bwd_fast_kernel<MV, 1, OWNER_PX>, MV)                              \
+        : a.ls.L == 2 ? gof(loss_bwd_fast_kernel<MV, 2, OWNER_PX>, MV)                              \
+                      : gof(loss_bwd_fast_kernel<MV, 3, OWNER_PX>, MV)
+    if (a.c == 64) HSGK_BWD_FAST(1);
+    else if (a.c == 128) HSGK_BWD_FAST(2);
+    else HSGK_BWD_FAST(4);
+#undef HSGK_BWD_FAST
+    if (rcf) return rcf;
+    return finish_split();
+  }
   const int ct = (a.c + 15) / 16;
   const bool vec4 = (a.c % 4) == 0;
   auto go = [&](auto kern, int CT, int NW) -> int {
@@ -695,14 +950,7 @@ static int launch_loss_bwd(BwdArgs a, float *out, float *scratch, hipStream_t s)
   }
 #undef HSGK_BWD_CASE
   if (rc) return rc;
-  if (split > 1) {
-    const int64_t total = a.n_owner * a.c;
-    const int64_t gsz = (total + 255) / 256;
-    hipLaunchKernelGGL(loss_bwd_reduce_kernel, dim3((unsigned)(gsz > 4096 ? 4096 : gsz)), dim3(256), 0, s, scratch,
-                       split, total, out);
-    HSGK_LAUNCH_CHECK();
-  }
-  return 0;
+  return finish_split();
 }
 
 static int make_sets(int L, const hsgk_loss_set *sets, const int64_t *qgroup, const int64_t *pgroup, LossSets *ls) {
