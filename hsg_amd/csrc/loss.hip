@@ -652,9 +652,18 @@ __global__ __launch_bounds__(NW * 64) void loss_bwd_kernel(BwdArgs a) {
 //     contiguous output channels per m;
 //   * the next block's label / weight words are prefetched into registers with its rows;
 //   * L is a template parameter; the label words come from LDS through a shared-memory pointer.
-template <int M, int L, bool OWNER_PX>
+//   * SPLIT: the score contraction runs on the fp16 matrix pipe with the forward's scaled split
+//     (score_tiles_bf16.h: hi = fp16(x), lo = fp16((x - hi) * 2048); s = hi.hi + (hi.lo + lo.hi) * 2^-11, error
+//     ~2^-22 |x||y|): 3 x C/32 v_mfma_f32_16x16x32_f16 (~17 cycles each) instead of C/4 fp32 ones (32 cycles) --
+//     a fifth of the cycles for that half of the work.  The second contraction stays fp32: its W operand spans
+//     exp(kappa s) and the 1/num weights, and its sum is the gradient itself.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+template <int M, int L, bool OWNER_PX, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void loss_bwd_fast_kernel(BwdArgs a) {
   constexpr int CP = 64 * M, RS = CP + 4, NT = 512, OT = 128;
+  constexpr int RSH = CP + 8;                 // fp16 plane row stride (halfs): 16-B rows, odd multiple of 16 B
+  constexpr int KS2 = CP / 32;                // k-steps of the fp16 score contraction
   constexpr int F4 = 4 * CP;                  // float4 per staged 16-row block
   constexpr int L4 = (F4 + NT - 1) / NT;
   constexpr int QS = CP / 16;
@@ -662,6 +671,7 @@ __global__ __launch_bounds__(512, 2) void loss_bwd_fast_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds_fast[];
   float *tbuf = lds_fast;                                                       // [2][16][RS]
   unsigned char *mbase = reinterpret_cast<unsigned char *>(lds_fast + 2 * 16 * RS);
+  uint16_t *hbuf = reinterpret_cast<uint16_t *>(mbase + 2 * kMetaBytes);        // [2][hi, lo][16][RSH]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
@@ -676,8 +686,24 @@ __global__ __launch_bounds__(512, 2) void loss_bwd_fast_kernel(BwdArgs a) {
   const bool grouped = a.ls.qgroup != nullptr;
 
   // owner rows: B operand of the score contraction, lane (j, g) holds O[o][16 q + 4 g + i] in bop[4 q + i]
-  float bop[4 * QS];
-  {
+  // (SPLIT: O[o][32 s + 8 g + i], i < 8, as fp16 hi / lo in bh[s] / blo[s])
+  float bop[SPLIT ? 1 : 4 * QS];
+  h16x8 bh[SPLIT ? KS2 : 1], blo[SPLIT ? KS2 : 1];
+  if constexpr (SPLIT) {
+    const float *orow = a.owner + o_ld * c + 8 * g;
+#pragma unroll
+    for (int s = 0; s < KS2; ++s) {
+      const float4 v0 = *reinterpret_cast<const float4 *>(orow + 32 * s);
+      const float4 v1 = *reinterpret_cast<const float4 *>(orow + 32 * s + 4);
+      uint32_t h[4], lw[4];
+      f16s_split2(v0.x, v0.y, h[0], lw[0]);
+      f16s_split2(v0.z, v0.w, h[1], lw[1]);
+      f16s_split2(v1.x, v1.y, h[2], lw[2]);
+      f16s_split2(v1.z, v1.w, h[3], lw[3]);
+      bh[s] = __builtin_bit_cast(h16x8, uint4{h[0], h[1], h[2], h[3]});
+      blo[s] = __builtin_bit_cast(h16x8, uint4{lw[0], lw[1], lw[2], lw[3]});
+    }
+  } else {
     const float *orow = a.owner + o_ld * c + 4 * g;
 #pragma unroll
     for (int q = 0; q < QS; ++q) {
@@ -747,7 +773,17 @@ __global__ __launch_bounds__(512, 2) void loss_bwd_fast_kernel(BwdArgs a) {
     for (int u = 0; u < L4; ++u) {
       const int f = tid + NT * u;
       const int row = f / (CP / 4), c4 = (f - row * (CP / 4)) * 4;
-      if (f < F4) *reinterpret_cast<float4 *>(dst + row * RS + c4) = pre[u];
+      if (f < F4) {
+        *reinterpret_cast<float4 *>(dst + row * RS + c4) = pre[u];
+        if constexpr (SPLIT) {
+          uint32_t h0, h1, l0, l1;
+          f16s_split2(pre[u].x, pre[u].y, h0, l0);
+          f16s_split2(pre[u].z, pre[u].w, h1, l1);
+          uint16_t *hp = hbuf + buf * (2 * 16 * RSH) + row * RSH + c4;
+          *reinterpret_cast<uint2 *>(hp) = uint2{h0, h1};
+          *reinterpret_cast<uint2 *>(hp + 16 * RSH) = uint2{l0, l1};
+        }
+      }
     }
     if (tid < 64) {
       unsigned char *mb = mbase + buf * kMetaBytes;
@@ -773,7 +809,19 @@ __global__ __launch_bounds__(512, 2) void loss_bwd_fast_kernel(BwdArgs a) {
 
     // ---- score tile S[t][o]: lane (j, g) register r <-> streamed row 4 g + r, owner row j
     f32x4 sacc;
-    {
+    if constexpr (SPLIT) {
+      f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, s3 = {0.f, 0.f, 0.f, 0.f};
+      const uint16_t *hp = hbuf + buf * (2 * 16 * RSH) + j * RSH + 8 * g;
+#pragma unroll
+      for (int s = 0; s < KS2; ++s) {
+        const h16x8 ah = *reinterpret_cast<const h16x8 *>(hp + 32 * s);
+        const h16x8 al = *reinterpret_cast<const h16x8 *>(hp + 16 * RSH + 32 * s);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[s], s1, 0, 0, 0);
+        s2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[s], s2, 0, 0, 0);
+        s3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, blo[s], s3, 0, 0, 0);
+      }
+      sacc = s1 + (s2 + s3) * (1.0f / 2048.0f);
+    } else {
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
       const float *ap = tb + j * RS + 4 * g;
 #pragma unroll
@@ -903,8 +951,10 @@ static int launch_loss_bwd(BwdArgs a, float *out, float *scratch, hipStream_t s)
     return 0;
   };
   if (loss_bwd_fast_ok(a)) {
+    const bool split_scores = loss_split_enabled(a.c);           // HSGK_LOSS=fp32: fp32 scores, as the forward
     auto gof = [&](auto kern, int M) -> int {
-      const size_t lds = (size_t)2 * 16 * (64 * M + 4) * 4 + 2 * (3 * 16 * 8 + 16 * 8 + 3 * 16 * 16 + 16 * 4);
+      const size_t lds = (size_t)2 * 16 * (64 * M + 4) * 4 + 2 * (3 * 16 * 8 + 16 * 8 + 3 * 16 * 16 + 16 * 4) +
+                         (split_scores ? (size_t)2 * 2 * 16 * (64 * M + 8) * 2 : 0);
       HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kern, dim3((unsigned)((a.n_owner + 127) / 128), split), dim3(512), lds, s, a);
@@ -913,9 +963,12 @@ static int launch_loss_bwd(BwdArgs a, float *out, float *scratch, hipStream_t s)
     };
     int rcf;
 #define HSGK_BWD_FAST(MV)                                                                           \
-  rcf = a.ls.L == 1   ? gof(loss_bwd_fast_kernel<MV, 1, OWNER_PX>, MV)                              \
-        : a.ls.L == 2 ? gof(loss_bwd_fast_kernel<MV, 2, OWNER_PX>, MV)                              \
-                      : gof(loss_bwd_fast_kernel<MV, 3, OWNER_PX>, MV)
+  rcf = split_scores ? (a.ls.L == 1   ? gof(loss_bwd_fast_kernel<MV, 1, OWNER_PX, true>, MV)        \
+                        : a.ls.L == 2 ? gof(loss_bwd_fast_kernel<MV, 2, OWNER_PX, true>, MV)        \
+                                      : gof(loss_bwd_fast_kernel<MV, 3, OWNER_PX, true>, MV))       \
+                     : (a.ls.L == 1   ? gof(loss_bwd_fast_kernel<MV, 1, OWNER_PX, false>, MV)       \
+                        : a.ls.L == 2 ? gof(loss_bwd_fast_kernel<MV, 2, OWNER_PX, false>, MV)       \
+                                      : gof(loss_bwd_fast_kernel<MV, 3, OWNER_PX, false>, MV))
     if (a.c == 64) HSGK_BWD_FAST(1);
     else if (a.c == 128) HSGK_BWD_FAST(2);
     else HSGK_BWD_FAST(4);
