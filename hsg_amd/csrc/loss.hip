@@ -669,8 +669,8 @@ __global__ __launch_bounds__(512, 2) void loss_bwd_fast_kernel(BwdArgs a) {
   constexpr int QS = CP / 16;
   constexpr int kMetaBytes = 3 * 16 * 8 + 16 * 8 + 3 * 16 * 16 + 16 * 4;     // labels, group, weights, instance
   extern __shared__ __attribute__((aligned(16))) float lds_fast[];
-  float *tbuf = lds_fast;                                                       // [2][16][RS]
-  unsigned char *mbase = reinterpret_cast<unsigned char *>(lds_fast + 2 * 16 * RS);
+  float *tbuf = lds_fast;                                                       // [3][16][RS]
+  unsigned char *mbase = reinterpret_cast<unsigned char *>(lds_fast + 3 * 16 * RS);
   uint16_t *hbuf = reinterpret_cast<uint16_t *>(mbase + 2 * kMetaBytes);        // [2][hi, lo][16][RSH]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -767,8 +767,8 @@ __global__ __launch_bounds__(512, 2) void loss_bwd_fast_kernel(BwdArgs a) {
       }
     }
   };
-  auto store_block = [&](int buf) {
-    float *dst = tbuf + buf * (16 * RS);
+  auto store_block = [&](int tile, int buf) {
+    float *dst = tbuf + tile * (16 * RS);
 #pragma unroll
     for (int u = 0; u < L4; ++u) {
       const int f = tid + NT * u;
@@ -797,18 +797,41 @@ __global__ __launch_bounds__(512, 2) void loss_bwd_fast_kernel(BwdArgs a) {
     }
   };
 
+  // second contraction: G[ch][o] += sum_t T[t][ch] W[t][o], k-step r = streamed rows 4 g + r
+  auto second = [&](const float *tile, const f32x4 &wt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float *tp = tile + (4 * g + r) * RS + 4 * j;
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const float4 t4 = *reinterpret_cast<const float4 *>(tp + 64 * m);
+        gacc[4 * m] = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.x, wt[r], gacc[4 * m], 0, 0, 0);
+        gacc[4 * m + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.y, wt[r], gacc[4 * m + 1], 0, 0, 0);
+        gacc[4 * m + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.z, wt[r], gacc[4 * m + 2], 0, 0, 0);
+        gacc[4 * m + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.w, wt[r], gacc[4 * m + 3], 0, 0, 0);
+      }
+    }
+  };
+  // Waves w and w + 4 share a SIMD and meet at every block's barrier: run in the same order they would both
+  // want the matrix pipe, then both the vector ALU (W epilogue, staging) while the pipe idles.  The late half
+  // of the workgroup therefore carries its W one block: it runs the second contraction of block b - 1 at the
+  // START of block b, under the early wave's epilogue, and its own epilogue under the early wave's second
+  // contraction (three fp32 tile buffers keep block b - 1 alive).
+  const bool late = __builtin_amdgcn_readfirstlane(w) >= 4;
+  f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+  int tcur = 0, tprev = 0;
   if (b_begin < b_end) {
     load_block(b_begin);
-    store_block(0);
+    store_block(0, 0);
   }
   for (int64_t b = b_begin; b < b_end; ++b) {
     const int buf = (int)((b - b_begin) & 1);
-    __syncthreads();                                // buffer `buf` is complete
+    __syncthreads();                                // block b is staged
     if (b + 1 < b_end) load_block(b + 1);          // in flight during the MFMAs below
-    const float *tb = tbuf + buf * (16 * RS);
+    const float *tb = tbuf + tcur * (16 * RS);
+    if (late && b > b_begin) second(tbuf + tprev * (16 * RS), sacc);
 
     // ---- score tile S[t][o]: lane (j, g) register r <-> streamed row 4 g + r, owner row j
-    f32x4 sacc;
     if constexpr (SPLIT) {
       f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, s3 = {0.f, 0.f, 0.f, 0.f};
       const uint16_t *hp = hbuf + buf * (2 * 16 * RSH) + j * RSH + 8 * g;
@@ -870,21 +893,13 @@ __global__ __launch_bounds__(512, 2) void loss_bwd_fast_kernel(BwdArgs a) {
         sacc[r] = live ? wv : 0.0f;
       }
     }
-    // ---- second contraction: G[ch][o] += sum_t T[t][ch] W[t][o], k-step r = streamed rows 4 g + r
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float *tp = tb + (4 * g + r) * RS + 4 * j;
-#pragma unroll
-      for (int m = 0; m < M; ++m) {
-        const float4 t4 = *reinterpret_cast<const float4 *>(tp + 64 * m);
-        gacc[4 * m] = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.x, sacc[r], gacc[4 * m], 0, 0, 0);
-        gacc[4 * m + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.y, sacc[r], gacc[4 * m + 1], 0, 0, 0);
-        gacc[4 * m + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.z, sacc[r], gacc[4 * m + 2], 0, 0, 0);
-        gacc[4 * m + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.w, sacc[r], gacc[4 * m + 3], 0, 0, 0);
-      }
-    }
-    if (b + 1 < b_end) store_block(buf ^ 1);
+    if (!late) second(tb, sacc);
+    const int tnext = tcur == 2 ? 0 : tcur + 1;
+    if (b + 1 < b_end) store_block(tnext, buf ^ 1);
+    tprev = tcur;
+    tcur = tnext;
   }
+  if (late && b_begin < b_end) second(tbuf + tprev * (16 * RS), sacc);
 
   // ---- partial output: gacc[4 m + v][e] of lane (j, g) is G[channel 64 m + 16 g + 4 e + v][o = j]
   if (o_valid) {
@@ -953,7 +968,7 @@ static int launch_loss_bwd(BwdArgs a, float *out, float *scratch, hipStream_t s)
   if (loss_bwd_fast_ok(a)) {
     const bool split_scores = loss_split_enabled(a.c);           // HSGK_LOSS=fp32: fp32 scores, as the forward
     auto gof = [&](auto kern, int M) -> int {
-      const size_t lds = (size_t)2 * 16 * (64 * M + 4) * 4 + 2 * (3 * 16 * 8 + 16 * 8 + 3 * 16 * 16 + 16 * 4) +
+      const size_t lds = (size_t)3 * 16 * (64 * M + 4) * 4 + 2 * (3 * 16 * 8 + 16 * 8 + 3 * 16 * 16 + 16 * 4) +
                          (split_scores ? (size_t)2 * 2 * 16 * (64 * M + 8) * 2 : 0);
       HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
