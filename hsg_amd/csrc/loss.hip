@@ -408,22 +408,36 @@ static int launch_loss_tiles(const float *emb, int64_t N, int c, const float *pr
 // loss.py:71-78 / 118-127).  With the upstream gradient g and s_p = exp(kappa e.p):
 //   W[i][p] = sum over sets of  s_p * (a_p * A + (same_p ? 0 : B)),
 //   A = g kappa (1/den - 1/num),  B = g kappa / den.
-struct PxMeta { float A, B; int32_t plus_us; int32_t pad; };      // [L][N]
+// sg: sum over the sets of |g kappa| of the pixel -- the bound of |W| its row / column of the backward's W
+// matrix obeys wherever x_p <= num (every case but the fp32-cancelled 'segsort+' numerators): the scale of the
+// fp16 second contraction (loss_bwd_h16_kernel)
+struct PxMeta { float A, B; int32_t plus_us; float sg; };      // [L][N]
 
 __global__ void loss_bwd_prep_kernel(const float *__restrict__ num, const float *__restrict__ den,
                                      const int32_t *__restrict__ use_same, const float *__restrict__ gscale,
-                                     int64_t N, LossSets ls, PxMeta *__restrict__ meta) {
+                                     int64_t N, LossSets ls, PxMeta *__restrict__ meta,
+                                     uint32_t *__restrict__ sg_max) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= N) return;
-  for (int l = 0; l < ls.L; ++l) {
-    const int64_t i = (int64_t)l * N + r;
-    const float gs = gscale[i] * ls.kappa[l];
-    const float inv_num = 1.0f / num[i], inv_den = 1.0f / den[i];
-    // a pixel without upstream gradient (masked out by the caller: its own prototype may be outside its
-    // group, num = 0) contributes exactly nothing
-    meta[i] = gs == 0.0f ? PxMeta{0.0f, 0.0f, 0, 0}
-                         : PxMeta{gs * (inv_den - inv_num), gs * inv_den, (ls.plus[l] && use_same[i]) ? 1 : 0, 0};
+  float sg = 0.0f;
+  if (r < N) {
+    for (int l = 0; l < ls.L; ++l) sg += fabsf(gscale[(int64_t)l * N + r] * (l == 0 ? ls.kappa[0] : l == 1 ? ls.kappa[1] : ls.kappa[2]));
+    if (!(sg < 3.0e38f)) sg = 0.0f;                 // (inf / nan upstream: no scaling; the gradients are theirs anyway)
+    for (int l = 0; l < ls.L; ++l) {
+      const int64_t i = (int64_t)l * N + r;
+      const float gs = gscale[i] * (l == 0 ? ls.kappa[0] : l == 1 ? ls.kappa[1] : ls.kappa[2]);
+      const float inv_num = 1.0f / num[i], inv_den = 1.0f / den[i];
+      // a pixel without upstream gradient (masked out by the caller: its own prototype may be outside its
+      // group, num = 0) contributes exactly nothing
+      const int pl = l == 0 ? ls.plus[0] : l == 1 ? ls.plus[1] : ls.plus[2];
+      meta[i] = gs == 0.0f ? PxMeta{0.0f, 0.0f, 0, sg}
+                           : PxMeta{gs * (inv_den - inv_num), gs * inv_den, (pl && use_same[i]) ? 1 : 0, sg};
+    }
   }
+  // the largest sg of the launch (non-negative floats order as their bit patterns): one atomic per wave
+  float m = sg;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(sg_max, __float_as_uint(m));
 }
 
 struct BwdArgs {
@@ -433,6 +447,7 @@ struct BwdArgs {
   int c;
   const int64_t *inst;       // [N]
   const PxMeta *meta;        // [L][N]
+  const uint32_t *sg_max;    // bits of the largest PxMeta::sg of the launch
   LossSets ls;
   float *out;                // [split][n_owner][c]
   int split, blocks_per_split;
@@ -491,7 +506,7 @@ __global__ __launch_bounds__(NW * 64) void loss_bwd_kernel(BwdArgs a) {
   for (int i = 0; i < kLabSlots; ++i) o_lab[i] = 0;
 #pragma unroll
   for (int l = 0; l < kMaxSets; ++l) {
-    o_px[l] = PxMeta{0.f, 0.f, 0, 0};
+    o_px[l] = PxMeta{0.f, 0.f, 0, 0.f};
     if (l < L) {
       load_labels(a.ls, !OWNER_PX, l, o_ld, o_lab);
       if constexpr (OWNER_PX) o_px[l] = a.meta[(int64_t)l * a.N + o_ld];
@@ -543,7 +558,7 @@ __global__ __launch_bounds__(NW * 64) void loss_bwd_kernel(BwdArgs a) {
         int64_t labw[kLabSlots];
 #pragma unroll
         for (int i = 0; i < kLabSlots; ++i) labw[i] = 0;
-        PxMeta pm = PxMeta{0.f, 0.f, 0, 0};
+        PxMeta pm = PxMeta{0.f, 0.f, 0, 0.f};
         if (t < a.n_stream) {
           load_labels(a.ls, OWNER_PX, l, t, labw);
           if constexpr (!OWNER_PX) pm = a.meta[(int64_t)l * a.N + t];
@@ -913,6 +928,299 @@ __global__ __launch_bounds__(512, 2) void loss_bwd_fast_kernel(BwdArgs a) {
   }
 }
 
+
+// ---- backward tile with BOTH contractions on the fp16 matrix pipe ---------------------------------------------
+// (plain labels, c = 64 M; 32-row streamed blocks.)  The fast tile above leaves the second contraction --
+// G[ch][o] += sum_t T[t][ch] W[t][o], half the flops -- on v_mfma_f32_16x16x4_f32: 64 x 32 cycles per 16 streamed
+// rows against 24 x 17 for the split score contraction, i.e. 5/6 of the matrix-pipe time.  Here it runs as
+// v_mfma_f32_16x16x32_f16 over k = 32 streamed rows:
+//   * A operand (T transposed): ds_read_b64_tr_b16 straight from the row-major hi / lo planes the score
+//     contraction reads -- a 16-lane group hands in the addresses of a [4 rows][16 channels] block and each lane
+//     receives one channel's four rows (tools/probes/tr_read_probe.hip) -- so k-slot (g, i) of the MFMA is
+//     streamed row 4 g + i (i < 4) or 16 + 4 g + i - 4: exactly the rows whose scores lane group g holds after
+//     the two 16 x 16 score tiles.  No transposed copy, no shuffle.
+//   * B operand (W): the lane's own eight W values, scaled by a power of two sigma so that the bound of |W|
+//     (PxMeta::sg; per owner pixel, or the launch maximum when pixels are streamed) sits at 2^8..2^9 -- far from
+//     fp16's 65504 (values beyond +-6e4 are clamped: only an fp32-cancelled numerator, whose gradient is noise in
+//     the reference itself, gets there) and with hi = fp16(w), lo = fp16(w - hi) both normal numbers.
+//   * T = Thi + 2^-11 Tlo (the forward's scaled split), W = Whi + Wlo:
+//       T W ~= Thi Whi + Thi Wlo + Tlo (2^-11 Whi)      (2^-11 Whi exact in fp16; the dropped Tlo Wlo is 2^-22)
+//     into ONE accumulator set, 3 MFMAs of ~17 cycles per 16 channels and 32 streamed rows; G / sigma at the end.
+//   Per 32 streamed rows a wave now spends 48 + 48 MFMAs x 17 cycles where the fast tile spends 2 x 2 456: the
+//   W epilogue on the vector ALU is what the two waves of a SIMD overlap with (the late / early split below).
+typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 lds_h16x4;
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+
+template <int M, int L, bool OWNER_PX>
+__global__ __launch_bounds__(512, 2) void loss_bwd_h16_kernel(BwdArgs a) {
+  constexpr int CP = 64 * M, NT = 512, OT = 128, BR = 32;
+  constexpr int RSH = CP + 16;                // plane row stride (halfs): 2 CP + 32 bytes = 8 dwords mod 64
+  constexpr int KS2 = CP / 32;                // k-steps of the score contraction
+  constexpr int CT = CP / 16;                 // 16-channel output tiles
+  constexpr int F4 = BR * CP / 4;             // float4 per staged block
+  constexpr int L4 = (F4 + NT - 1) / NT;
+  constexpr int kPlane = BR * RSH;            // halfs per plane
+  constexpr int kMetaBytes = 3 * BR * 8 + BR * 8 + 3 * BR * 16 + BR * 4;
+  constexpr int kOffGrp = 3 * BR * 8, kOffPx = kOffGrp + BR * 8, kOffInst = kOffPx + 3 * BR * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_h16[];
+  uint16_t *hbuf = reinterpret_cast<uint16_t *>(lds_h16);                      // [3][hi, lo][BR][RSH]
+  unsigned char *mbase = lds_h16 + (size_t)3 * 2 * kPlane * 2;                  // [2][kMetaBytes]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int c = a.c;
+  const int64_t o_row = (int64_t)blockIdx.x * OT + w * 16 + j;
+  const bool o_valid = o_row < a.n_owner;
+  const int64_t o_ld = o_valid ? o_row : a.n_owner - 1;
+  const int sp = blockIdx.y;
+  const int64_t nblocks = (a.n_stream + BR - 1) / BR;
+  const int64_t b_begin = (int64_t)sp * a.blocks_per_split;
+  const int64_t b_end = min(nblocks, b_begin + a.blocks_per_split);
+  const bool grouped = a.ls.qgroup != nullptr;
+
+  // owner rows: B operand of the score contraction, O[o][32 s + 8 g + i] as fp16 hi / lo
+  h16x8 bh[KS2], blo[KS2];
+  {
+    const float *orow = a.owner + o_ld * c + 8 * g;
+#pragma unroll
+    for (int s = 0; s < KS2; ++s) {
+      const float4 v0 = *reinterpret_cast<const float4 *>(orow + 32 * s);
+      const float4 v1 = *reinterpret_cast<const float4 *>(orow + 32 * s + 4);
+      uint32_t h[4], lw[4];
+      f16s_split2(v0.x, v0.y, h[0], lw[0]);
+      f16s_split2(v0.z, v0.w, h[1], lw[1]);
+      f16s_split2(v1.x, v1.y, h[2], lw[2]);
+      f16s_split2(v1.z, v1.w, h[3], lw[3]);
+      bh[s] = __builtin_bit_cast(h16x8, uint4{h[0], h[1], h[2], h[3]});
+      blo[s] = __builtin_bit_cast(h16x8, uint4{lw[0], lw[1], lw[2], lw[3]});
+    }
+  }
+  int64_t o_lab[L];
+  float o_A[L], o_B[L];
+  int o_pu[L];
+  float sg = __uint_as_float(*a.sg_max);           // the scale bound: launch maximum, or the owner pixel's own
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    o_lab[l] = (OWNER_PX ? (l == 0 ? a.ls.sem[0] : l == 1 ? a.ls.sem[1] : a.ls.sem[2])
+                         : (l == 0 ? a.ls.psem[0] : l == 1 ? a.ls.psem[1] : a.ls.psem[2]))[o_ld];
+    o_A[l] = o_B[l] = 0.0f;
+    o_pu[l] = 0;
+    if constexpr (OWNER_PX) {
+      const PxMeta pm = a.meta[(int64_t)l * a.N + o_ld];
+      o_A[l] = pm.A; o_B[l] = pm.B; o_pu[l] = pm.plus_us;
+      if (l == 0) sg = pm.sg;
+    }
+  }
+  float sigma = 1.0f, inv_sigma = 1.0f;
+  if (sg > 0.0f && sg < 3.0e38f) {
+    int e;
+    (void)frexpf(sg, &e);                          // sg = m 2^e, m in [0.5, 1)
+    e = e < -100 ? -100 : e > 100 ? 100 : e;
+    sigma = ldexpf(1.0f, 9 - e);                   // sigma sg in [2^8, 2^9)
+    inv_sigma = ldexpf(1.0f, e - 9);
+  }
+  const int o_own = OWNER_PX ? (int)a.inst[o_ld] : (int)o_row;
+  const int64_t o_grp = grouped ? (OWNER_PX ? a.ls.qgroup[o_ld] : a.ls.pgroup[o_ld]) : 0;
+  const float k0 = a.ls.kappa[0], k1 = a.ls.kappa[L > 1 ? 1 : 0], k2 = a.ls.kappa[L > 2 ? 2 : 0];
+  const bool e1 = L > 1 && k1 != k0, e2 = L > 2 && k2 != k1;
+
+  f32x4 gacc[CT];
+#pragma unroll
+  for (int i = 0; i < CT; ++i) gacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // label / weight words of the streamed block: thread (ml, mrow) = (tid >> 5, tid & 31), tid < 128
+  const int ml = tid >> 5, mrow = tid & 31;
+  const int64_t *lab_src = nullptr;
+  if (ml == 0) lab_src = OWNER_PX ? a.ls.psem[0] : a.ls.sem[0];
+  else if (ml == 1 && L > 1) lab_src = OWNER_PX ? a.ls.psem[1] : a.ls.sem[1];
+  else if (ml == 2 && L > 2) lab_src = OWNER_PX ? a.ls.psem[2] : a.ls.sem[2];
+  else if (ml == 3 && grouped) lab_src = OWNER_PX ? a.ls.pgroup : a.ls.qgroup;
+  float4 pre[L4];
+  int64_t lab_pre = 0;
+  float4 px_pre = make_float4(0.f, 0.f, 0.f, 0.f);
+  int inst_pre = -1;
+  auto load_block = [&](int64_t b) {
+#pragma unroll
+    for (int u = 0; u < L4; ++u) {
+      const int f = tid + NT * u;
+      const int row = f / (CP / 4), c4 = (f - row * (CP / 4)) * 4;
+      const int64_t t = b * BR + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < F4 && t < a.n_stream) v = *reinterpret_cast<const float4 *>(a.stream + t * c + c4);
+      pre[u] = v;
+    }
+    if (tid < 128) {
+      const int64_t t = b * BR + mrow;
+      const bool ok = t < a.n_stream;
+      lab_pre = (ok && lab_src) ? lab_src[t] : 0;
+      if constexpr (!OWNER_PX) {
+        px_pre = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && ml < L) px_pre = *reinterpret_cast<const float4 *>(a.meta + (int64_t)ml * a.N + t);
+        inst_pre = (ok && ml == 3) ? (int)a.inst[t] : -1;
+      }
+    }
+  };
+  auto store_block = [&](int tile, int buf) {
+    uint16_t *dst = hbuf + tile * (2 * kPlane);
+#pragma unroll
+    for (int u = 0; u < L4; ++u) {
+      const int f = tid + NT * u;
+      const int row = f / (CP / 4), c4 = (f - row * (CP / 4)) * 4;
+      if (f < F4) {
+        uint32_t h0, h1, l0, l1;
+        f16s_split2(pre[u].x, pre[u].y, h0, l0);
+        f16s_split2(pre[u].z, pre[u].w, h1, l1);
+        uint16_t *hp = dst + row * RSH + c4;
+        *reinterpret_cast<uint2 *>(hp) = uint2{h0, h1};
+        *reinterpret_cast<uint2 *>(hp + kPlane) = uint2{l0, l1};
+      }
+    }
+    if (tid < 128) {
+      unsigned char *mb = mbase + buf * kMetaBytes;
+      if (ml < 3) {
+        reinterpret_cast<int64_t *>(mb)[ml * BR + mrow] = lab_pre;
+        if constexpr (!OWNER_PX) reinterpret_cast<float4 *>(mb + kOffPx)[ml * BR + mrow] = px_pre;
+      } else {
+        reinterpret_cast<int64_t *>(mb + kOffGrp)[mrow] = lab_pre;
+        if constexpr (!OWNER_PX) reinterpret_cast<int *>(mb + kOffInst)[mrow] = inst_pre;
+      }
+    }
+  };
+
+  // W of the lane's eight streamed rows as MFMA B operands: whi, wlo, whi 2^-11
+  h16x8 wh = {0, 0, 0, 0, 0, 0, 0, 0}, wl = wh, wh2 = wh;
+  auto pack_w = [&](const float (&wv)[8]) {
+    uint32_t ph[4], pl[4], p2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      f32x2 v = {wv[2 * q] * sigma, wv[2 * q + 1] * sigma};
+      v[0] = fminf(fmaxf(v[0], -6.0e4f), 6.0e4f);
+      v[1] = fminf(fmaxf(v[1], -6.0e4f), 6.0e4f);
+      const h16x2 h = __builtin_convertvector(v, h16x2);
+      const f32x2 r = v - __builtin_convertvector(h, f32x2);
+      const h16x2 lo = __builtin_convertvector(r, h16x2);
+      const h16x2 sc = {(_Float16)0.00048828125f, (_Float16)0.00048828125f};
+      const h16x2 h2 = h * sc;
+      ph[q] = __builtin_bit_cast(uint32_t, h);
+      pl[q] = __builtin_bit_cast(uint32_t, lo);
+      p2[q] = __builtin_bit_cast(uint32_t, h2);
+    }
+    wh = __builtin_bit_cast(h16x8, uint4{ph[0], ph[1], ph[2], ph[3]});
+    wl = __builtin_bit_cast(h16x8, uint4{pl[0], pl[1], pl[2], pl[3]});
+    wh2 = __builtin_bit_cast(h16x8, uint4{p2[0], p2[1], p2[2], p2[3]});
+  };
+  // second contraction of one staged block against the packed W
+  auto second = [&](const uint16_t *tile) {
+    // lane (g, p = j) hands in the address of rows 4 g + p / 4 (+ 16), channels 16 ct + 4 (p % 4) ...
+    const uint16_t *tp = tile + (4 * g + (j >> 2)) * RSH + 4 * (j & 3);
+    auto tr = [&](const uint16_t *q) {
+      return __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) lds_h16x4 *)(q));
+    };
+#pragma unroll
+    for (int c0 = 0; c0 < CT; c0 += 4) {
+      h16x8 ah[4], al[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint16_t *q = tp + 16 * (c0 + u);
+        const lds_h16x4 h0 = tr(q), h1 = tr(q + 16 * RSH), l0 = tr(q + kPlane), l1 = tr(q + kPlane + 16 * RSH);
+        ah[u] = __builtin_bit_cast(h16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+        al[u] = __builtin_bit_cast(h16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) gacc[c0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], wh, gacc[c0 + u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) gacc[c0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], wl, gacc[c0 + u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) gacc[c0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u], wh2, gacc[c0 + u], 0, 0, 0);
+    }
+  };
+
+  // waves w and w + 4 share a SIMD: the late half runs the second contraction of block b - 1 at the start of
+  // block b (see loss_bwd_fast_kernel)
+  const bool late = __builtin_amdgcn_readfirstlane(w) >= 4;
+  int tcur = 0, tprev = 0;
+  if (b_begin < b_end) {
+    load_block(b_begin);
+    store_block(0, 0);
+  }
+  for (int64_t b = b_begin; b < b_end; ++b) {
+    const int buf = (int)((b - b_begin) & 1);
+    __syncthreads();                                // block b is staged
+    if (b + 1 < b_end) load_block(b + 1);          // in flight during the MFMAs below
+    const uint16_t *tile = hbuf + tcur * (2 * kPlane);
+    if (late && b > b_begin) second(hbuf + tprev * (2 * kPlane));
+
+    // ---- two 16 x 16 score tiles: register r of lane (j, g) <-> streamed row 16 h + 4 g + r, owner row j
+    float wv[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, s3 = {0.f, 0.f, 0.f, 0.f};
+      const uint16_t *hp = tile + (16 * h + j) * RSH + 8 * g;
+#pragma unroll
+      for (int s = 0; s < KS2; ++s) {
+        const h16x8 ah = *reinterpret_cast<const h16x8 *>(hp + 32 * s);
+        const h16x8 al = *reinterpret_cast<const h16x8 *>(hp + kPlane + 32 * s);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[s], s1, 0, 0, 0);
+        s2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[s], s2, 0, 0, 0);
+        s3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, blo[s], s3, 0, 0, 0);
+      }
+      const f32x4 sc4 = s1 + (s2 + s3) * (1.0f / 2048.0f);
+      // ---- W
+      const unsigned char *mb = mbase + buf * kMetaBytes;
+      const int64_t *bl = reinterpret_cast<const int64_t *>(mb);
+      const int64_t *bg = reinterpret_cast<const int64_t *>(mb + kOffGrp);
+      const PxMeta *bp = reinterpret_cast<const PxMeta *>(mb + kOffPx);
+      const int *bi = reinterpret_cast<const int *>(mb + kOffInst);
+      const int t0 = (int)(b * BR);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tr_ = 16 * h + 4 * g + r;
+        const float sc = sc4[r];
+        float x[3];
+        x[0] = expf(sc * k0);
+        x[1] = e1 ? expf(sc * k1) : x[0];
+        x[2] = e2 ? expf(sc * k2) : x[1];
+        bool own;
+        if constexpr (OWNER_PX) own = o_own == t0 + tr_; else own = bi[tr_] == o_own;
+        float acc = 0.0f;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+          const bool same = bl[l * BR + tr_] == o_lab[l];
+          float A = o_A[l], B = o_B[l];
+          int pu = o_pu[l];
+          if constexpr (!OWNER_PX) {
+            const PxMeta pm = bp[l * BR + tr_];
+            A = pm.A; B = pm.B; pu = pm.plus_us;
+          }
+          const float av = pu ? (float)((int)same - (int)own) : (own ? 1.0f : 0.0f);
+          acc += x[l] * (av * A + (same ? 0.0f : B));
+        }
+        bool live = o_valid && (int64_t)(t0 + tr_) < a.n_stream;
+        if (grouped) live = live && bg[tr_] == o_grp;
+        wv[4 * h + r] = live ? acc : 0.0f;
+      }
+    }
+    pack_w(wv);
+    if (!late) second(tile);
+    const int tnext = tcur == 2 ? 0 : tcur + 1;
+    if (b + 1 < b_end) store_block(tnext, buf ^ 1);
+    tprev = tcur;
+    tcur = tnext;
+  }
+  if (late && b_begin < b_end) second(hbuf + tprev * (2 * kPlane));
+
+  // ---- partial output: gacc[ct][e] of lane (j, g) is sigma G[channel 16 ct + 4 g + e][o = j]
+  if (o_valid) {
+    float *orow = a.out + ((int64_t)sp * a.n_owner + o_row) * c + 4 * g;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+      *reinterpret_cast<float4 *>(orow + 16 * ct) = make_float4(gacc[ct][0] * inv_sigma, gacc[ct][1] * inv_sigma,
+                                                                 gacc[ct][2] * inv_sigma, gacc[ct][3] * inv_sigma);
+  }
+}
+
 static bool loss_bwd_fast_ok(const BwdArgs &a) {
   const char *e = getenv("HSGK_LOSS_BWD");             // "generic": the general tile for every shape
   if (e && e[0] == 'g') return false;
@@ -967,6 +1275,30 @@ static int launch_loss_bwd(BwdArgs a, float *out, float *scratch, hipStream_t s)
   };
   if (loss_bwd_fast_ok(a)) {
     const bool split_scores = loss_split_enabled(a.c);           // HSGK_LOSS=fp32: fp32 scores, as the forward
+    const char *bwd_env = getenv("HSGK_LOSS_BWD");               // "mixed": fp16 scores, fp32 second contraction
+    if (split_scores && !(bwd_env && bwd_env[0] == 'm')) {
+      const int64_t blocks32 = (a.n_stream + 31) / 32;
+      a.blocks_per_split = (int)((blocks32 + split - 1) / split);
+      auto goh = [&](auto kern, int M) -> int {
+        const size_t lds = (size_t)3 * 2 * 32 * (64 * M + 16) * 2 + 2 * (3 * 32 * 8 + 32 * 8 + 3 * 32 * 16 + 32 * 4);
+        HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)((a.n_owner + 127) / 128), split), dim3(512), lds, s, a);
+        HSGK_LAUNCH_CHECK();
+        return 0;
+      };
+      int rch;
+#define HSGK_BWD_H16(MV)                                                                            \
+  rch = a.ls.L == 1   ? goh(loss_bwd_h16_kernel<MV, 1, OWNER_PX>, MV)                               \
+        : a.ls.L == 2 ? goh(loss_bwd_h16_kernel<MV, 2, OWNER_PX>, MV)                               \
+                      : goh(loss_bwd_h16_kernel<MV, 3, OWNER_PX>, MV)
+      if (a.c == 64) HSGK_BWD_H16(1);
+      else if (a.c == 128) HSGK_BWD_H16(2);
+      else HSGK_BWD_H16(4);
+#undef HSGK_BWD_H16
+      if (rch) return rch;
+      return finish_split();
+    }
     auto gof = [&](auto kern, int M) -> int {
       const size_t lds = (size_t)3 * 16 * (64 * M + 4) * 4 + 2 * (3 * 16 * 8 + 16 * 8 + 3 * 16 * 16 + 16 * 4) +
                          (split_scores ? (size_t)2 * 2 * 16 * (64 * M + 8) * 2 : 0);
@@ -1091,6 +1423,7 @@ int hsgk_segsort_loss_fwd(const float *emb, int64_t n, int c, const int64_t *ins
 size_t hsgk_segsort_loss_bwd_workspace_bytes(int64_t n, int c, int64_t P, int L) {
   Carver cv(nullptr);
   cv.take<PxMeta>((size_t)(L > 0 ? L : 1) * (size_t)(n > 0 ? n : 1));
+  cv.take<uint32_t>(64);
   const size_t a = (size_t)bwd_split_for(n, P, c) * (size_t)(n > 0 ? n : 1) * c;
   const size_t b = (size_t)bwd_split_for(P, n, c) * (size_t)(P > 0 ? P : 1) * c;
   cv.take<float>(a > b ? a : b);
@@ -1114,12 +1447,14 @@ int hsgk_segsort_loss_bwd(const float *emb, int64_t n, int c, const int64_t *ins
   }
   Carver cv(workspace);
   PxMeta *meta = cv.take<PxMeta>((size_t)L * n);
+  uint32_t *sg_max = cv.take<uint32_t>(64);
   float *scratch = reinterpret_cast<float *>(cv.base + cv.off);
+  HSGK_CHECK_HIP(hipMemsetAsync(sg_max, 0, sizeof(uint32_t), s));
   hipLaunchKernelGGL(loss_bwd_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, num, den,
-                     use_same, gscale, n, ls, meta);
+                     use_same, gscale, n, ls, meta, sg_max);
   HSGK_LAUNCH_CHECK();
   BwdArgs a{};
-  a.N = n; a.P = P; a.c = c; a.inst = inst; a.meta = meta; a.ls = ls;
+  a.N = n; a.P = P; a.c = c; a.inst = inst; a.meta = meta; a.sg_max = sg_max; a.ls = ls;
   if (g_emb) {
     a.owner = emb; a.stream = proto; a.n_owner = n; a.n_stream = P;
     if (int rc = launch_loss_bwd<true>(a, g_emb, scratch, s)) return rc;
