@@ -448,6 +448,7 @@ struct BwdArgs {
   const int64_t *inst;       // [N]
   const PxMeta *meta;        // [L][N]
   const uint32_t *sg_max;    // bits of the largest PxMeta::sg of the launch
+  const uint16_t *emb_hi, *emb_lo, *proto_hi, *proto_lo;     // scaled-split fp16 planes (loss_bwd_h16_kernel)
   LossSets ls;
   float *out;                // [split][n_owner][c]
   int split, blocks_per_split;
@@ -948,7 +949,38 @@ __global__ __launch_bounds__(512, 2) void loss_bwd_fast_kernel(BwdArgs a) {
 //     into ONE accumulator set, 3 MFMAs of ~17 cycles per 16 channels and 32 streamed rows; G / sigma at the end.
 //   Per 32 streamed rows a wave now spends 48 + 48 MFMAs x 17 cycles where the fast tile spends 2 x 2 456: the
 //   W epilogue on the vector ALU is what the two waves of a SIMD overlap with (the late / early split below).
+//   * the streamed matrix is re-read by every owner tile, so its hi / lo planes are made ONCE per launch by
+//     loss_planes_kernel (4 bytes per element of workspace) and staged by plain 16-byte copies: converting in the
+//     staging loop cost every workgroup ~70 vector instructions per block on the pipe that bounds the tile.
 typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 lds_h16x4;
+
+// rows [n][c] fp32 -> scaled-split fp16 planes hi, lo [n][c] (c % 8 == 0)
+__global__ void loss_planes_kernel(const float *__restrict__ x, int64_t total8, uint16_t *__restrict__ hi,
+                                   uint16_t *__restrict__ lo) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v0 = *reinterpret_cast<const float4 *>(x + 8 * i);
+    const float4 v1 = *reinterpret_cast<const float4 *>(x + 8 * i + 4);
+    uint32_t h[4], l[4];
+    f16s_split2(v0.x, v0.y, h[0], l[0]);
+    f16s_split2(v0.z, v0.w, h[1], l[1]);
+    f16s_split2(v1.x, v1.y, h[2], l[2]);
+    f16s_split2(v1.z, v1.w, h[3], l[3]);
+    *reinterpret_cast<uint4 *>(hi + 8 * i) = uint4{h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<uint4 *>(lo + 8 * i) = uint4{l[0], l[1], l[2], l[3]};
+  }
+}
+
+// exp(y) to ~2 ulp in six instructions: y log2(e) in two parts (product + its fma residual + the constant's low
+// part), v_exp_f32 of the head, first-order correction by the tail.  (expf's range handling -- overflow to inf,
+// denormal results -- is what the 12-instruction library sequence spends the rest on; beyond |y| ~ 87 both
+// saturate the same way through v_exp_f32.)
+__device__ __forceinline__ float exp_fast(float y) {
+  const float t = y * 1.4426950216293335f;
+  float r = fmaf(y, 1.4426950216293335f, -t);
+  r = fmaf(y, 1.92596298909109e-08f, r);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * 0.693147181f, e);
+}
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 
@@ -958,8 +990,8 @@ __global__ __launch_bounds__(512, 2) void loss_bwd_h16_kernel(BwdArgs a) {
   constexpr int RSH = CP + 16;                // plane row stride (halfs): 2 CP + 32 bytes = 8 dwords mod 64
   constexpr int KS2 = CP / 32;                // k-steps of the score contraction
   constexpr int CT = CP / 16;                 // 16-channel output tiles
-  constexpr int F4 = BR * CP / 4;             // float4 per staged block
-  constexpr int L4 = (F4 + NT - 1) / NT;
+  constexpr int F8 = 2 * BR * CP / 8;         // 16-byte pieces per staged block (both planes)
+  constexpr int L4 = (F8 + NT - 1) / NT;
   constexpr int kPlane = BR * RSH;            // halfs per plane
   constexpr int kMetaBytes = 3 * BR * 8 + BR * 8 + 3 * BR * 16 + BR * 4;
   constexpr int kOffGrp = 3 * BR * 8, kOffPx = kOffGrp + BR * 8, kOffInst = kOffPx + 3 * BR * 16;
@@ -970,6 +1002,8 @@ __global__ __launch_bounds__(512, 2) void loss_bwd_h16_kernel(BwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int c = a.c;
+  const uint16_t *s_hi = OWNER_PX ? a.proto_hi : a.emb_hi, *s_lo = OWNER_PX ? a.proto_lo : a.emb_lo;
+  const uint16_t *o_hi = OWNER_PX ? a.emb_hi : a.proto_hi, *o_lo = OWNER_PX ? a.emb_lo : a.proto_lo;
   const int64_t o_row = (int64_t)blockIdx.x * OT + w * 16 + j;
   const bool o_valid = o_row < a.n_owner;
   const int64_t o_ld = o_valid ? o_row : a.n_owner - 1;
@@ -981,20 +1015,10 @@ __global__ __launch_bounds__(512, 2) void loss_bwd_h16_kernel(BwdArgs a) {
 
   // owner rows: B operand of the score contraction, O[o][32 s + 8 g + i] as fp16 hi / lo
   h16x8 bh[KS2], blo[KS2];
-  {
-    const float *orow = a.owner + o_ld * c + 8 * g;
 #pragma unroll
-    for (int s = 0; s < KS2; ++s) {
-      const float4 v0 = *reinterpret_cast<const float4 *>(orow + 32 * s);
-      const float4 v1 = *reinterpret_cast<const float4 *>(orow + 32 * s + 4);
-      uint32_t h[4], lw[4];
-      f16s_split2(v0.x, v0.y, h[0], lw[0]);
-      f16s_split2(v0.z, v0.w, h[1], lw[1]);
-      f16s_split2(v1.x, v1.y, h[2], lw[2]);
-      f16s_split2(v1.z, v1.w, h[3], lw[3]);
-      bh[s] = __builtin_bit_cast(h16x8, uint4{h[0], h[1], h[2], h[3]});
-      blo[s] = __builtin_bit_cast(h16x8, uint4{lw[0], lw[1], lw[2], lw[3]});
-    }
+  for (int s = 0; s < KS2; ++s) {
+    bh[s] = *reinterpret_cast<const h16x8 *>(o_hi + o_ld * c + 8 * g + 32 * s);
+    blo[s] = *reinterpret_cast<const h16x8 *>(o_lo + o_ld * c + 8 * g + 32 * s);
   }
   int64_t o_lab[L];
   float o_A[L], o_B[L];
@@ -1036,18 +1060,21 @@ __global__ __launch_bounds__(512, 2) void loss_bwd_h16_kernel(BwdArgs a) {
   else if (ml == 1 && L > 1) lab_src = OWNER_PX ? a.ls.psem[1] : a.ls.sem[1];
   else if (ml == 2 && L > 2) lab_src = OWNER_PX ? a.ls.psem[2] : a.ls.sem[2];
   else if (ml == 3 && grouped) lab_src = OWNER_PX ? a.ls.pgroup : a.ls.qgroup;
-  float4 pre[L4];
+  uint4 pre[L4];
   int64_t lab_pre = 0;
   float4 px_pre = make_float4(0.f, 0.f, 0.f, 0.f);
   int inst_pre = -1;
+  // piece f of a block: plane f / (BR CP / 8), row, 8-half column group
   auto load_block = [&](int64_t b) {
 #pragma unroll
     for (int u = 0; u < L4; ++u) {
       const int f = tid + NT * u;
-      const int row = f / (CP / 4), c4 = (f - row * (CP / 4)) * 4;
+      const int pln = f / (BR * CP / 8), fr = f - pln * (BR * CP / 8);
+      const int row = fr / (CP / 8), c8 = (fr - row * (CP / 8)) * 8;
       const int64_t t = b * BR + row;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (f < F4 && t < a.n_stream) v = *reinterpret_cast<const float4 *>(a.stream + t * c + c4);
+      const int64_t tl = t < a.n_stream ? t : a.n_stream - 1;                   // (no divergent branch around the load)
+      uint4 v = *reinterpret_cast<const uint4 *>((pln ? s_lo : s_hi) + tl * c + c8);
+      if (t >= a.n_stream) v = uint4{0u, 0u, 0u, 0u};
       pre[u] = v;
     }
     if (tid < 128) {
@@ -1066,15 +1093,9 @@ __global__ __launch_bounds__(512, 2) void loss_bwd_h16_kernel(BwdArgs a) {
 #pragma unroll
     for (int u = 0; u < L4; ++u) {
       const int f = tid + NT * u;
-      const int row = f / (CP / 4), c4 = (f - row * (CP / 4)) * 4;
-      if (f < F4) {
-        uint32_t h0, h1, l0, l1;
-        f16s_split2(pre[u].x, pre[u].y, h0, l0);
-        f16s_split2(pre[u].z, pre[u].w, h1, l1);
-        uint16_t *hp = dst + row * RSH + c4;
-        *reinterpret_cast<uint2 *>(hp) = uint2{h0, h1};
-        *reinterpret_cast<uint2 *>(hp + kPlane) = uint2{l0, l1};
-      }
+      const int pln = f / (BR * CP / 8), fr = f - pln * (BR * CP / 8);
+      const int row = fr / (CP / 8), c8 = (fr - row * (CP / 8)) * 8;
+      if (F8 % NT == 0 || f < F8) *reinterpret_cast<uint4 *>(dst + pln * kPlane + row * RSH + c8) = pre[u];
     }
     if (tid < 128) {
       unsigned char *mb = mbase + buf * kMetaBytes;
@@ -1179,9 +1200,9 @@ __global__ __launch_bounds__(512, 2) void loss_bwd_h16_kernel(BwdArgs a) {
         const int tr_ = 16 * h + 4 * g + r;
         const float sc = sc4[r];
         float x[3];
-        x[0] = expf(sc * k0);
-        x[1] = e1 ? expf(sc * k1) : x[0];
-        x[2] = e2 ? expf(sc * k2) : x[1];
+        x[0] = exp_fast(sc * k0);
+        x[1] = e1 ? exp_fast(sc * k1) : x[0];
+        x[2] = e2 ? exp_fast(sc * k2) : x[1];
         bool own;
         if constexpr (OWNER_PX) own = o_own == t0 + tr_; else own = bi[tr_] == o_own;
         float acc = 0.0f;
@@ -1197,9 +1218,10 @@ __global__ __launch_bounds__(512, 2) void loss_bwd_h16_kernel(BwdArgs a) {
           const float av = pu ? (float)((int)same - (int)own) : (own ? 1.0f : 0.0f);
           acc += x[l] * (av * A + (same ? 0.0f : B));
         }
-        bool live = o_valid && (int64_t)(t0 + tr_) < a.n_stream;
-        if (grouped) live = live && bg[tr_] == o_grp;
-        wv[4 * h + r] = live ? acc : 0.0f;
+        // (streamed rows past the end are zero rows of the planes and owner rows past the end are never stored:
+        //  their W needs no masking; a group mismatch does)
+        if (grouped) acc = bg[tr_] == o_grp ? acc : 0.0f;
+        wv[4 * h + r] = acc;
       }
     }
     pack_w(wv);
@@ -1221,14 +1243,23 @@ __global__ __launch_bounds__(512, 2) void loss_bwd_h16_kernel(BwdArgs a) {
   }
 }
 
+static bool loss_bwd_planes_shape(int c) { return c == 64 || c == 128 || c == 256; }
+
 static bool loss_bwd_fast_ok(const BwdArgs &a) {
   const char *e = getenv("HSGK_LOSS_BWD");             // "generic": the general tile for every shape
   if (e && e[0] == 'g') return false;
-  if (a.c != 64 && a.c != 128 && a.c != 256) return false;
-  if (a.ls.words != 1 || a.n_stream >= (int64_t)1 << 31 || a.n_owner >= (int64_t)1 << 31) return false;
+  if (!loss_bwd_planes_shape(a.c)) return false;
+  if (a.ls.words != 1 || a.N >= (int64_t)1 << 31 || a.P >= (int64_t)1 << 31) return false;
   for (int l = 0; l < a.ls.L; ++l)
     if (a.ls.setm[l]) return false;
   return true;
+}
+
+// both contractions on the fp16 pipe (HSGK_LOSS_BWD=mixed: fp16 scores, fp32 second contraction;
+// HSGK_LOSS=fp32: everything fp32, as the forward)
+static bool loss_bwd_h16_selected(const BwdArgs &a) {
+  const char *e = getenv("HSGK_LOSS_BWD");
+  return loss_bwd_fast_ok(a) && loss_split_enabled(a.c) && !(e && e[0] == 'm');
 }
 
 // out[i] = sum over splits (split order) of part[s][i]
@@ -1275,8 +1306,7 @@ static int launch_loss_bwd(BwdArgs a, float *out, float *scratch, hipStream_t s)
   };
   if (loss_bwd_fast_ok(a)) {
     const bool split_scores = loss_split_enabled(a.c);           // HSGK_LOSS=fp32: fp32 scores, as the forward
-    const char *bwd_env = getenv("HSGK_LOSS_BWD");               // "mixed": fp16 scores, fp32 second contraction
-    if (split_scores && !(bwd_env && bwd_env[0] == 'm')) {
+    if (loss_bwd_h16_selected(a)) {
       const int64_t blocks32 = (a.n_stream + 31) / 32;
       a.blocks_per_split = (int)((blocks32 + split - 1) / split);
       auto goh = [&](auto kern, int M) -> int {
@@ -1424,6 +1454,10 @@ size_t hsgk_segsort_loss_bwd_workspace_bytes(int64_t n, int c, int64_t P, int L)
   Carver cv(nullptr);
   cv.take<PxMeta>((size_t)(L > 0 ? L : 1) * (size_t)(n > 0 ? n : 1));
   cv.take<uint32_t>(64);
+  if (loss_bwd_planes_shape(c)) {
+    cv.take<uint16_t>((size_t)2 * (n > 0 ? n : 1) * c);
+    cv.take<uint16_t>((size_t)2 * (P > 0 ? P : 1) * c);
+  }
   const size_t a = (size_t)bwd_split_for(n, P, c) * (size_t)(n > 0 ? n : 1) * c;
   const size_t b = (size_t)bwd_split_for(P, n, c) * (size_t)(P > 0 ? P : 1) * c;
   cv.take<float>(a > b ? a : b);
@@ -1448,6 +1482,11 @@ int hsgk_segsort_loss_bwd(const float *emb, int64_t n, int c, const int64_t *ins
   Carver cv(workspace);
   PxMeta *meta = cv.take<PxMeta>((size_t)L * n);
   uint32_t *sg_max = cv.take<uint32_t>(64);
+  uint16_t *emb_pl = nullptr, *proto_pl = nullptr;
+  if (loss_bwd_planes_shape(c)) {
+    emb_pl = cv.take<uint16_t>((size_t)2 * n * c);
+    proto_pl = cv.take<uint16_t>((size_t)2 * P * c);
+  }
   float *scratch = reinterpret_cast<float *>(cv.base + cv.off);
   HSGK_CHECK_HIP(hipMemsetAsync(sg_max, 0, sizeof(uint32_t), s));
   hipLaunchKernelGGL(loss_bwd_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, num, den,
@@ -1455,6 +1494,17 @@ int hsgk_segsort_loss_bwd(const float *emb, int64_t n, int c, const int64_t *ins
   HSGK_LAUNCH_CHECK();
   BwdArgs a{};
   a.N = n; a.P = P; a.c = c; a.inst = inst; a.meta = meta; a.sg_max = sg_max; a.ls = ls;
+  if (loss_bwd_h16_selected(a)) {
+    a.emb_hi = emb_pl; a.emb_lo = emb_pl + (size_t)n * c;
+    a.proto_hi = proto_pl; a.proto_lo = proto_pl + (size_t)P * c;
+    const int64_t e8 = n * c / 8, p8 = P * c / 8;
+    hipLaunchKernelGGL(loss_planes_kernel, dim3((unsigned)((e8 + 255) / 256 > 8192 ? 8192 : (e8 + 255) / 256)), dim3(256), 0,
+                       s, emb, e8, const_cast<uint16_t *>(a.emb_hi), const_cast<uint16_t *>(a.emb_lo));
+    HSGK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_planes_kernel, dim3((unsigned)((p8 + 255) / 256 > 8192 ? 8192 : (p8 + 255) / 256)), dim3(256), 0,
+                       s, proto, p8, const_cast<uint16_t *>(a.proto_hi), const_cast<uint16_t *>(a.proto_lo));
+    HSGK_LAUNCH_CHECK();
+  }
   if (g_emb) {
     a.owner = emb; a.stream = proto; a.n_owner = n; a.n_stream = P;
     if (int rc = launch_loss_bwd<true>(a, g_emb, scratch, s)) return rc;
