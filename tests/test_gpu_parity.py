@@ -608,6 +608,81 @@ def test_segsort_loss_at_training_and_benchmark_scale(dev, oracle, monkeypatch, 
     assert (np.abs(got - want) <= 1e-5 * np.maximum(10.0, cond[idx].cpu().numpy())).all()
 
 
+@pytest.mark.parametrize('c', [64, 128, 256])
+@pytest.mark.parametrize('route', ['h16', 'mixed', 'fast32', 'generic'])
+def test_loss_backward_routes_vs_float64(dev, oracle, monkeypatch, c, route):
+  """The four backward tiles of loss.hip -- both contractions on the fp16 pipe (default), fp16 scores + fp32
+  second contraction (HSGK_LOSS_BWD=mixed), all fp32 with wide operand reads (HSGK_LOSS=fp32), the general tile
+  (HSGK_LOSS_BWD=generic) -- for three label sets in one pass and for a grouped single set, ragged against the
+  16- / 32-row blocks, with per-pixel upstream gradients spanning six decades (the fp16 W operand is scaled per
+  owner pixel / by the launch maximum) and some exactly zero: both gradients against float64 autograd of the
+  reference formula."""
+  import torch
+  from hsg_amd.utils.segsort import loss as sl
+  if route == 'mixed': monkeypatch.setenv('HSGK_LOSS_BWD', 'mixed')
+  if route == 'generic': monkeypatch.setenv('HSGK_LOSS_BWD', 'generic')
+  if route == 'fast32': monkeypatch.setenv('HSGK_LOSS', 'fp32')
+  n, P = 2531, 333
+  e_np = oracle.normalize_embedding(synth.gaussish(171 + c, n * c).reshape(n, c))
+  p_np = oracle.normalize_embedding(synth.gaussish(172 + c, P * c).reshape(P, c))
+  T = lambda a: torch.from_numpy(a).to(dev)
+  inst = T((synth.hash_u64(173 + c, n) % np.uint64(P)).astype(np.int64))
+  sets = []
+  for i, (classes, kappa, mode) in enumerate(((5, 16.0, 'segsort+'), (P // 3, 10.0, 'segsort'), (2, 16.0, 'segsort+'))):
+    psem = T((synth.hash_u64(180 + i + c, P) % np.uint64(classes)).astype(np.int64))
+    sem = psem[inst].clone()
+    flip = T((synth.hash_u64(190 + i + c, n) % np.uint64(7) == 0))
+    sem[flip] = (sem[flip] + 1) % classes
+    sets.append((sem, psem, kappa, mode))
+  # upstream gradient per pixel: 1e-3 .. 1e3, every 11th pixel exactly zero
+  up = T(np.exp(np.log(10.0) * 3.0 * synth.gaussish(199 + c, n).clip(-1, 1)).astype(np.float32))
+  up[::11] = 0.0
+  # 'segsort+' pixels whose fp32 numerator same - own cancels (loss.py:63-66) are rounding noise in the reference
+  # itself (DESIGN.md section 7, a15): no upstream gradient for them, as in the scale test above
+  with torch.no_grad():
+    for sem_, psem_, kappa_, mode_ in sets:
+      if mode_ != 'segsort+': continue
+      for kk in (kappa_, 12.0):
+        sd = torch.exp(torch.mm(T(e_np).double(), T(p_np).double().t()) * kk)
+        own_ = torch.gather(sd, 1, inst.view(-1, 1)).view(-1)
+        same_ = (sd * (sem_.view(-1, 1) == psem_.view(1, -1))).sum(1)
+        up[(same_ + own_) / (same_ - own_).abs() >= 20.0] = 0.0
+  assert float((up > 0).float().mean()) > 0.4
+  for nsets in (1, 3):
+    e, pr = T(e_np).requires_grad_(True), T(p_np).requires_grad_(True)
+    nll = sl.segsort_losses(e, inst, pr, sets[:nsets], reduction='none')
+    sum((l.view(-1) * up).sum() * w for l, w in zip(nll, (1.0, 0.5, 2.0))).backward()
+    e2, p2 = T(e_np).double().requires_grad_(True), T(p_np).double().requires_grad_(True)
+    refs = [_ref_nll_torch(e2, s_, inst, p2, ps, k, m == 'segsort+') for s_, ps, k, m in sets[:nsets]]
+    sum((l * up.double()).sum() * w for l, w in zip(refs, (1.0, 0.5, 2.0))).backward()
+    for got, ref in ((e.grad, e2.grad), (pr.grad, p2.grad)):
+      scale = max(ref.abs().max().item(), 1e-9)
+      assert (got.double() - ref).abs().max().item() <= 1e-5 * scale, (nsets, (got.double() - ref).abs().max().item(), scale)
+    # per owner pixel: its gradient row against its own scale (six decades between rows)
+    rows = e2.grad.abs().amax(1)
+    err = (e.grad.double() - e2.grad).abs().amax(1)
+    assert (err <= 2e-5 * rows + 1e-30).all(), float((err / rows.clamp_min(1e-30)).max())
+    assert float(e.grad[up == 0].abs().max()) == 0.0
+  # grouped single set == float64 with the other groups' prototypes masked out of every sum
+  pg = T(np.sort((synth.hash_u64(201 + c, P) % np.uint64(3)).astype(np.int64)))
+  qg = pg[inst]
+  sem, psem = sets[0][0], sets[0][1]
+  e, pr = T(e_np).requires_grad_(True), T(p_np).requires_grad_(True)
+  nll = sl.segsort_nll(e, sem, inst, pr, psem, 12.0, 'segsort+', pixel_groups=qg, prototype_groups=pg)
+  (nll * up).sum().backward()
+  e2, p2 = T(e_np).double().requires_grad_(True), T(p_np).double().requires_grad_(True)
+  sim = torch.exp(torch.mm(e2, p2.t()) * 12.0) * (qg.view(-1, 1) == pg.view(1, -1)).double()
+  own = torch.gather(sim, 1, inst.view(-1, 1))
+  same = (sem.view(-1, 1) == psem.view(1, -1)).double()
+  sw = (sim * same).sum(1, keepdim=True) - own
+  num = torch.where(sw > 0, sw, own)
+  ref = -(num / ((sim * (1.0 - same)).sum(1, keepdim=True) + num)).log().view(-1)
+  (ref * up.double()).sum().backward()
+  for got, r in ((e.grad, e2.grad), (pr.grad, p2.grad)):
+    scale = max(r.abs().max().item(), 1e-9)
+    assert (got.double() - r).abs().max().item() <= 1e-5 * scale
+
+
 def test_grouped_loss_equals_per_group_tables(dev, oracle):
   """pixel / prototype groups of the loss kernels (include/hsgk.h): the grouped call == one plain call per group
   on the compacted rows (forward per-pixel nll vs the oracle, both gradients vs the plain GPU calls); a pixel
