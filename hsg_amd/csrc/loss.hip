@@ -1162,14 +1162,20 @@ __global__ __launch_bounds__(512, 2) void loss_bwd_h16_kernel(BwdArgs a) {
   // block b (see loss_bwd_fast_kernel)
   const bool late = __builtin_amdgcn_readfirstlane(w) >= 4;
   int tcur = 0, tprev = 0;
+  // per iteration: barrier, LDS stores of block b + 1 (its loads were issued an iteration ago; tile buffer
+  // (b + 1) % 3 was last read -- by the late waves -- before this barrier), loads of block b + 2 into the same
+  // registers, then the MFMAs (stores at the end of the iteration instead: same time within noise)
   if (b_begin < b_end) {
     load_block(b_begin);
     store_block(0, 0);
+    if (b_begin + 1 < b_end) load_block(b_begin + 1);
   }
   for (int64_t b = b_begin; b < b_end; ++b) {
     const int buf = (int)((b - b_begin) & 1);
+    const int tnext = tcur == 2 ? 0 : tcur + 1;
     __syncthreads();                                // block b is staged
-    if (b + 1 < b_end) load_block(b + 1);          // in flight during the MFMAs below
+    if (b + 1 < b_end) store_block(tnext, buf ^ 1);
+    if (b + 2 < b_end) load_block(b + 2);          // in flight during the MFMAs below
     const uint16_t *tile = hbuf + tcur * (2 * kPlane);
     if (late && b > b_begin) second(hbuf + tprev * (2 * kPlane));
 
@@ -1226,8 +1232,6 @@ __global__ __launch_bounds__(512, 2) void loss_bwd_h16_kernel(BwdArgs a) {
     }
     pack_w(wv);
     if (!late) second(tile);
-    const int tnext = tcur == 2 ? 0 : tcur + 1;
-    if (b + 1 < b_end) store_block(tnext, buf ^ 1);
     tprev = tcur;
     tcur = tnext;
   }
@@ -1242,6 +1246,7 @@ __global__ __launch_bounds__(512, 2) void loss_bwd_h16_kernel(BwdArgs a) {
                                                                  gacc[ct][2] * inv_sigma, gacc[ct][3] * inv_sigma);
   }
 }
+
 
 static bool loss_bwd_planes_shape(int c) { return c == 64 || c == 128 || c == 256; }
 
@@ -1415,9 +1420,11 @@ using namespace hsgk;
 extern "C" {
 
 size_t hsgk_segsort_loss_workspace_bytes(int64_t n, int c, int64_t P, int L) {
-  (void)c;
   const int64_t npb = (P + 63) / 64;
-  return (size_t)(npb > 0 ? npb : 1) * (size_t)(n > 0 ? n : 1) * 3 * (size_t)(L > 0 ? L : 1) * sizeof(float) + 256;
+  Carver cv(nullptr);
+  (void)c;
+  cv.take<float>((size_t)(npb > 0 ? npb : 1) * (size_t)(n > 0 ? n : 1) * 3 * (size_t)(L > 0 ? L : 1));
+  return cv.off + 256;
 }
 
 int hsgk_segsort_loss_fwd(const float *emb, int64_t n, int c, const int64_t *inst, const float *proto,
@@ -1432,18 +1439,19 @@ int hsgk_segsort_loss_fwd(const float *emb, int64_t n, int c, const int64_t *ins
   if (n == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   (void)hipGetLastError();
-  float *part = static_cast<float *>(workspace);
+  const int npb = (int)((P + 63) / 64);
+  Carver cv(workspace);
+  float *part = cv.take<float>((size_t)npb * n * 3 * L);
   bool plain = true;
   for (int l = 0; l < L; ++l) plain = plain && !ls.setm[l];
+  int plus_mask = 0;
+  for (int l = 0; l < L; ++l) plus_mask |= ls.plus[l] << l;
   int rc;
   if (plain && L == 1) rc = launch_loss_tiles(emb, n, c, proto, P, LossFwdEpiFast<1>{0, 0, 0, P, n, 0, inst, ls, part, nullptr, 0}, s);
   else if (plain && L == 2) rc = launch_loss_tiles(emb, n, c, proto, P, LossFwdEpiFast<2>{0, 0, 0, P, n, 0, inst, ls, part, nullptr, 0}, s);
   else if (plain) rc = launch_loss_tiles(emb, n, c, proto, P, LossFwdEpiFast<3>{0, 0, 0, P, n, 0, inst, ls, part, nullptr, 0}, s);
   else rc = launch_loss_tiles(emb, n, c, proto, P, LossFwdEpi{0, 0, 0, P, n, 0, inst, ls, part, nullptr, 0}, s);
   if (rc) return rc;
-  const int npb = (int)((P + 63) / 64);
-  int plus_mask = 0;
-  for (int l = 0; l < L; ++l) plus_mask |= ls.plus[l] << l;
   hipLaunchKernelGGL(loss_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, npb,
                      n, L, plus_mask, nll, num, den, use_same);
   HSGK_LAUNCH_CHECK();
