@@ -294,7 +294,7 @@ __global__ __launch_bounds__(NW * 64) void loss_tiles_kernel(
 // bf16x3 form, 16 significant bits, kept the loss within 1e-4 too but moved gradients by 2e-4 of their scale.)
 // The contract here is a tolerance, not bit-exactness; HSGK_LOSS=fp32 keeps the fp32 engine (needed for
 // values beyond fp16's range, |x| > 6e4).
-template <int NW, int DEPTH, class Epi>
+template <int NW, int DEPTH, class Epi, bool XPRE>
 __global__ __launch_bounds__(NW * 64) void loss_tiles_split_kernel(
     const float *__restrict__ emb, int c, const float *__restrict__ proto, int64_t P, int64_t N,
     int split, Epi epi_proto) {
@@ -325,8 +325,8 @@ __global__ __launch_bounds__(NW * 64) void loss_tiles_split_kernel(
   epi.blab = blab;
   epi.blab_off = (int)split_lds_bytes<NW>(c);
   const int kvalid = (int)((P - (int64_t)pb * KB) < KB ? (P - (int64_t)pb * KB) : KB);
-  score_tiles_split<NW, DEPTH, Epi, false, true>(emb, c, proto + (int64_t)pb * KB * c, kvalid, epi.crow0, nrows, lds_split,
-                                                 epi);
+  score_tiles_split<NW, DEPTH, Epi, false, true, XPRE>(emb, c, proto + (int64_t)pb * KB * c, kvalid, epi.crow0, nrows,
+                                                       lds_split, epi);
 }
 
 static bool loss_split_enabled(int c) {
@@ -334,6 +334,18 @@ static bool loss_split_enabled(int c) {
   if (e && e[0] == 'f') return false;
   return split_shape_ok(c) && split_lds_bytes<8>(c) + kLossBlockLabBytes <= 160 * 1024;
 }
+
+// fp32 rows -> the split engine's image of them: per column pair (hi pair, lo pair), 8 bytes where the two floats were
+__global__ void loss_pairs_kernel(const float *__restrict__ x, int64_t total2, uint2 *__restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total2; i += (int64_t)gridDim.x * blockDim.x) {
+    const float2 v = *reinterpret_cast<const float2 *>(x + 2 * i);
+    uint32_t hi, lo;
+    f16s_split2(v.x, v.y, hi, lo);
+    out[i] = uint2{hi, lo};
+  }
+}
+
+static bool loss_fwd_xpre_shape(int c) { return split_shape_ok(c) && c % 32 == 0; }
 
 // per-row finish: sums over prototype blocks in block order, then
 // loss.py:63-80 (numerator choice, -log(num / (num + diff))); outputs [L][N].
@@ -367,9 +379,10 @@ __global__ void loss_rows_kernel(const float *__restrict__ part, int npb, int64_
   }
 }
 
+// xpre: the pixel rows in the split engine's own image (loss_pairs_kernel), or null
 template <class Epi>
 static int launch_loss_tiles(const float *emb, int64_t N, int c, const float *proto, int64_t P,
-                             Epi epi, hipStream_t s) {
+                             Epi epi, hipStream_t s, const float *xpre = nullptr) {
   if (N <= 0 || P <= 0) return 0;
   const int nch = (int)((N + HSGK_CHUNK - 1) / HSGK_CHUNK);
   const int npb = (int)((P + 63) / 64);
@@ -385,8 +398,13 @@ static int launch_loss_tiles(const float *emb, int64_t N, int c, const float *pr
     HSGK_LAUNCH_CHECK();
     return 0;
   };
-  if (loss_split_enabled(c))
-    return go(loss_tiles_split_kernel<8, 4, Epi>, split_lds_bytes<8>(c) + kLossBlockLabBytes, HSGK_CHUNK / 256);
+  if (loss_split_enabled(c)) {
+    if (xpre != nullptr && c % 32 == 0) {
+      emb = xpre;
+      return go(loss_tiles_split_kernel<8, 4, Epi, true>, split_lds_bytes<8>(c) + kLossBlockLabBytes, HSGK_CHUNK / 256);
+    }
+    return go(loss_tiles_split_kernel<8, 4, Epi, false>, split_lds_bytes<8>(c) + kLossBlockLabBytes, HSGK_CHUNK / 256);
+  }
   const size_t l32 = score_tiles_lds_bytes<64, 8, 32>(c), l16 = score_tiles_lds_bytes<64, 8, 16>(c);
   if (l32 + kLossBlockLabBytes <= 160 * 1024)
     return even ? go(loss_tiles_kernel<64, 8, 32, true, Epi>, l32 + kLossBlockLabBytes, HSGK_CHUNK / 256)
@@ -1422,8 +1440,8 @@ extern "C" {
 size_t hsgk_segsort_loss_workspace_bytes(int64_t n, int c, int64_t P, int L) {
   const int64_t npb = (P + 63) / 64;
   Carver cv(nullptr);
-  (void)c;
   cv.take<float>((size_t)(npb > 0 ? npb : 1) * (size_t)(n > 0 ? n : 1) * 3 * (size_t)(L > 0 ? L : 1));
+  if (loss_fwd_xpre_shape(c)) cv.take<float>((size_t)(n > 0 ? n : 1) * c);
   return cv.off + 256;
 }
 
@@ -1446,11 +1464,22 @@ int hsgk_segsort_loss_fwd(const float *emb, int64_t n, int c, const int64_t *ins
   for (int l = 0; l < L; ++l) plain = plain && !ls.setm[l];
   int plus_mask = 0;
   for (int l = 0; l < L; ++l) plus_mask |= ls.plus[l] << l;
+  // the pixel rows in the split engine's own image, made once (HSGK_LOSS_FWD=convert: per prototype block, as before)
+  const float *xpre = nullptr;
+  const char *fwd_env = getenv("HSGK_LOSS_FWD");
+  if (loss_fwd_xpre_shape(c) && loss_split_enabled(c) && P > 64 && !(fwd_env && fwd_env[0] == 'c')) {
+    float *xp = cv.take<float>((size_t)n * c);
+    const int64_t t2 = n * c / 2, gsz = (t2 + 255) / 256;
+    hipLaunchKernelGGL(loss_pairs_kernel, dim3((unsigned)(gsz > 16384 ? 16384 : gsz)), dim3(256), 0, s, emb, t2,
+                       reinterpret_cast<uint2 *>(xp));
+    HSGK_LAUNCH_CHECK();
+    xpre = xp;
+  }
   int rc;
-  if (plain && L == 1) rc = launch_loss_tiles(emb, n, c, proto, P, LossFwdEpiFast<1>{0, 0, 0, P, n, 0, inst, ls, part, nullptr, 0}, s);
-  else if (plain && L == 2) rc = launch_loss_tiles(emb, n, c, proto, P, LossFwdEpiFast<2>{0, 0, 0, P, n, 0, inst, ls, part, nullptr, 0}, s);
-  else if (plain) rc = launch_loss_tiles(emb, n, c, proto, P, LossFwdEpiFast<3>{0, 0, 0, P, n, 0, inst, ls, part, nullptr, 0}, s);
-  else rc = launch_loss_tiles(emb, n, c, proto, P, LossFwdEpi{0, 0, 0, P, n, 0, inst, ls, part, nullptr, 0}, s);
+  if (plain && L == 1) rc = launch_loss_tiles(emb, n, c, proto, P, LossFwdEpiFast<1>{0, 0, 0, P, n, 0, inst, ls, part, nullptr, 0}, s, xpre);
+  else if (plain && L == 2) rc = launch_loss_tiles(emb, n, c, proto, P, LossFwdEpiFast<2>{0, 0, 0, P, n, 0, inst, ls, part, nullptr, 0}, s, xpre);
+  else if (plain) rc = launch_loss_tiles(emb, n, c, proto, P, LossFwdEpiFast<3>{0, 0, 0, P, n, 0, inst, ls, part, nullptr, 0}, s, xpre);
+  else rc = launch_loss_tiles(emb, n, c, proto, P, LossFwdEpi{0, 0, 0, P, n, 0, inst, ls, part, nullptr, 0}, s, xpre);
   if (rc) return rc;
   hipLaunchKernelGGL(loss_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, npb,
                      n, L, plus_mask, nll, num, den, use_same);

@@ -88,7 +88,11 @@ __host__ __device__ constexpr size_t split_lds_bytes(int d) {
 // rl_lds[NW][2][32] (tile parity), loaded two tiles ahead: an id fetched from global
 // right before its use would drain the whole prefetch queue (loads return in order).
 // Epi may read the ids of tile t from the slot t & 1 inside its call.
-template <int NW, int DEPTH, class Epi, bool ROWS = false, bool F16S = false>
+// XPRE: x is not fp32 rows but the already split image of them -- per pair of columns one 32-bit pair of hi halves
+// and one of lo halves, at the byte offset of the two floats (loss.hip: every pixel row is streamed once per
+// prototype block, 48 times at P = 3 072; converting it each time was a third of that kernel's vector work).
+// The caller guarantees d % 32 == 0 (no tail columns).
+template <int NW, int DEPTH, class Epi, bool ROWS = false, bool F16S = false, bool XPRE = false>
 __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, int d,
                                          const float *__restrict__ table, int kvalid,
                                          int64_t crow0, int nrows, unsigned char *lds_raw,
@@ -192,7 +196,12 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
     for (int i = 0; i < LOADS; ++i) {
       const int px = lpx + 4 * i;
       uint32_t hi, lo;
-      split2(pre[i].x, pre[i].y, hi, lo);
+      if constexpr (XPRE) {
+        hi = __float_as_uint(pre[i].x);
+        lo = __float_as_uint(pre[i].y);
+      } else {
+        split2(pre[i].x, pre[i].y, hi, lo);
+      }
       *reinterpret_cast<uint32_t *>(hp + px * XSB + 2 * lf2) = hi;
       *reinterpret_cast<uint32_t *>(lp + px * XSB + 2 * lf2) = lo;
     }
