@@ -108,6 +108,9 @@ SIGNATURES = {
     'hsgk_overlap_finish': (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     'hsgk_majority_labels': (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     'hsgk_knn_affinity': (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    'hsgk_dmon_pool_workspace_bytes': (_sz, [_i32, _i32, _i32]),
+    'hsgk_dmon_pool_fwd': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    'hsgk_dmon_pool_bwd': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'hsgk_topk_workspace_bytes': (_sz, [_i64, _i32, _i64, _i32]),
     'hsgk_topk_prototypes': (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),
     'hsgk_topk_prototypes_grouped': (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

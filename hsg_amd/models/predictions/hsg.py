@@ -47,9 +47,11 @@ def _dmon_terms(self, datas):
   every level's grouping logits are scored against the same k-NN graph inputs (node prototypes, padding
   masks, node -> image indices)."""
   graph = (datas['nd_prototype'], datas['nd_prototype_padding_mask'], datas['nd_prototype_batch_index'])
+  # the k-NN graph depends on the nodes only: built once for both levels (the reference rebuilds it per call)
+  extra = {'adjacency': self.dmon_loss.adjacency(*graph)} if hasattr(self.dmon_loss, 'adjacency') else {}
   total = None
   for level in _HIERARCHY_LEVELS:
-    cut, collapse = self.dmon_loss(datas[level + 'hrchy_nd_prototype_grouping_logit'], *graph)
+    cut, collapse = self.dmon_loss(datas[level + 'hrchy_nd_prototype_grouping_logit'], *graph, **extra)
     total = cut + collapse if total is None else total + cut + collapse
   return total
 

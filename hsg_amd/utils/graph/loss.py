@@ -4,22 +4,72 @@ The adjacency comes from the fused k-NN affinity kernel (graph/common.py); it is
 so no gradient flows through it and the pooling terms below are a handful of small
 batched GEMMs on [B, num_nodes, num_clusters] tensors, left to rocBLAS through torch.
 """
+import ctypes
+import math
+
 import torch
 from torch.nn.modules.loss import _Loss
 
+from hsg_amd import _lib
 from hsg_amd.utils.graph import common as graph_common
+
+MAX_FUSED_CLUSTERS = 32
+
+
+class _DmonPool(torch.autograd.Function):
+  """Per image t = (Tr(S^T A S) - |S^T d|^2 / 2m) / 2m and c = |sum_i S_i|_2 for an adjacency without gradient:
+  one libhsgk launch forward, one backward (`hsgk_dmon_pool_fwd / _bwd`, csrc/graph.hip) in place of the
+  reference's chain of batched GEMMs and reductions (loss.py:62-94: 55 device operations per level and as many
+  again in its backward)."""
+
+  @staticmethod
+  def forward(ctx, adj, s, valid):
+    B, N, K = s.shape
+    dev = s.device
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+      t = torch.empty((B,), dtype=torch.float32, device=dev)
+      c = torch.empty((B,), dtype=torch.float32, device=dev)
+      nbytes = L.hsgk_dmon_pool_workspace_bytes(B, N, K)
+      saved = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+      _lib.check(L.hsgk_dmon_pool_fwd(adj.data_ptr(), s.data_ptr(), valid.data_ptr() if valid is not None else None,
+                                      B, N, K, t.data_ptr(), c.data_ptr(), saved.data_ptr(), nbytes,
+                                      _lib.stream_ptr()))
+    ctx.save_for_backward(adj, s, valid, saved)
+    return t, c
+
+  @staticmethod
+  def backward(ctx, gt, gc):
+    adj, s, valid, saved = ctx.saved_tensors
+    B, N, K = s.shape
+    with torch.cuda.device(s.device):
+      grad = torch.empty_like(s)
+      gt = gt.to(torch.float32).contiguous()
+      gc = gc.to(torch.float32).contiguous()
+      _lib.check(_lib.lib().hsgk_dmon_pool_bwd(adj.data_ptr(), s.data_ptr(),
+                                               valid.data_ptr() if valid is not None else None, B, N, K,
+                                               saved.data_ptr(), gt.data_ptr(), gc.data_ptr(), grad.data_ptr(),
+                                               _lib.stream_ptr()))
+    return None, grad, None
 
 
 def dmon_pool_loss(x, adj, s, mask=None, softmax=False):
   """Reference loss.py:27-96.  adj [B,N,N], s [B,N,K] (cluster assignments), mask
   [B,N] valid nodes.  Returns (dmon_loss, collapse_loss), both batch means.
       dmon     = 1 - Tr(S^T A S - S^T d d^T S / 2m) / 2m,   d = A 1,  2m = 2 sum(d)
-      collapse = |sum_i S_i|_2 * sqrt(K) / N"""
+      collapse = |sum_i S_i|_2 * sqrt(K) / N
+  An adjacency without gradient (DMonLoss: the binary k-NN graph) on the GPU takes the fused kernels; one that
+  carries a gradient (the pooled adjacencies of HierarchicalDMonLoss) the formulas below."""
   adj = adj.unsqueeze(0) if adj.dim() == 2 else adj
   s = s.unsqueeze(0) if s.dim() == 2 else s
   B, N, K = s.shape
   if softmax:
     s = torch.softmax(s, dim=-1)
+  kt = 4 if K <= 4 else 8 if K <= 8 else 16 if K <= 16 else 32        # the kernels' padded cluster count (LDS: 64 KiB)
+  if s.is_cuda and not adj.requires_grad and K <= MAX_FUSED_CLUSTERS and (N + 3) * kt <= 14000:
+    valid = None if mask is None else mask.reshape(B, N).to(torch.uint8).contiguous()
+    t, c = _DmonPool.apply(adj.detach().to(torch.float32).contiguous(), s.to(torch.float32).contiguous(), valid)
+    return torch.mean(1 - t), torch.mean(c) * (math.sqrt(K) / N)
   if mask is not None:
     s = s * mask.view(B, N, 1).to(s.dtype)
   st = s.transpose(1, 2)
@@ -45,9 +95,14 @@ class DMonLoss(_Loss):
   def __repr__(self):
     return 'DMonLoss(adj_knn={})'.format(self._knn)
 
-  def forward(self, logits, x, x_padding_mask=None, x_segment_labels=None):
-    adj = graph_common.affinity_matrix_as_attention(
+  def adjacency(self, x, x_padding_mask=None, x_segment_labels=None):
+    """The binary k-NN graph the loss scores assignments against (no gradient): a caller that scores several
+    sets of logits on the same nodes builds it once and passes it as `adjacency=`."""
+    return graph_common.affinity_matrix_as_attention(
         x, x_padding_mask, x_segment_labels, self._knn, True, True, concentration=5)
+
+  def forward(self, logits, x, x_padding_mask=None, x_segment_labels=None, adjacency=None):
+    adj = self.adjacency(x, x_padding_mask, x_segment_labels) if adjacency is None else adjacency
     return dmon_pool_loss(x.transpose(1, 2), adj, logits.transpose(1, 2), ~x_padding_mask)
 
 

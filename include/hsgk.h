@@ -432,6 +432,21 @@ HSGK_API int hsgk_knn_affinity(const float *x, const float *affinity_in, int B, 
                                int binarize, float *affinity_tmp, float *out,
                                hsgk_stream_t stream);
 
+/* ---- hsg/utils/graph/loss.py:27-96 dmon_pool_loss, for an adjacency that carries no gradient (the binary
+ * k-NN graph of DMonLoss, loss.py:99-145) -------------------------------------------------------------------
+ * adj [B,N,N], s [B,N,K] cluster assignments (K <= 32), valid [B,N] (nullable; rows with 0 count as zero rows).
+ * Per image: t = (Tr(S^T A S) - |S^T d|^2 / 2m) / 2m with d = A 1, 2m = 2 sum(d), and c = |sum_i S_i|_2 -- so
+ * that dmon_loss = mean(1 - t), collapse_loss = mean(c) * sqrt(K) / N as the reference defines them.  `saved`
+ * (hsgk_dmon_pool_workspace_bytes) keeps A S, d and the per-image sums for the backward:
+ * grad_s = g_t[b] * dt/dS + g_c[b] * dc/dS.                                                                   */
+HSGK_API size_t hsgk_dmon_pool_workspace_bytes(int B, int N, int K);
+HSGK_API int hsgk_dmon_pool_fwd(const float *adj, const float *s, const uint8_t *valid, int B, int N, int K,
+                                float *t_out, float *c_out, void *saved, size_t saved_bytes,
+                                hsgk_stream_t stream);
+HSGK_API int hsgk_dmon_pool_bwd(const float *adj, const float *s, const uint8_t *valid, int B, int N, int K,
+                                const void *saved, const float *g_t, const float *g_c, float *grad_s,
+                                hsgk_stream_t stream);
+
 /* ---- synthetic inputs of the benchmark (hsg_amd/utils/synth.py; no reference counterpart:
  * the reference ships no benchmark, BASELINE.md section 2 defines the generator) ------------
  * out[i] = gaussish(hash(key, offset + i)); key = synth.stream_key(seed).  Bit-identical to

@@ -1735,6 +1735,36 @@ def test_dmon_affinity_graph_and_loss_vs_reference_golden(dev, oracle):
   assert np.abs(lg.grad.cpu().numpy() - g['g_logits']).max() <= 1e-6
 
 
+@pytest.mark.parametrize('B,N,K,masked', [(3, 256, 8, True), (2, 8, 4, False), (4, 100, 32, True), (1, 1000, 5, True)])
+def test_dmon_pool_fused_kernels_vs_reference_formula(dev, B, N, K, masked):
+  """hsgk_dmon_pool_fwd / _bwd (an adjacency without gradient: DMonLoss) against the reference's chain of batched
+  GEMMs (loss.py:62-94, the path `dmon_pool_loss` keeps for adjacencies that carry a gradient) evaluated in
+  float64: both loss values and the gradient w.r.t. the assignments; masked rows get exactly zero gradient."""
+  import torch
+  from hsg_amd.utils.graph import loss as gl
+  g = torch.Generator(device=dev).manual_seed(B * 1000 + N + K)
+  adj = (torch.rand((B, N, N), device=dev, generator=g) < 0.1).float()
+  adj[:, torch.arange(N), torch.arange(N)] = 0.0
+  adj[:, 0, 1] = 1.0                                                   # (never an empty graph)
+  logits = torch.randn((B, N, K), device=dev, generator=g)
+  mask = (torch.rand((B, N), device=dev, generator=g) < 0.9) if masked else None
+  if mask is not None:
+    mask[:, :2] = True
+  s1 = logits.clone().requires_grad_(True)
+  d1, c1 = gl.dmon_pool_loss(None, adj, s1, mask, softmax=True)
+  (d1 + 0.7 * c1).backward()
+  s2 = logits.double().requires_grad_(True)
+  a2 = adj.double().requires_grad_(True)                               # a gradient-carrying adjacency: the formula path
+  d2, c2 = gl.dmon_pool_loss(None, a2, s2, mask, softmax=True)
+  (d2 + 0.7 * c2).backward()
+  assert abs(d1.item() - d2.item()) <= 1e-5 and abs(c1.item() - c2.item()) <= 1e-5
+  scale = max(s2.grad.abs().max().item(), 1e-12)
+  assert (s1.grad.double() - s2.grad).abs().max().item() <= 2e-5 * scale
+  if mask is not None:
+    # (through the softmax the masked rows' logit gradient is zero as well)
+    assert float(s1.grad[~mask].abs().max()) == 0.0
+
+
 def test_dmon_affinity_graph_larger_vs_oracle(dev, oracle):
   """256 nodes, 3 segments, knn 10, ties from duplicated nodes."""
   import torch
