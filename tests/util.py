@@ -173,13 +173,20 @@ def train_step_inputs(seed):
               cent_f=g(4, Bp, C, KF), cent_c=g(5, Bp, C, KC))
 
 
+def device_inputs(inp, device):
+  """The numpy inputs of `run_train_step` as tensors resident on `device`."""
+  import torch
+  return {k: torch.from_numpy(v).to(device) for k, v in inp.items()}
+
+
 def run_train_step(mods, inp, device):
   """mods: dict(embedding_cls, prediction_cls, model_utils, loc_fn); returns a dict of tensors
   (losses, accuracy, gradient w.r.t. the embeddings, the integer bookkeeping of the step)."""
   import types
   import torch
   c = TRAIN_STEP
-  T = lambda k: torch.from_numpy(inp[k]).to(device)
+  # (a caller that times the step uploads the batch once -- `device_inputs` -- as a training loop's loader does)
+  T = lambda k: inp[k].detach() if torch.is_tensor(inp[k]) else torch.from_numpy(inp[k]).to(device)
   mu = mods['model_utils']
   cfg = train_step_config()
   cent_f, cent_c = T('cent_f').requires_grad_(True), T('cent_c').requires_grad_(True)

@@ -28,6 +28,15 @@ for _ in range(n):
   out = util.run_train_step(mods, inp, dev)
 torch.cuda.synchronize()
 print('whole step (incl. host->device copies of the inputs): %.2f ms' % ((time.perf_counter() - t0) / n * 1e3))
+inp_dev = util.device_inputs(inp, dev)
+for _ in range(3):
+  util.run_train_step(mods, inp_dev, dev)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(n):
+  util.run_train_step(mods, inp_dev, dev)
+torch.cuda.synchronize()
+print('whole step, batch resident on the device: %.2f ms' % ((time.perf_counter() - t0) / n * 1e3))
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
   for _ in range(3):
