@@ -722,7 +722,7 @@ struct HalfWideEpi {
     // mantissa bits (<= 1.8e-6, added to the gap), so a block's running top-2 is max + med3 without index
     // bookkeeping; blocks entirely below K are unmasked, above skipped; the candidate scan only visits blocks
     // whose maximum reaches an ambiguous row's threshold.
-    float bm1[MB];
+    float bm1[MB], bm2[MB];
     float t1 = -INFINITY, t2 = -INFINITY;
     int tm = 0;
 #pragma unroll
@@ -748,6 +748,7 @@ struct HalfWideEpi {
         }
       }
       bm1[m] = b1;
+      bm2[m] = b2;
       const bool up = b1 > t1;
       t2 = up ? fmaxf(t1, b2) : fmaxf(t2, b1);
       tm = up ? m : tm;
@@ -769,13 +770,26 @@ struct HalfWideEpi {
     if (!__any(amb)) return;
     // candidates of this lane's half, merged with the partner half (<= 7, else "all")
     const float thr = amb ? t1 - gap - 2.0e-6f : INFINITY;
+    // The scan used to read all 16 scores of every block some ambiguous row reaches, with a 64-bit shift / or per
+    // score: ~10 vector instructions per score on most tiles -- more than the top-2 pass itself.  A lane's block
+    // maximum and runner-up are already known: below thr2 (thr less the tag of the tested value) the block holds no
+    // candidate of the lane, with only the maximum above it exactly one, whose index is its tag.
+    const float thr2 = thr - 2.0e-6f;
     unsigned long long list = 0;
     int cnt = 0;
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
-      if (!__any(bm1[m] >= thr)) continue;
+      if (!__any(bm1[m] >= thr2)) continue;
+      if (!__any(bm2[m] >= thr2)) {                     // at most the block maximum: its index is its tag
+        const uint32_t tgm = __float_as_uint(bm1[m]) & 15u;
+        const uint32_t k = m * 32 + (tgm & 3u) + 8 * (tgm >> 2) + 4 * h;
+        const bool hit = bm1[m] >= thr2;
+        list = hit ? ((list << 8) | k) : list;
+        cnt += hit ? 1 : 0;
+        continue;
+      }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 16; ++r) {                    // some lane holds two candidates in this block: scan it
         const uint32_t k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const bool hit = k < (uint32_t)K && sacc[m][r] >= thr;  // NaN scores never hit
         list = hit ? ((list << 8) | k) : list;
@@ -1137,7 +1151,7 @@ struct HalfWide1Epi {
     // v_and_or with an inline constant; a perturbation of at most 15 ulp <= 1.8e-6 that the gap accounts for),
     // so the running top-2 of a block needs no index bookkeeping: b1 = max, b2 = med3(b1, b2, v) -- three
     // vector instructions per score.  Blocks entirely below K are unmasked, entirely above skipped (uniform).
-    float bm1[MB];
+    float bm1[MB], bm2[MB];
     float t1 = -INFINITY, t2 = -INFINITY;
     int tm = 0;
 #pragma unroll
@@ -1163,6 +1177,7 @@ struct HalfWide1Epi {
         }
       }
       bm1[m] = b1;
+      bm2[m] = b2;
       // merge into the lane's running top-2 (strict >: the lower block wins a tie)
       const bool up = b1 > t1;
       t2 = up ? fmaxf(t1, b2) : fmaxf(t2, b1);
@@ -1186,13 +1201,26 @@ struct HalfWide1Epi {
     // candidates of this lane's half, merged with the partner half (<= 7, else "all"); only table blocks
     // whose maximum reaches some ambiguous row's threshold are scanned
     const float thr = amb ? t1 - gap - 2.0e-6f : INFINITY;
+    // The scan used to read all 16 scores of every block some ambiguous row reaches, with a 64-bit shift / or per
+    // score: ~10 vector instructions per score on most tiles -- more than the top-2 pass itself.  A lane's block
+    // maximum and runner-up are already known: below thr2 (thr less the tag of the tested value) the block holds no
+    // candidate of the lane, with only the maximum above it exactly one, whose index is its tag.
+    const float thr2 = thr - 2.0e-6f;
     unsigned long long list = 0;
     int cnt = 0;
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
-      if (!__any(bm1[m] >= thr)) continue;
+      if (!__any(bm1[m] >= thr2)) continue;
+      if (!__any(bm2[m] >= thr2)) {                     // at most the block maximum: its index is its tag
+        const uint32_t tgm = __float_as_uint(bm1[m]) & 15u;
+        const uint32_t k = m * 32 + (tgm & 3u) + 8 * (tgm >> 2) + 4 * h;
+        const bool hit = bm1[m] >= thr2;
+        list = hit ? ((list << 8) | k) : list;
+        cnt += hit ? 1 : 0;
+        continue;
+      }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 16; ++r) {                    // some lane holds two candidates in this block: scan it
         const uint32_t k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const bool hit = k < (uint32_t)K && sacc[m][r] >= thr;      // NaN scores never hit
         list = hit ? ((list << 8) | k) : list;
@@ -1482,7 +1510,7 @@ __global__ __launch_bounds__(512) void assign_half_pair_kernel(
 #endif
       // ---------------- epilogue: this wave's half of the table, then the pair
       const int h = g;
-      float bm1[MBW];
+      float bm1[MBW], bm2[MBW];
       float t1 = -INFINITY, t2 = -INFINITY;
       int tm = 0;
 #pragma unroll
@@ -1509,6 +1537,7 @@ __global__ __launch_bounds__(512) void assign_half_pair_kernel(
           }
         }
         bm1[m] = b1;
+        bm2[m] = b2;
         const bool up = b1 > t1;
         t2 = up ? fmaxf(t1, b2) : fmaxf(t2, b1);
         tm = up ? mg : tm;
@@ -1548,10 +1577,19 @@ __global__ __launch_bounds__(512) void assign_half_pair_kernel(
       int cnt = 0;
       if (any) {
         thr = ex_thr[j];
+        const float thr2 = thr - 2.0e-6f;              // (see HalfWideEpi: block maximum / runner-up instead of a scan)
 #pragma unroll
         for (int m = 0; m < MBW; ++m) {
-          if (!__any(bm1[m] >= thr)) continue;
+          if (!__any(bm1[m] >= thr2)) continue;
           const int mg = 4 * hf + m;
+          if (!__any(bm2[m] >= thr2)) {
+            const uint32_t tgm = __float_as_uint(bm1[m]) & 15u;
+            const uint32_t k = mg * 32 + (tgm & 3u) + 8 * (tgm >> 2) + 4 * h;
+            const bool hit = bm1[m] >= thr2;
+            list = hit ? ((list << 8) | k) : list;
+            cnt += hit ? 1 : 0;
+            continue;
+          }
 #pragma unroll
           for (int rr = 0; rr < 16; ++rr) {
             const uint32_t k = mg * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
