@@ -24,3 +24,12 @@ for _ in range(10): z.copy_(y)
 b.record(); torch.cuda.synchronize()
 ms = a.elapsed_time(b) / 10
 print('copy     %.3f ms  %.2f TB/s (read + write)' % (ms, 2 * n / ms / 1e9))
+w = torch.empty(n // 4, dtype=torch.float32, device=dev)
+for _ in range(2): w.fill_(1.0)
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(10): w.fill_(1.0)
+b.record(); torch.cuda.synchronize()
+ms = a.elapsed_time(b) / 10
+print('fill     %.3f ms  %.2f TB/s (write only)' % (ms, n / ms / 1e9))
