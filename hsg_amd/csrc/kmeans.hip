@@ -1633,6 +1633,278 @@ __global__ __launch_bounds__(512) void assign_half_pair_kernel(
   if (tid == 0) seg.count[blockIdx.x] = qnp[0];
 }
 
+// ---------------------------------------------------------------------------
+// K <= 256, d / 64 == 4: the TABLE IN REGISTERS.  The kernels above keep the 256 x d fp16 table in LDS (143 KB)
+// and move a 32-row window per pair of waves through what is left of it -- two pair synchronisations per
+// 64-column chunk, twelve per 32-row tile, the matrix pipe 28 % busy.  Here a wave OWNS 32 centroids: their fp16
+// rows are the MFMA A operand, resident in 68 registers for a whole image, so the LDS is free for the ROWS --
+// 128-row tiles, double buffered, staged by contiguous 16-byte copies of the fp16 copy, read by all eight waves
+// as B operands.  A wave scores the tile's four 32-row blocks against its 32 centroids (68 MFMAs), leaves each
+// row's tagged top-2 of its block in LDS, and after one barrier every wave merges the eight blocks of a row in
+// block order (the lower block wins a tie, as the single-pass kernels do), so that every wave knows the row's
+// decision and threshold and appends the candidates of ITS block for the undecided rows (block maximum /
+// runner-up rule, HalfWideEpi).  Three workgroup barriers per 128 rows instead of twelve pair syncs per 32.
+// Same approximation (fp16 hi rows x fp16 hi table, fp32 accumulation over 16-column blocks), same gap, same
+// queue format as assign_half_pair_kernel: the labels stay those of the exact argmax.
+// MEASURED SLOWER than the pair kernel and therefore opt-in (HSGK_WIDE2=regs): 0.65-0.75 ms per launch against
+// 0.527 at cfg4.  rocprofv3: the matrix pipe is busy the same 320 M cycles, but a 128-row interval takes ~20 K
+// cycles for 4.4 K of MFMA work per SIMD -- 59 % of the wave cycles in s_waitcnt, LDS 41 % busy (42 % of that in
+// bank conflicts the row layout should not have), three barriers with all eight waves in the same phase, and every
+// wave merging every row.  A variant that let the accumulators die per block (tagged top-3, a third candidate in
+// one lane = all centroids) sent 65 K rows per iteration to the all-K exact path (the pair kernel: 574).
+__global__ __launch_bounds__(512, 2) void assign_half_regs_kernel(
+    const _Float16 *__restrict__ xm, const uint2 *__restrict__ xt, int d,
+    const float *__restrict__ cent, const float *__restrict__ errc, int K,
+    const int64_t *__restrict__ img_row0, int B, int32_t *__restrict__ klab,
+    SplitEntry *__restrict__ gqueue, SegQueue seg, const hsgk_segkm_meta *__restrict__ meta) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int DM = 256, RS = DM + 8, TR = 128, NSUB = 4, KS = DM / 16;
+  constexpr int kTileBytes = TR * RS * 2;
+  uint16_t *tiles = reinterpret_cast<uint16_t *>(lds_raw);                       // [2][TR][RS]
+  uint2 *tails = reinterpret_cast<uint2 *>(lds_raw + 2 * kTileBytes);            // [2][TR]
+  float4 *part = reinterpret_cast<float4 *>(tails + 2 * TR);                     // [NSUB][8][32] (p1, p2, index)
+  int *ccnt = reinterpret_cast<int *>(part + NSUB * 8 * 32);                     // [TR] candidates of a row
+  unsigned char *clist = reinterpret_cast<unsigned char *>(ccnt + TR);           // [TR][8]
+  int *qnp = reinterpret_cast<int *>(clist + TR * 8);                            // [0] queue length of the workgroup
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int j = lane & 31, g = lane >> 5;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+
+  const int64_t N = meta->n_rows;
+  const int64_t per = (N + (int64_t)gridDim.x * TR - 1) / ((int64_t)gridDim.x * TR) * TR;
+  int64_t r = (int64_t)blockIdx.x * per;
+  const int64_t r_end = min(N, r + per);
+  if (tid == 0) { seg.count[blockIdx.x] = 0; seg.row0[blockIdx.x] = r < r_end ? r : 0; qnp[0] = 0; }
+  if (tid < TR) ccnt[tid] = 0;
+  if (r >= r_end) return;
+  SplitEntry *slice = gqueue + r;
+  int b = image_of_row(img_row0, B, r);
+  int staged_img = -1;
+  float errc_max = 0.0f;
+  const bool has_tail = d > DM;
+  const bool mine = 32 * wu < K;                       // (waves whose block lies past K only take part in the barriers)
+  f16x8 ta[KS + 1];                                    // this wave's 32 centroids: lane (i, g) holds C[32 w + i][16 s + 8 g ..]
+#pragma unroll
+  for (int s2 = 0; s2 <= KS; ++s2) ta[s2] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+
+  while (r < r_end) {
+    while (img_row0[b + 1] <= r) ++b;
+    const int64_t seg_end = min(r_end, img_row0[b + 1]);
+    const int nrows = (int)min(seg_end - r, (int64_t)1 << 24);
+    const int64_t crow0 = r;
+    if (b != staged_img) {
+      float m = 0.0f;
+      for (int k = lane; k < K; k += 64) m = fmaxf(m, errc[(int64_t)b * K + k]);
+      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+      errc_max = m;
+      const int kc = 32 * wu + j;
+      const float *crow = cent + ((int64_t)b * K + min(kc, K - 1)) * d;
+      const bool live = kc < K;
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) {
+        const float4 v0 = *reinterpret_cast<const float4 *>(crow + 16 * s2 + 8 * g);
+        const float4 v1 = *reinterpret_cast<const float4 *>(crow + 16 * s2 + 8 * g + 4);
+        uint32_t h[4], lo;
+        f16_split2(v0.x, v0.y, h[0], lo);
+        f16_split2(v0.z, v0.w, h[1], lo);
+        f16_split2(v1.x, v1.y, h[2], lo);
+        f16_split2(v1.z, v1.w, h[3], lo);
+        const u32x4 hv = {live ? h[0] : 0u, live ? h[1] : 0u, live ? h[2] : 0u, live ? h[3] : 0u};
+        ta[s2] = __builtin_bit_cast(f16x8, hv);
+      }
+      {                                                // the two location columns: k = 0, 1 of one more k-block
+        uint32_t h0 = 0u, lo;
+        if (has_tail && live && g == 0) f16_split2(crow[DM], crow[DM + 1], h0, lo);
+        const u32x4 hv = {h0, 0u, 0u, 0u};
+        ta[KS] = __builtin_bit_cast(f16x8, hv);
+      }
+      staged_img = b;
+    }
+    const int ntile = (nrows + TR - 1) / TR;
+    // ---- staging: a tile is TR contiguous rows of the fp16 copy (kHalfSlackRows readable rows past the end).
+    //      (Macros, not lambdas: captured by a lambda the eight staging registers went to scratch memory -- stored
+    //       right behind their loads, i.e. every tile waited for its own prefetch.)
+#define HSGK_REGS_LOAD(TILE)                                                                              \
+  {                                                                                                       \
+    const uint4 *src_ = reinterpret_cast<const uint4 *>(xm + (crow0 + (int64_t)(TILE) * TR) * DM);        \
+    pre0 = src_[tid]; pre1 = src_[tid + 512]; pre2 = src_[tid + 1024]; pre3 = src_[tid + 1536];           \
+    pre4 = src_[tid + 2048]; pre5 = src_[tid + 2560]; pre6 = src_[tid + 3072]; pre7 = src_[tid + 3584];   \
+    if (tid < TR) pret = xt[crow0 + (int64_t)(TILE) * TR + tid];                                          \
+  }
+#define HSGK_REGS_PUT(P, U) *reinterpret_cast<uint4 *>(dst_ + ((tid + 512 * (U)) >> 5) * RS + 8 * ((tid + 512 * (U)) & 31)) = P
+#define HSGK_REGS_STORE(BUF)                                                                              \
+  {                                                                                                       \
+    uint16_t *dst_ = tiles + (BUF) * (TR * RS);                                                           \
+    HSGK_REGS_PUT(pre0, 0); HSGK_REGS_PUT(pre1, 1); HSGK_REGS_PUT(pre2, 2); HSGK_REGS_PUT(pre3, 3);       \
+    HSGK_REGS_PUT(pre4, 4); HSGK_REGS_PUT(pre5, 5); HSGK_REGS_PUT(pre6, 6); HSGK_REGS_PUT(pre7, 7);       \
+    if (tid < TR) tails[(BUF) * TR + tid] = pret;                                                         \
+  }
+    uint4 pre0, pre1, pre2, pre3, pre4, pre5, pre6, pre7;
+    uint2 pret = {0u, 0u};
+    HSGK_REGS_LOAD(0)
+    __syncthreads();                                   // nobody still reads the buffers of the previous pass
+    HSGK_REGS_STORE(0)
+    if (ntile > 1) HSGK_REGS_LOAD(1)
+    for (int tile = 0; tile < ntile; ++tile) {
+      const int buf = tile & 1;
+      __syncthreads();                                 // B0: tile staged; the previous tile's partials and lists are consumed
+      const uint16_t *tb = tiles + buf * (TR * RS);
+      const uint2 *tt = tails + buf * TR;
+      // ---- 4 x (16 + 1) MFMAs: block (rows 32 u .., this wave's 32 centroids); operand reads four k-steps ahead
+      f32x16 acc[NSUB];
+      float bm1[NSUB], bm2[NSUB];
+      if (mine) {
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) {
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) acc[u][rr] = 0.0f;
+          const uint16_t *bp = tb + (32 * u + j) * RS + 8 * g;
+          f16x8 bv[KS];
+#pragma unroll
+          for (int s2 = 0; s2 < KS; ++s2) bv[s2] = *reinterpret_cast<const f16x8 *>(bp + 16 * s2);
+#pragma unroll
+          for (int s2 = 0; s2 < KS; ++s2) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta[s2], bv[s2], acc[u], 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+          for (int s2 = 0; s2 < KS - 4; ++s2) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          if (has_tail) {
+            const u32x4 tv = {g == 0 ? tt[32 * u + j].x : 0u, 0u, 0u, 0u};
+            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta[KS], __builtin_bit_cast(f16x8, tv), acc[u], 0, 0, 0);
+          }
+        }
+        // ---- tagged top-2 of the block per row (lane = row, 16 centroids per lane half), halves merged
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) {
+          float b1 = -INFINITY, b2 = -INFINITY;
+          if (32 * (wu + 1) <= K) {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+              const float v = __uint_as_float((__float_as_uint(acc[u][rr]) & ~15u) | (uint32_t)rr);
+              b2 = __builtin_amdgcn_fmed3f(b1, b2, v);
+              b1 = fmaxf(b1, v);
+            }
+          } else {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+              const int k = 32 * wu + (rr & 3) + 8 * (rr >> 2) + 4 * g;
+              float v = __uint_as_float((__float_as_uint(acc[u][rr]) & ~15u) | (uint32_t)rr);
+              v = k < K ? v : -INFINITY;
+              b2 = __builtin_amdgcn_fmed3f(b1, b2, v);
+              b1 = fmaxf(b1, v);
+            }
+          }
+          bm1[u] = b1;
+          bm2[u] = b2;
+          const uint32_t tg = __float_as_uint(b1) & 15u;
+          int ti = 32 * wu + (int)(tg & 3u) + 8 * (int)(tg >> 2) + 4 * g;
+          float t1 = b1, t2 = b2;
+          const float o1 = __shfl_xor(t1, 32), o2 = __shfl_xor(t2, 32);
+          const int oi = __shfl_xor(ti, 32);
+          if (o1 > t1 || (o1 == t1 && oi < ti)) { t2 = fmaxf(t1, o2); t1 = o1; ti = oi; }
+          else { t2 = fmaxf(o1, t2); }
+          if (g == 0) part[(u * 8 + wu) * 32 + j] = make_float4(t1, t2, __int_as_float(ti), 0.0f);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) {
+          bm1[u] = bm2[u] = -INFINITY;
+          if (g == 0) part[(u * 8 + wu) * 32 + j] = make_float4(-INFINITY, -INFINITY, __int_as_float(0x7fffffff), 0.0f);
+        }
+      }
+      __syncthreads();                                 // B1: the eight blocks' top-2 of every row are in LDS
+      // ---- every wave merges every row (block order: the lower block wins a tie) and appends ITS candidates
+      bool ambu[NSUB];
+      int tiu[NSUB];
+#pragma unroll
+      for (int u = 0; u < NSUB; ++u) {
+        float t1 = -INFINITY, t2 = -INFINITY;
+        int ti = 0;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) {
+          const float4 pv = part[(u * 8 + ww) * 32 + j];
+          const bool up = pv.x > t1;
+          t2 = up ? fmaxf(t1, pv.y) : fmaxf(t2, pv.x);
+          ti = up ? __float_as_int(pv.z) : ti;
+          t1 = up ? pv.x : t1;
+        }
+        const int px = tile * TR + 32 * u + j;
+        const bool valid = px < nrows;
+        const float err = __uint_as_float(tt[32 * u + j].y);
+        const float gap = half_wide_gap(err, errc_max) + 4.0e-6f;
+        const bool amb = valid && !(t1 - t2 > gap);
+        ambu[u] = amb;
+        tiu[u] = ti;
+        if (wu == 0 && g == 0 && valid) klab[crow0 + px] = ti;          // provisional for ambiguous rows
+        if (!mine || !__any(amb)) continue;
+        const float thr = amb ? t1 - gap - 2.0e-6f : INFINITY;
+        const float thr2 = thr - 2.0e-6f;
+        // this lane's candidates: the block maximum by its tag, or -- its runner-up reaches the threshold as well
+        // in some lane -- a scan of the lane's 16 scores (up to four kept; more: the row asks for all centroids)
+        uint32_t hits = 0u;
+        int nh = 0;
+        if (!__any(bm2[u] >= thr2)) {
+          const uint32_t tgm = __float_as_uint(bm1[u]) & 15u;
+          const bool hit = bm1[u] >= thr2;
+          hits = 32 * wu + (tgm & 3u) + 8 * (tgm >> 2) + 4 * g;
+          nh = hit ? 1 : 0;
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) {
+            const uint32_t k = 32 * wu + (rr & 3) + 8 * (rr >> 2) + 4 * g;
+            const bool hit = k < (uint32_t)K && acc[u][rr] >= thr;
+            hits = (hit && nh < 4) ? (hits | (k << (8 * nh))) : hits;
+            nh += hit ? 1 : 0;
+          }
+        }
+        if (nh > 0) {
+          const int pos = atomicAdd(&ccnt[32 * u + j], nh > 4 ? 8 : nh);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q < nh && pos + q < 8) clist[(32 * u + j) * 8 + pos + q] = (unsigned char)((hits >> (8 * q)) & 255u);
+        }
+      }
+      __syncthreads();                                 // B2: the candidate lists are complete
+      // ---- wave u composes the queue entries of block u and clears its counters
+      if (wu < NSUB) {
+        bool amb = false;
+        int ti = 0;
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u)
+          if (u == wu) { amb = ambu[u]; ti = tiu[u]; }
+        const int row = 32 * wu + j;
+        if (g == 0) {
+          const int tot = ccnt[row];
+          if (amb) {
+            uint32_t cand = 255u << 24, cand_hi = 0u;
+            if (tot >= 1 && tot <= 7) {
+              const unsigned long long all = *reinterpret_cast<const unsigned long long *>(clist + row * 8) &
+                                             ((1ull << (8 * tot)) - 1ull);
+              cand = (uint32_t)(all & 0xFFFFFFull) | ((uint32_t)tot << 24);
+              cand_hi = (uint32_t)(all >> 24);
+            }
+            slice[atomicAdd(qnp, 1)] = SplitEntry{(int32_t)(crow0 + tile * TR + row), cand, cand_hi};
+          }
+          ccnt[row] = 0;
+        }
+        (void)ti;
+      }
+      // ---- the next tile into the other buffer (last read before B0 of this iteration), the one after into registers
+      if (tile + 1 < ntile) HSGK_REGS_STORE(buf ^ 1)
+      if (tile + 2 < ntile) HSGK_REGS_LOAD(tile + 2)
+    }
+#undef HSGK_REGS_LOAD
+#undef HSGK_REGS_PUT
+#undef HSGK_REGS_STORE
+    r += nrows;
+  }
+  __syncthreads();
+  if (tid == 0) seg.count[blockIdx.x] = qnp[0];
+}
+
 // exact pass over the per-workgroup slices of the queue (nseg <= 1024)
 __global__ __launch_bounds__(256) void assign_requeue_seg_kernel(
     const float *__restrict__ x, int d, const float *__restrict__ cent, int K,
@@ -1720,6 +1992,22 @@ int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt
     const int grid1 = (int)(tiles1 < n_cu ? tiles1 : n_cu);
     SegQueue seg{reinterpret_cast<int32_t *>(state), reinterpret_cast<int64_t *>(static_cast<char *>(state) + 4096)};
     const size_t lds = half_lds_bytes<NW1, MB1, 1, 1>(d) + 64;
+    if (d / 64 == 4 && two && two[0] == 'r') {
+      // HSGK_WIDE2=regs: the table in registers, 128-row tiles through LDS (A/B: slower than the pair kernel)
+      constexpr int TRr = 128;
+      const int64_t tilesr = ((int64_t)max_chunks * HSGK_CHUNK + TRr - 1) / TRr;
+      const int gridr = (int)(tilesr < n_cu ? tilesr : n_cu);
+      const size_t ldsr = (size_t)2 * TRr * (256 + 8) * 2 + 2 * TRr * 8 + 4 * 8 * 32 * 16 + TRr * 4 + TRr * 8 + 64;
+      HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(assign_half_regs_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
+      hipLaunchKernelGGL(assign_half_regs_kernel, dim3(gridr), dim3(512), ldsr, s, xm, xt, d, cent, errc, K, t.img_row0, B,
+                         klab, reinterpret_cast<SplitEntry *>(qrows), seg, meta);
+      HSGK_LAUNCH_CHECK();
+      hipLaunchKernelGGL(assign_requeue_seg_kernel, dim3(2048), dim3(256), 0, s, x, d, cent, K, klab,
+                         reinterpret_cast<const SplitEntry *>(qrows), seg, gridr, t.img_row0, B);
+      HSGK_LAUNCH_CHECK();
+      return 0;
+    }
     if (two && two[0] == 'o') {                       // "one": the four-wave kernel (one wave per SIMD)
       auto kern = d / 64 == 4 ? assign_half_wide1_kernel<NW1, 4, MB1, 4> : assign_half_wide1_kernel<NW1, 2, MB1, 2>;
       HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),

@@ -1341,13 +1341,17 @@ def test_full_size_configs_filters_verified_and_spot_parity(dev, oracle, name, s
     assert np.array_equal(ids - ids.min(), ref[3] - ref[3].min()), 'clusters image %d' % b
 
 
-def test_cfg4_end_to_end_c256_grid16_labels_ignore_vs_oracle(dev, oracle):
+@pytest.mark.parametrize('filter_kernel', ['', 'regs', 'one', 'two'])
+def test_cfg4_end_to_end_c256_grid16_labels_ignore_vs_oracle(dev, oracle, monkeypatch, filter_kernel):
   """BASELINE.json configs[3] route end to end on a reduced map: C = 256 with a 16x16 seed
-  grid (K = 256 -> the two-half fp16 filter `assign_half_wide2_kernel`, the cluster-split
+  grid (K = 256 -> the one-pass fp16 filter in pairs of waves by default; HSGK_WIDE2 = regs / one / two: the
+  table-in-registers, four-wave and two-half variants kept for the A/B of DESIGN.md 5a; the cluster-split
   exact-sum M-step), over-segmentation labels + ignore band, mixture and i.i.d. inputs --
   all five outputs bit-exact vs the oracle, every filtered label verified on the device."""
   from hsg_amd import _lib
   from hsg_amd.utils.segsort import common as sc
+  if filter_kernel:
+    monkeypatch.setenv('HSGK_WIDE2', filter_kernel)
   for flavour, shape, iters in (('iid', (2, 256, 96, 96), 10), ('mixture', (1, 256, 128, 80), 6)):
     B, C, H, W = shape
     x = synth.embeddings_nchw(synth.SEED_BASE + 4, shape, flavour)
