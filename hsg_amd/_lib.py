@@ -101,6 +101,7 @@ SIGNATURES = {
                                      _vp, _vp, _vp, _sz, _vp]),
     'hsgk_lloyd_requeued_rows': (_i32, [_i32, _i64, _i32, _i32, _vp, _sz, _vp, _vp]),
     'hsgk_hier_assign': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'hsgk_hier_assign_bwd': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'hsgk_group_mean': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     'hsgk_gather_labels': (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _vp]),
     'hsgk_cluster_topk': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

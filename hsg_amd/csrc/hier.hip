@@ -62,6 +62,86 @@ __global__ __launch_bounds__(256) void hier_assign_kernel(
   }
 }
 
+// Backward of hier_assign_kernel's two probability outputs (the labels carry no gradient):
+//   pf = softmax_KF(fine), pc = softmax_KC(coarse) per fine column, coarse_prob = pc x pf
+//   g_pf[f][n] = G1[f][n] + sum_c pc[c][f] G2[c][n]
+//   g_fine[f][n]   = pf[f][n] (g_pf[f][n] - sum_f' pf[f'][n] g_pf[f'][n])
+//   g_pc[c][f]     = sum_n G2[c][n] pf[f][n]
+//   g_coarse[c][f] = pc[c][f] (g_pc[c][f] - sum_c' pc[c'][f] g_pc[c'][f])
+// One workgroup per image: thread = node for the fine part, the node sum of g_pc through per-thread partials
+// summed in a fixed order (wave shuffles, then the four waves in order).  KF * KC <= 1024.
+__global__ __launch_bounds__(256) void hier_assign_bwd_kernel(
+    const float *__restrict__ fine_logits, const float *__restrict__ coarse_logits, int KF, int KC, int N,
+    const float *__restrict__ g_fprob, const float *__restrict__ g_cprob, float *__restrict__ g_fine,
+    float *__restrict__ g_coarse) {
+  extern __shared__ float hb[];
+  float *pc = hb;                              // [KC][KF]
+  float *gpc = hb + (size_t)KC * KF;           // [4 waves][KC][KF] partials, then [KC][KF] totals in the first slab
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float *fl = fine_logits + (int64_t)b * KF * N;
+  const float *g1 = g_fprob ? g_fprob + (int64_t)b * KF * N : nullptr;
+  const float *g2 = g_cprob ? g_cprob + (int64_t)b * KC * N : nullptr;
+  const bool coarse = coarse_logits != nullptr && g2 != nullptr;
+  if (coarse) {
+    const float *cl = coarse_logits + (int64_t)b * KC * KF;
+    for (int f = tid; f < KF; f += 256) {
+      float m = -INFINITY;
+      for (int c = 0; c < KC; ++c) m = fmaxf(m, cl[c * KF + f]);
+      float sum = 0.0f;
+      for (int c = 0; c < KC; ++c) sum = sum + expf(cl[c * KF + f] - m);
+      for (int c = 0; c < KC; ++c) pc[c * KF + f] = expf(cl[c * KF + f] - m) / sum;
+    }
+    for (int i = tid; i < 4 * KC * KF; i += 256) gpc[i] = 0.0f;
+  }
+  __syncthreads();
+  for (int n0 = 0; n0 < N; n0 += 256) {
+    const int n = n0 + tid;
+    const bool live = n < N;
+    // softmax of the node's fine column (recomputed as the forward computed it)
+    float m = -INFINITY, sum = 0.0f;
+    if (live) {
+      for (int f = 0; f < KF; ++f) m = fmaxf(m, fl[f * N + n]);
+      for (int f = 0; f < KF; ++f) sum = sum + expf(fl[f * N + n] - m);
+    }
+    float dot = 0.0f;
+    if (live)
+      for (int f = 0; f < KF; ++f) {
+        const float p = expf(fl[f * N + n] - m) / sum;
+        float g = g1 ? g1[f * N + n] : 0.0f;
+        if (coarse)
+          for (int c = 0; c < KC; ++c) g = fmaf(pc[c * KF + f], g2[c * N + n], g);
+        dot = fmaf(p, g, dot);
+      }
+    if (live)
+      for (int f = 0; f < KF; ++f) {
+        const float p = expf(fl[f * N + n] - m) / sum;
+        float g = g1 ? g1[f * N + n] : 0.0f;
+        if (coarse)
+          for (int c = 0; c < KC; ++c) g = fmaf(pc[c * KF + f], g2[c * N + n], g);
+        g_fine[(int64_t)b * KF * N + f * N + n] = p * (g - dot);
+      }
+    if (coarse) {
+      // g_pc[c][f] += sum over the 256 nodes of this step: wave reduction, one partial per wave
+      for (int c = 0; c < KC; ++c)
+        for (int f = 0; f < KF; ++f) {
+          float v = live ? g2[c * N + n] * (expf(fl[f * N + n] - m) / sum) : 0.0f;
+          for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+          if (lane == 0) gpc[(w * KC + c) * KF + f] += v;
+        }
+    }
+  }
+  if (!coarse) return;
+  __syncthreads();
+  for (int i = tid; i < KC * KF; i += 256) gpc[i] = ((gpc[i] + gpc[KC * KF + i]) + gpc[2 * KC * KF + i]) + gpc[3 * KC * KF + i];
+  __syncthreads();
+  for (int f = tid; f < KF; f += 256) {
+    float dot = 0.0f;
+    for (int c = 0; c < KC; ++c) dot = fmaf(pc[c * KF + f], gpc[c * KF + f], dot);
+    for (int c = 0; c < KC; ++c)
+      g_coarse[(int64_t)b * KC * KF + c * KF + f] = pc[c * KF + f] * (gpc[c * KF + f] - dot);
+  }
+}
+
 // prototypes [B,C,N]; labels [B,N]; masks [B,N] (uint8, nullable: nothing
 // padded); out [B,C,G].  Node n contributes to group labels[n] unless padded.
 __global__ __launch_bounds__(256) void group_mean_kernel(
@@ -204,6 +284,26 @@ int hsgk_hier_assign(const float *fine_logits, const float *coarse_logits, int B
   HSGK_REQUIRE(lds <= 64 * 1024, "hierarchy too large");
   hipLaunchKernelGGL(hier_assign_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream),
                      fine_logits, coarse_logits, KF, KC, N, fine_prob, fine_lab, coarse_prob, coarse_lab);
+  HSGK_LAUNCH_CHECK();
+  return 0;
+}
+
+int hsgk_hier_assign_bwd(const float *fine_logits, const float *coarse_logits, int B, int KF, int KC, int N,
+                         const float *g_fine_prob, const float *g_coarse_prob, float *g_fine_logits,
+                         float *g_coarse_logits, hsgk_stream_t stream) {
+  HSGK_REQUIRE(B >= 0 && KF >= 1 && N >= 1, "bad shape");
+  HSGK_REQUIRE(fine_logits && g_fine_logits, "null argument");
+  const bool coarse = coarse_logits != nullptr && g_coarse_prob != nullptr;
+  HSGK_REQUIRE(!coarse || (KC >= 1 && g_coarse_logits), "null coarse gradient");
+  if (B == 0) return 0;
+  (void)hipGetLastError();
+  const size_t lds = (size_t)(coarse ? 5 * KC * KF : 0) * 4 + 16;
+  HSGK_REQUIRE(lds <= 64 * 1024 && (!coarse || (int64_t)KC * KF <= 1024), "hierarchy too large");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (coarse_logits && !coarse && g_coarse_logits)
+    HSGK_CHECK_HIP(hipMemsetAsync(g_coarse_logits, 0, sizeof(float) * (size_t)B * KC * KF, st));
+  hipLaunchKernelGGL(hier_assign_bwd_kernel, dim3(B), dim3(256), lds, st, fine_logits, coarse ? coarse_logits : nullptr,
+                     KF, KC, N, g_fine_prob, coarse ? g_coarse_prob : nullptr, g_fine_logits, g_coarse_logits);
   HSGK_LAUNCH_CHECK();
   return 0;
 }

@@ -127,19 +127,24 @@ class _HierAssign(torch.autograd.Function):
 
   @staticmethod
   def backward(ctx, g_fprob, _g1, g_cprob, _g2):
+    """One launch (`hsgk_hier_assign_bwd`): softmax backward of both levels and the chain through
+    coarse_prob = softmax_KC(coarse) x fine_prob -- what autograd did with two softmaxes, an einsum and their
+    backward graph (34 device operations)."""
     fl, cl = ctx.saved_tensors
-    with torch.enable_grad():
-      a = fl.detach().requires_grad_(True)
-      pf = torch.softmax(a, dim=1)
-      outs, grads = [pf], [g_fprob]
-      c = None
-      if ctx.has_coarse:
-        c = cl.detach().requires_grad_(True)
-        outs.append(torch.einsum('bij,bjk->bik', torch.softmax(c, dim=1), pf))
-        grads.append(g_cprob)
-      ins = [a] + ([c] if c is not None else [])
-      res = torch.autograd.grad(outs, ins, grads, allow_unused=True)
-    return res[0], (res[1] if c is not None else None)
+    B, KF, N = fl.shape
+    has_c = ctx.has_coarse
+    KC = cl.shape[1] if has_c else 0
+    dev = fl.device
+    with torch.cuda.device(dev):
+      g1 = g_fprob.contiguous().float() if g_fprob is not None else None
+      g2 = g_cprob.contiguous().float() if (has_c and g_cprob is not None) else None
+      g_fl = torch.empty_like(fl)
+      g_cl = torch.empty_like(cl) if has_c else None
+      _lib.check(_lib.lib().hsgk_hier_assign_bwd(
+          fl.data_ptr(), cl.data_ptr() if has_c else None, B, KF, KC, N,
+          g1.data_ptr() if g1 is not None else None, g2.data_ptr() if g2 is not None else None,
+          g_fl.data_ptr(), g_cl.data_ptr() if g_cl is not None else None, _lib.stream_ptr()))
+    return g_fl, g_cl
 
 
 def hierarchical_grouping_from_logits(fine_logits, coarse_logits=None):

@@ -360,6 +360,11 @@ HSGK_API int hsgk_comm_all_gather_bytes(const void *send, void *recv, size_t byt
 HSGK_API int hsgk_hier_assign(const float *fine_logits, const float *coarse_logits, int B, int KF,
                               int KC, int N, float *fine_prob, int64_t *fine_lab,
                               float *coarse_prob, int64_t *coarse_lab, hsgk_stream_t stream);
+/* backward of the two probability outputs: g_fine_prob [B,KF,N] (nullable = zero), g_coarse_prob [B,KC,N]
+ * (nullable: no coarse branch in the gradient) -> g_fine_logits [B,KF,N], g_coarse_logits [B,KC,KF]          */
+HSGK_API int hsgk_hier_assign_bwd(const float *fine_logits, const float *coarse_logits, int B, int KF,
+                                  int KC, int N, const float *g_fine_prob, const float *g_coarse_prob,
+                                  float *g_fine_logits, float *g_coarse_logits, hsgk_stream_t stream);
 /* ---- resnet_fcn_hsg.py:683-748 _collect_nd_coarser_prototype ------------------
  * protos [B,C,N], labels int64 [B,N], masks uint8 [B,N] (nullable) -> out [B,C,G]:
  * mean of the unpadded nodes of every group, optionally L2-normalised over C.   */

@@ -1019,6 +1019,45 @@ def test_hierarchy_ops_vs_reference_golden(dev, fixture):
   assert np.array_equal(px_coarse.cpu().numpy(), g['px_coarse'])
 
 
+@pytest.mark.parametrize('B,KF,KC,N', [(3, 8, 4, 256), (2, 44, 9, 700), (1, 5, 0, 33), (4, 16, 2, 64)])
+def test_hier_assign_backward_kernel_vs_autograd(dev, B, KF, KC, N):
+  """hsgk_hier_assign_bwd (softmax backward of both levels and the chain through coarse_prob = softmax(coarse) x
+  fine_prob in one launch) against float64 autograd of the ATen formulation, with weights on both probability
+  outputs, on one of them only, and without a coarse level."""
+  import torch
+  from hsg_amd.models.embeddings import hierarchy as hz
+  g = torch.Generator(device=dev).manual_seed(B * 100 + KF + N)
+  fine = 2 * torch.randn((B, KF, N), device=dev, generator=g)
+  coarse = 2 * torch.randn((B, KC, KF), device=dev, generator=g) if KC else None
+  w1 = torch.randn((B, KF, N), device=dev, generator=g)
+  w2 = torch.randn((B, max(KC, 1), N), device=dev, generator=g)
+  for use1, use2 in ((True, True), (False, True), (True, False)):
+    if not KC and not use1:
+      continue
+    fl = fine.clone().requires_grad_(True)
+    cl = coarse.clone().requires_grad_(True) if KC else None
+    out = hz.hierarchical_grouping_from_logits(fl, cl)
+    f_prob = out[1]
+    loss = (f_prob * w1).sum() * (1.0 if use1 else 0.0)
+    if KC and use2:
+      loss = loss + (out[3] * w2).sum()
+    if not use1 and not (KC and use2):
+      continue
+    loss.backward()
+    a = fine.double().requires_grad_(True)
+    b2 = coarse.double().requires_grad_(True) if KC else None
+    pf = torch.softmax(a, 1)
+    ref = (pf * w1.double()).sum() * (1.0 if use1 else 0.0)
+    if KC and use2:
+      ref = ref + (torch.einsum('bij,bjk->bik', torch.softmax(b2, 1), pf) * w2.double()).sum()
+    ref.backward()
+    assert (fl.grad.double() - a.grad).abs().max().item() <= 2e-6 * max(a.grad.abs().max().item(), 1.0)
+    if KC:
+      want = b2.grad if b2.grad is not None else torch.zeros_like(b2)
+      got = cl.grad if cl.grad is not None else torch.zeros_like(cl)
+      assert (got.double() - want).abs().max().item() <= 2e-5 * max(want.abs().max().item(), 1.0)
+
+
 @pytest.mark.parametrize('shape,grid,iters', [
     ((2, 64, 64, 64), (16, 16), 5),      # cfg4-style K = 256: four 64-row table blocks, K-blocked M-step
     ((1, 384, 32, 48), (8, 16), 6),      # cfg5-style C = 384, K = 128
