@@ -57,23 +57,26 @@ def calculate_kmeans_prototypes(cluster_embeddings, cluster_indices, cluster_bat
   c = cluster_indices.view(-1).long()
   lab = cluster_labels.view(-1).long()
   img = b if image_indices is None else image_indices.view(-1).long()[b]      # (:1051-1054)
-  # one sorted unique over (image, cluster, batch * div^2 + label) replaces the per-image loop
+  # The segments are the distinct (image, cluster, batch * div^2 + label) triples in ascending order -- the order
+  # of the exchange's tuple kernels (hash, compaction, sort on the device; models/utils.py), run here on this
+  # GPU's rows only: one host read for the count instead of two sorted `unique`s, a radix read and their glue.
+  from hsg_amd.models import utils as model_utils
   ldiv = int(label_divisor) ** 2
   bl = b * ldiv + lab                                                  # (:1079-1080) batch index rides on the label
-  if c.numel():
-    radix = torch.stack([c.max(), bl.max()]).cpu().tolist()
-    cdiv, blmax = radix[0] + 1, radix[1] + 1
+  rows = cluster_embeddings.reshape(-1, cluster_embeddings.shape[-1])
+  protos, _, ubl, _, uimg, gid = model_utils.exchange_prototypes(rows, rows, c, img, bl, torch.zeros_like(bl),
+                                                                  tag='kmeans_protos', local=True)
+  P = ubl.shape[0]
+  seg = torch.arange(P, device=dev)
+  first = torch.ones((P,), dtype=torch.bool, device=dev)
+  first[1:] = uimg[1:] != uimg[:-1]                                    # the table is ordered by image
+  img_of_seg = torch.cumsum(first.long(), 0) - 1                      # dense image number, ascending image id
+  local = seg - torch.cummax(torch.where(first, seg, torch.zeros_like(seg)), 0).values if P else seg
+  if P:
+    B, most = torch.stack([img_of_seg[-1] + 1, local.max()]).tolist()  # the shape of the tables: one host read
   else:
-    cdiv = blmax = 1
-  keys = (img * cdiv + c) * blmax + bl
-  ukeys, gid = torch.unique(keys, return_inverse=True)
-  ubl = ukeys % blmax
-  uimg = ukeys // (blmax * cdiv)
-  images, img_of_seg = torch.unique(uimg, return_inverse=True)        # ascending image id
-  B = images.shape[0]
-  first = torch.searchsorted(uimg, images)                             # first global id per image
-  local = torch.arange(ukeys.shape[0], device=dev) - first[img_of_seg]
-  if int(local.max()) >= M if local.numel() else False:
+    B, most = 0, -1
+  if most >= M:
     raise IndexError('an image has more than max_num_clusters=%d segments' % M)
   slot = img_of_seg * M + local                                        # position in the padded table
   cluster_indices_by_image = local[gid]
@@ -81,9 +84,7 @@ def calculate_kmeans_prototypes(cluster_embeddings, cluster_indices, cluster_bat
   if order is not None:
     cluster_indices_by_image = cluster_indices_by_image[order]
 
-  P = ukeys.shape[0]
   C = cluster_embeddings.shape[-1]
-  protos = ops.segment_reduce(cluster_embeddings, gid, P, 0)           # normalised segment sums
   table = torch.zeros((B * M, C), dtype=torch.float32, device=dev).index_copy(0, slot, protos)
   prototypes = table.view(B, M, C).permute(0, 2, 1)
   pos_prototypes = None
