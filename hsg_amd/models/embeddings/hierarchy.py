@@ -13,11 +13,11 @@ The transformer stacks that produce the logits stay stock PyTorch-ROCm
 one launch per operator instead of tens of ATen calls and a Python loop per
 image.  Differentiable outputs (probabilities, group means, prototypes) keep
 their autograd connection: the fused forward values are produced by the HIP
-kernels and the backward pass re-derives the tiny local graph with ATen ops.
+kernels (`hsgk_hier_assign` and its one-launch backward).
 """
 import ctypes
-
 import math
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -33,6 +33,25 @@ def _group_order(group_of_row):
   if group_of_row.numel() < 2 or bool((group_of_row[1:] >= group_of_row[:-1]).all()):
     return None
   return torch.argsort(group_of_row, stable=True)
+
+
+_dense_memo = None                         # (weak reference to the last index tensor, its version, the result)
+
+
+def _dense_image_index(batch_indices):
+  """(rank of every pixel's image id among the distinct ids, the image-by-image permutation or None).
+  `generate_clusters` asks for it twice per step with the same tensor (fine and coarse level): the sorted
+  `unique` and the order check -- two host reads -- run once per tensor object and version.  (One immutable
+  tuple, replaced as a whole: threads driving different GPUs only ever evict each other's entry.)"""
+  global _dense_memo
+  memo = _dense_memo
+  if memo is not None and memo[0]() is batch_indices and memo[1] == batch_indices._version:
+    return memo[2]
+  _, img = torch.unique(batch_indices.view(-1).long(), return_inverse=True)
+  img = img.contiguous()
+  result = (img, _group_order(img))
+  _dense_memo = (weakref.ref(batch_indices), batch_indices._version, result)
+  return result
 
 
 def calculate_kmeans_prototypes(cluster_embeddings, cluster_indices, cluster_batch_indices,
@@ -230,8 +249,7 @@ def collect_pixel_hierarchical_clustering_indices(cluster_indices_by_batch,
   concatenated image by image, exactly as the reference's loop does."""
   ops.require_gpu(cluster_indices_by_batch, 'cluster_indices_by_batch')
   seg = cluster_indices_by_batch.view(-1).long().contiguous()
-  _, img = torch.unique(cluster_batch_indices.view(-1).long(), return_inverse=True)
-  img = img.contiguous()
+  img, order = _dense_image_index(cluster_batch_indices)
   table = finehrchy_prototype_grouping_labels.long().contiguous()
   out = torch.empty_like(seg)
   if seg.numel() == 0:
@@ -240,7 +258,6 @@ def collect_pixel_hierarchical_clustering_indices(cluster_indices_by_batch,
     _lib.check(_lib.lib().hsgk_gather_labels(table.data_ptr(), table.shape[1], img.data_ptr(),
                                              seg.data_ptr(), seg.shape[0], out.data_ptr(),
                                              _lib.stream_ptr()))
-  order = _group_order(img)
   return out if order is None else out[order]
 
 
