@@ -63,7 +63,7 @@ class LossSet(ctypes.Structure):
 
 
 _lib = None
-ABI_VERSION = 300          # HSGK_VERSION the struct layouts / signatures below were written for
+ABI_VERSION = 310          # HSGK_VERSION the struct layouts / signatures below were written for
 
 _vp, _i64, _i32, _f32, _sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                               ctypes.c_float, ctypes.c_size_t)

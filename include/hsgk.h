@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HSGK_VERSION 300
+#define HSGK_VERSION 310
 #define HSGK_CHUNK 2048          /* rows per segment-sum chunk (order C2)      */
 #define HSGK_EPS 1e-12f          /* normalize_embedding eps (general/common.py:101) */
 
