@@ -112,7 +112,7 @@ def calculate_kmeans_prototypes(cluster_embeddings, cluster_indices, cluster_bat
     ptab = torch.zeros((B * M, pos.shape[1]), dtype=torch.float32, device=dev).index_copy(0, slot, pos)
     pos_prototypes = ptab.view(B, M, -1).permute(0, 2, 1)
   masks = torch.ones((B * M,), dtype=torch.bool, device=dev)
-  masks[slot] = False
+  masks.index_fill_(0, slot, False)                                   # (an indexed assignment of a Python scalar uploads it)
   plabs = torch.full((B * M,), -1, dtype=torch.long, device=dev)
   plabs[slot] = ubl % ldiv                                             # (:524-525 / :1084-1085)
   pbatch = torch.full((B * M,), -1, dtype=torch.long, device=dev)
