@@ -1464,10 +1464,11 @@ int hsgk_segsort_loss_fwd(const float *emb, int64_t n, int c, const int64_t *ins
   for (int l = 0; l < L; ++l) plain = plain && !ls.setm[l];
   int plus_mask = 0;
   for (int l = 0; l < L; ++l) plus_mask |= ls.plus[l] << l;
-  // the pixel rows in the split engine's own image, made once (HSGK_LOSS_FWD=convert: per prototype block, as before)
+  // the pixel rows in the split engine's own image, made once (HSGK_LOSS_FWD=convert: per prototype block, as before);
+  // the extra pass over the rows pays from ~17 prototype blocks on (measured: slower at P = 256 / 512, faster at 1 568 / 3 072)
   const float *xpre = nullptr;
   const char *fwd_env = getenv("HSGK_LOSS_FWD");
-  if (loss_fwd_xpre_shape(c) && loss_split_enabled(c) && P > 64 && !(fwd_env && fwd_env[0] == 'c')) {
+  if (loss_fwd_xpre_shape(c) && loss_split_enabled(c) && P >= 1280 && !(fwd_env && fwd_env[0] == 'c')) {
     float *xp = cv.take<float>((size_t)n * c);
     const int64_t t2 = n * c / 2, gsz = (t2 + 255) / 256;
     hipLaunchKernelGGL(loss_pairs_kernel, dim3((unsigned)(gsz > 16384 ? 16384 : gsz)), dim3(256), 0, s, emb, t2,
