@@ -1778,6 +1778,29 @@ def test_dmon_affinity_graph_and_loss_vs_reference_golden(dev, oracle):
   assert np.abs(lg.grad.cpu().numpy() - g['g_logits']).max() <= 1e-6
 
 
+def test_hierarchical_dmon_loss_vs_reference_golden(dev):
+  """HierarchicalDMonLoss (reference graph/loss.py:148-231) with two levels -- the first on the binary k-NN graph
+  (fused pooling kernels), the second on the adjacency pooled with the first level's masked probabilities (it
+  carries a gradient: the formula path) -- against the reference's values and logit gradients
+  (tests/golden/f17_hier_dmon.npz, tools/gen_golden.py f17)."""
+  import torch
+  from hsg_amd.utils.graph import loss as gl
+  g = util.load('f17_hier_dmon')
+  B, C, N, K1, K2, knn = (int(v) for v in g['shape'])
+  x, pad, seg, logits1 = util.graph_inputs(int(g['seed']), B + 1, C, N, K1)
+  keep = [0, 1, 3, 4]
+  T = lambda a: torch.from_numpy(a).to(dev)
+  logits2 = synth.gaussish(int(g['seed']) + 5, B * K2 * K1).reshape(B, K2, K1).copy()
+  l1, l2 = T(logits1[keep]).requires_grad_(True), T(logits2).requires_grad_(True)
+  dm, co = gl.HierarchicalDMonLoss(adj_knn=knn)([torch.softmax(l1, 1), torch.softmax(l2, 1)], T(x[keep]),
+                                                [T(pad[keep]), T(g['pad2'])], T(seg[keep]))
+  (dm[0] + 0.5 * co[0] + 2.0 * dm[1] + 0.25 * co[1]).backward()
+  for i in range(2):
+    assert abs(dm[i].item() - float(g['dmon'][i])) <= 1e-5 and abs(co[i].item() - float(g['collapse'][i])) <= 1e-5
+  assert np.abs(l1.grad.cpu().numpy() - g['g_logits1']).max() <= 2e-6
+  assert np.abs(l2.grad.cpu().numpy() - g['g_logits2']).max() <= 2e-6
+
+
 @pytest.mark.parametrize('B,N,K,masked', [(3, 256, 8, True), (2, 8, 4, False), (4, 100, 32, True), (1, 1000, 5, True)])
 def test_dmon_pool_fused_kernels_vs_reference_formula(dev, B, N, K, masked):
   """hsgk_dmon_pool_fwd / _bwd (an adjacency without gradient: DMonLoss) against the reference's chain of batched

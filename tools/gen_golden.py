@@ -315,6 +315,29 @@ def f13():
        dmon=np.float64(d.item()), collapse=np.float64(c.item()), g_logits=lg.grad.numpy())
 
 
+# ---- F17 HierarchicalDMonLoss (graph/loss.py:148-231): two levels, the second on the pooled adjacency ----
+def f17():
+  import hsg.utils.graph.loss as ref_gl
+  from tests import util as tutil
+  seed = synth.SEED_BASE + 171
+  B, C, N, K1, K2, knn = 4, 24, 48, 6, 3, 7
+  x, pad, seg, logits1 = tutil.graph_inputs(seed, B + 1, C, N, K1)
+  keep = [0, 1, 3, 4]                                # (image 2 has no valid node: NaN in the reference too)
+  x, pad, seg, logits1 = x[keep], pad[keep], seg[keep], logits1[keep]
+  logits2 = synth.gaussish(seed + 5, B * K2 * K1).reshape(B, K2, K1).copy()
+  pad2 = np.zeros((B, K1), bool)
+  pad2[1, K1 - 1] = True                             # one padded cluster of the first level
+  l1 = torch.from_numpy(logits1).requires_grad_(True)
+  l2 = torch.from_numpy(logits2).requires_grad_(True)
+  probs = [torch.softmax(l1, 1), torch.softmax(l2, 1)]
+  dm, co = ref_gl.HierarchicalDMonLoss(adj_knn=knn)(probs, torch.from_numpy(x),
+                                                    [torch.from_numpy(pad), torch.from_numpy(pad2)], torch.from_numpy(seg))
+  (dm[0] + 0.5 * co[0] + 2.0 * dm[1] + 0.25 * co[1]).backward()
+  save('f17_hier_dmon', seed=seed, shape=np.array([B, C, N, K1, K2, knn]), pad2=pad2,
+       dmon=np.array([v.item() for v in dm]), collapse=np.array([v.item() for v in co]),
+       g_logits1=l1.grad.numpy(), g_logits2=l2.grad.numpy())
+
+
 # ---- F8 cross-GPU glue (hsg/models/utils.py) with 2 simulated GPUs ------------
 def f8():
   import torch.nn.parallel.scatter_gather as sg
@@ -553,6 +576,6 @@ def f15():
 
 if __name__ == '__main__':
   os.makedirs(OUT, exist_ok=True)
-  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13', 'f14', 'f15', 'f16']
+  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13', 'f14', 'f15', 'f16', 'f17']
   for w in which:
     globals()[w]()
