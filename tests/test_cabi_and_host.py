@@ -102,3 +102,14 @@ def test_host_helpers_match_torch_tables():
     loc = np.empty((H, W, 2), np.float32)
     assert L.hsgk_host_location_features(H, W, loc.ctypes.data_as(ctypes.c_void_p)) == 0
     assert np.array_equal(loc.view(np.uint32), sc._default_loc(H, W, torch.device('cpu')).numpy().view(np.uint32))
+
+
+def test_one_hot_helper_matches_the_reference_definition():
+  """general/common.py:76-98: an (N+1)-D long tensor with a single 1 per label, width max + 1 by default."""
+  import torch
+  from hsg_amd.utils.general import common as gc
+  lab = torch.tensor([[0, 3, 1], [2, 2, 0]])
+  got = gc.one_hot(lab)
+  assert got.dtype == torch.long and tuple(got.shape) == (2, 3, 4)
+  assert torch.equal(got, torch.nn.functional.one_hot(lab, 4))
+  assert tuple(gc.one_hot(lab, 7).shape) == (2, 3, 7)
