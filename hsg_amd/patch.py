@@ -67,7 +67,7 @@ def patch_reference(package='hsg'):
       ('utils.segsort.loss', sl, ['SegSortLoss', 'SetSegSortLoss']),
       ('utils.segsort.eval', se, ['top_k_ranking']),
       ('utils.graph.common', graph_c, ['affinity_matrix_as_attention']),
-      ('utils.graph.loss', graph_l, ['DMonLoss', 'HierarchicalDMonLoss', 'dmon_pool_loss']),
+      ('utils.graph.loss', graph_l, ['DMonLoss', 'HierarchicalDMonLoss', 'dmon_pool_loss', 'NCutLoss', 'ncut_pool_loss']),
       ('utils.segsort.others', so, ['load_memory_banks']),
       ('models.utils', mu, ['gather_and_reorder_image_indices', 'gather_and_update_cluster_mappings',
                             'gather_clustering_and_update_prototypes', 'gather_and_update_datas',

@@ -134,3 +134,41 @@ class HierarchicalDMonLoss(_Loss):
       collapse_losses.append(c)
       prev_probs, prev_masks = cur_probs, cur_masks
     return dmon_losses, collapse_losses
+
+
+def ncut_pool_loss(x, adj, s, mask=None):
+  """Reference loss.py:234-288 (normalised cut + entropy terms; no model of the reference uses it).  s [B,N,K]
+  logits (the softmax is applied here), mask [B,N] valid nodes.  Returns (ncut_loss, self_loss):
+      ncut = mean_b sum_k  S_k^T A (1 - S_k) / (d^T S_k + 1e-2),   d = A 1
+      self = mean over (b, k) of  sum_i -S_ik log S_ik   with S clamped to [1e-5, 1]
+  Since A (1 - S) = d 1^T - A S, the numerator of cluster k is d^T S_k - S_k^T (A S)_k: one batched product
+  with the adjacency instead of the reference's two and its [K, K] intermediate."""
+  adj = adj.unsqueeze(0) if adj.dim() == 2 else adj
+  s = s.unsqueeze(0) if s.dim() == 2 else s
+  B, N, K = s.shape
+  s = torch.softmax(s, dim=-1)
+  if mask is not None:
+    s = s * mask.view(B, N, 1).to(s.dtype)
+  deg = adj.sum(dim=2, keepdim=True)                                     # d [B,N,1]
+  reach = (deg * s).sum(dim=1)                                           # d^T S_k [B,K]
+  inside = (s * torch.matmul(adj, s)).sum(dim=1)                         # S_k^T A S_k [B,K]
+  ncut_loss = torch.mean(((reach - inside) / (reach + 1e-2)).sum(dim=1))
+  safe = torch.clamp(s, min=1e-5, max=1)
+  self_loss = torch.mean((-safe * torch.log(safe)).sum(dim=1))
+  return ncut_loss, self_loss
+
+
+class NCutLoss(_Loss):
+  """Reference loss.py:291-345: the normalised-cut objective on the symmetrised binary k-NN graph."""
+
+  def __init__(self, adj_knn=None, size_average=None, reduce=None, reduction='mean'):
+    super(NCutLoss, self).__init__(size_average, reduce, reduction)
+    self._knn = adj_knn
+
+  def __repr__(self):
+    return 'NCutLoss(adj_knn={:.2f})'.format(self._knn)
+
+  def forward(self, logits, x, x_padding_mask=None, x_segment_labels=None):
+    adj = graph_common.affinity_matrix_as_attention(x, x_padding_mask, x_segment_labels, self._knn, True, True)
+    adj = (adj + adj.transpose(1, 2)) * 0.5
+    return ncut_pool_loss(x.transpose(1, 2), adj, logits.transpose(1, 2), ~x_padding_mask)

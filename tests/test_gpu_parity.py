@@ -1801,6 +1801,23 @@ def test_hierarchical_dmon_loss_vs_reference_golden(dev):
   assert np.abs(l2.grad.cpu().numpy() - g['g_logits2']).max() <= 2e-6
 
 
+def test_ncut_loss_vs_reference_golden(dev):
+  """NCutLoss / ncut_pool_loss (reference graph/loss.py:234-345) against the reference's values and logit gradient
+  (tests/golden/f18_ncut.npz)."""
+  import torch
+  from hsg_amd.utils.graph import loss as gl
+  g = util.load('f18_ncut')
+  B, C, N, K, knn = (int(v) for v in g['shape'])
+  x, pad, seg, logits = util.graph_inputs(int(g['seed']), B, C, N, K)
+  keep = [0, 1, 3, 4]
+  T = lambda a: torch.from_numpy(a).to(dev)
+  lg = T(logits[keep]).requires_grad_(True)
+  nc, se = gl.NCutLoss(adj_knn=knn)(lg, T(x[keep]), T(pad[keep]), T(seg[keep]))
+  (nc + 0.5 * se).backward()
+  assert abs(nc.item() - float(g['ncut'])) <= 1e-5 and abs(se.item() - float(g['self_loss'])) <= 1e-5
+  assert np.abs(lg.grad.cpu().numpy() - g['g_logits']).max() <= 2e-6
+
+
 @pytest.mark.parametrize('B,N,K,masked', [(3, 256, 8, True), (2, 8, 4, False), (4, 100, 32, True), (1, 1000, 5, True)])
 def test_dmon_pool_fused_kernels_vs_reference_formula(dev, B, N, K, masked):
   """hsgk_dmon_pool_fwd / _bwd (an adjacency without gradient: DMonLoss) against the reference's chain of batched

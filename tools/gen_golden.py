@@ -338,6 +338,22 @@ def f17():
        g_logits1=l1.grad.numpy(), g_logits2=l2.grad.numpy())
 
 
+# ---- F18 NCutLoss (graph/loss.py:234-345; not used by the reference's models, part of the module surface) ----
+def f18():
+  import hsg.utils.graph.loss as ref_gl
+  from tests import util as tutil
+  seed = synth.SEED_BASE + 181
+  B, C, N, K, knn = 5, 24, 48, 6, 7
+  x, pad, seg, logits = tutil.graph_inputs(seed, B, C, N, K)
+  keep = [0, 1, 3, 4]
+  lg = torch.from_numpy(logits[keep]).requires_grad_(True)
+  nc, se = ref_gl.NCutLoss(adj_knn=knn)(lg, torch.from_numpy(x[keep]), torch.from_numpy(pad[keep]),
+                                        torch.from_numpy(seg[keep]))
+  (nc + 0.5 * se).backward()
+  save('f18_ncut', seed=seed, shape=np.array([B, C, N, K, knn]), ncut=np.float64(nc.item()),
+       self_loss=np.float64(se.item()), g_logits=lg.grad.numpy())
+
+
 # ---- F8 cross-GPU glue (hsg/models/utils.py) with 2 simulated GPUs ------------
 def f8():
   import torch.nn.parallel.scatter_gather as sg
@@ -576,6 +592,6 @@ def f15():
 
 if __name__ == '__main__':
   os.makedirs(OUT, exist_ok=True)
-  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13', 'f14', 'f15', 'f16', 'f17']
+  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13', 'f14', 'f15', 'f16', 'f17', 'f18']
   for w in which:
     globals()[w]()
