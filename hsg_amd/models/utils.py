@@ -528,6 +528,28 @@ def gather_clustering_and_update_prototypes(embeddings, embeddings_with_loc, clu
   return fan(protos), fan(protos_loc), fan(psem), fan(pinst), fan(pbatch), list(outs[5:])
 
 
+# ---- hsg/models/utils.py:12-38 ---------------------------------------------------
+def get_params(model, prefixs, suffixes, exclude=None):
+  """The trainable parameters of the sub-modules named in `prefixs` whose (last component of the) name starts or
+  ends with one of `suffixes`; `exclude`: a list of full parameter names, or a substring.  Optimiser bookkeeping
+  of the training script (reference :12-38), kept so that the module swap of INTEGRATION.md is complete."""
+  wanted = set(prefixs)
+  for mod_name, module in model.named_modules():
+    if mod_name not in wanted:
+      continue
+    for par_name, par in module.named_parameters():
+      full = mod_name + '.' + par_name
+      if isinstance(exclude, list) and full in exclude:
+        continue
+      if isinstance(exclude, str) and exclude in full:
+        continue
+      last = full.split('.')[-1]
+      # (one yield per matching suffix, as the reference's nested loop does)
+      for suffix in suffixes:
+        if par.requires_grad and (last.startswith(suffix) or full.endswith(suffix)):
+          yield par
+
+
 # ---- hsg/models/utils.py:41-74 ---------------------------------------------------
 def reorder_image_indices(image_ids_all):
   """Dense image index by first-occurrence order over the gathered id list."""

@@ -1,4 +1,5 @@
-"""Drop-in for `hsg.utils.general.common` (hot-path members only).
+"""Drop-in for `hsg.utils.general.common`: the hot-path members on libhsgk, the bookkeeping / visualisation
+helpers (`one_hot`, `resize_labels`, `pca`) as ATen so that the import swap of INTEGRATION.md is complete.
 
 Same names, argument meaning and return conventions as the reference
 (hsg/utils/general/common.py); the arithmetic runs in libhsgk's gfx950
@@ -6,6 +7,7 @@ kernels.  Tensors must live on a ROCm device: like the reference's multi-GPU
 code path, CPU tensors are not a supported device here.
 """
 import torch
+import torch.nn.functional as F
 
 from hsg_amd import _lib, ops
 
@@ -37,3 +39,30 @@ def one_hot(labels, max_label=None):
   out = torch.zeros((flat.shape[0], max_label), dtype=torch.long, device=labels.device)
   out.scatter_(1, flat, 1)
   return out.view(list(labels.shape) + [max_label])
+
+
+def resize_labels(labels, size):
+  """Reference general/common.py:11-26: nearest-neighbour resize of [batch, height, width] long label maps to
+  `size` (what `generate_clusters`' callers do to bring the annotation to the embedding resolution, :316-321).
+  Out of the hot path: ATen."""
+  b, h, w = labels.shape
+  resized = F.interpolate(labels.reshape(b, 1, h, w).float(), size=size, mode='nearest')
+  return resized[:, 0].long()
+
+
+def calculate_principal_components(embeddings, num_components=3):
+  """Reference general/common.py:29-42: the leading right singular vectors [embedding_dims, num_components] of
+  the centred [num_pixels, embedding_dims] matrix (visualisation helper; ATen)."""
+  centred = embeddings - embeddings.mean(dim=0, keepdim=True)
+  _, _, v = torch.svd(centred)
+  return v[:, :num_components]
+
+
+def pca(embeddings, num_components=3, principal_components=None):
+  """Reference general/common.py:45-73: projects the last dimension onto `principal_components` (computed from the
+  input when not given); the leading dimensions are kept."""
+  lead = list(embeddings.shape[:-1])
+  flat = embeddings.reshape(-1, embeddings.shape[-1])
+  if principal_components is None:
+    principal_components = calculate_principal_components(flat, num_components)
+  return torch.mm(flat, principal_components).reshape(lead + [num_components])

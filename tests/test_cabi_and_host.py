@@ -113,3 +113,29 @@ def test_one_hot_helper_matches_the_reference_definition():
   assert got.dtype == torch.long and tuple(got.shape) == (2, 3, 4)
   assert torch.equal(got, torch.nn.functional.one_hot(lab, 4))
   assert tuple(gc.one_hot(lab, 7).shape) == (2, 3, 7)
+
+
+def test_bookkeeping_helpers_of_the_swapped_modules():
+  """resize_labels / pca / calculate_principal_components (general/common.py:11-73) and get_params
+  (models/utils.py:12-38): ATen helpers outside the hot path, present so that the import swap is complete."""
+  import torch
+  from hsg_amd.utils.general import common as gc
+  from hsg_amd.models import utils as mu
+  lab = torch.arange(2 * 6 * 8).reshape(2, 6, 8)
+  small = gc.resize_labels(lab, (3, 4))
+  assert small.dtype == torch.long and tuple(small.shape) == (2, 3, 4)
+  assert torch.equal(small, lab[:, ::2, ::2])
+  x = torch.randn(50, 7, generator=torch.Generator().manual_seed(3))
+  pc = gc.calculate_principal_components(x, 3)
+  assert tuple(pc.shape) == (7, 3) and torch.allclose(pc.t() @ pc, torch.eye(3), atol=1e-5)
+  y = gc.pca(x.reshape(5, 10, 7), 3)
+  assert tuple(y.shape) == (5, 10, 3) and torch.allclose(y.reshape(50, 3), x @ pc, atol=1e-5)
+  # the variance captured decreases along the components
+  v = (gc.pca(x - x.mean(0, keepdim=True), 3) ** 2).sum(0)
+  assert v[0] >= v[1] >= v[2]
+  net = torch.nn.Sequential()
+  net.add_module('head', torch.nn.Linear(3, 2))
+  net.add_module('body', torch.nn.Linear(3, 2))
+  got = list(mu.get_params(net, ['head'], ['weight']))
+  assert len(got) == 1 and got[0] is net.head.weight
+  assert [p is net.head.bias for p in mu.get_params(net, ['head', 'body'], ['bias'], exclude='body')] == [True]
