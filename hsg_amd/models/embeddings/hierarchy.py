@@ -65,13 +65,14 @@ def calculate_kmeans_prototypes(cluster_embeddings, cluster_indices, cluster_bat
   Returns (prototypes [B',C,M], pos_prototypes [B',C,M] or None, padding masks
   [B',M] bool, prototype_labels [B',M], prototype_batch_indices [B',M],
   cluster_indices_by_image [N]); B' = distinct images (ascending id), padded entries are
-  0 / True / -1 / -1.  Segment ids inside an image are the ranks of (cluster index,
+  0 / True / -1 / -1.  `max_num_clusters=None`: M = the largest number of segments of an image in this call (the
+  Cityscapes twin of the model, resnet_fcn_hsg_cs.py:499-502 / :1061-1064).  Segment ids inside an image are the ranks of (cluster index,
   batch index, label) triples (prepare_prototype_labels, :1082); like the reference,
   `cluster_indices_by_image` lists the pixels image by image.
   """
   ops.require_gpu(cluster_embeddings, 'cluster_embeddings')
   dev = cluster_embeddings.device
-  M = int(max_num_clusters)
+  M = None if max_num_clusters is None else int(max_num_clusters)
   b = cluster_batch_indices.view(-1).long()
   c = cluster_indices.view(-1).long()
   lab = cluster_labels.view(-1).long()
@@ -95,6 +96,8 @@ def calculate_kmeans_prototypes(cluster_embeddings, cluster_indices, cluster_bat
     B, most = torch.stack([img_of_seg[-1] + 1, local.max()]).tolist()  # the shape of the tables: one host read
   else:
     B, most = 0, -1
+  if M is None:
+    M = most + 1                                     # (a cluster carries one label: segments == distinct clusters)
   if most >= M:
     raise IndexError('an image has more than max_num_clusters=%d segments' % M)
   slot = img_of_seg * M + local                                        # position in the padded table

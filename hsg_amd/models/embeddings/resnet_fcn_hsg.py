@@ -33,7 +33,7 @@ def _calculate_kmeans_prototypes(self, cluster_embeddings, cluster_indices, clus
   return hierarchy.calculate_kmeans_prototypes(
       cluster_embeddings, cluster_indices, cluster_batch_indices, cluster_pos_embeddings,
       cluster_labels, image_indices, label_divisor=self.label_divisor,
-      max_num_clusters=self.max_num_clusters)
+      max_num_clusters=None if getattr(self, 'dynamic_max_num_clusters', False) else self.max_num_clusters)
 
 
 def _collect_nd_coarser_prototype(self, prototypes, prototype_grouping_labels,
@@ -175,3 +175,15 @@ class ClusteringMixin:
 class MultiviewClusteringMixin(ClusteringMixin):
   """Methods of `MultiviewResnetFcn` (the model train.py builds)."""
   generate_clusters = generate_clusters_multiview
+
+
+class ClusteringMixinCs(ClusteringMixin):
+  """`resnet_fcn_hsg_cs.ResnetFcn` (the Cityscapes twin): the same methods, the padded
+  tables as long as the largest number of clusters of an image in the call (:499-502) instead of
+  `self.max_num_clusters`."""
+  dynamic_max_num_clusters = True
+
+
+class MultiviewClusteringMixinCs(MultiviewClusteringMixin):
+  """`resnet_fcn_hsg_cs.MultiviewResnetFcn` (:1061-1064)."""
+  dynamic_max_num_clusters = True

@@ -46,7 +46,10 @@ def _dmon_terms(self, datas):
   """Spectral (DMon) clustering objective + collapse regulariser of both hierarchy levels (reference :163-186):
   every level's grouping logits are scored against the same k-NN graph inputs (node prototypes, padding
   masks, node -> image indices)."""
-  graph = (datas['nd_prototype'], datas['nd_prototype_padding_mask'], datas['nd_prototype_batch_index'])
+  # (the Cityscapes twin, predictions/hsg_cs.py:173-175, builds the k-NN graph over ALL nodes of an image row:
+  #  no per-view segments)
+  segments = datas['nd_prototype_batch_index'] if getattr(self, 'dmon_graph_per_view', True) else None
+  graph = (datas['nd_prototype'], datas['nd_prototype_padding_mask'], segments)
   # the k-NN graph depends on the nodes only: built once for both levels (the reference rebuilds it per call)
   extra = {'adjacency': self.dmon_loss.adjacency(*graph)} if hasattr(self.dmon_loss, 'adjacency') else {}
   total = None
@@ -194,3 +197,14 @@ class Hsg(nn.Module):
 def hsg(config):
   """Non-parametric prototype predictor (reference :270-273)."""
   return Hsg(config)
+
+
+class HsgCs(Hsg):
+  """`hsg/models/predictions/hsg_cs.py`: the same losses; the DMon k-NN graph is not restricted to the nodes of
+  one view (`hsg_cs.py:173-175` passes no segment labels)."""
+  dmon_graph_per_view = False
+
+
+def hsg_cs(config):
+  """Reference hsg_cs.py:269-272."""
+  return HsgCs(config)

@@ -982,6 +982,16 @@ def test_hierarchy_ops_vs_reference_golden(dev, fixture):
   assert np.abs(pos_protos.cpu().numpy() - g['pos_protos']).max() <= 1e-5
   protos.sum().backward()
   assert emb.grad is not None and torch.isfinite(emb.grad).all()
+  # the Cityscapes twin (resnet_fcn_hsg_cs.py:499-502, :1061-1064): the same tables, padded only to the largest
+  # number of clusters of an image
+  dyn = hz.calculate_kmeans_prototypes(emb.detach(), T('cidx'), T('bidx'), pos, T('labels'), img_idx,
+                                       label_divisor=256, max_num_clusters=None)
+  Md = int((~masks).sum(1).max())
+  assert dyn[0].shape[2] == Md and dyn[2].shape[1] == Md
+  assert torch.equal(dyn[0], protos.detach()[:, :, :Md]) and torch.equal(dyn[1], pos_protos[:, :, :Md])
+  for a, b2 in zip(dyn[2:5], (masks, plabs, pbatch)):
+    assert torch.equal(a, b2[:, :Md])
+  assert torch.equal(dyn[5], c_by_img)
 
   fine_logits = (torch.from_numpy(synth.gaussish(seed + 2, B * KF * M).reshape(B, KF, M).copy()) * 2).to(dev)
   coarse_logits = (torch.from_numpy(synth.gaussish(seed + 3, B * KC * KF).reshape(B, KC, KF).copy()) * 2).to(dev)
@@ -1799,6 +1809,35 @@ def test_hierarchical_dmon_loss_vs_reference_golden(dev):
     assert abs(dm[i].item() - float(g['dmon'][i])) <= 1e-5 and abs(co[i].item() - float(g['collapse'][i])) <= 1e-5
   assert np.abs(l1.grad.cpu().numpy() - g['g_logits1']).max() <= 2e-6
   assert np.abs(l2.grad.cpu().numpy() - g['g_logits2']).max() <= 2e-6
+
+
+def test_cityscapes_twins_of_the_model_classes(dev):
+  """`hsg_cs.Hsg` scores the grouping logits against a k-NN graph over all nodes of an image row (no per-view
+  segments, hsg_cs.py:173-175): HsgCs's DMon terms == Hsg's with a constant segment label, != with real views;
+  the embedding mix-ins of resnet_fcn_hsg_cs.py only switch the pad length to the call's maximum."""
+  import types
+  import torch
+  from hsg_amd.models.predictions import hsg as pm
+  from hsg_amd.models.embeddings import resnet_fcn_hsg as em
+  from hsg_amd.utils.graph import loss as gl
+  B, C, N = 3, 24, 40
+  g = torch.Generator(device=dev).manual_seed(7)
+  nodes = torch.nn.functional.normalize(torch.randn((B, C, N), device=dev, generator=g), dim=1)
+  datas = {'nd_prototype': nodes, 'nd_prototype_padding_mask': torch.zeros((B, N), dtype=torch.bool, device=dev),
+           'nd_prototype_batch_index': (torch.arange(N, device=dev) % 2).expand(B, N).contiguous(),
+           'finehrchy_nd_prototype_grouping_logit': torch.randn((B, 6, N), device=dev, generator=g),
+           'coarsehrchy_nd_prototype_grouping_logit': torch.randn((B, 3, N), device=dev, generator=g)}
+  loss = gl.DMonLoss(adj_knn=4)
+  per_view = types.SimpleNamespace(dmon_loss=loss, dmon_graph_per_view=True)
+  whole = types.SimpleNamespace(dmon_loss=loss, dmon_graph_per_view=pm.HsgCs.dmon_graph_per_view)
+  a = pm._dmon_terms(per_view, datas)
+  b2 = pm._dmon_terms(whole, datas)
+  one = dict(datas, nd_prototype_batch_index=torch.zeros_like(datas['nd_prototype_batch_index']))
+  c = pm._dmon_terms(per_view, one)
+  assert abs(b2.item() - c.item()) <= 1e-6 and abs(a.item() - b2.item()) > 1e-4
+  assert pm.hsg_cs.__name__ == 'hsg_cs' and issubclass(pm.HsgCs, pm.Hsg)
+  assert em.ClusteringMixinCs.dynamic_max_num_clusters and em.MultiviewClusteringMixinCs.dynamic_max_num_clusters
+  assert em.MultiviewClusteringMixinCs.generate_clusters is em.MultiviewClusteringMixin.generate_clusters
 
 
 def test_ncut_loss_vs_reference_golden(dev):
