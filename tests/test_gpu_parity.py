@@ -1838,6 +1838,22 @@ def test_cityscapes_twins_of_the_model_classes(dev):
   assert pm.hsg_cs.__name__ == 'hsg_cs' and issubclass(pm.HsgCs, pm.Hsg)
   assert em.ClusteringMixinCs.dynamic_max_num_clusters and em.MultiviewClusteringMixinCs.dynamic_max_num_clusters
   assert em.MultiviewClusteringMixinCs.generate_clusters is em.MultiviewClusteringMixin.generate_clusters
+  # the stage-1 / inference model (resnet_fcn.py:90-148): k-means only, six dict entries
+  from hsg_amd.models.embeddings import resnet_fcn as s1
+  from hsg_amd.utils.segsort import common as sc
+  stub = types.SimpleNamespace(label_divisor=255, semantic_ignore_index=255, kmeans_num_clusters=[3, 3], kmeans_iterations=4)
+  x = torch.from_numpy(synth.embeddings_nchw(11, (2, 16, 20, 24), 'mixture')).to(dev)
+  over = synth.overseg_labels(12, 2, 20, 24, regions=4, ignore_rows=2, ignore_index=255)
+  sem = torch.from_numpy(np.where(over == 255, 255, over % 3).astype(np.int64)).to(dev)
+  inst = torch.from_numpy(np.where(over == 255, 0, over // 3).astype(np.int64)).to(dev)
+  out = s1.generate_clusters(stub, x, sem, inst)
+  lab = sem * 255 + inst
+  ign = lab.max() + 1
+  ref = sc.segment_by_kmeans(x, lab.masked_fill(sem == 255, ign), [3, 3], ignore_index=ign, iterations=4)
+  assert sorted(out) == ['cluster_batch_index', 'cluster_embedding', 'cluster_embedding_with_loc', 'cluster_index',
+                         'cluster_instance_label', 'cluster_semantic_label']
+  assert torch.equal(out['cluster_embedding'], ref[0]) and torch.equal(out['cluster_index'], ref[3])
+  assert torch.equal(out['cluster_semantic_label'] * 255 + out['cluster_instance_label'], ref[2])
 
 
 def test_ncut_loss_vs_reference_golden(dev):
