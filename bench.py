@@ -24,8 +24,8 @@ Prints ONE JSON line on rank 0, including
                 bytes the group actually moves (PMC counters of profiles/, else the bytes it
                 streams by construction) over its average duration, measured with HIP events
                 on the launch stream inside the timed region (libhsgk's event profiler);
-                `algorithmic_*` is SURVEY 8(d)'s 4D+8 B per pixel over the same time (it can
-                exceed the peak: the filter level reads a half-size copy of the rows);
+                `algorithmic_bytes_over_time_GBps` is SURVEY 8(d)'s 4D+8 B per pixel over the same
+                time (not a roofline fraction: the filter level reads a half-size copy of the rows);
                 roofline_mstep / roofline_prep / roofline_iteration: M-step update, prep
                 kernel and one whole Lloyd iteration;
   cpu_baseline  oracle/torch_ref.py (same ATen op sequence as the reference's
@@ -43,7 +43,8 @@ import subprocess
 import sys
 import time
 
-os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL across processes needs it on this driver
+if os.environ.get('HSGK_BENCH_NO_IPC_DEFAULT') != '1':      # (set by the one-shot retry of main() after a failed RCCL start-up)
+  os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL across processes needs it on this driver
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -204,11 +205,38 @@ def main():
     os.environ.setdefault('WORLD_SIZE', '1')
     torch.cuda.set_device(local)
     backend = os.environ.get('HSGK_BENCH_BACKEND', 'nccl')
-    if backend == 'nccl':
-      dist.init_process_group('nccl', device_id=torch.device('cuda', local),
-                              timeout=datetime.timedelta(seconds=300))
-    else:
-      dist.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
+    try:
+      if backend == 'nccl':
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local),
+                                timeout=datetime.timedelta(seconds=300))
+      else:
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
+      # the first collective sets up the RCCL channels (IPC handles between the ranks' buffers): it is where a
+      # wrong HSA IPC mode shows (`hipIpcGetMemHandle: invalid argument`)
+      probe = torch.ones((1,), device=torch.device('cuda', local))
+      dist.all_reduce(probe)
+      torch.cuda.synchronize(torch.device('cuda', local))
+      if int(probe.item()) != world:
+        raise RuntimeError('first all_reduce returned %r for %d ranks' % (probe.item(), world))
+    except Exception as e:                      # noqa: BLE001
+      # One retry in a fresh process image with the other IPC mode (the variable is read when the HSA runtime
+      # starts, so it cannot be changed in place).  Every rank that fails does the same; a rank that did not fail
+      # runs into the collective's time-out and follows.  The line reports which setting worked.
+      if os.environ.get('HSGK_BENCH_RETRIED') != '1' and backend == 'nccl' and world > 1:
+        sys.stderr.write('[bench rank %d] RCCL start-up failed (%s: %s); retrying without HSA_ENABLE_IPC_MODE_LEGACY\n'
+                         % (rank, type(e).__name__, str(e)[:200]))
+        sys.stderr.flush()
+        env = dict(os.environ)
+        env['HSGK_BENCH_RETRIED'] = '1'
+        env['HSGK_BENCH_FIRST_ERROR'] = ('%s: %s' % (type(e).__name__, str(e)))[:300]
+        env.pop('HSA_ENABLE_IPC_MODE_LEGACY', None)
+        env['HSGK_BENCH_NO_IPC_DEFAULT'] = '1'
+        os.execve(sys.executable, [sys.executable] + sys.argv, env)
+      if rank == 0:
+        print(json.dumps({'metric': 'pixel-embeddings clustered/sec', 'value': None, 'unit': 'pixels/s',
+                          'n_gpus': world, 'error': 'RCCL start-up failed: %s: %s' % (type(e).__name__, str(e)[:300]),
+                          'first_error': os.environ.get('HSGK_BENCH_FIRST_ERROR')}), flush=True)
+      sys.exit(1)
   dev = torch.device('cuda', local)
   torch.cuda.set_device(dev)
 
@@ -268,6 +296,8 @@ def main():
   for _ in range(args.steps):
     del out
     out = run(x, labels)
+  torch.cuda.synchronize(dev)
+  own_elapsed = time.perf_counter() - t0       # this rank's own K steps (before it waits for the others)
   fence()
   elapsed = time.perf_counter() - t0
   prof = _lib.profile_collect()
@@ -300,7 +330,19 @@ def main():
       if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
       tl = tt.tolist()
+      # every rank must hold the SAME batch-wide tables: a bit-level checksum of both float tables and the three
+      # label vectors, gathered from all ranks
+      chk = torch.stack([res[0].contiguous().view(torch.int32).long().sum(), res[1].contiguous().view(torch.int32).long().sum(),
+                         res[2].sum(), res[3].sum(), res[4].sum(),
+                         torch.tensor(res[0].shape[0], device=dev)]).to(torch.int64)
+      allchk = [chk]
+      if dist is not None:
+        allchk = [torch.empty_like(chk) for _ in range(world)]
+        dist.all_gather(allchk, chk)
+      same = all(bool(torch.equal(c, allchk[0])) for c in allchk)
       return {'ms': round(statistics.median(tl) * 1e3, 3), 'runs_ms': [round(t * 1e3, 3) for t in tl],
+              'table_checksum': [int(v) for v in allchk[0].tolist()], 'table_checksum_equal_on_all_ranks': same,
+              'ranks_compared': len(allchk),
               'segments_total': int(res[0].shape[0]), 'collectives_per_call': int(ncoll),
               'payload_MB': round(res[0].shape[0] * (2 * C + 2) * 4 / 1e6, 2),
               'transport': ('libhsgk RCCL communicator, in-stream' if library_comm else
@@ -315,10 +357,15 @@ def main():
       exch = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
   if not (world > 1 and backend_name == 'nccl'):
     out = None                                  # (kept for the in-stream variant at the end otherwise)
+  own_rates = [B * H * W * args.steps / own_elapsed]
   if dist is not None:
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    mine = torch.tensor(own_rates, device=dev, dtype=torch.float64)
+    every = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    own_rates = [float(v.item()) for v in every]
 
   px_per_step = B * H * W * world
   value = px_per_step * args.steps / elapsed
@@ -347,7 +394,9 @@ def main():
            'bytes_source': moved_source, 'traffic_measured_in_this_run': False,
            'avg_launch_ms': round(ms / n, 4), 'launches': int(n),
            'algorithmic_bytes_per_launch': int(algorithmic),
-           'algorithmic_achieved': round(alg, 1), 'algorithmic_frac': round(alg / HBM_PEAK_GBS, 4)}
+           # SURVEY 8(d)'s per-pixel bytes over the same time: NOT a roofline fraction (the filter level reads a
+           # half-size copy of the rows, so this rate can exceed what the memory system delivers)
+           'algorithmic_bytes_over_time_GBps': round(alg, 1)}
     res.update(extra)
     return res
 
@@ -445,6 +494,11 @@ def main():
         'exchange_ms': exch.get('ms') if exch else None, 'prototype_exchange': exch,
         'prototype_exchange_instream': instream, 'dist_backend': backend_name,
         'rccl_ranks': world if backend_name == 'nccl' else 0, 'dry_ranks': args.dry_ranks if args.dry_ranks > 1 else 0,
+        # rank 0's own rate over its K steps before the closing barrier (at N = 1 it equals `value`), and every rank's
+        'n1_value': round(own_rates[0], 1), 'per_rank_pixels_per_s': [round(v, 1) for v in own_rates],
+        'hsa_ipc_mode_legacy_env': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'),
+        'rccl_startup_retried': os.environ.get('HSGK_BENCH_RETRIED') == '1',
+        'rccl_startup_first_error': os.environ.get('HSGK_BENCH_FIRST_ERROR'),
         'roofline': roofline, 'roofline_mstep': roofline_mstep, 'roofline_prep': roofline_prep,
         'roofline_iteration': roofline_iteration, 'cpu_baseline': cpu, 'extra_runs': extra}), flush=True)
 

@@ -199,8 +199,9 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
   {
     const char *se = getenv("HSGK_SMALL");
     const int64_t rows_per_image = B > 0 ? (int64_t)(k.rows_cap / (size_t)B) : 0;
+    // (single_group: one workgroup holds at most kSmallRowsMax rows -- larger maps take the per-kernel route)
     const bool can = fx && half && iterations >= 1 && k.q1 && lloyd_small_eligible(d, K, B, rows_per_image) &&
-                     !g_verify_on.load();
+                     (!single_group || rows_per_image <= lloyd_small_rows_max()) && !g_verify_on.load();
     const bool want = se ? se[0] == '1' : true;
     if (can && want) {
       if (m0_ready)

@@ -168,6 +168,7 @@ int launch_lloyd_small(const float *x, const _Float16 *xm, const uint2 *xt, int 
                        void *qrows, int32_t *counters, bool first_sums_ready, hsgk_segkm_meta *meta,
                        int64_t rows_per_image, bool single_group, float *cent_multi, hipStream_t s);
 int lloyd_small_groups(int B, int64_t rows_per_image);
+int lloyd_small_rows_max();        // rows per image ONE workgroup of the fused kernel accepts
 size_t lloyd_small_cent_floats(int d, int K, int B);
 
 size_t relabel_scan_bytes(int64_t table_cap);      // scratch of the chained scans (scan_tmp of launch_relabel)

@@ -14,6 +14,7 @@
 //      argmax takes the first maximal index.
 #include "common.h"
 #include <atomic>
+#include <mutex>
 
 #include "accumulate.h"
 #include "score_tiles.h"
@@ -2326,8 +2327,8 @@ __global__ __launch_bounds__(NW * 64) void lloyd_small_kernel(
   // tick counter of the image: every workgroup ticks twice per iteration (sums added, sums read)
   int &bar_dead = qnp[2];                        // a wait timed out: stop waiting (the call reports error 3);
   if (tid == 0) bar_dead = 0;                    // (in the list header: no static LDS beside the 160 KiB array)
-  // The grid is launched co-operatively (hipLaunchCooperativeKernel: the runtime only accepts a grid
-  // that fits the device at once), so the other shares of the image are running or will start as soon as
+  // The launcher admits the grid only if it fits half of the device and keeps at most two such grids in
+  // flight per device (small_admit), so the other shares of the image are running or will start as soon as
   // kernels of OTHER streams release their CUs: the wait is bounded by wall-clock time (10 s of the 100 MHz
   // real-time counter, far beyond any kernel a training step runs beside this one), not by a spin count a
   // profiler or a busy neighbour could exhaust.  On a time-out the call reports error 3 in its meta block
@@ -2616,14 +2617,45 @@ static int small_cu_count() {              // of the CURRENT device (cached per 
   if (dev < 64 && cu > 0) cache[dev].store(cu, std::memory_order_relaxed);
   return cu;
 }
-// HSGK_SMALL_COOP=1: hipLaunchCooperativeKernel for the multi-workgroup grids.  The default is a plain launch
-// behind the SAME admission test the co-operative API applies (occupancy x CUs >= grid, queried once per
-// kernel and device): the co-operative path costs ~30 us per call on this runtime (reftrain 0.294 -> 0.328 ms,
-// train28 0.382 -> 0.412 ms, tools/probes/coop_ab.sh) and guards against nothing else -- a neighbour stream that
-// holds CUs only DELAYS the remaining workgroups, which the wall-clock bounded waits tolerate.  Read per call.
+// The multi-workgroup grids are PLAIN launches (HSGK_SMALL_COOP=1 switches to hipLaunchCooperativeKernel: ~30 us per
+// call on this runtime -- reftrain 0.294 -> 0.328 ms, train28 0.382 -> 0.412 ms, tools/probes/coop_ab.sh -- and the
+// same residency: the co-operative API only adds the launch-time size check that small_resident_capacity repeats
+// here).  What makes the inter-workgroup waits safe is that
+//   (1) a grid is admitted only within HALF of what the device holds of this kernel, and
+//   (2) at most TWO such grids of this process are in flight per device, whatever the number of streams
+//       (small_admit below: a third launch first waits, on the device, for the one two launches back),
+// so every admitted grid finds its CUs as soon as ordinary neighbour kernels (which wait for nobody) drain; two
+// half-resident grids holding CUs while each waits for its own missing workgroups cannot occur.  The wall-clock
+// bounded wait (error 3) remains for what the process cannot see: another PROCESS running such grids on this GPU.
 static bool small_coop_enabled() {
   const char *e = getenv("HSGK_SMALL_COOP");
   return e && e[0] == '1';
+}
+// In-flight bound of the multi-workgroup launches (per device): a ring of two events.  Before launch n the
+// stream waits for the event of launch n - 2; after it the stream records launch n's event.  Capturing streams
+// skip the ring (an event recorded outside a capture cannot be waited for inside one): a captured call is
+// ordered by its graph and callers that replay such graphs on more than two streams at once should pass
+// HSGK_SEGKM_ONE_GROUP.
+struct SmallRing { std::mutex mu; hipEvent_t ev[2] = {nullptr, nullptr}; bool used[2] = {false, false}; unsigned n = 0; };
+static SmallRing &small_ring(int dev) { static SmallRing rings[64]; return rings[dev & 63]; }
+static bool stream_capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return st != hipStreamCaptureStatusNone;
+}
+template <typename F>
+static int small_admit(hipStream_t s, F &&launch) {
+  int dev = 0;
+  if (stream_capturing(s) || hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return launch(); }
+  SmallRing &r = small_ring(dev);
+  std::lock_guard<std::mutex> g(r.mu);
+  const unsigned slot = r.n++ & 1u;
+  if (!r.ev[slot]) HSGK_CHECK_HIP(hipEventCreateWithFlags(&r.ev[slot], hipEventDisableTiming));
+  if (r.used[slot]) HSGK_CHECK_HIP(hipStreamWaitEvent(s, r.ev[slot], 0));
+  if (int rc = launch()) return rc;
+  HSGK_CHECK_HIP(hipEventRecord(r.ev[slot], s));
+  r.used[slot] = true;
+  return 0;
 }
 // workgroups of `kern` (512 threads, `lds` bytes) the current device holds at once
 static int small_resident_capacity(const void *kern, size_t lds) {
@@ -2643,6 +2675,7 @@ static int small_resident_capacity(const void *kern, size_t lds) {
   }
   return cap;
 }
+int lloyd_small_rows_max() { return kSmallRowsMax; }
 int lloyd_small_groups(int B, int64_t rows_per_image) {
   const char *fe = getenv("HSGK_SMALL_GROUPS");        // tests: force the number of workgroups per image (read per call)
   const int forced = fe ? atoi(fe) : 0;
@@ -2692,26 +2725,31 @@ int launch_lloyd_small(const float *x, const _Float16 *xm, const uint2 *xt, int 
       HSGK_CHECK_HIP(hipMemsetAsync(bar, 0, sizeof(unsigned int) * B, s));
       if (!first_sums_ready) HSGK_CHECK_HIP(hipMemsetAsync(sumq, 0, sizeof(long long) * (size_t)B * K * d, s));
     }
-    if (G > 1 && small_coop_enabled()) {
-      // several workgroups per image wait for each other: a co-operative launch (the runtime rejects a grid
-      // that cannot be resident at once -- hipErrorCooperativeLaunchTooLarge -- instead of letting it hang)
-      const int64_t *img_row0 = t.img_row0;
-      SplitEntry *gq = reinterpret_cast<SplitEntry *>(qrows);
-      int fsr = first_sums_ready ? 1 : 0, g = G;
-      float eps = HSGK_EPS;
-      void *kargs[] = {(void *)&x, (void *)&xm, (void *)&xt, (void *)&d, (void *)&K, (void *)&iterations,
-                       (void *)&img_row0, (void *)&lab_a, (void *)&lab_b, (void *)&sumq, (void *)&cent, (void *)&gq,
-                       (void *)&counters, (void *)&fsr, (void *)&eps, (void *)&g, (void *)&bar, (void *)&meta,
-                       (void *)&cent_multi};
-      HSGK_CHECK_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(kern), dim3(B * G), dim3(NW * 64),
-                                                kargs, (unsigned int)lds, s));
+    auto plain = [&]() -> int {
+      hipLaunchKernelGGL(kern, dim3(B * G), dim3(NW * 64), lds, s, x, xm, xt, d, K, iterations, t.img_row0, lab_a,
+                         lab_b, sumq, cent, reinterpret_cast<SplitEntry *>(qrows), counters,
+                         first_sums_ready ? 1 : 0, HSGK_EPS, G, bar, meta, cent_multi);
+      HSGK_LAUNCH_CHECK();
       return 0;
+    };
+    if (G <= 1) return plain();                // one workgroup per image waits for nobody
+    if (small_coop_enabled()) {
+      // (the runtime rejects a grid that cannot be resident at once -- hipErrorCooperativeLaunchTooLarge)
+      return small_admit(s, [&]() -> int {
+        const int64_t *img_row0 = t.img_row0;
+        SplitEntry *gq = reinterpret_cast<SplitEntry *>(qrows);
+        int fsr = first_sums_ready ? 1 : 0, g = G;
+        float eps = HSGK_EPS;
+        void *kargs[] = {(void *)&x, (void *)&xm, (void *)&xt, (void *)&d, (void *)&K, (void *)&iterations,
+                         (void *)&img_row0, (void *)&lab_a, (void *)&lab_b, (void *)&sumq, (void *)&cent, (void *)&gq,
+                         (void *)&counters, (void *)&fsr, (void *)&eps, (void *)&g, (void *)&bar, (void *)&meta,
+                         (void *)&cent_multi};
+        HSGK_CHECK_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(kern), dim3(B * G), dim3(NW * 64),
+                                                  kargs, (unsigned int)lds, s));
+        return 0;
+      });
     }
-    hipLaunchKernelGGL(kern, dim3(B * G), dim3(NW * 64), lds, s, x, xm, xt, d, K, iterations, t.img_row0, lab_a,
-                       lab_b, sumq, cent, reinterpret_cast<SplitEntry *>(qrows), counters,
-                       first_sums_ready ? 1 : 0, HSGK_EPS, G, bar, meta, cent_multi);
-    HSGK_LAUNCH_CHECK();
-    return 0;
+    return small_admit(s, plain);
   };
   if (K <= 32) {
     if (d <= 259) return deep ? go(lloyd_small_kernel<NW, 4, 1, 1>) : go(lloyd_small_kernel<NW, 2, 1, 1>);

@@ -80,13 +80,18 @@ def calculate_kmeans_prototypes(cluster_embeddings, cluster_indices, cluster_bat
   # The segments are the distinct (image, cluster, batch * div^2 + label) triples in ascending order -- the order
   # of the exchange's tuple kernels (hash, compaction, sort on the device; models/utils.py), run here on this
   # GPU's rows only: one host read for the count instead of two sorted `unique`s, a radix read and their glue.
+  # The key batch * div^2 + label (:1079-1080) travels as its two digits (semantic slot = the high digit,
+  # instance slot = the low one): same lexicographic order, and the packed tuple needs log2(div^2) fewer bits
+  # than with the whole key in one slot and an idle second one (label_divisor = 2048, the Cityscapes / COCO
+  # value, left ~3 bits of the 62 for image and batch ids).
   from hsg_amd.models import utils as model_utils
   ldiv = int(label_divisor) ** 2
-  bl = b * ldiv + lab                                                  # (:1079-1080) batch index rides on the label
+  hi = b + torch.div(lab, ldiv, rounding_mode='floor')                 # (a label >= div^2 carries into the batch digit,
+  lo = torch.remainder(lab, ldiv)                                      #  exactly as the reference's sum does)
   rows = cluster_embeddings.reshape(-1, cluster_embeddings.shape[-1])
-  protos, _, ubl, _, uimg, gid = model_utils.exchange_prototypes(rows, rows, c, img, bl, torch.zeros_like(bl),
-                                                                  tag='kmeans_protos', local=True)
-  P = ubl.shape[0]
+  protos, _, uhi, ulo, uimg, gid = model_utils.exchange_prototypes(rows, rows, c, img, hi, lo,
+                                                                   tag='kmeans_protos', local=True)
+  P = uhi.shape[0]
   seg = torch.arange(P, device=dev)
   first = torch.ones((P,), dtype=torch.bool, device=dev)
   first[1:] = uimg[1:] != uimg[:-1]                                    # the table is ordered by image
@@ -117,9 +122,9 @@ def calculate_kmeans_prototypes(cluster_embeddings, cluster_indices, cluster_bat
   masks = torch.ones((B * M,), dtype=torch.bool, device=dev)
   masks.index_fill_(0, slot, False)                                   # (an indexed assignment of a Python scalar uploads it)
   plabs = torch.full((B * M,), -1, dtype=torch.long, device=dev)
-  plabs[slot] = ubl % ldiv                                             # (:524-525 / :1084-1085)
+  plabs[slot] = ulo                                                    # (:524-525 / :1084-1085)
   pbatch = torch.full((B * M,), -1, dtype=torch.long, device=dev)
-  pbatch[slot] = ubl // ldiv
+  pbatch[slot] = uhi
   return (prototypes, pos_prototypes, masks.view(B, M), plabs.view(B, M), pbatch.view(B, M),
           cluster_indices_by_image)
 

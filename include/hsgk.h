@@ -137,8 +137,11 @@ typedef struct hsgk_segkm_args {
   int32_t flags;               /* HSGK_SEGKM_* */
 } hsgk_segkm_args;
 /* small feature maps (training resolution) run the whole Lloyd loop of an image in one launch; maps of
- * more than 512 rows are shared by several co-operating workgroups (co-operative launch).  ONE_GROUP keeps
- * one workgroup per image (no inter-workgroup wait).  hsgk_small_map_groups: the workgroups per image the
+ * more than 512 rows are shared by several workgroups that wait for each other: a plain launch, admitted only
+ * within half of the device, at most two such grids in flight per device and process (a third waits in-stream);
+ * HSGK_SMALL_COOP=1 uses hipLaunchCooperativeKernel instead.  A wait that still times out (10 s: another process
+ * on the GPU) sets meta error 3.  ONE_GROUP keeps one workgroup per image (no inter-workgroup wait); maps beyond
+ * that kernel's 1024 rows per image then take the per-kernel route.  hsgk_small_map_groups: the workgroups per image the
  * call would use on the current device (0: the shape does not take the one-launch route).          */
 #define HSGK_SEGKM_ONE_GROUP 1
 HSGK_API int hsgk_small_map_groups(int B, int C, int H, int W, int K);

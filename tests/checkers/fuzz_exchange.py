@@ -1,6 +1,7 @@
 """Randomised parity run of the prototype exchange (hsg_amd/csrc/exchange.hip through the list API of
 hsg_amd/models/utils.py) against oracle.exchange_prototypes: ids, labels exact, both float tables bit for
-bit.  Not part of the test suite; output committed as profiles/r03_fuzz_exchange.txt.
+bit.  Sources sit on different devices when the box has more than one GPU (the list API's cross-device copies of
+tuple blocks and sum tables).  Not part of the test suite; output committed as profiles/r04_fuzz_exchange.txt.
 
   python tests/checkers/fuzz_exchange.py [n_cases] [seed]
 """
@@ -22,7 +23,9 @@ def main():
   n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
   rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
   dev = torch.device('cuda:0')
+  ndev = torch.cuda.device_count()
   bad = 0
+  max_rows = 0                         # largest prototype table (segments) seen
   t0 = time.time()
   for case in range(n_cases):
     nsrc = int(rng.integers(1, 4))
@@ -54,7 +57,10 @@ def main():
     if sum(p['emb'].shape[0] for p in parts) == 0:
       continue
     want = oracle.exchange_prototypes(parts)
-    T = lambda k: [torch.from_numpy(p[k]).to(dev) for p in parts]
+    spread = ndev > 1 and bool(rng.integers(0, 2))
+    devs = [torch.device('cuda', g % ndev) if spread else dev for g in range(nsrc)]
+    T = lambda k: [torch.from_numpy(p[k]).to(devs[g]) for g, p in enumerate(parts)]
+    max_rows = max(max_rows, int(want[2].shape[0]))
     got = mu.gather_clustering_and_update_prototypes(T('emb'), T('emb_loc'), T('cluster'), T('batch'), T('sem'), T('inst'), dev)
     ok = all(np.array_equal(got[j][0].cpu().numpy(), want[j]) for j in (2, 3, 4))
     ok = ok and all(np.array_equal(got[5][g].cpu().numpy(), want[5][g]) for g in range(nsrc))
@@ -66,7 +72,8 @@ def main():
             % (case, nsrc, C, nimg, ncl, [p['emb'].shape[0] for p in parts], sorted_rows, sparse, share_images), flush=True)
     if (case + 1) % 20 == 0:
       print('%d cases, %d mismatching, %.0f s' % (case + 1, bad, time.time() - t0), flush=True)
-  print('fuzz_exchange: %d cases, %d mismatching (segments up to %d)' % (n_cases, bad, 0))
+  print('fuzz_exchange: %d cases, %d mismatching (prototype tables of up to %d segments, %d device(s))'
+        % (n_cases, bad, max_rows, ndev))
   return 1 if bad else 0
 
 

@@ -954,7 +954,7 @@ def test_split_estep_matches_exact_labels(dev, oracle, B, HW, C, K):
 
 
 @pytest.mark.parametrize('fixture', ['f7_hierarchy', 'f7_hierarchy_multiview', 'f7_hierarchy_multiview_b',
-                                     'f7_hierarchy_m256'])
+                                     'f7_hierarchy_m256', 'f7_hierarchy_div2048'])
 def test_hierarchy_ops_vs_reference_golden(dev, fixture):
   """a10-a14: padded per-image prototypes (base and MULTIVIEW variant: the views of one image
   stacked in one row, `image_indices`), softmax/argmax/Bayes-chain grouping, group means and the
@@ -964,6 +964,7 @@ def test_hierarchy_ops_vs_reference_golden(dev, fixture):
   from hsg_amd.models.embeddings import hierarchy as hz
   g = util.load(fixture)
   M, KF, KC = int(g['M']), int(g['KF']), int(g['KC'])
+  div = int(g['label_divisor']) if 'label_divisor' in g else 256     # `_div2048`: 16 views, panoptic-coded labels
   seed = int(g['seed'])
   _, C, H, W = (int(v) for v in g['shape'])
   emb = torch.from_numpy(g['emb']).to(dev).requires_grad_(True)
@@ -972,7 +973,7 @@ def test_hierarchy_ops_vs_reference_golden(dev, fixture):
   T = lambda k: torch.from_numpy(g[k]).to(dev)
   img_idx = T('image_indices') if g['image_indices'].size else None
   protos, pos_protos, masks, plabs, pbatch, c_by_img = hz.calculate_kmeans_prototypes(
-      emb, T('cidx'), T('bidx'), pos, T('labels'), img_idx, label_divisor=256, max_num_clusters=M)
+      emb, T('cidx'), T('bidx'), pos, T('labels'), img_idx, label_divisor=div, max_num_clusters=M)
   B = protos.shape[0]
   assert np.array_equal(masks.cpu().numpy(), g['masks'])
   assert np.array_equal(plabs.cpu().numpy(), g['plabs'])
@@ -985,7 +986,7 @@ def test_hierarchy_ops_vs_reference_golden(dev, fixture):
   # the Cityscapes twin (resnet_fcn_hsg_cs.py:499-502, :1061-1064): the same tables, padded only to the largest
   # number of clusters of an image
   dyn = hz.calculate_kmeans_prototypes(emb.detach(), T('cidx'), T('bidx'), pos, T('labels'), img_idx,
-                                       label_divisor=256, max_num_clusters=None)
+                                       label_divisor=div, max_num_clusters=None)
   Md = int((~masks).sum(1).max())
   assert dyn[0].shape[2] == Md and dyn[2].shape[1] == Md
   assert torch.equal(dyn[0], protos.detach()[:, :, :Md]) and torch.equal(dyn[1], pos_protos[:, :, :Md])
@@ -1168,7 +1169,7 @@ def test_small_maps_two_streams_concurrently(dev):
 
 
 def test_small_maps_beside_a_saturating_stream(dev):
-  """The multi-workgroup small-map route (co-operative launch, wall-clock bounded waits) while a SECOND stream
+  """The multi-workgroup small-map route (plain launch within half the device, at most two in flight, wall-clock bounded waits) while a SECOND stream
   keeps every CU busy with long streaming kernels (a backbone / collective stand-in): the reference's own
   training shape, with and without labels -- no error 3, no hang, every result bit-identical to the quiet run."""
   import torch

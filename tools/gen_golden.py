@@ -383,7 +383,7 @@ def f8():
 
 # ---- F7 hierarchical prototypes / grouping (resnet_fcn_hsg.py:455-780, :1005-1136) ----------
 def _f7_case(name, seed, B, C, H, W, grid, M, KF, KC2, regions, image_indices=None, iters=4,
-             flavour='mixture'):
+             flavour='mixture', label_divisor=256, wide_labels=False):
   """The reference's own methods called on a stub `self`.  image_indices given: the multiview
   variant (MultiviewResnetFcn._calculate_kmeans_prototypes, the one train.py runs) and the
   pixel lookups keyed by image id as in MultiviewResnetFcn.generate_clusters:942-957."""
@@ -392,11 +392,13 @@ def _f7_case(name, seed, B, C, H, W, grid, M, KF, KC2, regions, image_indices=No
   cls = ref_model.ResnetFcn
   x = synth.embeddings_nchw(seed, (B, C, H, W), flavour)
   lab = synth.overseg_labels(seed + 7, B, H, W, regions=regions, ignore_rows=2, ignore_index=255)
+  if wide_labels:                          # semantic * divisor + instance, as the panoptic label maps are coded
+    lab = np.where(lab == 255, 255, (lab + 1) * label_divisor * 97 + lab % 5).astype(lab.dtype)
   emb, emb_loc, labels, cidx, bidx = ref_segment_by_kmeans(
       torch.from_numpy(x), torch.from_numpy(lab), list(grid), ignore_index=255, iterations=iters)
   n = emb.shape[0]
   pos = torch.from_numpy(synth.gaussish(seed + 1, n * C).reshape(n, C).copy())
-  stub = types.SimpleNamespace(label_divisor=256, max_num_clusters=M, fine_hrchy_clusters=KF)
+  stub = types.SimpleNamespace(label_divisor=label_divisor, max_num_clusters=M, fine_hrchy_clusters=KF)
   if image_indices is None:
     protos, pos_protos, masks, plabs, pbatch, c_by_img = cls._calculate_kmeans_prototypes(
         stub, emb, cidx, bidx, pos, labels)
@@ -425,7 +427,7 @@ def _f7_case(name, seed, B, C, H, W, grid, M, KF, KC2, regions, image_indices=No
   px_coarse = cls._collect_pixel_hierarchical_clustering_indices(stub, c_by_img, px_ids, c_lab)
   big = emb.numel() > 200000              # large cases: strided rows of the float tensors
   save(name, seed=seed, shape=np.array([B, C, H, W]), grid=np.array(grid), M=M, KF=KF, KC=KC2,
-       label_seed=seed + 7, regions=regions, iters=iters, flavour=flavour, ylin=lin01(H), xlin=lin01(W),
+       label_divisor=label_divisor, label_seed=seed + 7, regions=regions, iters=iters, flavour=flavour, ylin=lin01(H), xlin=lin01(W),
        image_indices=np.array(image_indices if image_indices is not None else [], np.int64),
        emb=emb.numpy(), cidx=cidx.numpy(), bidx=bidx.numpy(), labels=labels.numpy(),
        protos=protos.numpy(), pos_protos=pos_protos.numpy(), masks=masks.numpy(),
@@ -446,6 +448,11 @@ def f7():
   # BASELINE.json configs[3]'s hierarchy sizes: up to 256 segments per image -> 64 -> 16
   _f7_case('f7_hierarchy_m256', synth.SEED_BASE + 64, 2, 32, 48, 48, (6, 6), 256, 64, 16, 6, iters=5,
            flavour='iid')
+  # label_divisor = 2048 (bashscripts/{cityscapes,coco}/*: the key batch * div^2 + label is 2^22 per batch index)
+  # with 16 views of 8 images and panoptic-coded labels
+  _f7_case('f7_hierarchy_div2048', synth.SEED_BASE + 65, 16, 8, 12, 12, (2, 2), 32, 4, 2, 4,
+           image_indices=[0, 1, 2, 3, 4, 5, 6, 7, 7, 6, 5, 4, 3, 2, 1, 0], iters=3, label_divisor=2048,
+           wide_labels=True)
 
 
 # ---- F10 TransformerClustering tail (transformer_clusters.py:99-114) -------------
