@@ -59,10 +59,26 @@ __global__ void verify_compare_kernel(const int32_t *__restrict__ a, const int32
   const int64_t n = meta->n_rows < cap ? meta->n_rows : cap;
   unsigned long long bad = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    bad += a[i] != b[i];
+    bad += get_label(a, i) != get_label(b, i);
   for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off);
   if ((threadIdx.x & 63) == 0 && bad) atomicAdd(&g_verify[1], bad);
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_verify[0], (unsigned long long)n);
+}
+
+// byte labels (common.h: labels_as_u8) -> int32, for the consumers outside the Lloyd loop
+__global__ void labels_u8_to_i32_kernel(const uint8_t *__restrict__ in, int64_t n, int32_t *__restrict__ out) {
+  const int64_t nq = n >> 2;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t v = reinterpret_cast<const uint32_t *>(in)[q];
+    reinterpret_cast<int4 *>(out)[q] = make_int4((int)(v & 255u), (int)((v >> 8) & 255u), (int)((v >> 16) & 255u), (int)(v >> 24));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[(nq << 2) + threadIdx.x] = in[(nq << 2) + threadIdx.x];
+}
+
+// HSGK_LABELS=i32 keeps int32 working labels inside the Lloyd loop (read per call, for the tests)
+static bool label_u8_enabled() {
+  const char *e = getenv("HSGK_LABELS");
+  return !(e && e[0] == 'i');
 }
 
 struct KmeansScratch {
@@ -76,6 +92,7 @@ struct KmeansScratch {
   int32_t *qcount;     // [1] queue length
   int32_t *klab_prev;  // [rows] labels the exact sums currently hold (-1 = row not added yet), or null
   long long *sumq;     // [B][K][d] exact fixed-point segment sums (sums_fx.hip)
+  _Float16 *xhT;       // the same copy in tile order (score_tiles_f16t.h), or null
   _Float16 *xh;        // [rows][half_main_cols(d)] fp16 copy of the rows' main columns (first filter level), or null
   void *state;         // [rows] 16-byte records of the two-half filter (128 < K <= 256)
   float *errc;         // [B][K] measured fp16 rounding error of the centroid rows (wide filter)
@@ -89,6 +106,12 @@ struct KmeansScratch {
   PrepM0 m0;           // partial sums of the first M-step, written by the prep kernel (or part == null)
   int m0_wt;           // prep workgroups per image
 };
+
+// HSGK_TLAYOUT=1 (experiment): the first E-step level reads a tile-ordered fp16 copy
+static bool tlayout_env() {
+  const char *e = getenv("HSGK_TLAYOUT");
+  return e && e[0] == '1';
+}
 
 static int max_chunks_for(int B, int64_t rows_per_img) {
   return (int)(B * ((rows_per_img + HSGK_CHUNK - 1) / HSGK_CHUNK));
@@ -124,6 +147,7 @@ static void carve_kmeans(Carver &cv, int B, int64_t rows_per_img, int d, int K,
   k->m0 = PrepM0{nullptr, nullptr, nullptr, 0};
   k->m0_wt = 0;
   k->xh = nullptr;
+  k->xhT = nullptr;
   k->xt = nullptr;
   k->q1 = k->q1count = nullptr;
   k->q1cap = rows_per_img;
@@ -135,6 +159,8 @@ static void carve_kmeans(Carver &cv, int B, int64_t rows_per_img, int d, int K,
     // + slack rows: the fp16 engine reads past the end of a pass instead of clamping
     k->xh = cv.take<_Float16>(((size_t)B * rows_per_img + kHalfSlackRowsHost) * half_main_cols_host(d) + 8);
     k->xt = cv.take<uint2>((size_t)B * rows_per_img + kHalfSlackRowsHost);
+    if (tlayout_env() && (assign_half_eligible(d, K) || assign_half_wide2_eligible(d, K)) && d / 64 == 4 && rows_per_img % 32 == 0)
+      k->xhT = cv.take<_Float16>(((size_t)B * rows_per_img + kHalfSlackRowsHost) * half_main_cols_host(d) + 8);
     k->q1 = cv.take<int32_t>((size_t)B * rows_per_img + 1);
     k->q1count = cv.take<int32_t>((size_t)B + 1);
   }
@@ -180,7 +206,7 @@ static int assign_mode() {
 static int lloyd(const float *x, int d, int K, int B, int iterations,
                  const KmeansScratch &k, const hsgk_segkm_meta *meta, hipStream_t s,
                  bool unit_rows = false, bool half_ready = false, bool m0_ready = false,
-                 bool single_group = false) {
+                 bool single_group = false, const int32_t **final_labels = nullptr) {
   const bool half_any = unit_rows && assign_mode() == 2 && k.xh && (half_ready || iterations >= 3);
   const bool half = half_any && assign_half_eligible(d, K);
   const bool wide = half_any && !half && assign_half_wide_eligible(d, K);
@@ -207,6 +233,7 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
       if (m0_ready)
         if (int rc = launch_m0_reduce(k.m0, B, k.m0_wt, d, s)) return rc;
       ProfScope p(HSGK_PROF_ASSIGN, s);
+      if (final_labels) *final_labels = k.klab;
       // (k.q1, the first level's row queue of the per-kernel route, holds the fused kernel's counters)
       return launch_lloyd_small(x, k.xh, k.xt, d, K, B, iterations, k.t, k.klab, k.klab_prev, k.sumq, k.cent,
                                 k.qrows, k.q1, m0_ready, const_cast<hsgk_segkm_meta *>(meta), rows_per_image, single_group, k.cent_multi, s);
@@ -220,6 +247,17 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
   // rows): after the sums are brought up to date with `cur`, that buffer becomes `prev` and the
   // E-step writes the other one -- no label copy per iteration.
   int32_t *cur = k.klab, *prev = k.klab_prev;
+  // Inside the loop the E-step levels write ONE BYTE per label (common.h: labels_as_u8; the buffers keep their
+  // int32 size, the bytes use the front quarter): a quarter of the isolated line writes.  The seed labels arrive
+  // as int32 (prep / the caller); the sums update reads either format, tagged per buffer.
+  const bool u8 = label_u8_enabled() && fx && K <= 256 && (half || wide || wide2);
+  const _Float16 *xhT = nullptr;
+  if ((half || wide2) && k.xhT && !single_group) {
+    // (experiment) every image holds rows_cap / B rows only when nothing was compacted away: the caller of the
+    // experiment guarantees it
+    if (int rc = launch_rows_to_tiles(k.xh, d, (int64_t)k.rows_cap, k.xhT, s)) return rc;
+    xhT = k.xhT;
+  }
   for (int it = 0; it < iterations; ++it) {
     bool counters_zeroed = false;
     if (fx) {
@@ -239,13 +277,14 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
       { ProfScope p(HSGK_PROF_FINALIZE, s);
         if (int rc = launch_finalize(k.partial, k.pmask, d, K, B, k.t, k.max_chunks / B, HSGK_EPS, k.cent, s)) return rc; }
     }
+    if (u8) cur = labels_as_u8(labels_base(cur));          // this iteration's labels: bytes in this buffer
     { ProfScope p(HSGK_PROF_ASSIGN, s);
       if (int rc = half ? launch_assign_half(x, k.xh, k.xt, d, k.cent, K, B, k.t, k.max_chunks, cur, k.q1,
-                                             k.q1count, k.q1cap, k.qrows, k.qcount, meta, s, counters_zeroed)
+                                             k.q1count, k.q1cap, k.qrows, k.qcount, meta, s, counters_zeroed, xhT)
                : wide ? launch_assign_half_wide(x, k.xh, k.xt, d, k.cent, k.errc, K, B, k.t, k.max_chunks, cur,
                                                 k.qrows, k.qcount, meta, s)
                : wide2 ? launch_assign_half_wide2(x, k.xh, k.xt, d, k.cent, k.errc, K, B, k.t, k.max_chunks,
-                                                  cur, k.state, k.qrows, k.qcount, meta, s)
+                                                  cur, k.state, k.qrows, k.qcount, meta, s, xhT)
                : unit_rows && assign_mode() >= 1
                    ? launch_assign_fast(x, d, k.cent, K, B, k.t, k.max_chunks, cur, k.best,
                                         k.qrows, k.qcount, meta, s)
@@ -258,6 +297,19 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
       hipLaunchKernelGGL(verify_compare_kernel, dim3(1024), dim3(256), 0, s, cur, k.q1, meta, (int64_t)k.rows_cap);
       HSGK_LAUNCH_CHECK();
     }
+  }
+  if (final_labels) {        // the caller reads the labels where (and in the format) the loop left them
+    *final_labels = cur;
+    return 0;
+  }
+  if (labels_are_u8(cur)) {
+    // bytes -> int32 in k.klab (through the other buffer when the bytes sit in k.klab itself)
+    int32_t *base = labels_base(cur);
+    int32_t *dst = base == k.klab ? k.klab_prev : k.klab;
+    hipLaunchKernelGGL(labels_u8_to_i32_kernel, dim3(2048), dim3(256), 0, s, reinterpret_cast<const uint8_t *>(base),
+                       (int64_t)k.rows_cap, dst);
+    HSGK_LAUNCH_CHECK();
+    cur = dst;
   }
   if (cur != k.klab)      // odd number of swaps: the final labels sit in the other buffer
     HSGK_CHECK_HIP(hipMemcpyAsync(k.klab, cur, sizeof(int32_t) * k.rows_cap, hipMemcpyDeviceToDevice, s));
@@ -438,11 +490,13 @@ int hsgk_segment_by_kmeans(const hsgk_segkm_args *a, hsgk_stream_t stream) {
                              want_half ? k.xh : nullptr, k.xt, &half_ready,
                              want_m0 ? &k.m0 : nullptr, &m0_ready)) return rc;
   }
+  const int32_t *final_labels = k.klab;      // int32 or byte labels (common.h), in either label buffer
   if (int rc = lloyd(a->out_embeddings_loc, D, a->K, a->B, a->iterations, k, a->meta, s,
-                     /*unit_rows=*/true, half_ready, m0_ready, /*single_group=*/(a->flags & HSGK_SEGKM_ONE_GROUP) != 0)) return rc;
+                     /*unit_rows=*/true, half_ready, m0_ready, /*single_group=*/(a->flags & HSGK_SEGKM_ONE_GROUP) != 0,
+                     &final_labels)) return rc;
   {
     ProfScope p(HSGK_PROF_RELABEL, s);
-    if (int rc = launch_relabel(*a, k.t, k.max_chunks, k.klab, table, scan_tmp, s)) return rc;
+    if (int rc = launch_relabel(*a, k.t, k.max_chunks, final_labels, table, scan_tmp, s)) return rc;
   }
   return 0;
 }
@@ -550,14 +604,19 @@ int hsgk_lloyd_estep(const float *x, int B, int64_t rows_per_image, int d, int K
   ProfScope p(HSGK_PROF_ASSIGN, s);
   if (unit_rows == 2 && k.xh) {              // fp16 filter first (the copy is made here)
     if (int rc = launch_to_half_rows(x, k.t, k.max_chunks, d, k.xh, k.xt, meta, s)) return rc;
+    const _Float16 *xhT = nullptr;
+    if (k.xhT) {                              // (tile-ordered copy: every image here holds rows_per_image rows)
+      if (int rc = launch_rows_to_tiles(k.xh, d, (int64_t)k.rows_cap, k.xhT, s)) return rc;
+      xhT = k.xhT;
+    }
     if (assign_half_eligible(d, K))
       return launch_assign_half(x, k.xh, k.xt, d, centroids, K, B, k.t, k.max_chunks, labels_out, k.q1,
-                                k.q1count, k.q1cap, k.qrows, k.qcount, meta, s);
+                                k.q1count, k.q1cap, k.qrows, k.qcount, meta, s, false, xhT);
     if (assign_half_wide_eligible(d, K))
       return launch_assign_half_wide(x, k.xh, k.xt, d, centroids, k.errc, K, B, k.t, k.max_chunks, labels_out,
                                      k.qrows, k.qcount, meta, s);
     return launch_assign_half_wide2(x, k.xh, k.xt, d, centroids, k.errc, K, B, k.t, k.max_chunks, labels_out,
-                                    k.state, k.qrows, k.qcount, meta, s);
+                                    k.state, k.qrows, k.qcount, meta, s, xhT);
   }
   if (unit_rows)
     return launch_assign_fast(x, d, centroids, K, B, k.t, k.max_chunks, labels_out, k.best, k.qrows,

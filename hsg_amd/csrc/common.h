@@ -81,6 +81,33 @@ __device__ inline long long to_fixed(float x) {
 }
 #endif
 
+// Working labels of the Lloyd loop.  A label buffer is int32 per row -- or, when bit 0 of the pointer is set
+// (labels_as_u8), ONE BYTE per row (K <= 256).  Why: every E-step rewrites all labels, 128 bytes per 32-row wave
+// tile, and such isolated line writes into a read stream cost a DRAM row activation and a bus turn-around each
+// (~66 ns of a channel: 38.5 MB of int32 labels cost the first-level kernel 78 us per launch at 48 x 448 x 448,
+// 21 us as bytes, tools/probes/ab_estore.sh) -- the price follows the number of 128-byte lines, not the number of
+// store instructions or their cache policy (nt / sc1 / staged bursts: no change).  The tag travels inside the
+// pointer so that the kernels that read or write labels (every E-step level, the sums update, the verify pass)
+// keep their signatures; buffers are 256-byte aligned, so the bit is free.
+inline int32_t *labels_as_u8(void *bytes) {
+  return reinterpret_cast<int32_t *>(reinterpret_cast<uintptr_t>(bytes) | (uintptr_t)1);
+}
+inline bool labels_are_u8(const int32_t *lab) { return (reinterpret_cast<uintptr_t>(lab) & (uintptr_t)1) != 0; }
+inline int32_t *labels_base(const int32_t *lab) {
+  return reinterpret_cast<int32_t *>(reinterpret_cast<uintptr_t>(lab) & ~(uintptr_t)1);
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ void put_label(int32_t *lab, int64_t i, int v) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(lab);
+  if (a & 1) reinterpret_cast<uint8_t *>(a ^ 1)[i] = (uint8_t)v;
+  else lab[i] = v;
+}
+__device__ __forceinline__ int get_label(const int32_t *lab, int64_t i) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(lab);
+  return (a & 1) ? (int)reinterpret_cast<const uint8_t *>(a ^ 1)[i] : lab[i];
+}
+#endif
+
 // First M-step fused into the prep kernel (the seed-grid labels are known there): every
 // 32-pixel prep workgroup leaves the exact sums of its rows, split over at most two seed
 // labels, in part [B][WT][2][D] / lab [B][WT][2] (WT = workgroups per image; lab = -1: unused);
@@ -155,11 +182,13 @@ bool assign_half_wide2_eligible(int d, int K);         // 128 < K <= 256: two ta
 int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent,
                              float *errc, int K, int B, const ChunkTable &t, int max_chunks, int32_t *klab,
                              void *state, void *qrows, int32_t *qcount, const hsgk_segkm_meta *meta,
-                             hipStream_t s);
+                             hipStream_t s, const _Float16 *xmT = nullptr);
 int launch_assign_half(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent, int K, int B,
                        const ChunkTable &t, int max_chunks, int32_t *klab, int32_t *q1,
                        int32_t *q1count, int64_t q1cap, void *qrows, int32_t *qcount,
-                       const hsgk_segkm_meta *meta, hipStream_t s, bool counters_zeroed = false);
+                       const hsgk_segkm_meta *meta, hipStream_t s, bool counters_zeroed = false,
+                       const _Float16 *xmT = nullptr);      // xmT: the rows in tile order (score_tiles_f16t.h)
+int launch_rows_to_tiles(const _Float16 *xm, int d, int64_t rows, _Float16 *xmT, hipStream_t s);
 
 // small feature maps: the whole Lloyd loop of an image in one workgroup, one launch per call
 bool lloyd_small_eligible(int d, int K, int B, int64_t rows_per_image);

@@ -20,6 +20,7 @@
 #include "score_tiles.h"
 #include "score_tiles_bf16.h"
 #include "score_tiles_f16.h"
+#include "score_tiles_f16t.h"
 
 static_assert(hsgk::kHalfSlackRows == hsgk::kHalfSlackRowsHost, "fp16 copy slack");
 
@@ -211,10 +212,10 @@ struct ArgmaxEpi {
       const int64_t row = crow0 + px;
       if (bi == 0x7fffffff) bi = kb0;           // every score NaN: keep first index
       if (first_block) {
-        klab[row] = bi;
+        put_label(klab, row, bi);
         if (best) best[row] = bv;
       } else if (bv > best[row]) {              // later blocks win only strictly
-        klab[row] = bi;
+        put_label(klab, row, bi);
         best[row] = bv;
       }
     }
@@ -302,7 +303,7 @@ struct SplitEpi {
     const bool valid = px < nrows;
     const bool amb = valid && !(t1 - t2 > kSplitGap);       // ambiguous (or NaN)
     const int64_t grow = rlw ? (int64_t)rlw[(tile & 1) * 32 + j] : crow0 + px;
-    if (h == 0 && valid) klab[grow] = ti;
+    if (h == 0 && valid) put_label(klab, grow, ti);
     if (!__any(amb)) return;
     // candidate list of this lane's half, then merged with the partner half
     const float thr = t1 - kSplitGap;
@@ -470,7 +471,7 @@ __device__ __forceinline__ void exact_rescore16(const SplitEntry ent, const bool
     const int oi = __shfl_xor(bi, off);
     if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
   }
-  if (ci == 0 && n >= 1 && n <= 7) klab[ent.row] = bi == 0x7fffffff ? 0 : bi;
+  if (ci == 0 && n >= 1 && n <= 7) put_label(klab, ent.row, bi == 0x7fffffff ? 0 : bi);
   // rare: entries that need all K centroids, one at a time on the whole wave
   unsigned long long hard = __ballot(ci == 0 && n == 255);
   while (hard) {
@@ -492,7 +493,7 @@ __device__ __forceinline__ void exact_rescore16(const SplitEntry ent, const bool
       const int oi = __shfl_xor(hi, off);
       if (ov > hv || (ov == hv && oi < hi)) { hv = ov; hi = oi; }
     }
-    if (lane == 0) klab[row] = hi < K ? hi : 0;
+    if (lane == 0) put_label(klab, row, hi < K ? hi : 0);
   }
 }
 
@@ -597,28 +598,46 @@ struct HalfEpi {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int TPX = (int)(blockDim.x >> 1);
-    float b1 = -INFINITY, b2 = -INFINITY;
-    int bi = 0;
+    // Tagged top-2: a score carries its position among the lane's 32 scores (table block m, register r) in its
+    // low 5 mantissa bits -- one v_and_or per score, a perturbation below 32 ulp <= 3.8e-6 that the gap accounts
+    // for -- so the running top-2 is max + med3 with no index bookkeeping: three vector instructions per score
+    // instead of the ~9 of compare / select / min / max with an explicit index (the epilogue was 11 % of the
+    // kernel, tools/probes/ab_tkernel.sh: 863 -> 766 us without it; the matrix work hides completely).  Blocks
+    // entirely below K are unmasked, entirely above skipped (uniform).
+    float t1 = -INFINITY, t2 = -INFINITY;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 2; ++m) {
+      if (m * 32 >= K) continue;
+      if ((m + 1) * 32 <= K) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float v = k < K ? sacc[m][r] : -INFINITY;
-        b2 = fmaxf(b2, fminf(b1, v));
-        bi = v > b1 ? k : bi;
-        b1 = fmaxf(b1, v);
+        for (int r = 0; r < 16; ++r) {
+          const float v = __uint_as_float((__float_as_uint(sacc[m][r]) & ~31u) | (uint32_t)(m * 16 + r));
+          t2 = __builtin_amdgcn_fmed3f(t1, t2, v);
+          t1 = fmaxf(t1, v);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          float v = __uint_as_float((__float_as_uint(sacc[m][r]) & ~31u) | (uint32_t)(m * 16 + r));
+          v = k < K ? v : -INFINITY;
+          t2 = __builtin_amdgcn_fmed3f(t1, t2, v);
+          t1 = fmaxf(t1, v);
+        }
       }
-    const float o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
-    const int oi = __shfl_xor(bi, 32);
-    float t1, t2;
-    int ti;
-    if (o1 > b1) { t1 = o1; ti = oi; t2 = fmaxf(b1, o2); }
-    else { t1 = b1; ti = bi; t2 = fmaxf(o1, b2); }
+    }
+    const uint32_t tg = __float_as_uint(t1) & 31u;
+    int ti = (int)(tg >> 4) * 32 + (int)(tg & 3u) + 8 * (int)((tg >> 2) & 3u) + 4 * h;
+    {
+      const float o1 = __shfl_xor(t1, 32), o2 = __shfl_xor(t2, 32);
+      const int oi = __shfl_xor(ti, 32);
+      if (o1 > t1) { t2 = fmaxf(t1, o2); t1 = o1; ti = oi; }
+      else { t2 = fmaxf(o1, t2); }
+    }
     const int px = tile * TPX + w * 32 + j;
     const bool valid = px < nrows;
-    const bool amb = h == 0 && valid && !(t1 - t2 > half_gap(err));  // ambiguous (or NaN)
-    if (h == 0 && valid) klab[crow0 + px] = ti;     // provisional for ambiguous rows
+    const bool amb = h == 0 && valid && !(t1 - t2 > half_gap(err) + 8.0e-6f);  // ambiguous (or NaN); + 2 x the tag perturbation
+    if (h == 0 && valid) put_label(klab, crow0 + px, ti);     // provisional for ambiguous rows
     const unsigned long long m = __ballot(amb);
     if (!m) return;
     // one LDS atomic per wave-tile
@@ -661,8 +680,12 @@ __global__ __launch_bounds__(NW * 64) void assign_half_kernel(
     const int64_t crow0 = r;
     if (threadIdx.x == 0) qnp[0] = 0;       // ordered before any epilogue by the engine's barrier
     HalfEpi epi{K, nrows, crow0, klab, qpx, qnp, q1 + (int64_t)b * q1cap, q1count + b};
-    score_tiles_half<NW, DEPTH>(xm, xt, d, cent + (int64_t)b * K * d, K, crow0, nrows, lds_raw, epi,
-                                b != staged_img);
+    if constexpr (DEPTH == 6)
+      score_tiles_half<NW, 6, HalfEpi, 2, 2, 2, false, false, 4>(xm, xt, d, cent + (int64_t)b * K * d, K, crow0, nrows,
+                                                                lds_raw, epi, b != staged_img);
+    else
+      score_tiles_half<NW, DEPTH>(xm, xt, d, cent + (int64_t)b * K * d, K, crow0, nrows, lds_raw, epi,
+                                  b != staged_img);
     staged_img = b;
     __syncthreads();
     const int qn = min(qnp[0], kHalfLdsList);
@@ -675,6 +698,68 @@ __global__ __launch_bounds__(NW * 64) void assign_half_kernel(
     __syncthreads();                        // queue drained before the next pass resets it
     r += nrows;
   }
+}
+
+// The same first level fed from the TILE-ORDERED copy (score_tiles_f16t.h): rows go from global memory
+// straight into the MFMA B operand registers, the LDS holds only the table planes and the queue staging.
+// Needs every image to start on a multiple of 32 rows (no compaction, H W % 32 == 0).
+template <int NW, int NFULL>
+__global__ __launch_bounds__(NW * 64) void assign_half_t_kernel(
+    const _Float16 *__restrict__ xmT, const uint2 *__restrict__ xt, int d,
+    const float *__restrict__ cent, int K, const int64_t *__restrict__ img_row0, int B,
+    int32_t *__restrict__ klab, int32_t *__restrict__ q1, int32_t *__restrict__ q1count,
+    int64_t q1cap, const hsgk_segkm_meta *__restrict__ meta) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int TPX = NW * 32;
+  uint16_t *qpx = reinterpret_cast<uint16_t *>(lds_raw + half_t_lds_bytes<2, 2>(d));
+  int *qnp = reinterpret_cast<int *>(qpx + kHalfLdsList);
+  const int64_t N = meta->n_rows;
+  const int64_t per = (N + (int64_t)gridDim.x * TPX - 1) / ((int64_t)gridDim.x * TPX) * TPX;
+  int64_t r = (int64_t)blockIdx.x * per;
+  const int64_t r_end = min(N, r + per);
+  if (r >= r_end) return;
+  int b = image_of_row(img_row0, B, r);
+  int staged_img = -1;
+  while (r < r_end) {
+    while (img_row0[b + 1] <= r) ++b;
+    const int64_t seg_end = min(r_end, img_row0[b + 1]);
+    const int nrows = (int)min(seg_end - r, (int64_t)(0xFFFF / TPX) * TPX);
+    const int64_t crow0 = r;
+    if (threadIdx.x == 0) qnp[0] = 0;       // ordered before any epilogue by the engine's barrier
+    HalfEpi epi{K, nrows, crow0, klab, qpx, qnp, q1 + (int64_t)b * q1cap, q1count + b};
+    score_tiles_half_t<NW, NFULL>(xmT, xt, d, cent + (int64_t)b * K * d, K, crow0, nrows, lds_raw, epi,
+                                  b != staged_img);
+    staged_img = b;
+    __syncthreads();
+    const int qn = min(qnp[0], kHalfLdsList);
+    if (qn > 0) {
+      if (threadIdx.x == 0) qnp[1] = atomicAdd(q1count + b, qn);
+      __syncthreads();
+      int32_t *dst = q1 + (int64_t)b * q1cap + qnp[1];
+      for (int i = threadIdx.x; i < qn; i += NW * 64) dst[i] = (int32_t)(crow0 + qpx[i]);
+    }
+    __syncthreads();
+    r += nrows;
+  }
+}
+
+// row-major fp16 copy xm[n][DM] -> tile order (score_tiles_f16t.h); a wave per 32-row block
+__global__ __launch_bounds__(256) void rows_to_tiles_kernel(const _Float16 *__restrict__ xm, int DM, int64_t nblk,
+                                                            _Float16 *__restrict__ xmT) {
+  const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
+  const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blk >= nblk) return;
+  const char *src = reinterpret_cast<const char *>(xm + (blk * 32 + j) * DM) + 16 * g;
+  char *dst = reinterpret_cast<char *>(xmT + blk * 32 * DM) + lane * 16;
+  for (int kb = 0; kb < DM / 16; ++kb)
+    *reinterpret_cast<uint4 *>(dst + kb * 1024) = *reinterpret_cast<const uint4 *>(src + kb * 32);
+}
+int launch_rows_to_tiles(const _Float16 *xm, int d, int64_t rows, _Float16 *xmT, hipStream_t s) {
+  const int64_t nblk = (rows + 31) / 32;
+  if (nblk <= 0) return 0;
+  hipLaunchKernelGGL(rows_to_tiles_kernel, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, s, xm, half_main_cols(d), nblk, xmT);
+  HSGK_LAUNCH_CHECK();
+  return 0;
 }
 
 // ===========================================================================
@@ -767,7 +852,7 @@ struct HalfWideEpi {
     const bool valid = px < nrows;
     const float gap = (HILO ? half_gap(err) : half_wide_gap(err, errc_max)) + 4.0e-6f;   // (hi + lo table planes: no table error term)
     const bool amb = valid && !(t1 - t2 > gap);               // ambiguous (or NaN)
-    if (h == 0 && valid) klab[crow0 + px] = ti;               // provisional for ambiguous rows
+    if (h == 0 && valid) put_label(klab, crow0 + px, ti);     // provisional for ambiguous rows
     if (!__any(amb)) return;
     // candidates of this lane's half, merged with the partner half (<= 7, else "all")
     const float thr = amb ? t1 - gap - 2.0e-6f : INFINITY;
@@ -1028,7 +1113,7 @@ struct HalfMergeEpi {
     const bool valid = px < nrows;
     const float gap = half_wide_gap(err, errc_max);
     const bool amb = valid && !(t1 - t2 > gap);                    // ambiguous (or NaN)
-    if (h == 0 && valid) klab[crow0 + px] = ti;                    // provisional for ambiguous rows
+    if (h == 0 && valid) put_label(klab, crow0 + px, ti);          // provisional for ambiguous rows
     if (!__any(amb)) return;
     // candidate set {k : score >= best - gap}: second-half members from the registers; first-half
     // members: the stored list (a superset) whenever the first half's best is itself within the gap
@@ -1197,7 +1282,7 @@ struct HalfWide1Epi {
     const bool valid = px < nrows;
     const float gap = half_wide_gap(err, errc_max) + 4.0e-6f;      // + 2 x the tag perturbation
     const bool amb = valid && !(t1 - t2 > gap);                    // ambiguous (or NaN)
-    if (h == 0 && valid) klab[crow0 + px] = ti;                    // provisional for ambiguous rows
+    if (h == 0 && valid) put_label(klab, crow0 + px, ti);          // provisional for ambiguous rows
     if (!__any(amb)) return;
     // candidates of this lane's half, merged with the partner half (<= 7, else "all"); only table blocks
     // whose maximum reaches some ambiguous row's threshold are scanned
@@ -1566,7 +1651,7 @@ __global__ __launch_bounds__(512) void assign_half_pair_kernel(
         if (o1 > t1 || (o1 == t1 && oi < ti)) { t2 = fmaxf(t1, o2); t1 = o1; ti = oi; }
         else { t2 = fmaxf(o1, t2); }
         amb = valid && !(t1 - t2 > gap);
-        if (h == 0 && valid) klab[crow0 + px] = ti;
+        if (h == 0 && valid) put_label(klab, crow0 + px, ti);
         thr = amb ? t1 - gap - 2.0e-6f : INFINITY;
         const bool any = __any(amb);
         if (h == 0) ex_thr[j] = thr;
@@ -1628,6 +1713,274 @@ __global__ __launch_bounds__(512) void assign_half_pair_kernel(
     if constexpr (DEPTH == 4) { HSGK_VMWAIT4(0, preC); HSGK_VMWAIT4(0, preD); }
 #undef HSGK_PAIR_STEP
 #undef HSGK_VMWAIT4
+    r += nrows;
+  }
+  __syncthreads();
+  if (tid == 0) seg.count[blockIdx.x] = qnp[0];
+}
+
+// ---------------------------------------------------------------------------
+// 128 < K <= 256, rows of four 64-column chunks, from the TILE-ORDERED copy (score_tiles_f16t.h): NO row traffic
+// through LDS and NO synchronisation between waves.  A wave loads its 32-row tile (16 KiB contiguous, sixteen 1-KiB
+// loads) straight into the registers the MFMA takes its B operand from, keeps it there, and scores it against the
+// resident hi plane of the table (143 KB of LDS) in FOUR passes of 64 centroids -- two accumulator sets instead of
+// the eight a one-pass kernel needs (assign_half_wide1_kernel: one wave per SIMD) or the pair synchronisations the
+// shared-window kernel pays (assign_half_pair_kernel: twelve per tile, matrix pipe 28 % busy): 2 x 64 row registers
+// (this tile + the next one in flight), 32 accumulators, two waves per SIMD, every wave on its own.
+// After a pass the 32 scores of a lane collapse to the pass's tagged top-3 (position among the lane's 32 scores
+// in the low five mantissa bits: <= 31 ulp <= 3.7e-6, in the gap), five v_med3 per score, and the accumulators are
+// free for the next pass.  At the end of the tile the row's best / second best come out of the 4 x 2 kept values of
+// both lane halves; an undecided row's candidate set {k : score >= best - gap} is exactly the kept values above
+// the threshold, unless some pass's THIRD value reaches it too -- then the entry asks for all K centroids (the
+// whole-wave path of the exact pass).  Same approximation, gap and queue format as the kernels above: the labels
+// stay those of the exact argmax.
+__global__ __launch_bounds__(512) void assign_half_t256_kernel(
+    const _Float16 *__restrict__ xmT, const uint2 *__restrict__ xt, int d,
+    const float *__restrict__ cent, const float *__restrict__ errc, int K,
+    const int64_t *__restrict__ img_row0, int B, int32_t *__restrict__ klab,
+    SplitEntry *__restrict__ gqueue, SegQueue seg, const hsgk_segkm_meta *__restrict__ meta) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int NW = 8, TPX = NW * 32, DM = 256, RS = DM + 16 + 8, NKB = DM / 16, NG = 4;
+  const uint16_t *chs = reinterpret_cast<const uint16_t *>(lds_raw);            // [256][RS] hi plane of the table
+  int *qnp = reinterpret_cast<int *>(lds_raw + (size_t)256 * RS * 2);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const bool has_tail = d > DM;
+  const int64_t N = meta->n_rows;
+  const int64_t per = (N + (int64_t)gridDim.x * TPX - 1) / ((int64_t)gridDim.x * TPX) * TPX;
+  int64_t r = (int64_t)blockIdx.x * per;
+  const int64_t r_end = min(N, r + per);
+  if (tid == 0) { seg.count[blockIdx.x] = 0; seg.row0[blockIdx.x] = r < r_end ? r : 0; qnp[0] = 0; }
+  if (r >= r_end) return;
+  SplitEntry *slice = gqueue + r;
+  int b = image_of_row(img_row0, B, r);
+  int staged_img = -1;
+  float errc_max = 0.0f;
+  // +/- infinity the compiler cannot see through: v_med3_f32(a, b, +inf) IS max(a, b) in one instruction, while a
+  // visible constant is folded to fmax / fmin, which add a canonicalising v_max per operand of unknown origin
+  float PINF, NINF;
+  asm volatile("s_mov_b32 %0, 0x7f800000" : "=s"(PINF));
+  asm volatile("s_mov_b32 %0, 0xff800000" : "=s"(NINF));
+  constexpr int64_t blk_bytes = (int64_t)32 * DM * 2;
+  const uint32_t voff = (uint32_t)lane * 16u;
+  const uint32_t toff = (uint32_t)(wu * 32 + j) * 8u;
+
+  while (r < r_end) {
+    while (img_row0[b + 1] <= r) ++b;
+    const int64_t seg_end = min(r_end, img_row0[b + 1]);
+    const int nrows = (int)min(seg_end - r, (int64_t)1 << 24);
+    const int64_t crow0 = r;
+    if (b != staged_img) {
+      float m = 0.0f;
+      for (int k = lane; k < K; k += 64) m = fmaxf(m, errc[(int64_t)b * K + k]);
+      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+      errc_max = m;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                  // nobody still reads the previous table
+      stage_half_planes<NW, 8, 1>(lds_raw, cent + (int64_t)b * K * d, d, K);
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      staged_img = b;
+    }
+    const int ntile = max(0, (nrows - wu * 32 + TPX - 1) / TPX);
+    const char *wbase = reinterpret_cast<const char *>(xmT) + ((crow0 >> 5) + wu) * blk_bytes;
+    const char *tbase = reinterpret_cast<const char *>(xt + crow0);
+    // the next tile's rows (and tail words) in flight while this one is scored; "+v": the set keeps its registers
+    // from load to load (an "=v" output may be given fresh registers and copied into place before it has landed)
+    u32x4 Bn[NKB];
+    uint2 tailn = {0u, 0u};
+#pragma unroll
+    for (int i = 0; i < NKB; ++i) Bn[i] = u32x4{0u, 0u, 0u, 0u};
+    auto issue = [&](int tile) {              // unclamped: the copy has kHalfSlackRows readable rows past its end
+      const char *tb = wbase + (int64_t)tile * (NW * blk_bytes);
+#pragma unroll
+      for (int i = 0; i < NKB; ++i)
+        asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "+v"(Bn[i]) : "v"(voff), "s"(tb + i * 1024));
+      asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(tailn) : "v"(toff), "s"(tbase + (int64_t)tile * TPX * 8));
+    };
+    if (ntile > 0) issue(0);
+    for (int tile = 0; tile < ntile; ++tile) {
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(Bn[0]), "+v"(Bn[1]), "+v"(Bn[2]), "+v"(Bn[3]), "+v"(Bn[4]), "+v"(Bn[5]), "+v"(Bn[6]), "+v"(Bn[7]),
+                     "+v"(Bn[8]), "+v"(Bn[9]), "+v"(Bn[10]), "+v"(Bn[11]), "+v"(Bn[12]), "+v"(Bn[13]), "+v"(Bn[14]),
+                     "+v"(Bn[15]), "+v"(tailn));
+      u32x4 Bc[NKB];
+#pragma unroll
+      for (int i = 0; i < NKB; ++i) { Bc[i] = Bn[i]; asm volatile("" : "+v"(Bc[i])); }
+      uint2 tailc = tailn;
+      asm volatile("" : "+v"(tailc));
+      __builtin_amdgcn_sched_barrier(0);
+      issue(tile + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const u32x4 tv = {h == 0 ? tailc.x : 0u, 0u, 0u, 0u};
+      const float err = __uint_as_float(tailc.y);
+
+      const float gap = half_wide_gap(err, errc_max) + 8.0e-6f;      // + 2 x the tag perturbation
+      float g1[NG], g2[NG], g3[NG];
+      // A pass whose THIRD value comes within the gap of the lane's best so far cannot be described by its top 2
+      // (the seed-grid centroids of the first iteration: a pixel near a cell corner has four near-equal neighbours,
+      // all in one pass and one lane half).  Such a pass is scanned again while its scores still sit in the
+      // accumulators and the lane keeps the LIST of its scores above (best so far - gap) -- a superset of what the
+      // final threshold admits; one listed pass per lane, a second one falls back to "all K centroids".
+      float rbest = NINF;                       // the lane's best over the passes so far
+      unsigned long long xlist = 0;
+      int xcnt = 0, xpass = -1;
+      bool xover = false;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        g1[g] = NINF; g2[g] = NINF; g3[g] = NINF;
+        if (g * 64 >= K) continue;                                   // (uniform)
+        // ---- scores of table blocks 2 g, 2 g + 1: 16 k-blocks + the tail k-block, operands one k-block ahead
+        f32x16 acc[2];
+        struct Ops { f16x8 a[2]; };
+        const uint16_t *hp = chs + (g * 64 + j) * RS + 8 * h;
+        auto ld = [&](int col0, Ops &o) {
+          o.a[0] = *reinterpret_cast<const f16x8 *>(hp + col0);
+          o.a[1] = *reinterpret_cast<const f16x8 *>(hp + 32 * RS + col0);
+        };
+        auto mm = [&](const Ops &o, const u32x4 &bv, bool first) {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          const f16x8 bb = __builtin_bit_cast(f16x8, bv);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.a[0], bb, first ? zero : acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.a[1], bb, first ? zero : acc[1], 0, 0, 0);
+        };
+        // operands TWO k-blocks ahead (three sets): with one set ahead every k-block's first MFMA waited for the
+        // LDS reads issued just before it (two MFMAs = 64 cycles of matrix work do not cover an LDS round trip)
+        Ops o[3];
+        ld(0, o[0]);
+        ld(16, o[1]);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (kb + 2 <= NKB) ld((kb + 2) * 16, o[(kb + 2) % 3]);      // (kb + 2 == NKB: the tail k-block's columns)
+          mm(o[kb % 3], Bc[kb], kb == 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_tail) mm(o[NKB % 3], tv, false);
+        // ---- tagged top-3 of the lane's 32 scores of this pass
+        float a1 = NINF, a2 = NINF, a3 = NINF;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int mg = 2 * g + m;
+          if (mg * 32 >= K) continue;                                // (uniform)
+          const bool full = (mg + 1) * 32 <= K;
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) {
+            float v = __uint_as_float((__float_as_uint(acc[m][rr]) & ~31u) | (uint32_t)(m * 16 + rr));
+            if (!full) v = mg * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h < K ? v : NINF;
+            const float drop = __builtin_amdgcn_fmed3f(a2, v, NINF);            // min(a2, v): what leaves the top 2
+            a2 = __builtin_amdgcn_fmed3f(a1, a2, v);
+            a1 = __builtin_amdgcn_fmed3f(a1, v, PINF);                          // max
+            a3 = __builtin_amdgcn_fmed3f(a3, drop, PINF);
+          }
+        }
+        g1[g] = a1; g2[g] = a2; g3[g] = a3;
+        rbest = __builtin_amdgcn_fmed3f(rbest, a1, PINF);
+        const bool third = a3 >= rbest - gap;
+        if (__any(third)) {
+          const float lthr = third ? rbest - gap : PINF;
+          unsigned long long sl = 0;
+          int sc = 0;
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const int mg = 2 * g + m;
+            if (mg * 32 >= K) continue;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+              const uint32_t k = mg * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+              const float v = __uint_as_float((__float_as_uint(acc[m][rr]) & ~31u) | (uint32_t)(m * 16 + rr));
+              const bool hit = k < (uint32_t)K && v >= lthr;
+              sl = hit ? ((sl << 8) | k) : sl;
+              sc += hit ? 1 : 0;
+            }
+          }
+          if (third) {
+            xover = xover || xpass >= 0 || sc > 8;
+            xlist = sl; xcnt = sc; xpass = g;
+          }
+        }
+      }
+      // ---- the row: best / second best over the passes and both lane halves
+      auto index_of = [&](float v, int g) {
+        const uint32_t tg = __float_as_uint(v) & 31u;
+        return (2 * g + (int)(tg >> 4)) * 32 + (int)(tg & 3u) + 8 * (int)((tg >> 2) & 3u) + 4 * h;
+      };
+      float t1 = NINF, t2 = NINF;
+      int tg = 0;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        tg = g1[g] > t1 ? g : tg;
+        t2 = __builtin_amdgcn_fmed3f(t1, t2, g1[g]);
+        t1 = __builtin_amdgcn_fmed3f(t1, g1[g], PINF);
+        t2 = __builtin_amdgcn_fmed3f(t1, t2, g2[g]);
+      }
+      int ti = 0;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) ti = tg == g ? index_of(t1, g) : ti;
+      {
+        const float o1 = __shfl_xor(t1, 32), o2 = __shfl_xor(t2, 32);
+        const int oi = __shfl_xor(ti, 32);
+        if (o1 > t1 || (o1 == t1 && oi < ti)) { t2 = fmaxf(t1, o2); t1 = o1; ti = oi; }
+        else { t2 = fmaxf(o1, t2); }
+      }
+      const int px = tile * TPX + wu * 32 + j;
+      const bool valid = px < nrows;
+#if defined(HSGK_T256_DEBUG) && (HSGK_T256_DEBUG & 2)          // probe: every row goes to the exact pass
+      const bool amb = valid;
+#else
+      const bool amb = valid && !(t1 - t2 > gap);                    // ambiguous (or NaN)
+#endif
+      if (h == 0 && valid) put_label(klab, crow0 + px, ti);          // provisional for ambiguous rows
+      if (!__any(amb)) continue;
+      // candidates: the kept values of both lane halves that reach the threshold (tagged values against a
+      // threshold from a tagged best: the 2 x 3.7e-6 of the tags are in the gap); a pass whose third value
+      // reaches it as well may hold more -> all K centroids
+      const float thr = amb ? t1 - gap : INFINITY;
+      unsigned long long list = 0;
+      int cnt = 0;
+#if defined(HSGK_T256_DEBUG) && (HSGK_T256_DEBUG & 1)          // probe: every queued row asks for all K centroids
+      bool over = true;
+#else
+      bool over = xover;
+#endif
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (g * 64 >= K) continue;
+        if (xpass == g) {                          // the listed pass: all of its list, if the pass matters at all
+          const bool use = g1[g] >= thr;
+          const bool take = use && cnt + xcnt <= 7;                  // (more than seven in all: all K anyway)
+          over = over || (use && !take);
+          const int sh = take ? 8 * xcnt : 0;                        // <= 56
+          list = take ? ((list << sh) | (xlist & ((1ull << sh) - 1ull))) : list;
+          cnt += take ? xcnt : 0;
+        } else {
+          const bool h1 = g1[g] >= thr, h2 = g2[g] >= thr;
+          over = over || g3[g] >= thr;
+          list = h1 ? ((list << 8) | (unsigned long long)index_of(g1[g], g)) : list;
+          cnt += h1 ? 1 : 0;
+          list = h2 ? ((list << 8) | (unsigned long long)index_of(g2[g], g)) : list;
+          cnt += h2 ? 1 : 0;
+        }
+      }
+      over = over || cnt > 8;
+      const unsigned long long olist = __shfl_xor(list, 32);
+      const int ocnt = __shfl_xor(cnt, 32);
+      const int oover = __shfl_xor((int)over, 32);       // (unconditional: a short-circuited shuffle would read inactive lanes)
+      over = over || oover != 0;
+      const int tot = cnt + ocnt;
+      uint32_t cand = 255u << 24, cand_hi = 0u;
+      if (!over && tot <= 7 && tot >= 1 && t1 == t1) {
+        const unsigned long long all = (list & ((1ull << (8 * cnt)) - 1ull)) | (olist << (8 * cnt));
+        cand = (uint32_t)(all & 0xFFFFFFull) | ((uint32_t)tot << 24);
+        cand_hi = (uint32_t)(all >> 24);
+      }
+      if (h == 0 && amb) slice[atomicAdd(qnp, 1)] = SplitEntry{(int32_t)(crow0 + px), cand, cand_hi};
+    }
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(Bn[0]), "+v"(Bn[1]), "+v"(Bn[2]), "+v"(Bn[3]), "+v"(Bn[4]), "+v"(Bn[5]), "+v"(Bn[6]), "+v"(Bn[7]),
+                   "+v"(Bn[8]), "+v"(Bn[9]), "+v"(Bn[10]), "+v"(Bn[11]), "+v"(Bn[12]), "+v"(Bn[13]), "+v"(Bn[14]),
+                   "+v"(Bn[15]), "+v"(tailn));
     r += nrows;
   }
   __syncthreads();
@@ -1839,7 +2192,7 @@ __global__ __launch_bounds__(512, 2) void assign_half_regs_kernel(
         const bool amb = valid && !(t1 - t2 > gap);
         ambu[u] = amb;
         tiu[u] = ti;
-        if (wu == 0 && g == 0 && valid) klab[crow0 + px] = ti;          // provisional for ambiguous rows
+        if (wu == 0 && g == 0 && valid) put_label(klab, crow0 + px, ti);   // provisional for ambiguous rows
         if (!mine || !__any(amb)) continue;
         const float thr = amb ? t1 - gap - 2.0e-6f : INFINITY;
         const float thr2 = thr - 2.0e-6f;
@@ -1969,7 +2322,7 @@ bool assign_half_wide2_eligible(int d, int K) {
 int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent,
                              float *errc, int K, int B, const ChunkTable &t, int max_chunks, int32_t *klab,
                              void *state, void *qrows, int32_t *qcount, const hsgk_segkm_meta *meta,
-                             hipStream_t s) {
+                             hipStream_t s, const _Float16 *xmT) {
   if (max_chunks <= 0 || B <= 0) return 0;
   constexpr int NW = 8, TPX = NW * 32, MB = 4;
   static const int n_cu = [] {
@@ -1993,6 +2346,20 @@ int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt
     const int grid1 = (int)(tiles1 < n_cu ? tiles1 : n_cu);
     SegQueue seg{reinterpret_cast<int32_t *>(state), reinterpret_cast<int64_t *>(static_cast<char *>(state) + 4096)};
     const size_t lds = half_lds_bytes<NW1, MB1, 1, 1>(d) + 64;
+    if (xmT && d / 64 == 4 && !two) {
+      // the rows in tile order: every wave on its own, four passes of 64 centroids over register-resident rows
+      const int gridt = (int)(max_tiles < n_cu ? max_tiles : n_cu);
+      const size_t ldst = (size_t)256 * (256 + 24) * 2 + 64;
+      HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(assign_half_t256_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst));
+      hipLaunchKernelGGL(assign_half_t256_kernel, dim3(gridt), dim3(512), ldst, s, xmT, xt, d, cent, errc, K, t.img_row0, B,
+                         klab, reinterpret_cast<SplitEntry *>(qrows), seg, meta);
+      HSGK_LAUNCH_CHECK();
+      hipLaunchKernelGGL(assign_requeue_seg_kernel, dim3(2048), dim3(256), 0, s, x, d, cent, K, klab,
+                         reinterpret_cast<const SplitEntry *>(qrows), seg, gridt, t.img_row0, B);
+      HSGK_LAUNCH_CHECK();
+      return 0;
+    }
     if (d / 64 == 4 && two && two[0] == 'r') {
       // HSGK_WIDE2=regs: the table in registers, 128-row tiles through LDS (A/B: slower than the pair kernel)
       constexpr int TRr = 128;
@@ -2139,7 +2506,7 @@ bool assign_half_eligible(int d, int K) {
 int launch_assign_half(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent, int K, int B,
                        const ChunkTable &t, int max_chunks, int32_t *klab, int32_t *q1,
                        int32_t *q1count, int64_t q1cap, void *qrows, int32_t *qcount,
-                       const hsgk_segkm_meta *meta, hipStream_t s, bool counters_zeroed) {
+                       const hsgk_segkm_meta *meta, hipStream_t s, bool counters_zeroed, const _Float16 *xmT) {
   if (max_chunks <= 0 || B <= 0) return 0;
   constexpr int NW = 8, TPX = NW * 32;
   static const int n_cu = [] {
@@ -2175,9 +2542,21 @@ int launch_assign_half(const float *x, const _Float16 *xm, const uint2 *xt, int 
     HSGK_LAUNCH_CHECK();
     return 0;
   }
-  {
+  if (xmT && (d / 64 == 2 || d / 64 == 4)) {
+    auto kern = d / 64 == 4 ? assign_half_t_kernel<NW, 4> : assign_half_t_kernel<NW, 2>;
+    const size_t lds = half_t_lds_bytes<2, 2>(d) + (size_t)kHalfLdsList * 2 + 16;
+    HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, xmT, xt, d, cent, K, t.img_row0, B,
+                       klab, q1, q1count, q1cap, meta);
+    HSGK_LAUNCH_CHECK();
+  } else {
     const bool deep = ((d / 64) & 3) == 0;
-    auto kern = deep ? assign_half_kernel<NW, 4> : assign_half_kernel<NW, 2>;
+    // rows of exactly four 64-column chunks (C = 256): six sets = one and a half tiles in flight per wave
+    // (HSGK_HALF_DEPTH=4 keeps four, read per call)
+    const char *de = getenv("HSGK_HALF_DEPTH");
+    const bool six = d / 64 == 4 && !(de && de[0] == '4');
+    auto kern = six ? assign_half_kernel<NW, 6> : deep ? assign_half_kernel<NW, 4> : assign_half_kernel<NW, 2>;
     const size_t lds = half_lds_bytes<NW>(d) + (size_t)kHalfLdsList * 2 + 16;
     HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

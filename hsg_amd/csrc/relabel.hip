@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void table_kernel(
     const int64_t row = row0 + r;
     int64_t lab = labels[row];
     if (ranked) lab = lrank[lab];
-    const int64_t key = (b * K + klab[row]) * L + lab;
+    const int64_t key = (b * K + get_label(klab, row)) * L + lab;      // (int32 or byte labels: common.h)
     if (WRITE) {
       out_cluster[row] = table[key];
       out_batch[row] = b + batch_offset;

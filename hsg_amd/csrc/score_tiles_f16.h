@@ -318,14 +318,24 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
   // always ends on the last set and there is ONE epilogue site.  The first sets are requested
   // before the table is staged: they do not depend on it (measured neutral so far: the staging
   // loads queue behind them).
-  static_assert(DEPTH == 2 || DEPTH == 4, "prefetch depth");
-  uint2 preA[LOADS], preB[LOADS], preC[DEPTH == 4 ? LOADS : 1], preD[DEPTH == 4 ? LOADS : 1];
+  // DEPTH == 6 (four chunks per row only): SIX sets rotate over the four chunks of a tile, so a wave has one and a
+  // half tiles (24 KiB) in flight and the set order repeats every three tiles (the tile loop is unrolled by three).
+  // The time of a tile is the memory latency of a set plus whatever part of the wave's own work (16 MFMAs per set,
+  // the epilogue) delays the re-issue of its slots; with the queue capped at one tile per wave that delay came
+  // straight out of the stream (tools/probes/ab_tkernel.sh: 863 us, 766 without the epilogue, 700 for the bare loads).
+  static_assert(DEPTH == 2 || DEPTH == 4 || (DEPTH == 6 && NFULL_CT == 4), "prefetch depth");
+  uint2 preA[LOADS], preB[LOADS], preC[DEPTH >= 4 ? LOADS : 1], preD[DEPTH >= 4 ? LOADS : 1];
+  uint2 preE[DEPTH == 6 ? LOADS : 1], preF[DEPTH == 6 ? LOADS : 1];
   if (nsteps > 0) {
     load_next(preA);
     load_next(preB);
-    if constexpr (DEPTH == 4) {
+    if constexpr (DEPTH >= 4) {
       load_next(preC);
       load_next(preD);
+    }
+    if constexpr (DEPTH == 6) {
+      load_next(preE);
+      load_next(preF);
     }
   }
 
@@ -394,6 +404,28 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
   __builtin_amdgcn_sched_barrier(0);                                          \
   compute_chunk(BUF, QQ, FIRST);                                              \
   __builtin_amdgcn_sched_barrier(0);
+  if constexpr (DEPTH == 6) {
+    // (the tail / aux loads of a tile are older than the four sets issued during it: vmcnt(8 * 4) before the epilogue)
+#define HSGK_HALF_TILE6(P0, P1, P2, P3)                                       \
+    load_tail(tile, tailv);                                                   \
+    if constexpr (AUX) load_aux(tile, auxv);                                  \
+    HSGK_HALF_STEP(0, P0, 0, ZERO_C)                                          \
+    HSGK_HALF_STEP(1, P1, 1, false)                                           \
+    HSGK_HALF_STEP(0, P2, 2, false)                                           \
+    HSGK_HALF_STEP(1, P3, 3, false)                                           \
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(tailv), "+v"(auxv) : "n"(8 * 4)); \
+    finish_tile(tile, tailv, auxv);                                           \
+    if constexpr (!ZERO_C) zero_acc();
+    for (int tile = 0; tile < ntile;) {
+      HSGK_HALF_TILE6(preA, preB, preC, preD)
+      if (++tile >= ntile) break;
+      HSGK_HALF_TILE6(preE, preF, preA, preB)
+      if (++tile >= ntile) break;
+      HSGK_HALF_TILE6(preC, preD, preE, preF)
+      ++tile;
+    }
+#undef HSGK_HALF_TILE6
+  } else
   for (int tile = 0; tile < ntile; ++tile) {
     load_tail(tile, tailv);
     if constexpr (AUX) load_aux(tile, auxv);
@@ -433,9 +465,13 @@ __device__ __forceinline__ void score_tiles_half(const _Float16 *__restrict__ xm
   // drain the look-ahead sets; naming them keeps their registers reserved until here
   HSGK_VMWAIT8(0, preA);
   HSGK_VMWAIT8(0, preB);
-  if constexpr (DEPTH == 4) {
+  if constexpr (DEPTH >= 4) {
     HSGK_VMWAIT8(0, preC);
     HSGK_VMWAIT8(0, preD);
+  }
+  if constexpr (DEPTH == 6) {
+    HSGK_VMWAIT8(0, preE);
+    HSGK_VMWAIT8(0, preF);
   }
   HSGK_ETS(7);
 #undef HSGK_HALF_STEP

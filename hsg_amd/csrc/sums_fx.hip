@@ -55,8 +55,8 @@ __global__ __launch_bounds__(NW * 64) void update_sums_kernel(
   for (int i = 0; i < PER; ++i) {
     const int r = (w * PER + i) * 64 + lane;                   // wave-contiguous rows
     const int rr = min(r, n - 1);
-    pl[i] = prev[row0 + rr];
-    cl[i] = cur[row0 + rr];
+    pl[i] = get_label(prev, row0 + rr);
+    cl[i] = get_label(cur, row0 + rr);
     if (r >= n) pl[i] = cl[i];                                 // past the end: unchanged
   }
   for (int i = tid; i < K; i += NW * 64) slot[i] = 0xFFFF;
@@ -310,8 +310,8 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
       for (int i = 0; i < 4; ++i) {
         const int r = 64 * i + lane;
         const int rr = min(r, n - 1);
-        pl[i] = prev[row0 + rr];
-        cl[i] = cur[row0 + rr];
+        pl[i] = get_label(prev, row0 + rr);
+        cl[i] = get_label(cur, row0 + rr);
         if (r >= n) pl[i] = cl[i];
       }
       int total = 0;

@@ -5,6 +5,8 @@
 //   p1n  the same with nt
 //   p2   dwordx4, 8 rows x 128 B per instruction, 4 instructions per set, nt (same 128-B chunk order)
 //   p3   dwordx4, 1 KiB contiguous per instruction (2 rows), 4 per set, nt    (whole-row order)
+//   p5   dwordx4, 32 rows x 32 B per instruction (lane j / j + 32 = the two 16-B halves of row j's 32 bytes: the
+//        MFMA 32x32x16 B-operand layout, rows straight into registers with no LDS staging), plain and nt
 //   p4   p2's shape as LDS-DMA (global_load_lds_dwordx4), 2 or 3 sets in flight per wave
 //   hipcc --offload-arch=gfx950 -O3 tools/probes/read_patterns3.hip -o tools/probes/read_patterns3
 #include <hip/hip_runtime.h>
@@ -16,7 +18,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define WAIT4(N, P) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(P[0]), "+v"(P[1]), "+v"(P[2]), "+v"(P[3]) : "n"(N))
 #define WAIT8(N, P) asm volatile("s_waitcnt vmcnt(%8)" : "+v"(P[0]), "+v"(P[1]), "+v"(P[2]), "+v"(P[3]), "+v"(P[4]), "+v"(P[5]), "+v"(P[6]), "+v"(P[7]) : "n"(N))
 
-// MODE 0: p1, 1: p1n, 2: p2, 3: p3
+// MODE 0: p1, 1: p1n, 2: p2, 3: p3, 4: p5, 5: p5n
 template <int MODE>
 __global__ __launch_bounds__(512) void pat(const char *__restrict__ x, long rows, unsigned *sink) {
   constexpr int NW = 8, RB = 512;
@@ -49,13 +51,17 @@ __global__ __launch_bounds__(512) void pat(const char *__restrict__ x, long rows
     }
     WAIT8(0, A); WAIT8(0, B); WAIT8(0, C); WAIT8(0, D);
   } else {
-    const unsigned voff = MODE == 2 ? (unsigned)((lane >> 3) * RB + (lane & 7) * 16) : (unsigned)(lane * 16);
+    const unsigned voff = MODE == 2 ? (unsigned)((lane >> 3) * RB + (lane & 7) * 16)
+                          : MODE >= 4 ? (unsigned)((lane & 31) * RB + (lane >> 5) * 16) : (unsigned)(lane * 16);
     auto load = [&](u32x4 (&b)[4]) {
       const long tile = t0 + (ld >> 2) * NW;
-      const char *base = x + tile * 32 * RB + (MODE == 2 ? (ld & 3) * 128 : (ld & 3) * 4096);
+      const char *base = x + tile * 32 * RB + (MODE == 2 || MODE >= 4 ? (ld & 3) * 128 : (ld & 3) * 4096);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(b[i]) : "v"(voff), "s"(base + (long)i * (MODE == 2 ? 8 * RB : 1024)));
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (MODE == 4) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[i]) : "v"(voff), "s"(base + (long)i * 32));
+        else if constexpr (MODE == 5) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(b[i]) : "v"(voff), "s"(base + (long)i * 32));
+        else asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(b[i]) : "v"(voff), "s"(base + (long)i * (MODE == 2 ? 8 * RB : 1024)));
+      }
       ++ld;
     };
     u32x4 A[4], B[4], C[4], D[4];
@@ -143,6 +149,8 @@ int main() {
       time("p1n dwordx2 nt, 4 rows x 128 B / instr", [&] { hipLaunchKernelGGL(pat<1>, dim3(grid), dim3(512), 0, 0, x, rows, sink); });
       time("p2  dwordx4 nt, 8 rows x 128 B / instr", [&] { hipLaunchKernelGGL(pat<2>, dim3(grid), dim3(512), 0, 0, x, rows, sink); });
       time("p3  dwordx4 nt, 1 KiB contiguous / instr", [&] { hipLaunchKernelGGL(pat<3>, dim3(grid), dim3(512), 0, 0, x, rows, sink); });
+      time("p5  dwordx4, 32 rows x 32 B / instr (MFMA B layout)", [&] { hipLaunchKernelGGL(pat<4>, dim3(grid), dim3(512), 0, 0, x, rows, sink); });
+      time("p5n dwordx4 nt, 32 rows x 32 B / instr (MFMA B layout)", [&] { hipLaunchKernelGGL(pat<5>, dim3(grid), dim3(512), 0, 0, x, rows, sink); });
       if (grid == 256) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pat_lds<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 3 * 4096);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pat_lds<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
