@@ -264,7 +264,7 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
       { ProfScope p(HSGK_PROF_ACCUMULATE, s);
         if (it == 0 && m0_ready) {
           if (int rc = launch_m0_reduce(k.m0, B, k.m0_wt, d, s)) return rc;
-        } else if (int rc = launch_update_sums(x, d, prev, cur, k.t, k.max_chunks, K, k.sumq, meta, s))
+        } else if (int rc = launch_update_sums(x, d, prev, cur, k.t, k.max_chunks, K, k.sumq, meta, s, unit_rows ? d - 2 : 0))
           return rc;
         std::swap(cur, prev); }
       { ProfScope p(HSGK_PROF_FINALIZE, s);
@@ -590,7 +590,7 @@ int hsgk_lloyd_mstep_exact(const float *x, int B, int64_t rows_per_image, int d,
   }
   { ProfScope p(HSGK_PROF_ACCUMULATE, s);
     if (int rc = launch_update_sums(x, d, prev, labels, k.t, k.max_chunks, K,
-                                    reinterpret_cast<long long *>(sums), meta, s)) return rc; }
+                                    reinterpret_cast<long long *>(sums), meta, s, d)) return rc; }   // (|x| <= 1: hsgk.h)
   ProfScope p(HSGK_PROF_FINALIZE, s);
   return launch_finalize_fx(reinterpret_cast<const long long *>(sums), d, K, B, HSGK_EPS, centroids, s);
 }

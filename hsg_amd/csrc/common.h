@@ -161,7 +161,9 @@ int launch_assign_fast(const float *x, int d, const float *cent, int K, int B, c
 bool sums_fx_eligible(int d);
 int launch_update_sums(const float *x, int d, const int32_t *prev, const int32_t *cur,
                        const ChunkTable &t, int max_chunks, int K, long long *sumq,
-                       const hsgk_segkm_meta *meta, hipStream_t s);
+                       const hsgk_segkm_meta *meta, hipStream_t s, int unit_cols = 0);
+// (unit_cols: leading columns the caller guarantees within [-1, 1] -- the normalised embedding columns; they may
+//  take the matrix-core route of the update, sums_fx.hip)
 // zero_a[0 .. na) and zero_b[0] (optional): queue counters of the E-step that follows, reset
 // here instead of by two memsets per iteration
 int launch_finalize_fx(const long long *sumq, int d, int K, int B, float eps, float *cent,

@@ -406,6 +406,295 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Matrix-core variant for K <= 64 and up to 8 x 32 bounded columns (|x| <= 1: the normalised
+// embedding columns of segment_by_kmeans): the exact integer sums as a contraction
+//     sums[k][c] += sum over changed rows r of  w[k][r] * q'(x[r][c]),     w = +1 (row joins k), -1 (row leaves k)
+// on v_mfma_i32_32x32x32_i8.  q' = rint(x * 2^40) + 2^41 (non-negative, < 2^42; the bias rides in the rounding
+// constant of to_fixed) is cut into three 14-bit digits, each fed as a 6-bit low piece (one-hot operand +-1) and an
+// 8-bit high piece (one-hot operand +-64, piece biased by -128 into int8): int8 x int8 products summed in int32 are
+// exact, three int32 accumulators per (cluster, column) hold the digit sums of every row the workgroup meets in an
+// image (|sum| <= rows x 8255 < 2^31 up to 260 K rows; the kernel folds earlier), and the biases leave at the fold
+// through the net row count of the cluster.  The result is the same integer as the LDS-atomic kernels above.
+// Why: those run at the LDS atomic rate (~280 CU cycles per changed row in the first update of a call); here the
+// table never touches LDS -- every wave owns 32 columns x 64 clusters x 3 digits in 96 accumulator registers, the
+// signed one-hot operand of a batch of 32 rows is a 2 KiB byte matrix in LDS that all eight waves read, and a row
+// costs ~12 vector instructions per element for the digit cut plus 12 matrix instructions per 32 rows and wave.
+// The changed rows travel global -> LDS by LDS-DMA (global_load_lds, 1 KiB = one row per instruction, three batches
+// of 32 rows in flight per workgroup: no register holds a row before its digits are cut), so the gather latency
+// hides behind two batches of work.  Sparse launches scan up to eight chunks of labels per list.
+// Columns beyond the 32-column blocks (d mod 32, at least the two location columns, whose range the caller owns)
+// keep the ds_add_u64 route on a small [K][tail] table.
+typedef int mx_v4i __attribute__((ext_vector_type(4)));
+typedef int mx_v16i __attribute__((ext_vector_type(16)));
+constexpr int kMxGroup = 8;                          // batches of 32 changed rows per one-hot matrix group
+constexpr int kMxTailMax = 40;                       // tail columns (d - 32 * blocks) the small table holds
+constexpr int kMxTailDma = 16;                       // ... of which the LDS-DMA path stages (4 rows x tail <= 64 lanes)
+constexpr int kMxCap = HSGK_CHUNK;                   // list entries
+constexpr int kMxRing = 3;                           // row batches in LDS
+constexpr long long kMxFoldRows = 200000;            // entries after which the int32 digit sums are folded
+
+__device__ __forceinline__ void mx_to_fixed_biased(float v, uint32_t &lo, uint32_t &hi) {
+  // rint(v * 2^40) + 2^41 in the low 42 mantissa bits of the sum (see to_fixed)
+  const double t = __builtin_fma((double)v, 1099511627776.0, 6755399441055744.0 + 2199023255552.0);
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, t);
+  lo = (uint32_t)b; hi = (uint32_t)(b >> 32);
+}
+
+// workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains vmcnt, i.e. the row
+// batches still in flight by LDS-DMA
+__device__ __forceinline__ void mx_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// LDS atomics the compiler does not see: it drains vmcnt before every LDS atomic it knows of once LDS-DMA is in
+// flight (the atomic might read what the DMA writes) -- these tables are never a DMA target
+__device__ __forceinline__ void mx_lds_add(int *p, int v) {
+  asm volatile("ds_add_u32 %0, %1" ::"v"((uint32_t)(uintptr_t)p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void mx_lds_add(unsigned long long *p, unsigned long long v) {
+  asm volatile("ds_add_u64 %0, %1" ::"v"((uint32_t)(uintptr_t)p), "v"(v) : "memory");
+}
+
+static size_t mx_lds_bytes(int K, int tw) {
+  return (size_t)kMxRing * 32 * 256 * 4 + (size_t)kMxGroup * 64 * 32 + 2 * (size_t)(kMxCap + 32) * 4 +
+         (size_t)kMxRing * 32 * kMxTailDma * 4 + (size_t)64 * (tw > 0 ? tw : 1) * 8 + 64 * 4 + 16;
+}
+
+#ifndef HSGK_MX_DEBUG
+#define HSGK_MX_DEBUG 0        // elimination builds (tools/probes/ab_mx.sh): 1 no digit cut / MFMA, 2 no row DMA, 3 neither, 4 no MFMA
+#endif
+template <int NMB>
+__global__ __launch_bounds__(512) void update_sums_mfma_kernel(
+    const float *__restrict__ x, int d, int ncb, const int32_t *__restrict__ prev,
+    const int32_t *__restrict__ cur, const int64_t *__restrict__ chunk_row0,
+    const int32_t *__restrict__ chunk_rows, const int32_t *__restrict__ chunk_img, int K,
+    unsigned long long *__restrict__ sumq, const hsgk_segkm_meta *__restrict__ meta) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int tail0 = 32 * ncb, tw = d - tail0;
+  float *rows = reinterpret_cast<float *>(lds_raw);                                        // [ring][32][256]
+  uint8_t *W = reinterpret_cast<uint8_t *>(rows + kMxRing * 32 * 256);                      // [group][64][32] signed one-hot bytes
+  uint32_t *ent = reinterpret_cast<uint32_t *>(W + kMxGroup * 64 * 32);                     // (new label + 1) << 8 | old label + 1
+  uint32_t *off = ent + kMxCap + 32;                                                        // row * d (elements from the list's first row)
+  float *tails = reinterpret_cast<float *>(off + kMxCap + 32);                              // [ring][32 * tw] (tw <= kMxTailDma)
+  unsigned long long *tail = reinterpret_cast<unsigned long long *>(tails + kMxRing * 32 * kMxTailDma);   // [64][tw]
+  int *cnt = reinterpret_cast<int *>(tail + 64 * max(tw, 1));                               // [64] net rows per cluster
+  int *ctl = cnt + 64;                                                                      // [0] entries, [1] overflow
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n = lane & 31, g = lane >> 5;
+  const int nc = (int)meta->n_chunks;
+  const int c_begin = (int)(((int64_t)blockIdx.x * nc) / gridDim.x);
+  const int c_end = (int)(((int64_t)(blockIdx.x + 1) * nc) / gridDim.x);
+  const bool tdma = tw > 0 && tw <= kMxTailDma;
+  mx_v16i acc[NMB][3];
+#pragma unroll
+  for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][j][i] = 0;
+  for (int i = tid; i < 64 * tw; i += 512) tail[i] = 0ull;
+  if (tid < 64) cnt[tid] = 0;
+  if (tid < 2) ctl[tid] = 0;
+  __syncthreads();
+  long long since = 0;                                   // entries since the last fold (workgroup-uniform)
+  int c = c_begin, kc = 1;
+  while (c < c_end) {
+    const int b = chunk_img[c];
+    int ce = c + 1;
+    while (ce < c_end && ce - c < kc && chunk_img[ce] == b) ++ce;
+    const int64_t row0 = chunk_row0[c];
+    const float *xr = x + row0 * d;
+    // ---- changed rows of the chunks [c, ce) -> ent / off (any order: the sums do not depend on it)
+    for (int cc = c; cc < ce; ++cc) {
+      const int nrows = chunk_rows[cc];
+      const int64_t crow0 = chunk_row0[cc];
+      const uint32_t rbase = (uint32_t)(crow0 - row0);
+#pragma unroll
+      for (int j = 0; j < HSGK_CHUNK / 512; ++j) {
+        const int r = j * 512 + tid;
+        const bool in = r < nrows;
+        const int pl = in ? get_label(prev, crow0 + r) : -1;
+        const int cl = in ? get_label(cur, crow0 + r) : -1;
+        const uint32_t ln = (uint32_t)cl < (uint32_t)K ? (uint32_t)cl + 1u : 0u;
+        const uint32_t lo = (uint32_t)pl < (uint32_t)K ? (uint32_t)pl + 1u : 0u;
+        const bool ch = ln != lo;
+        const unsigned long long m = __ballot(ch);
+        if (m) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&ctl[0], __popcll(m));
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (ch) {
+            const int idx = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (idx < kMxCap) {
+              ent[idx] = (ln << 8) | lo;
+              off[idx] = (rbase + (uint32_t)r) * (uint32_t)d;
+            } else {
+              ctl[1] = 1;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int total = ctl[0];
+    if (ctl[1]) {                                        // more changed rows than the list holds: one chunk at a time
+      __syncthreads();
+      if (tid < 2) ctl[tid] = 0;
+      __syncthreads();
+      kc = 1;
+      continue;
+    }
+    if (tid < 32 && total + tid < ((total + 31) & ~31)) { ent[total + tid] = 0u; off[total + tid] = 0u; }   // padding: row 0, no label
+    const int nb = (total + 31) >> 5;
+    // this wave's four rows of batch bi (and their tail columns) -> ring slot bi % kMxRing, by LDS-DMA
+    auto dma = [&](int bi) {
+      const int buf = bi % kMxRing;
+      const uint32_t *op = off + 32 * bi + 4 * w;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)op[i]);
+        if (4 * lane < tail0 && !(HSGK_MX_DEBUG & 2))
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(xr + o + 4 * lane),
+                                           (void __attribute__((address_space(3))) *)(rows + (buf * 32 + 4 * w + i) * 256), 16, 0, 0);
+      }
+      if (tdma && lane < 4 * tw && !(HSGK_MX_DEBUG & 2)) {
+        const int i = lane / tw, cc = lane - i * tw;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(xr + op[i] + tail0 + cc),
+                                         (void __attribute__((address_space(3))) *)(tails + (buf * 32 + 4 * w) * tw), 4, 0, 0);
+      }
+    };
+    if (nb > 0) {
+      __syncthreads();                                   // padding written, counters read by everyone
+      if (tid < 2) ctl[tid] = 0;
+      dma(0);
+      if (nb > 1) dma(1);
+    }
+    for (int bi = 0; bi < nb; ++bi) {
+      const int gb = bi & (kMxGroup - 1);
+      if (gb == 0) {
+        const int nbg = min(kMxGroup, nb - bi);
+        if (bi) mx_barrier();                            // the previous group's one-hot bytes are no longer read
+        for (int i = tid; i < nbg * 512; i += 512) reinterpret_cast<uint32_t *>(W)[i] = 0u;
+        mx_barrier();
+        const int e = 32 * bi + tid;
+        if (tid < 32 * nbg && e < total) {
+          const uint32_t en = ent[e];
+          const uint32_t ln = en >> 8, lo = en & 255u;
+          if (ln) { W[((tid >> 5) * 64 + ln - 1) * 32 + (tid & 31)] = (uint8_t)1; mx_lds_add(&cnt[ln - 1], 1); }
+          if (lo) { W[((tid >> 5) * 64 + lo - 1) * 32 + (tid & 31)] = (uint8_t)0xFF; mx_lds_add(&cnt[lo - 1], -1); }
+        }
+      }
+      // this wave's share of batch bi has landed (the loads of batch bi + 1 may still fly), then everybody's
+      if (bi + 1 < nb) {
+        if (tdma) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      mx_barrier();
+      if (bi + 2 < nb) dma(bi + 2);                      // (its ring slot was read in batch bi - 1: before the barrier)
+      const int buf = bi % kMxRing;
+      if (w < ncb && !(HSGK_MX_DEBUG & 1)) {
+        const float *src = rows + (buf * 32 + 16 * g) * 256 + 32 * w + n;
+        mx_v4i bn[3], bb[3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          uint32_t pn[3] = {0u, 0u, 0u}, pb[3] = {0u, 0u, 0u};
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            uint32_t lo, hi;
+            mx_to_fixed_biased(src[(4 * r + s4) * 256], lo, hi);
+            const uint32_t mid = __builtin_amdgcn_alignbit(hi, lo, 28);          // bits 28 .. 59
+            pn[0] |= (lo & 63u) << (8 * s4);
+            pb[0] |= __builtin_amdgcn_ubfe(lo, 6, 8) << (8 * s4);
+            pn[1] |= __builtin_amdgcn_ubfe(lo, 14, 6) << (8 * s4);
+            pb[1] |= __builtin_amdgcn_ubfe(lo, 20, 8) << (8 * s4);
+            pn[2] |= (mid & 63u) << (8 * s4);
+            pb[2] |= __builtin_amdgcn_ubfe(hi, 2, 8) << (8 * s4);
+          }
+#pragma unroll
+          for (int j = 0; j < 3; ++j) { bn[j][r] = (int)pn[j]; bb[j][r] = (int)(pb[j] ^ 0x80808080u); }
+        }
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb) {
+          const mx_v4i aw = *reinterpret_cast<const mx_v4i *>(W + ((gb * 64 + 32 * mb + n) * 32 + 16 * g));
+          mx_v4i a64;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a64[r] = (int)(((uint32_t)aw[r] << 6) & 0xC0C0C0C0u);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+#if HSGK_MX_DEBUG & 4
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mb][j][r] += (aw[r] & bn[j][r]) + (a64[r] & bb[j][r]);
+#else
+            acc[mb][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aw, bn[j], acc[mb][j], 0, 0, 0);
+            acc[mb][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a64, bb[j], acc[mb][j], 0, 0, 0);
+#endif
+          }
+        }
+      }
+      if (w == gb && tw > 0) {                           // the tail columns of the batch: one wave, lane = (row slot, column)
+        auto add_tail = [&](int e, int cc, float tvv) {
+          const uint32_t en = ent[e];
+          const long long qt = to_fixed(tvv);
+          if (en >> 8) mx_lds_add(tail + ((en >> 8) - 1) * tw + cc, (unsigned long long)qt);
+          if (en & 255u) mx_lds_add(tail + ((en & 255u) - 1) * tw + cc, (unsigned long long)(-qt));
+        };
+        if (tdma) {
+          for (int it = lane; it < 32 * tw; it += 64) {
+            const int e = 32 * bi + it / tw;
+            if (e < total) add_tail(e, it - (it / tw) * tw, tails[buf * 32 * tw + it]);
+          }
+        } else {                                         // (wide tails: plain loads; the compiler's waits also drain the ring)
+          for (int it = lane; it < 32 * tw; it += 64) {
+            const int e = 32 * bi + it / tw, cc = it - (it / tw) * tw;
+            if (e < total) add_tail(e, cc, xr[off[e] + tail0 + cc]);
+          }
+        }
+      }
+    }
+    __syncthreads();                                     // ent / off / the ring are free; cnt and tail are final
+    since += total;
+    // the next list: up to eight chunks when few rows change
+    kc = total * 16 < (ce - c) * HSGK_CHUNK ? 8 : (total * 8 < (ce - c) * HSGK_CHUNK ? 4 : 1);
+    c = ce;
+    const bool last = c >= c_end || chunk_img[c] != b || since > kMxFoldRows;
+    if (last) {
+      // ---- fold the digit sums of image b into its table
+      unsigned long long *gq = sumq + (int64_t)b * K * d;
+      if (w < ncb && since > 0) {
+        // sum of q = sum_j 2^(14 j) (acc_j + 8192 count) - 2^41 count
+        constexpr long long kBias = 8192ll * (1ll + (1ll << 14) + (1ll << 28)) - (1ll << 41);
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int m = 32 * mb + (i & 3) + 8 * (i >> 2) + 4 * g;
+            if (m < K) {
+              const long long sq = (long long)acc[mb][0][i] + ((long long)acc[mb][1][i] << 14) +
+                                   ((long long)acc[mb][2][i] << 28) + (long long)cnt[m] * kBias;
+              if (sq) atomicAdd(gq + (size_t)m * d + 32 * w + n, (unsigned long long)sq);
+            }
+          }
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mb][j][i] = 0;
+      }
+      if (since > 0)
+        for (int i = tid; i < K * tw; i += 512) {
+          const unsigned long long tvv = tail[i];
+          if (tvv) { atomicAdd(gq + (size_t)(i / tw) * d + tail0 + (i - (i / tw) * tw), tvv); tail[i] = 0ull; }
+        }
+      __syncthreads();
+      if (tid < 64) cnt[tid] = 0;
+      since = 0;
+      __syncthreads();
+    }
+  }
+}
+
 // centroid row = normalise((float)sum * 2^-40): one rounding per element, then the C1 norm chain
 __global__ __launch_bounds__(256) void finalize_fx_kernel(const long long *__restrict__ sumq, int d,
                                                           int K, float eps, float *__restrict__ cent,
@@ -511,11 +800,41 @@ int launch_m0_reduce(const PrepM0 &m0, int B, int WT, int d, hipStream_t s) {
 // any row length (the strip kernel walks the columns in windows of 512)
 bool sums_fx_eligible(int d) { return d >= 1; }
 
+// HSGK_MSTEP=mfma: the matrix-core update where it applies (opt-in: exact, measured SLOWER than the LDS-atomic
+// kernel -- first update launch of a 48 x 448 x 448 call 1.85 ms against 1.24 ms, the sparse launches 0.16-0.31
+// against 0.15-0.31 ms; elimination table in profiles/r04_mstep_mfma.txt: the digit cut costs as many vector
+// instructions per element as the 64-bit adds it replaces).  Read per call.
+static bool mstep_mfma_enabled() {
+  const char *e = getenv("HSGK_MSTEP");
+  return e && e[0] == 'm';
+}
+
 int launch_update_sums(const float *x, int d, const int32_t *prev, const int32_t *cur,
                        const ChunkTable &t, int max_chunks, int K, long long *sumq,
-                       const hsgk_segkm_meta *meta, hipStream_t s) {
+                       const hsgk_segkm_meta *meta, hipStream_t s, int unit_cols) {
   if (max_chunks <= 0) return 0;
   HSGK_REQUIRE(K <= 1023, "too many clusters for the exact-sum update (11-bit label fields)");
+  static const int n_cu = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess)
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus > 0 ? cus : 256;
+  }();
+  {
+    // matrix-core variant: K <= 64, the leading `unit_cols` columns bounded by 1 in 32-column blocks
+    const int ncb = unit_cols / 32 < 8 ? unit_cols / 32 : 8;
+    if (K <= 64 && ncb >= 1 && d - 32 * ncb <= kMxTailMax && d - 32 * ncb >= 0 && mstep_mfma_enabled()) {
+      const int nranges = max_chunks < n_cu ? max_chunks : n_cu;
+      auto km = K <= 32 ? update_sums_mfma_kernel<1> : update_sums_mfma_kernel<2>;
+      const size_t ldsm = mx_lds_bytes(K, d - 32 * ncb);
+      HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(km),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm));
+      hipLaunchKernelGGL(km, dim3(nranges), dim3(512), ldsm, s, x, d, ncb, prev, cur, t.chunk_row0, t.chunk_rows,
+                         t.chunk_img, K, reinterpret_cast<unsigned long long *>(sumq), meta);
+      HSGK_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   {
     // persistent variant: the image's table in LDS, split by clusters over P <= 8 workgroups
     // when it does not fit one (every part re-scans the labels and reads the rows of its clusters)
@@ -524,12 +843,6 @@ int launch_update_sums(const float *x, int d, const int32_t *prev, const int32_t
     while (P < 8 && (size_t)((K + P - 1) / P) * d * 8 + 16 + (size_t)NWP * 256 * 4 + 32 > 150 * 1024) ++P;
     const size_t ldsp = (size_t)((K + P - 1) / P) * d * 8 + 16 + (size_t)NWP * 256 * 4 + 32;
     if (ldsp <= 150 * 1024 && d <= 515 && d >= 4) {
-      static const int n_cu = [] {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess)
-          (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return cus > 0 ? cus : 256;
-      }();
       auto kp = d / 4 <= 64 ? update_sums_persistent_kernel<NWP, 8, 1> : update_sums_persistent_kernel<NWP, 8, 2>;
       HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kp),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));

@@ -1923,8 +1923,12 @@ def test_dmon_affinity_graph_larger_vs_oracle(dev, oracle):
 
 
 @pytest.mark.parametrize('B,HW,C,K', [(2, 5000, 256, 64), (3, 3000, 384, 128), (1, 700, 30, 5), (2, 900, 1030, 9),
-                                      (1, 600, 513, 20), (2, 400, 1, 3)])
-def test_exact_sum_mstep_full_and_incremental(dev, oracle, B, HW, C, K):
+                                      (1, 600, 513, 20), (2, 400, 1, 3),
+                                      # the matrix-core update (K <= 64, 32-column blocks + tail columns): one and two
+                                      # cluster blocks, 4 / 3 / 8 column blocks, tails of 2 / 6 / 39 / 0 columns
+                                      (2, 3000, 128, 16), (1, 4100, 100, 40), (3, 2500, 293, 64), (2, 2300, 62, 33)])
+@pytest.mark.parametrize('route', ['lds', 'mfma'])
+def test_exact_sum_mstep_full_and_incremental(dev, oracle, B, HW, C, K, route, monkeypatch):
   """C2x M-step (hsgk_lloyd_mstep_exact): from scratch == oracle exact sums (centroids
   bit-exact) with adversarial labels (every strip touches every cluster; K * d beyond the
   LDS table at C=384/K=128 -> strip kernel with several slot rounds); then two
@@ -1932,6 +1936,9 @@ def test_exact_sum_mstep_full_and_incremental(dev, oracle, B, HW, C, K):
   SAME int64 sums and centroids as from-scratch passes."""
   import torch
   from hsg_amd import _lib
+  if route == 'mfma' and (K > 64 or C + 2 < 32):
+    pytest.skip('the matrix-core update covers K <= 64 and rows of at least 32 columns')
+  monkeypatch.setenv('HSGK_MSTEP', route)                   # (read per call: sums_fx.hip)
   D = C + 2
   n = B * HW
   x = oracle.normalize_embedding(synth.gaussish(500 + C, n * D).reshape(n, D))
