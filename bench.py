@@ -179,6 +179,43 @@ def cpu_baseline(torch, x_cpu, grid, iters, shape_note):
           'rows': rows}
 
 
+def hierarchy_run(torch, dev, out, B, C, K):
+  """cfg4's 256 -> 64 -> 16 hierarchy on the k-means output of the per-GPU images (BASELINE configs[3];
+  resnet_fcn_hsg.py:228-267 of the reference without its transformer stacks, whose logits are random here):
+  padded per-image prototypes, fine / coarse assignment, position-prototype group means, pixel-wise fine and
+  coarse ids.  ms per call, best of 5 after a warm-up."""
+  from hsg_amd.models.embeddings import hierarchy as hz
+  emb, _, lab, cidx, bidx = out
+  KF, KC = 64, 16
+  gen = torch.Generator(device=dev)
+  gen.manual_seed(11)
+  fl = torch.randn((B, KF, K), device=dev, generator=gen)
+  cl = torch.randn((B, KC, KF), device=dev, generator=gen)
+  pos = torch.randn((emb.shape[0], C), device=dev, generator=gen)
+
+  def best(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+      t0 = time.perf_counter()
+      r = fn()
+      torch.cuda.synchronize()
+      ts.append(time.perf_counter() - t0)
+    return round(min(ts) * 1e3, 3), r
+  res = {'shape': 'B=%d images, %d pixels, nodes M=%d, fine %d, coarse %d, C=%d' % (B, emb.shape[0], K, KF, KC, C)}
+  res['kmeans_prototypes_ms'], protos = best(lambda: hz.calculate_kmeans_prototypes(
+      emb, cidx, bidx, pos, lab, None, label_divisor=2048, max_num_clusters=K))
+  prototypes, pos_prototypes, masks, _, _, by_image = protos
+  res['hier_assign_ms'], (flab, _, clab, _) = best(lambda: hz.hierarchical_grouping_from_logits(fl, cl))
+  res['group_mean_fine_ms'], fine_pos = best(lambda: hz.collect_nd_coarser_prototype(
+      pos_prototypes, flab, masks, num_groups=KF, normalized=False))
+  res['gather_labels_fine_ms'], _ = best(lambda: hz.collect_pixel_hierarchical_clustering_indices(by_image, bidx, flab))
+  res['gather_labels_coarse_ms'], _ = best(lambda: hz.collect_pixel_hierarchical_clustering_indices(by_image, bidx, clab))
+  res['hierarchy_ms'] = round(sum(v for k, v in res.items() if k.endswith('_ms')), 3)
+  return res
+
+
 def main():
   args = parse_args()
   if args.dry_ranks > 1 and 'WORLD_SIZE' not in os.environ:
@@ -471,6 +508,11 @@ def main():
       del o, lab2
     except Exception as e:                      # noqa: BLE001
       extra['error'] = '%s: %s' % (type(e).__name__, str(e)[:200])
+    if args.workload == 'cfg4':
+      try:
+        extra['hierarchy'] = hierarchy_run(torch, dev, timed(x, None, 0, 1)[1], B, C, K)
+      except Exception as e:                    # noqa: BLE001
+        extra['hierarchy_error'] = '%s: %s' % (type(e).__name__, str(e)[:200])
 
   cpu = None
   if rank == 0 and world == 1 and args.cpu_images > 0:

@@ -107,9 +107,20 @@ def calculate_kmeans_prototypes(cluster_embeddings, cluster_indices, cluster_bat
     raise IndexError('an image has more than max_num_clusters=%d segments' % M)
   slot = img_of_seg * M + local                                        # position in the padded table
   cluster_indices_by_image = local[gid]
-  order = _group_order(img_of_seg[gid])
+  pixel_image = img_of_seg[gid]                                        # dense image number of every pixel
+  # rows come view by view (batch-major): they already are image by image when the views' image ids ascend --
+  # known on the host when the id vector carries its host copy (gather_and_reorder_image_indices), else read
+  views = ops.noted(image_indices, 'host') if image_indices is not None else None
+  by_view = ops.noted(cluster_batch_indices, 'ascending') is True      # (segment_by_kmeans says so on its output)
+  if by_view and (image_indices is None or (views is not None and all(u <= v for u, v in zip(views[:-1], views[1:])))):
+    order = None
+  elif by_view and views is not None:
+    order = torch.argsort(pixel_image, stable=True)
+  else:
+    order = _group_order(pixel_image)
   if order is not None:
     cluster_indices_by_image = cluster_indices_by_image[order]
+  ops.note(cluster_indices_by_image, 'pixel_image', (pixel_image, order))
 
   C = cluster_embeddings.shape[-1]
   table = torch.zeros((B * M, C), dtype=torch.float32, device=dev).index_copy(0, slot, protos)
@@ -257,7 +268,8 @@ def collect_pixel_hierarchical_clustering_indices(cluster_indices_by_batch,
   concatenated image by image, exactly as the reference's loop does."""
   ops.require_gpu(cluster_indices_by_batch, 'cluster_indices_by_batch')
   seg = cluster_indices_by_batch.view(-1).long().contiguous()
-  img, order = _dense_image_index(cluster_batch_indices)
+  known = ops.noted(cluster_indices_by_batch, 'pixel_image')       # left by calculate_kmeans_prototypes
+  img, order = known if known is not None and known[0].shape[0] == seg.shape[0] else _dense_image_index(cluster_batch_indices)
   table = finehrchy_prototype_grouping_labels.long().contiguous()
   out = torch.empty_like(seg)
   if seg.numel() == 0:

@@ -17,12 +17,18 @@ from hsg_amd.models.embeddings import hierarchy
 from hsg_amd.utils.segsort import common as segsort_common
 
 
+_IGNORE_SENTINEL = (1 << 62) - 1
+
+
 def _labels_and_ignore(self, semantic_labels, instance_labels):
   """:189-197 / :853-861: combined label map and the value that marks ignored pixels."""
   if semantic_labels is None or instance_labels is None:
     return None, None
   labels = semantic_labels * self.label_divisor + instance_labels
-  ignore_index = labels.max() + 1
+  # The reference marks ignored pixels with `labels.max() + 1`, a device scalar that segment_by_kmeans would have
+  # to read back (a stalling read per step).  The marked pixels are dropped before anything else looks at their
+  # value, so any value no kept pixel carries gives the same outputs: a host constant beyond every label.
+  ignore_index = _IGNORE_SENTINEL
   labels = labels.masked_fill(semantic_labels == self.semantic_ignore_index, ignore_index)
   return labels, ignore_index
 
@@ -88,7 +94,9 @@ def _generate_clusters(self, embeddings, semantic_labels, instance_labels, image
   # :217-226: position embeddings of the kept pixels (they are not normalised, so they do
   # not travel through segment_by_kmeans)
   if pos_embeddings is not None and labels is not None:
-    valid_pixels = (labels != ignore_index).view(-1).nonzero().view(-1)
+    # (the number of kept pixels is the length of the k-means outputs: no host read for the size of `nonzero`)
+    valid_pixels = torch.nonzero_static((labels != ignore_index).view(-1),
+                                        size=int(cluster_embeddings.shape[0])).view(-1)
     flat_pos = pos_embeddings.permute(0, 2, 3, 1).contiguous().flatten(0, 2)
     cluster_pos_embeddings = torch.index_select(flat_pos, 0, valid_pixels)
   else:
@@ -118,6 +126,8 @@ def _generate_clusters(self, embeddings, semantic_labels, instance_labels, image
     pixel_image_indices = torch.gather(image_indices, 0, cluster_batch_indices)
   else:
     pixel_image_indices = cluster_batch_indices
+  # (the dense image number of every pixel and the image-by-image order were found while the prototype tables
+  #  were built; they ride on `cluster_indices_by_image` -- ops.note -- instead of a second `unique` + order check)
   finehrchy_cluster_indices = self._collect_pixel_hierarchical_clustering_indices(
       cluster_indices_by_image, pixel_image_indices, fine_labels)
   coarsehrchy_cluster_indices = self._collect_pixel_hierarchical_clustering_indices(

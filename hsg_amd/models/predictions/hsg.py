@@ -70,13 +70,16 @@ def _centroid_contrast_terms(self, datas, targets):
   table -- found ONCE for both levels (the reference, and the round-2 mirror, re-derived it per level with
   its own host read)."""
   image_indices = torch.gather(targets['image_index'], 0, datas['cluster_batch_index'])
-  first, last = torch.stack([image_indices.min(), image_indices.max()]).tolist()      # the block's one host read
+  first = image_indices.min()                 # stays on the device: the block's length is the local table's (no host read)
   total = None
   for level in _HIERARCHY_LEVELS:
     target = targets[level + 'hrchy_nd_prototype_grouping_centroid']
     images, groups = target.shape[0], target.shape[2]
     target_labels = torch.arange(images * groups, dtype=torch.long, device=target.device)
-    own_labels = target_labels[first * groups:(last + 1) * groups]
+    # the reference slices target_labels[first * groups : (last + 1) * groups] (:203-206), one label per local
+    # centroid row: images first .. last are this GPU's rows of the table, i.e. as many as the local table has
+    own_rows = datas[level + 'hrchy_nd_prototype_grouping_centroid'].shape[0] * groups
+    own_labels = target_labels[:own_rows] + first * groups
     loss = self.centroid_cont_loss(_centroid_rows(datas[level + 'hrchy_nd_prototype_grouping_centroid']),
                                    own_labels, own_labels, _centroid_rows(target), target_labels)
     total = loss if total is None else total + loss

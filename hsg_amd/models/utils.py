@@ -500,6 +500,8 @@ def gather_clustering_and_update_prototypes(embeddings, embeddings_with_loc, clu
   devices = [t.device for t in c_inds]
   if not listed or (len(c_inds) == 1 and _world(group) > 1):
     res = exchange_prototypes(embs[0], embs_loc[0], c_inds[0], b_inds[0], sems[0], insts[0], group=group)
+    if _world(group) == 1:
+      ops.note(res[5], 'index_count', int(res[0].shape[0]))
     if not listed:
       return res
     return tuple([r] for r in res)
@@ -524,6 +526,8 @@ def gather_clustering_and_update_prototypes(embeddings, embeddings_with_loc, clu
                              *[e.reshape(-1, C) for e in embs], *[e.reshape(-1, D) for e in embs_loc],
                              *c_inds, *b_inds, *sems, *insts)
   protos, protos_loc, psem, pinst, pbatch = outs[:5]
+  if ndev == 1:
+    ops.note(outs[5], 'index_count', int(protos.shape[0]))
   fan = lambda t: [t.to(d) for d in devices]
   return fan(protos), fan(protos_loc), fan(psem), fan(pinst), fan(pbatch), list(outs[5:])
 
@@ -574,9 +578,12 @@ def gather_and_reorder_image_indices(image_indices, anchor_device=None, group=No
   local = _cat_to(ids, anchor).long() if len(ids) > 1 else ids[0].long()
   gathered, _ = _all_gather_rows(local, group, 'image_ids')
   full = reorder_image_indices(gathered)
+  # (the `unique` above already waited for the device: the tiny vector's host copy costs nothing here and saves
+  #  the order checks of generate_clusters their reads)
+  host = full.tolist()
   if not listed:
-    return full
-  return [full.to(d) for d in devices]
+    return ops.note(full, 'host', host)
+  return [ops.note(full.to(d), 'host', host) for d in devices]
 
 
 # ---- hsg/models/utils.py:78-124 --------------------------------------------------
@@ -594,7 +601,11 @@ def gather_and_update_cluster_mappings(cluster_indices_1, cluster_indices_2,
     # one process: mapping[i] = the LARGEST partner of index i -- what the reference's duplicate-index
     # assignment leaves behind on sorted pairs (utils.py:112-121) -- is one scatter-max
     if a.numel():
-      size = int(a.max()) + 1                    # (the reference reads this maximum on the host too)
+      # (the reference reads this maximum on the host; an index vector that comes straight from the prototype
+      #  exchange carries its table length -- every table row has a pixel -- and needs no read)
+      size = ops.noted(a, 'index_count')
+      if size is None:
+        size = int(a.max()) + 1
       mapping = torch.zeros((size,), dtype=torch.long, device=a.device).scatter_reduce(0, a, b, 'amax', include_self=True)
     else:
       mapping = torch.zeros((0,), dtype=torch.long, device=a.device)

@@ -9,6 +9,23 @@ from hsg_amd import _lib
 EPS = 1e-12
 
 
+# Host-side facts about a device tensor, remembered on the tensor OBJECT by the function that had them on the
+# host anyway (an exchange knows its table length, the image-id gather its id list) and read back by the next
+# function that would otherwise fetch them from the device with a stalling read.  Valid for that object and its
+# current version only: any op makes a new object without the note, an in-place write bumps `_version`.
+def note(t, name, value):
+  try:
+    setattr(t, '_hsg_' + name, (value, t._version))
+  except (AttributeError, RuntimeError):
+    pass
+  return t
+
+
+def noted(t, name):
+  h = getattr(t, '_hsg_' + name, None) if torch.is_tensor(t) else None
+  return h[0] if h is not None and h[1] == t._version else None
+
+
 def require_gpu(t, name):
   if not t.is_cuda:
     raise _lib.HsgkError('%s must be a ROCm device tensor (got %s); hsg_amd has '

@@ -302,8 +302,10 @@ def segment_by_kmeans(embeddings,
     batch_offset = _batch_offset(B, dev)
   if isinstance(K, list):
     return _segment_by_kmeans_grouped(x, lab, loc, loc_sb, seed_map, K, has_ignore, ign, iterations, batch_offset)
-  return _SegmentByKmeans.apply(x, lab, loc, loc_sb, seed_map, K, has_ignore, ign,
-                                int(iterations), int(batch_offset), int(seed_sb))
+  out = _SegmentByKmeans.apply(x, lab, loc, loc_sb, seed_map, K, has_ignore, ign,
+                               int(iterations), int(batch_offset), int(seed_sb))
+  ops.note(out[4], 'ascending', True)          # rows leave image by image: downstream order checks need no read
+  return out
 
 
 def _segment_by_kmeans_grouped(x, lab, loc, loc_sb, dense, counts, has_ignore, ign, iterations,
