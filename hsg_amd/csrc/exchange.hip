@@ -394,7 +394,9 @@ __global__ __launch_bounds__(256) void xk_merge_place_kernel(const int64_t *__re
     for (int q = 0; q < world; ++q) most = recv[q * stride] > most ? recv[q * stride] : most;
     if (total > cap_total) atomicOr(&ctrl->error, 8);
     meta[1] = total;
+    meta[2] = ctrl->error | (total > cap_total ? 8 : 0);   // (complete: the kernels after this one set no error bit)
     meta[3] = most;                                  // rows the largest block needs (capacity regrowth)
+    meta[4] = -1; meta[5] = -1;
     if (my_rank >= 0) meta[0] = recv[my_rank * stride];
   }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
@@ -427,7 +429,39 @@ __global__ __launch_bounds__(256) void xk_single_place_kernel(const int64_t *__r
     if (e) atomicOr(&ctrl->error, e);
     meta[0] = cnt;
     meta[1] = m;
+    meta[2] = e | ctrl->error;          // every error bit is known here (keys + merge): the host may read meta before the sums
     meta[3] = cnt;
+  }
+  // meta[4], meta[5]: distinct FIRST keys of the sorted tuples and the longest run of one (the per-image prototype
+  // tables of the embedding models are [distinct images, most segments of an image]: hierarchy.py reads them from
+  // the same host copy as the table length instead of a second stalling read).  Block 0, tables up to 64 K rows.
+  if (blockIdx.x == 0) {
+    __shared__ int s_carry, s_cnt, s_most, s_wmax[4];
+    if (threadIdx.x == 0) { s_carry = -1; s_cnt = 0; s_most = 0; }
+    __syncthreads();
+    if (m <= 65536) {
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+      for (int64_t i0 = 0; i0 < m; i0 += 256) {
+        const int64_t i = i0 + threadIdx.x;
+        const bool in = i < m;
+        const bool first = in && (i == 0 || send[kXHdr + 4 * i] != send[kXHdr + 4 * (i - 1)]);
+        int v = first ? (int)i : -1;                       // start of the run entry i belongs to: inclusive max-scan
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(v, off); if (lane >= off) v = o > v ? o : v; }
+        if (lane == 63) s_wmax[wv] = v;
+        __syncthreads();
+        int carry = s_carry;
+        for (int q = 0; q < wv; ++q) carry = s_wmax[q] > carry ? s_wmax[q] : carry;
+        v = carry > v ? carry : v;
+        if (first) atomicAdd(&s_cnt, 1);
+        if (in) atomicMax(&s_most, (int)i - v + 1);
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = v;
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) { meta[4] = s_cnt; meta[5] = s_most; }
+    } else if (threadIdx.x == 0) {
+      meta[4] = -1; meta[5] = -1;
+    }
   }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
     gslot[i] = (int32_t)(i < cap_total ? i : cap_total - 1);

@@ -266,6 +266,82 @@ __global__ __launch_bounds__(256) void cluster_topk_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// padded per-image prototype tables (resnet_fcn_hsg.py:499-577 / :1061-1136): the segments arrive sorted by
+// image (the order of the tuple kernels of exchange.hip); a segment's table position is (dense image number,
+// rank inside its image).  pad_scan: one workgroup walks the P image ids in blocks of 256 -- a max-scan gives
+// every segment the first segment of its image, a sum-scan the dense image number -- and leaves the first
+// segment of every image.  pad_fill: one workgroup per table slot copies the segment's rows (or zeros), writes
+// mask / label / batch entries; the workgroups behind the slots map the pixels (segment -> rank, image).
+__global__ __launch_bounds__(256) void pad_scan_kernel(const int64_t *__restrict__ seg_image, int P, int B, int M,
+                                                       int32_t *__restrict__ seg_img, int32_t *__restrict__ seg_local,
+                                                       int32_t *__restrict__ img_start, int64_t *__restrict__ seg_slot) {
+  __shared__ int s_wmax[4], s_wsum[4], s_cstart, s_cimg;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) { s_cstart = -1; s_cimg = 0; }
+  __syncthreads();
+  for (int i0 = 0; i0 < P; i0 += 256) {
+    const int i = i0 + tid;
+    const bool in = i < P;
+    const bool first = in && (i == 0 || seg_image[i] != seg_image[i - 1]);
+    int v = first ? i : -1, c = first ? 1 : 0;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int ov = __shfl_up(v, off), oc = __shfl_up(c, off);
+      if (lane >= off) { v = ov > v ? ov : v; c += oc; }
+    }
+    if (lane == 63) { s_wmax[wv] = v; s_wsum[wv] = c; }
+    __syncthreads();
+    int start = s_cstart, img = s_cimg;
+    for (int q = 0; q < wv; ++q) { start = s_wmax[q] > start ? s_wmax[q] : start; img += s_wsum[q]; }
+    start = v > start ? v : start;
+    img += c;                                          // images up to and including this segment's
+    if (in) {
+      seg_img[i] = img - 1;
+      seg_local[i] = i - start;
+      if (seg_slot) seg_slot[i] = (int64_t)(img - 1) * M + (i - start);
+      if (first && img - 1 < B) img_start[img - 1] = i;
+    }
+    __syncthreads();
+    if (tid == 255) { s_cstart = start; s_cimg = img; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const int nimg = s_cimg;
+    for (int q = nimg; q <= B; ++q) img_start[q] = P;  // (images beyond the last: empty)
+  }
+}
+
+__global__ __launch_bounds__(128) void pad_fill_kernel(
+    const float *__restrict__ protos, int C, const float *__restrict__ pos, int Cp,
+    const int64_t *__restrict__ seg_lab, const int64_t *__restrict__ seg_batch, const int64_t *__restrict__ pixel_seg,
+    int64_t n, int slots, int M, const int32_t *__restrict__ seg_img, const int32_t *__restrict__ seg_local,
+    const int32_t *__restrict__ img_start, float *__restrict__ table, float *__restrict__ pos_table,
+    uint8_t *__restrict__ masks, int64_t *__restrict__ plabs, int64_t *__restrict__ pbatch,
+    int64_t *__restrict__ by_image, int64_t *__restrict__ pixel_image) {
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < slots) {
+    const int slot = blockIdx.x, img = slot / M, l = slot - img * M;
+    const int s = img_start[img] + l;
+    const bool used = s < img_start[img + 1];
+    for (int c = tid; c < C; c += 128) table[(int64_t)slot * C + c] = used ? protos[(int64_t)s * C + c] : 0.0f;
+    if (pos_table)
+      for (int c = tid; c < Cp; c += 128) pos_table[(int64_t)slot * Cp + c] = used ? pos[(int64_t)s * Cp + c] : 0.0f;
+    if (tid == 0) {
+      masks[slot] = used ? 0 : 1;
+      plabs[slot] = used ? seg_lab[s] : -1;
+      pbatch[slot] = used ? seg_batch[s] : -1;
+    }
+    return;
+  }
+  const int64_t nb = gridDim.x - slots;
+  for (int64_t i = ((int64_t)blockIdx.x - slots) * 128 + tid; i < n; i += nb * 128) {
+    const int64_t sg = pixel_seg[i];
+    by_image[i] = seg_local[sg];
+    pixel_image[i] = seg_img[sg];
+  }
+}
+
 }  // namespace hsgk
 
 using namespace hsgk;
@@ -331,6 +407,34 @@ int hsgk_gather_labels(const int64_t *table, int M, const int64_t *img, const in
   int64_t g = (n + 255) / 256;
   hipLaunchKernelGGL(gather_labels_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), table, M, img, seg, n, out);
+  HSGK_LAUNCH_CHECK();
+  return 0;
+}
+
+int hsgk_pad_prototype_tables(const int64_t *seg_image, int64_t P, const float *protos, int C, const float *pos,
+                              int Cp, const int64_t *seg_lab, const int64_t *seg_batch, const int64_t *pixel_seg,
+                              int64_t n, int B, int M, float *table, float *pos_table, uint8_t *masks,
+                              int64_t *plabs, int64_t *pbatch, int64_t *by_image, int64_t *pixel_image,
+                              int64_t *seg_slot, int32_t *work, hsgk_stream_t stream) {
+  HSGK_REQUIRE(P >= 0 && P < (1ll << 31) && n >= 0 && B >= 0 && M >= 1 && C >= 1, "bad shape");
+  HSGK_REQUIRE((int64_t)B * M < (1ll << 31), "table too large");
+  HSGK_REQUIRE(P == 0 || (seg_image && protos && seg_lab && seg_batch && work), "null argument");
+  HSGK_REQUIRE(B == 0 || (table && masks && plabs && pbatch), "null table");
+  HSGK_REQUIRE(n == 0 || (pixel_seg && by_image && pixel_image), "null pixel vectors");
+  HSGK_REQUIRE(!pos_table || (pos && Cp >= 1), "position rows required");
+  (void)hipGetLastError();
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int32_t *seg_img = work, *seg_local = work + P, *img_start = work + 2 * P;
+  hipLaunchKernelGGL(pad_scan_kernel, dim3(1), dim3(256), 0, st, seg_image, (int)P, B, M, seg_img, seg_local, img_start,
+                     seg_slot);
+  HSGK_LAUNCH_CHECK();
+  const int slots = B * M;
+  int64_t pb = (n + 127) / 128;
+  pb = pb > 2048 ? 2048 : pb;
+  if (slots + pb == 0) return 0;
+  hipLaunchKernelGGL(pad_fill_kernel, dim3((unsigned)(slots + pb)), dim3(128), 0, st, protos, C, pos, Cp, seg_lab,
+                     seg_batch, pixel_seg, n, slots, M, seg_img, seg_local, img_start, table, pos_table, masks,
+                     plabs, pbatch, by_image, pixel_image);
   HSGK_LAUNCH_CHECK();
   return 0;
 }

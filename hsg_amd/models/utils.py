@@ -32,6 +32,7 @@ the phases of include/hsgk.h's exchange section); the CPU tests swap in an oracl
 and run this very orchestration over `gloo`.
 """
 import ctypes
+import os
 import threading
 
 import torch
@@ -208,6 +209,24 @@ def _transport(group):
   return _DistTransport(group)
 
 
+_pin_pool = threading.local()
+
+
+def _pinned_meta():
+  free = getattr(_pin_pool, 'free', None)
+  if free is None:
+    free = _pin_pool.free = []
+  return free.pop() if free else torch.empty((8,), dtype=torch.int64).pin_memory()
+
+
+def _pinned_release(t):
+  _pin_pool.free.append(t)
+
+
+early_meta = os.environ.get('HSGK_EXCHANGE_EARLY_META', '1') != '0'     # (A/B switch of read_meta_begin)
+last_exchange = threading.local()          # .image_stats of this thread's last single-rank exchange (hierarchy.py)
+
+
 # ---- per-device backend: the phases of include/hsgk.h's exchange section -----
 class HsgkExchangeBackend:
   """One source (device) of an exchange: keys -> [gather] -> merge -> sums -> [reduce] -> finish,
@@ -283,8 +302,27 @@ class HsgkExchangeBackend:
                                                 slots_row.data_ptr() if slots_row is not None else None,
                                                 _lib.stream_ptr()))
 
+  def read_meta_begin(self):
+    """After `merge`: the meta block (complete from there on) starts its way to pinned host memory, so that the
+    one host read of the exchange waits for keys + merge only and the sums run behind it."""
+    pin = _pinned_meta()
+    with torch.cuda.device(self.dev):
+      pin.copy_(self.meta, non_blocking=True)
+      ev = torch.cuda.Event()
+      ev.record()
+    self._pending = (pin, ev)
+
   def read_meta(self):
-    m = self.meta.cpu().tolist()
+    pending = getattr(self, '_pending', None)
+    if pending is not None:
+      pin, ev = pending
+      ev.synchronize()
+      m = pin.tolist()
+      _pinned_release(pin)
+      self._pending = None
+    else:
+      m = self.meta.cpu().tolist()
+    self.image_stats = (m[4], m[5])       # distinct first keys, longest run (-1: not computed)
     return m[0], m[1], m[2], m[3]
 
   def finish(self, table_rows):
@@ -368,8 +406,11 @@ class _Exchange(torch.autograd.Function):
       if tr is not None:
         tr.all_gather(send, be.recv_blocks())
       be.merge(rank)
+      if early_meta and hasattr(be, 'read_meta_begin'):
+        be.read_meta_begin()
       be.sums(rank)
       n_local, rows, err, need = be.read_meta()          # the exchange's one host read
+      last_exchange.image_stats = getattr(be, 'image_stats', None) if world == 1 else None
       if err & (ERR_CAPACITY | ERR_ROWS):
         # some rank has more distinct tuples than the blocks hold: every rank sees the same
         # counts in the gathered headers and regrows alike
@@ -442,6 +483,8 @@ class _ExchangeList(torch.autograd.Function):
           bes[g].sums(-1, slots[g].to(embs[g].device, non_blocking=True))
       else:
         bes[0].merge(0)
+        if early_meta and hasattr(bes[0], 'read_meta_begin'):
+          bes[0].read_meta_begin()
         bes[0].sums(0)
       # one host read: the error bits of every device travel in its block header and are merged here
       _n, rows, err, need = bes[ai].read_meta()

@@ -1,6 +1,7 @@
 """torch.autograd glue over the libhsgk C ABI (internal; the public surface is
 the reference-shaped modules under hsg_amd/utils and hsg_amd/models)."""
 import ctypes
+import threading
 
 import torch
 
@@ -24,6 +25,27 @@ def note(t, name, value):
 def noted(t, name):
   h = getattr(t, '_hsg_' + name, None) if torch.is_tensor(t) else None
   return h[0] if h is not None and h[1] == t._version else None
+
+
+_pin_pool = threading.local()
+
+
+def read_i64(dev_tensor):
+  """Host list of a small int64 device vector through pinned memory (a pageable `.cpu()` stages the copy and costs
+  ~50 us more); the stream is waited for up to the copy only."""
+  free = getattr(_pin_pool, 'free', None)
+  if free is None:
+    free = _pin_pool.free = []
+  n = dev_tensor.numel()
+  pin = free.pop() if free else torch.empty((64,), dtype=torch.int64).pin_memory()
+  with torch.cuda.device(dev_tensor.device):
+    pin[:n].copy_(dev_tensor.view(-1), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+  ev.synchronize()
+  out = pin[:n].tolist()
+  free.append(pin)
+  return out
 
 
 def require_gpu(t, name):

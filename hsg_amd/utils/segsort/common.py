@@ -180,7 +180,7 @@ class _SegmentByKmeans(torch.autograd.Function):
                               'segment_by_kmeans: the co-operating workgroups of an image waited 10 s for each '
                               'other (labels invalid); set HSGK_SMALL_GROUPS=1')
         else:
-          m = meta.cpu().tolist()        # the operator's single host sync
+          m = ops.read_i64(meta)         # the operator's single host sync
       return m, (out_emb, out_loc, out_lab, out_cluster, out_batch, norms, rowmap)
 
     m, outs = run(lab, ign, table_cap)

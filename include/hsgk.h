@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HSGK_VERSION 310
+#define HSGK_VERSION 400
 #define HSGK_CHUNK 2048          /* rows per segment-sum chunk (order C2)      */
 #define HSGK_EPS 1e-12f          /* normalize_embedding eps (general/common.py:101) */
 
@@ -298,7 +298,11 @@ HSGK_API int hsgk_segsort_loss_bwd(const float *emb, int64_t n, int c, const int
  *   meta (device, int64[8]): [0] distinct local tuples, [1] distinct tuples over all ranks (= valid
  *   table rows), [2] error bits: 1 negative component, 2 more tuples than cap_local (on any rank),
  *   4 packed key overflows 2^62, 8 more rows than cap_total; [3] the largest tuple count of any rank
- *   (what cap_local has to hold).  With an error the outputs are undefined.
+ *   (what cap_local has to hold); [4] / [5] (one rank, tables up to 64 K rows; else -1): the number of distinct
+ *   batch values among the table rows and the most rows one of them has -- the shape of the per-image padded
+ *   prototype tables of resnet_fcn_hsg.py:499-502.  [0..5] are final once the merge stage has run (keys and merge
+ *   set every error bit), so a host may fetch the block BEFORE the sums stage and let the sums run behind its
+ *   read.  With an error the outputs are undefined.
  * hsgk_exchange_prototypes = hsgk_exchange_begin + hsgk_exchange_finish(rows = cap_total): fully
  * asynchronous.  A caller that needs the row count on the host anyway (to shape tensors) calls
  * begin, reads meta, then finish with rows = meta[1] (the all_reduce then moves only the used rows).
@@ -378,6 +382,21 @@ HSGK_API int hsgk_group_mean(const float *protos, const int64_t *labels, const u
  * out[i] = table[img[i] * M + seg[i]]                                           */
 HSGK_API int hsgk_gather_labels(const int64_t *table, int M, const int64_t *img,
                                 const int64_t *seg, int64_t n, int64_t *out, hsgk_stream_t stream);
+
+/* ---- resnet_fcn_hsg.py:499-577 / :1061-1136 the padded per-image tables of _calculate_kmeans_prototypes
+ * The P segments arrive sorted by image (seg_image int64 [P], ascending: the order of the tuple kernels of the
+ * exchange); segment s takes the slot (dense image number, rank inside its image) of the [B, M] tables:
+ * table [B*M, C] <- protos [P, C], pos_table [B*M, Cp] <- pos [P, Cp] (both nullable together), masks uint8 [B*M]
+ * (1 = padding), plabs / pbatch int64 [B*M] <- seg_lab / seg_batch [P] (-1 = padding); per pixel (pixel_seg int64 [n]
+ * = its segment): by_image = the segment's rank inside its image, pixel_image = its dense image number.
+ * B = distinct images and M >= the most segments of one are the caller's (hsgk_exchange meta [4], [5]).
+ * seg_slot int64 [P] (nullable): every segment's table row (what a backward pass gathers).  work: int32 [2 P + B + 1]. */
+HSGK_API int hsgk_pad_prototype_tables(const int64_t *seg_image, int64_t P, const float *protos, int C,
+                                       const float *pos, int Cp, const int64_t *seg_lab, const int64_t *seg_batch,
+                                       const int64_t *pixel_seg, int64_t n, int B, int M, float *table,
+                                       float *pos_table, uint8_t *masks, int64_t *plabs, int64_t *pbatch,
+                                       int64_t *by_image, int64_t *pixel_image, int64_t *seg_slot, int32_t *work,
+                                       hsgk_stream_t stream);
 
 /* ---- hsg/models/embeddings/transformer_clusters.py:99-114 TransformerClustering tail
  * centroids / centroid_feats [B,C,tl], node_features [B,C,sl] (the reference's
