@@ -153,8 +153,12 @@ struct LossFwdEpi {
 // score: ~22 vector instructions per score for one set, ~55 for three -- the generic path compiles to ~700.
 // (rocprofv3, N = 200 704, C = 256, P = 3 072: both MFMA engines ran 5.1 ms behind the generic epilogue,
 // i.e. the epilogue, not the contraction, set the time.)
-template <int L>
+// EXP2: exp(a k) as 2^(a (k log2 e)) -- v_mul + v_exp, relative error ~1e-6 for |a k| <= ~100 -- instead of expf's
+// range reduction and ldexp (eight instructions per score): the split-engine kernels, whose scores carry ~5e-6
+// already.  The fp32 engine (channel counts the split engine does not take) keeps expf.
+template <int L, bool EXP2 = false>
 struct LossFwdEpiFast {
+  static constexpr bool kExp2 = EXP2;
   int kb0, nrows, pb;
   int64_t P, N, crow0;
   const int64_t *inst;
@@ -181,6 +185,7 @@ struct LossFwdEpiFast {
     const int64_t s2 = L > 2 ? ls.sem[2][row] : 0;
     const float k0 = ls.kappa[0], k1 = ls.kappa[L > 1 ? 1 : 0], k2 = ls.kappa[L > 2 ? 2 : 0];
     const bool e1 = L > 1 && k1 != k0, e2 = L > 2 && k2 != k1;      // (wave-uniform)
+    const float kl0 = k0 * 1.44269504088896341f, kl1 = k1 * 1.44269504088896341f, kl2 = k2 * 1.44269504088896341f;
     const int pmax = (int)((P - kb0) < 64 ? (P - kb0) : 64);
     float own0 = 0.f, same0 = 0.f, diff0 = 0.f, own1 = 0.f, same1 = 0.f, diff1 = 0.f, own2 = 0.f, same2 = 0.f,
           diff2 = 0.f;
@@ -194,7 +199,7 @@ struct LossFwdEpiFast {
         bool live = pl < pmax;
         if (grouped) live = live && bl[kLabSlots * 64 + pl] == gj;
         const float a = acc[m][r];
-        float x0 = expf(a * k0);
+        float x0 = EXP2 ? __builtin_amdgcn_exp2f(a * kl0) : expf(a * k0);
         x0 = live ? x0 : 0.0f;
         const bool isown = pl == ij;
         {
@@ -205,14 +210,14 @@ struct LossFwdEpiFast {
         }
         if constexpr (L > 1) {
           float x1 = x0;
-          if (e1) { x1 = expf(a * k1); x1 = live ? x1 : 0.0f; }
+          if (e1) { x1 = EXP2 ? __builtin_amdgcn_exp2f(a * kl1) : expf(a * k1); x1 = live ? x1 : 0.0f; }
           const bool sm = bl[kMaskWords * 64 + pl] == s1;
           own1 += isown ? x1 : 0.0f;
           same1 += sm ? x1 : 0.0f;
           diff1 += sm ? 0.0f : x1;
           if constexpr (L > 2) {
             float x2 = x1;
-            if (e2) { x2 = expf(a * k2); x2 = live ? x2 : 0.0f; }
+            if (e2) { x2 = EXP2 ? __builtin_amdgcn_exp2f(a * kl2) : expf(a * k2); x2 = live ? x2 : 0.0f; }
             const bool sm2 = bl[(kMaskWords + 1) * 64 + pl] == s2;
             own2 += isown ? x2 : 0.0f;
             same2 += sm2 ? x2 : 0.0f;
@@ -379,6 +384,11 @@ __global__ void loss_rows_kernel(const float *__restrict__ part, int npb, int64_
   }
 }
 
+template <class Epi>
+constexpr bool epi_exp2() {
+  if constexpr (requires { Epi::kExp2; }) return Epi::kExp2; else return false;
+}
+
 // xpre: the pixel rows in the split engine's own image (loss_pairs_kernel), or null
 template <class Epi>
 static int launch_loss_tiles(const float *emb, int64_t N, int c, const float *proto, int64_t P,
@@ -398,13 +408,24 @@ static int launch_loss_tiles(const float *emb, int64_t N, int c, const float *pr
     HSGK_LAUNCH_CHECK();
     return 0;
   };
+  constexpr bool exp2_type = requires { Epi::kExp2; } && epi_exp2<Epi>();
+  constexpr bool fp32_type = !exp2_type;                 // (the generic epilogue serves both engines)
   if (loss_split_enabled(c)) {
-    if (xpre != nullptr && c % 32 == 0) {
-      emb = xpre;
-      return go(loss_tiles_split_kernel<8, 4, Epi, true>, split_lds_bytes<8>(c) + kLossBlockLabBytes, HSGK_CHUNK / 256);
+    if constexpr (exp2_type || !requires { Epi::kExp2; }) {
+      if (xpre != nullptr && c % 32 == 0) {
+        emb = xpre;
+        return go(loss_tiles_split_kernel<8, 4, Epi, true>, split_lds_bytes<8>(c) + kLossBlockLabBytes, HSGK_CHUNK / 256);
+      }
+      return go(loss_tiles_split_kernel<8, 4, Epi, false>, split_lds_bytes<8>(c) + kLossBlockLabBytes, HSGK_CHUNK / 256);
+    } else {
+      set_error("segsort loss: epilogue built for the fp32 engine");
+      return -1;
     }
-    return go(loss_tiles_split_kernel<8, 4, Epi, false>, split_lds_bytes<8>(c) + kLossBlockLabBytes, HSGK_CHUNK / 256);
   }
+  if constexpr (!fp32_type) {
+    set_error("segsort loss: epilogue built for the split engine");
+    return -1;
+  } else {
   const size_t l32 = score_tiles_lds_bytes<64, 8, 32>(c), l16 = score_tiles_lds_bytes<64, 8, 16>(c);
   if (l32 + kLossBlockLabBytes <= 160 * 1024)
     return even ? go(loss_tiles_kernel<64, 8, 32, true, Epi>, l32 + kLossBlockLabBytes, HSGK_CHUNK / 256)
@@ -414,6 +435,7 @@ static int launch_loss_tiles(const float *emb, int64_t N, int c, const float *pr
                 : go(loss_tiles_kernel<64, 8, 16, false, Epi>, l16 + kLossBlockLabBytes, HSGK_CHUNK / 256);
   set_error("segsort loss: embedding dimension %d does not fit the LDS prototype block", c);
   return -1;
+  }
 }
 
 // =============================================================================
@@ -1477,9 +1499,13 @@ int hsgk_segsort_loss_fwd(const float *emb, int64_t n, int c, const int64_t *ins
     xpre = xp;
   }
   int rc;
-  if (plain && L == 1) rc = launch_loss_tiles(emb, n, c, proto, P, LossFwdEpiFast<1>{0, 0, 0, P, n, 0, inst, ls, part, nullptr, 0}, s, xpre);
-  else if (plain && L == 2) rc = launch_loss_tiles(emb, n, c, proto, P, LossFwdEpiFast<2>{0, 0, 0, P, n, 0, inst, ls, part, nullptr, 0}, s, xpre);
-  else if (plain) rc = launch_loss_tiles(emb, n, c, proto, P, LossFwdEpiFast<3>{0, 0, 0, P, n, 0, inst, ls, part, nullptr, 0}, s, xpre);
+  const bool sp = loss_split_enabled(c);
+  if (plain && L == 1) rc = sp ? launch_loss_tiles(emb, n, c, proto, P, LossFwdEpiFast<1, true>{0, 0, 0, P, n, 0, inst, ls, part, nullptr, 0}, s, xpre)
+                               : launch_loss_tiles(emb, n, c, proto, P, LossFwdEpiFast<1, false>{0, 0, 0, P, n, 0, inst, ls, part, nullptr, 0}, s, xpre);
+  else if (plain && L == 2) rc = sp ? launch_loss_tiles(emb, n, c, proto, P, LossFwdEpiFast<2, true>{0, 0, 0, P, n, 0, inst, ls, part, nullptr, 0}, s, xpre)
+                                    : launch_loss_tiles(emb, n, c, proto, P, LossFwdEpiFast<2, false>{0, 0, 0, P, n, 0, inst, ls, part, nullptr, 0}, s, xpre);
+  else if (plain) rc = sp ? launch_loss_tiles(emb, n, c, proto, P, LossFwdEpiFast<3, true>{0, 0, 0, P, n, 0, inst, ls, part, nullptr, 0}, s, xpre)
+                          : launch_loss_tiles(emb, n, c, proto, P, LossFwdEpiFast<3, false>{0, 0, 0, P, n, 0, inst, ls, part, nullptr, 0}, s, xpre);
   else rc = launch_loss_tiles(emb, n, c, proto, P, LossFwdEpi{0, 0, 0, P, n, 0, inst, ls, part, nullptr, 0}, s, xpre);
   if (rc) return rc;
   hipLaunchKernelGGL(loss_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, npb,

@@ -189,6 +189,45 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
       }
     }
   };
+  // Streaming rows (not ROWS): the chunks are fetched strictly in order, four ahead of their use, so the address of a
+  // load is (a wave-uniform base that moves with the column chunk) + (a per-lane byte offset that changes once per
+  // tile).  load_chunk above recomputes tile, column and eight clamped row addresses for every chunk -- ~6 vector
+  // instructions per load, a quarter of the vector work of the loss forward; this stream costs none per load and
+  // ~40 per tile.
+  uint32_t voff[LOADS];
+  int pf_g = 0, pf_q = 0, pf_tile = 0;
+  // (buffer loads: descriptor = the pass's rows, built from wave-uniform values made provably so; voffset = the
+  //  lane's byte offset, soffset = the column chunk: no address arithmetic and no 64-bit address registers)
+  const float *xbase = x + crow0 * (int64_t)d;
+  const uint64_t xb = reinterpret_cast<uint64_t>(xbase);
+  const uint32_t xb_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xb);
+  const uint32_t xb_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(xb >> 32));
+  const int xbytes = __builtin_amdgcn_readfirstlane((int)min((int64_t)max(nrows, 1) * d * 4, (int64_t)0x7FFFFFFF));
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void *>(((uint64_t)xb_hi << 32) | xb_lo), 0, xbytes, 0x00020000);
+  auto set_stream_tile = [&](int tile) {
+    const int n = nrows - tile * TPX - wu * 32;
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      const int pxc = max(min(lpx + 4 * i, n - 1), -(tile * TPX + wu * 32));          // rows past the end: a valid row
+      voff[i] = (uint32_t)((tile * TPX + wu * 32 + pxc) * d + 2 * lf2) * 4u;
+    }
+  };
+  if constexpr (!ROWS) set_stream_tile(0);
+  auto next_chunk = [&](float2 (&pre)[LOADS]) {
+    const int soff = __builtin_amdgcn_readfirstlane(pf_q * KC * 4);
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrsrc, (int)voff[i], soff, 0);
+      pre[i].x = __uint_as_float(v.x);
+      pre[i].y = __uint_as_float(v.y);
+    }
+    if (pf_g < nsteps - 1) {                       // (the last chunk is re-read by the calls past the end)
+      ++pf_g;
+      if (++pf_q == nfull) { pf_q = 0; ++pf_tile; set_stream_tile(pf_tile); }
+    }
+  };
   auto store_chunk = [&](int buf, const float2 (&pre)[LOADS]) {
     uint16_t *hp = xw + buf * (2 * 32 * XSB);
     uint16_t *lp = hp + 32 * XSB;
@@ -315,11 +354,14 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
   static_assert(DEPTH == 2 || DEPTH == 4, "prefetch depth");
   float2 preA[LOADS], preB[LOADS], preC[DEPTH == 4 ? LOADS : 1], preD[DEPTH == 4 ? LOADS : 1];
   if (nsteps <= 0) return;
-  load_chunk(0, preA);
-  load_chunk(min(1, nsteps - 1), preB);
+  auto fetch = [&](int gi, float2 (&pre)[LOADS]) {
+    if constexpr (ROWS) load_chunk(gi, pre); else next_chunk(pre);
+  };
+  fetch(0, preA);
+  fetch(min(1, nsteps - 1), preB);
   if constexpr (DEPTH == 4) {
-    load_chunk(min(2, nsteps - 1), preC);
-    load_chunk(min(3, nsteps - 1), preD);
+    fetch(min(2, nsteps - 1), preC);
+    fetch(min(3, nsteps - 1), preD);
   }
   float2 tail_cur = {0.0f, 0.0f}, tail_next = {0.0f, 0.0f};
   if (two_tail) load_tail2(0, tail_cur);
@@ -327,7 +369,7 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
 #define HSGK_SPLIT_STEP(BUF, PRE, STEP, QQ)                                   \
   store_chunk(BUF, PRE);                                                      \
   __builtin_amdgcn_sched_barrier(0);                                          \
-  load_chunk(min(gidx + (STEP) + DEPTH, nsteps - 1), PRE);                    \
+  fetch(min(gidx + (STEP) + DEPTH, nsteps - 1), PRE);                         \
   __builtin_amdgcn_sched_barrier(0);                                          \
   compute_chunk(BUF, QQ);                                                     \
   __builtin_amdgcn_sched_barrier(0);
