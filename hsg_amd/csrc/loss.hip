@@ -340,13 +340,28 @@ static bool loss_split_enabled(int c) {
   return split_shape_ok(c) && split_lds_bytes<8>(c) + kLossBlockLabBytes <= 160 * 1024;
 }
 
-// fp32 rows -> the split engine's image of them: per column pair (hi pair, lo pair), 8 bytes where the two floats were
-__global__ void loss_pairs_kernel(const float *__restrict__ x, int64_t total2, uint2 *__restrict__ out) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total2; i += (int64_t)gridDim.x * blockDim.x) {
-    const float2 v = *reinterpret_cast<const float2 *>(x + 2 * i);
-    uint32_t hi, lo;
-    f16s_split2(v.x, v.y, hi, lo);
-    out[i] = uint2{hi, lo};
+// fp32 rows -> the split engine's image of them in OPERAND ORDER (score_tiles_bf16.h, XPRE): for every 32 rows and
+// 16-column block one KiB of hi words then one of lo words; thread = (32-row tile, k-block, lane l = 32 g + j) reads
+// the eight floats of row j, columns 16 kb + 8 g .. + 7, and writes its four hi and four lo words.  Rows past n: zeros.
+__global__ void loss_image_kernel(const float *__restrict__ x, int64_t n, int c, uint4 *__restrict__ out) {
+  const int nkb = c / 16;
+  const int64_t total = (n + 31) / 32 * nkb * 64;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int l = (int)(i & 63);
+    const int64_t tk = i >> 6;
+    const int kb = (int)(tk % nkb);
+    const int64_t row = (tk / nkb) * 32 + (l & 31);
+    uint4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
+    if (row < n) {
+      const float4 *src = reinterpret_cast<const float4 *>(x + row * c + kb * 16 + 8 * (l >> 5));
+      const float4 a = src[0], b = src[1];
+      f16s_split2(a.x, a.y, hi.x, lo.x);
+      f16s_split2(a.z, a.w, hi.y, lo.y);
+      f16s_split2(b.x, b.y, hi.z, lo.z);
+      f16s_split2(b.z, b.w, hi.w, lo.w);
+    }
+    out[tk * 128 + l] = hi;
+    out[tk * 128 + 64 + l] = lo;
   }
 }
 
@@ -1463,7 +1478,7 @@ size_t hsgk_segsort_loss_workspace_bytes(int64_t n, int c, int64_t P, int L) {
   const int64_t npb = (P + 63) / 64;
   Carver cv(nullptr);
   cv.take<float>((size_t)(npb > 0 ? npb : 1) * (size_t)(n > 0 ? n : 1) * 3 * (size_t)(L > 0 ? L : 1));
-  if (loss_fwd_xpre_shape(c)) cv.take<float>((size_t)(n > 0 ? n : 1) * c);
+  if (loss_fwd_xpre_shape(c)) cv.take<float>((size_t)(((n > 0 ? n : 1) + 31) / 32 * 32) * c);
   return cv.off + 256;
 }
 
@@ -1491,10 +1506,10 @@ int hsgk_segsort_loss_fwd(const float *emb, int64_t n, int c, const int64_t *ins
   const float *xpre = nullptr;
   const char *fwd_env = getenv("HSGK_LOSS_FWD");
   if (loss_fwd_xpre_shape(c) && loss_split_enabled(c) && P >= 1280 && !(fwd_env && fwd_env[0] == 'c')) {
-    float *xp = cv.take<float>((size_t)n * c);
-    const int64_t t2 = n * c / 2, gsz = (t2 + 255) / 256;
-    hipLaunchKernelGGL(loss_pairs_kernel, dim3((unsigned)(gsz > 16384 ? 16384 : gsz)), dim3(256), 0, s, emb, t2,
-                       reinterpret_cast<uint2 *>(xp));
+    float *xp = cv.take<float>((size_t)((n + 31) / 32 * 32) * c);
+    const int64_t t2 = (n + 31) / 32 * (c / 16) * 64, gsz = (t2 + 255) / 256;
+    hipLaunchKernelGGL(loss_image_kernel, dim3((unsigned)(gsz > 16384 ? 16384 : gsz)), dim3(256), 0, s, emb, n, c,
+                       reinterpret_cast<uint4 *>(xp));
     HSGK_LAUNCH_CHECK();
     xpre = xp;
   }

@@ -88,10 +88,13 @@ __host__ __device__ constexpr size_t split_lds_bytes(int d) {
 // rl_lds[NW][2][32] (tile parity), loaded two tiles ahead: an id fetched from global
 // right before its use would drain the whole prefetch queue (loads return in order).
 // Epi may read the ids of tile t from the slot t & 1 inside its call.
-// XPRE: x is not fp32 rows but the already split image of them -- per pair of columns one 32-bit pair of hi halves
-// and one of lo halves, at the byte offset of the two floats (loss.hip: every pixel row is streamed once per
-// prototype block, 48 times at P = 3 072; converting it each time was a third of that kernel's vector work).
-// The caller guarantees d % 32 == 0 (no tail columns).
+// XPRE: x is not fp32 rows but the already split image of them IN OPERAND ORDER (loss.hip: loss_image_kernel) --
+// for every 32 rows and 16-column block one KiB of hi words and one of lo words, lane l = 32 g + j holding the four
+// words of row j's columns 8 g .. 8 g + 7: a wave's B operands of a k-block are two 16-byte buffer loads per lane
+// straight into registers, contiguous per instruction, and the rows never pass through LDS (every pixel row is
+// streamed once per prototype block, 48 times at P = 3 072: converting it each time was a third of that kernel's
+// vector work, staging it through LDS half of its LDS instructions).  The caller guarantees d % 32 == 0 (no tail
+// columns) and crow0 % 32 == 0; x points at the image of row 0.
 template <int NW, int DEPTH, class Epi, bool ROWS = false, bool F16S = false, bool XPRE = false>
 __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, int d,
                                          const float *__restrict__ table, int kvalid,
@@ -352,6 +355,58 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
   // per CU are in flight -- and a tile always ends on the last set, so there is
   // ONE epilogue site and the accumulators never move between code paths.
   static_assert(DEPTH == 2 || DEPTH == 4, "prefetch depth");
+  if constexpr (XPRE && !ROWS) {
+    // ---- operands straight from the operand-order image: four register sets of one chunk (two k-blocks) each
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    if (nsteps <= 0) return;
+    const int nkb = d / 16;
+    const int64_t img0 = (crow0 / 32) * (int64_t)nkb * 512;          // dwords: (32-row tile, k-block) -> 512
+    const uint64_t ib = reinterpret_cast<uint64_t>(x + img0);
+    const uint32_t ib_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ib);
+    const uint32_t ib_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ib >> 32));
+    const int ibytes = __builtin_amdgcn_readfirstlane((nrows + 31) / 32 * nkb * 2048);
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void *>(((uint64_t)ib_hi << 32) | ib_lo), 0, ibytes, 0x00020000);
+    const int lane16 = lane * 16;
+    int sg = 0, sq = 0, stile = 0;                                   // the fetch stream (sequential, clamped at the end)
+    auto fetchx = [&](u32x4 (&h)[2], u32x4 (&l)[2]) {
+      const int soff = __builtin_amdgcn_readfirstlane(((stile * (TPX / 32) + wu) * nkb + 2 * sq) * 2048);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {                               // (tiles past the end of the pass read zeros)
+        h[kb] = __builtin_amdgcn_raw_buffer_load_b128(irsrc, lane16, soff + kb * 2048, 0);
+        l[kb] = __builtin_amdgcn_raw_buffer_load_b128(irsrc, lane16 + 1024, soff + kb * 2048, 0);
+      }
+      if (sg < nsteps - 1) {
+        ++sg;
+        if (++sq == nfull) { sq = 0; ++stile; }
+      }
+    };
+    auto computex = [&](const u32x4 (&h)[2], const u32x4 (&l)[2], int q) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        kblock(__builtin_bit_cast(bf16x8, h[kb]), __builtin_bit_cast(bf16x8, l[kb]), q * KC + kb * 16);
+    };
+    u32x4 hA[2], lA[2], hB[2], lB[2], hC[2], lC[2], hD[2], lD[2];
+    fetchx(hA, lA); fetchx(hB, lB); fetchx(hC, lC); fetchx(hD, lD);
+    const float2 notail = {0.0f, 0.0f};
+#define HSGK_SPLIT_XSTEP(H, L, QQ)                                            \
+    computex(H, L, QQ);                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                        \
+    fetchx(H, L);                                                             \
+    __builtin_amdgcn_sched_barrier(0);
+    for (int tile = 0; tile < ntile; ++tile) {
+      for (int q = 0; q < nfull; q += 4) {
+        HSGK_SPLIT_XSTEP(hA, lA, q)
+        HSGK_SPLIT_XSTEP(hB, lB, q + 1)
+        HSGK_SPLIT_XSTEP(hC, lC, q + 2)
+        HSGK_SPLIT_XSTEP(hD, lD, q + 3)
+      }
+      finish_tile(tile, notail);
+      zero_acc();
+    }
+#undef HSGK_SPLIT_XSTEP
+    return;
+  }
   float2 preA[LOADS], preB[LOADS], preC[DEPTH == 4 ? LOADS : 1], preD[DEPTH == 4 ? LOADS : 1];
   if (nsteps <= 0) return;
   auto fetch = [&](int gi, float2 (&pre)[LOADS]) {
