@@ -65,7 +65,7 @@ WORKLOADS = {
     'reftrain': (8, 4, 128, 56, 56, (4, 4), 15),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
-PMC_FILES = ('r03_cfg2_pmc.txt', 'r02_pmc.txt', 'r01_pmc.txt')
+PMC_FILES = ('r04_cfg2_pmc.txt', 'r03_cfg2_pmc.txt', 'r02_pmc.txt', 'r01_pmc.txt')
 
 
 def pmc_traffic(kernels, files=None):

@@ -207,6 +207,23 @@ class _HierAssign(torch.autograd.Function):
     has_c = ctx.has_coarse
     KC = cl.shape[1] if has_c else 0
     dev = fl.device
+    if has_c and KC * KF > 1024:
+      # (beyond the one-launch backward's LDS working set -- the forward accepts such hierarchies: the same
+      #  gradients through the ATen formulas the kernel fuses)
+      with torch.enable_grad():
+        a = fl.detach().requires_grad_(True)
+        c = cl.detach().requires_grad_(True)
+        fp = torch.softmax(a, dim=1)
+        cp = torch.einsum('bij,bjk->bik', torch.softmax(c, dim=1), fp)
+        outs, grads = [], []
+        if g_fprob is not None:
+          outs.append(fp); grads.append(g_fprob.float())
+        if g_cprob is not None:
+          outs.append(cp); grads.append(g_cprob.float())
+        if not outs:
+          return torch.zeros_like(fl), torch.zeros_like(cl)
+        ga, gc = torch.autograd.grad(outs, [a, c], grads, allow_unused=True)
+      return (ga if ga is not None else torch.zeros_like(fl)), (gc if gc is not None else torch.zeros_like(cl))
     with torch.cuda.device(dev):
       g1 = g_fprob.contiguous().float() if g_fprob is not None else None
       g2 = g_cprob.contiguous().float() if (has_c and g_cprob is not None) else None

@@ -81,14 +81,24 @@ _CAP_START = 4096
 collective_calls = 0        # incremented per collective issued (tests / bench read it)
 
 
+def _group_key(group):
+  """A token of the process group that outlives the Python object: c10d names every group it creates (unique in
+  the process, the same on all ranks); `id(group)` -- reused by the interpreter once a group has been collected,
+  so a NEW group could inherit a dead one's capacities or communicator -- only where no name exists."""
+  if group is None:
+    return None
+  name = getattr(group, 'group_name', None)
+  return ('name', name) if name else ('id', id(group))
+
+
 def _cap_get(group, tag, default=None):
   with _state_lock:
-    return _capacity.get((id(group) if group is not None else None, tag), _CAP_START if default is None else default)
+    return _capacity.get((_group_key(group), tag), _CAP_START if default is None else default)
 
 
 def _cap_set(group, tag, value):
   with _state_lock:
-    _capacity[(id(group) if group is not None else None, tag)] = value
+    _capacity[(_group_key(group), tag)] = value
 
 
 def _count_collective():
@@ -179,7 +189,7 @@ use_library_comm = False     # one process per GPU: in-stream RCCL through libhs
 def library_transport(group=None):
   """Creates (once per process group) libhsgk's RCCL communicator over the ranks of `group`: rank 0
   draws the unique id, the process group carries its 128 bytes to the others."""
-  key = id(group) if group is not None else None
+  key = _group_key(group)
   with _state_lock:
     hit = _library_comms.get(key)
   if hit is not None:
