@@ -144,47 +144,64 @@ __global__ __launch_bounds__(256) void hier_assign_bwd_kernel(
 
 // prototypes [B,C,N]; labels [B,N]; masks [B,N] (uint8, nullable: nothing
 // padded); out [B,C,G].  Node n contributes to group labels[n] unless padded.
-__global__ __launch_bounds__(256) void group_mean_kernel(
+// One wave per (image, 64 channels): thread = channel walks the N nodes ONCE in ascending order and adds every
+// value to its group's LDS cell (its own column: no conflicts) -- per (group, channel) the same sequential sum as a
+// loop over groups, at 1 / G of the work and B * C / 64 workgroups instead of B (cfg4's 256 -> 64 grouping of four
+// images: 0.98 -> ~0.03 ms).  Normalisation needs the whole channel range of a group: second, tiny kernel.
+__global__ __launch_bounds__(64) void group_mean_kernel(
     const float *__restrict__ protos, const int64_t *__restrict__ labels,
-    const uint8_t *__restrict__ masks, int C, int N, int G, int normalized, float eps,
-    float *__restrict__ out) {
-  extern __shared__ float sm[];              // [G][C] means, then [G] norms, then int labels [N]
-  float *means = sm;
-  float *norms = sm + (size_t)G * C;
-  int *lab = reinterpret_cast<int *>(norms + G);
-  const int b = blockIdx.x, tid = threadIdx.x;
-  for (int n = tid; n < N; n += 256) {
+    const uint8_t *__restrict__ masks, int C, int N, int G, float *__restrict__ out) {
+  extern __shared__ float sm[];              // [G][64] sums, [G] counts, int labels [N]
+  float *sums = sm;
+  float *cnt = sm + (size_t)G * 64;
+  int *lab = reinterpret_cast<int *>(cnt + G);
+  const int b = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x;
+  for (int n = tid; n < N; n += 64) {
     const bool pad = masks ? masks[(int64_t)b * N + n] != 0 : false;
     const int64_t l = labels[(int64_t)b * N + n];
     lab[n] = (pad || l < 0 || l >= G) ? -1 : (int)l;
   }
+  for (int i = tid; i < G * 64; i += 64) sums[i] = 0.0f;
   __syncthreads();
-  const float *p = protos + (int64_t)b * C * N;
-  for (int c = tid; c < C; c += 256) {
-    for (int g = 0; g < G; ++g) {
-      float s = 0.0f, cnt = 0.0f;
-      for (int n = 0; n < N; ++n)
-        if (lab[n] == g) { s = s + p[(int64_t)c * N + n]; cnt = cnt + 1.0f; }
-      means[g * C + c] = s / fmaxf(cnt, 1e-12f);
+  for (int g = tid; g < G; g += 64) {
+    float k = 0.0f;
+    for (int n = 0; n < N; ++n) k = k + (lab[n] == g ? 1.0f : 0.0f);
+    cnt[g] = k;
+  }
+  const int c = c0 + tid;
+  if (c < C) {
+    const float *p = protos + ((int64_t)b * C + c) * N;
+    for (int n0 = 0; n0 < N; n0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[min(n0 + u, N - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int n = n0 + u;
+        if (n < N) {
+          const int g = lab[n];
+          if (g >= 0) sums[g * 64 + tid] = sums[g * 64 + tid] + v[u];
+        }
+      }
     }
   }
   __syncthreads();
-  if (normalized) {
-    for (int g = tid; g < G; g += 256) {
-      float ss = 0.0f;
-      for (int c = 0; c < C; ++c) ss = fmaf(means[g * C + c], means[g * C + c], ss);
-      float nrm = sqrtf(ss);
-      if (!(nrm >= eps)) nrm = eps;
-      norms[g] = nrm;
-    }
-    __syncthreads();
+  if (c < C) {
+    float *o = out + ((int64_t)b * C + c) * G;
+    for (int g = 0; g < G; ++g) o[g] = sums[g * 64 + tid] / fmaxf(cnt[g], 1e-12f);
   }
-  float *o = out + (int64_t)b * C * G;
-  for (int i = tid; i < C * G; i += 256) {
-    const int c = i / G, g = i - c * G;
-    const float v = means[g * C + c];
-    o[(int64_t)c * G + g] = normalized ? v / norms[g] : v;
-  }
+}
+
+// out [B][C][G] /= max(|column g|, eps), the norm as the C1 chain over ascending channels
+__global__ __launch_bounds__(64) void group_normalize_kernel(float *__restrict__ out, int C, int G, float eps) {
+  const int b = blockIdx.y, g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= G) return;
+  float *o = out + (int64_t)b * C * G + g;
+  float ss = 0.0f;
+  for (int c = 0; c < C; ++c) ss = fmaf(o[(int64_t)c * G], o[(int64_t)c * G], ss);
+  float nrm = sqrtf(ss);
+  if (!(nrm >= eps)) nrm = eps;
+  for (int c = 0; c < C; ++c) o[(int64_t)c * G] = o[(int64_t)c * G] / nrm;
 }
 
 __global__ void gather_labels_kernel(const int64_t *__restrict__ table, int M,
@@ -389,13 +406,17 @@ int hsgk_group_mean(const float *protos, const int64_t *labels, const uint8_t *m
   HSGK_REQUIRE(B >= 0 && C >= 1 && N >= 1 && G >= 1, "bad shape");
   if (B == 0) return 0;
   (void)hipGetLastError();
-  const size_t lds = ((size_t)G * C + G) * 4 + (size_t)N * 4;
-  HSGK_REQUIRE(lds <= 150 * 1024, "groups x channels too large for one workgroup");
+  const size_t lds = ((size_t)G * 64 + G) * 4 + (size_t)N * 4;
+  HSGK_REQUIRE(lds <= 150 * 1024, "too many groups / nodes for one workgroup");
   HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(group_mean_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(group_mean_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream),
-                     protos, labels, masks, C, N, G, normalized, eps, out);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(group_mean_kernel, dim3((C + 63) / 64, B), dim3(64), lds, st, protos, labels, masks, C, N, G, out);
   HSGK_LAUNCH_CHECK();
+  if (normalized) {
+    hipLaunchKernelGGL(group_normalize_kernel, dim3((G + 63) / 64, B), dim3(64), 0, st, out, C, G, eps);
+    HSGK_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -104,7 +104,9 @@ def calculate_kmeans_prototypes(cluster_embeddings, cluster_indices, cluster_bat
   hi = b + torch.div(lab, ldiv, rounding_mode='floor')                 # (a label >= div^2 carries into the batch digit,
   lo = torch.remainder(lab, ldiv)                                      #  exactly as the reference's sum does)
   rows = cluster_embeddings.reshape(-1, cluster_embeddings.shape[-1])
-  protos, _, uhi, ulo, uimg, gid = model_utils.exchange_prototypes(rows, rows, c, img, hi, lo,
+  # (only the first table is wanted: the exchange's second row set is one detached column, not the rows again --
+  #  half the columns for its sums kernel)
+  protos, _, uhi, ulo, uimg, gid = model_utils.exchange_prototypes(rows, rows.detach()[:, :1], c, img, hi, lo,
                                                                    tag='kmeans_protos', local=True)
   P = uhi.shape[0]
   stats = getattr(model_utils.last_exchange, 'image_stats', None)      # (distinct images, most segments of one): they
