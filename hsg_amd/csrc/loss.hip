@@ -166,76 +166,106 @@ struct LossFwdEpiFast {
   float *part;                                   // [npb][N][3 L]
   const int64_t *blab;                           // (unused here; same staging as the generic epilogue)
   int blab_off;                                  // byte offset of the staged labels in the dynamic LDS
-  template <int MB>
-  __device__ inline void operator()(int tile, const f32x16 (&acc)[MB]) const {
+  // The epilogue of a tile in three parts, so that an engine can spread the per-score work over the matrix
+  // instructions of the NEXT tile (score_tiles_split, NFULLC > 0): begin() reads the rows' labels, piece<M, R0, NR>()
+  // folds scores acc[M][R0 .. R0 + NR) into the running sums, end() reduces the two half-waves and stores.
+  struct State {
+    const int64_t *bl;
+    int64_t row, gj, s0, s1, s2;
+    int ij, pmax, h;
+    bool valid, grouped, e1, e2;
+    float k0, k1, k2, kl0, kl1, kl2;
+    float own0, same0, diff0, own1, same1, diff1, own2, same2, diff2;
+  };
+  __device__ inline void begin(int tile, State &st) const {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_epi_base[];
-    const int64_t *bl = reinterpret_cast<const int64_t *>(lds_epi_base + blab_off);
+    st.bl = reinterpret_cast<const int64_t *>(lds_epi_base + blab_off);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int j = lane & 31, h = lane >> 5;
+    const int j = lane & 31;
+    st.h = lane >> 5;
     const int TPX = (int)(blockDim.x >> 1);
     const int px = tile * TPX + w * 32 + j;
-    const bool valid = px < nrows;
-    const int64_t row = crow0 + (valid ? px : 0);
-    const int64_t ijg = inst[row] - kb0;
-    const int ij = (ijg >= 0 && ijg < 64) ? (int)ijg : -1;       // own prototype within this block, or none
-    const bool grouped = ls.qgroup != nullptr;
-    const int64_t gj = grouped ? ls.qgroup[row] : 0;
-    const int64_t s0 = ls.sem[0][row];
-    const int64_t s1 = L > 1 ? ls.sem[1][row] : 0;
-    const int64_t s2 = L > 2 ? ls.sem[2][row] : 0;
-    const float k0 = ls.kappa[0], k1 = ls.kappa[L > 1 ? 1 : 0], k2 = ls.kappa[L > 2 ? 2 : 0];
-    const bool e1 = L > 1 && k1 != k0, e2 = L > 2 && k2 != k1;      // (wave-uniform)
-    const float kl0 = k0 * 1.44269504088896341f, kl1 = k1 * 1.44269504088896341f, kl2 = k2 * 1.44269504088896341f;
-    const int pmax = (int)((P - kb0) < 64 ? (P - kb0) : 64);
-    float own0 = 0.f, same0 = 0.f, diff0 = 0.f, own1 = 0.f, same1 = 0.f, diff1 = 0.f, own2 = 0.f, same2 = 0.f,
-          diff2 = 0.f;
+    st.valid = px < nrows;
+    st.row = crow0 + (st.valid ? px : 0);
+    const int64_t ijg = inst[st.row] - kb0;
+    st.ij = (ijg >= 0 && ijg < 64) ? (int)ijg : -1;       // own prototype within this block, or none
+    st.grouped = ls.qgroup != nullptr;
+    st.gj = st.grouped ? ls.qgroup[st.row] : 0;
+    st.s0 = ls.sem[0][st.row];
+    st.s1 = L > 1 ? ls.sem[1][st.row] : 0;
+    st.s2 = L > 2 ? ls.sem[2][st.row] : 0;
+    st.k0 = ls.kappa[0]; st.k1 = ls.kappa[L > 1 ? 1 : 0]; st.k2 = ls.kappa[L > 2 ? 2 : 0];
+    st.e1 = L > 1 && st.k1 != st.k0; st.e2 = L > 2 && st.k2 != st.k1;      // (wave-uniform)
+    st.kl0 = st.k0 * 1.44269504088896341f; st.kl1 = st.k1 * 1.44269504088896341f; st.kl2 = st.k2 * 1.44269504088896341f;
+    st.pmax = (int)((P - kb0) < 64 ? (P - kb0) : 64);
+    st.own0 = st.same0 = st.diff0 = st.own1 = st.same1 = st.diff1 = st.own2 = st.same2 = st.diff2 = 0.f;
+  }
+  template <int M, int R0, int NR>
+  __device__ inline void piece(State &st, const f32x16 &accm) const {
+    const int64_t *bl = st.bl;
 #pragma unroll
-    for (int m = 0; m < MB; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        // (keeps the scheduler from hoisting all 32 x L label reads and exps of a tile: spills with L >= 2)
-        if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-        const int pl = (m * 32 + (r & 3) + 8 * (r >> 2)) | (h << 2);
-        bool live = pl < pmax;
-        if (grouped) live = live && bl[kLabSlots * 64 + pl] == gj;
-        const float a = acc[m][r];
-        float x0 = EXP2 ? __builtin_amdgcn_exp2f(a * kl0) : expf(a * k0);
-        x0 = live ? x0 : 0.0f;
-        const bool isown = pl == ij;
-        {
-          const bool sm = bl[pl] == s0;
-          own0 += isown ? x0 : 0.0f;
-          same0 += sm ? x0 : 0.0f;
-          diff0 += sm ? 0.0f : x0;
-        }
-        if constexpr (L > 1) {
-          float x1 = x0;
-          if (e1) { x1 = EXP2 ? __builtin_amdgcn_exp2f(a * kl1) : expf(a * k1); x1 = live ? x1 : 0.0f; }
-          const bool sm = bl[kMaskWords * 64 + pl] == s1;
-          own1 += isown ? x1 : 0.0f;
-          same1 += sm ? x1 : 0.0f;
-          diff1 += sm ? 0.0f : x1;
-          if constexpr (L > 2) {
-            float x2 = x1;
-            if (e2) { x2 = EXP2 ? __builtin_amdgcn_exp2f(a * kl2) : expf(a * k2); x2 = live ? x2 : 0.0f; }
-            const bool sm2 = bl[(kMaskWords + 1) * 64 + pl] == s2;
-            own2 += isown ? x2 : 0.0f;
-            same2 += sm2 ? x2 : 0.0f;
-            diff2 += sm2 ? 0.0f : x2;
-          }
+    for (int r = R0; r < R0 + NR; ++r) {
+      const int pl = (M * 32 + (r & 3) + 8 * (r >> 2)) | (st.h << 2);
+      // (no branches in a piece: it has to stay ONE scheduling region with the matrix instructions it hides behind)
+      const int64_t grp = bl[kLabSlots * 64 + pl];                   // (always a staged word: pl < 64)
+      const bool live = (pl < st.pmax) & (!st.grouped | (grp == st.gj));
+      const float a = accm[r];
+      float x0 = EXP2 ? __builtin_amdgcn_exp2f(a * st.kl0) : expf(a * st.k0);
+      x0 = live ? x0 : 0.0f;
+      const bool isown = pl == st.ij;
+      {
+        const bool sm = bl[pl] == st.s0;
+        st.own0 += isown ? x0 : 0.0f;
+        st.same0 += sm ? x0 : 0.0f;
+        st.diff0 += sm ? 0.0f : x0;
+      }
+      if constexpr (L > 1) {
+        float x1 = EXP2 ? __builtin_amdgcn_exp2f(a * st.kl1) : expf(a * st.k1);
+        x1 = st.e1 ? (live ? x1 : 0.0f) : x0;
+        const bool sm = bl[kMaskWords * 64 + pl] == st.s1;
+        st.own1 += isown ? x1 : 0.0f;
+        st.same1 += sm ? x1 : 0.0f;
+        st.diff1 += sm ? 0.0f : x1;
+        if constexpr (L > 2) {
+          float x2 = EXP2 ? __builtin_amdgcn_exp2f(a * st.kl2) : expf(a * st.k2);
+          x2 = st.e2 ? (live ? x2 : 0.0f) : x1;
+          const bool sm2 = bl[(kMaskWords + 1) * 64 + pl] == st.s2;
+          st.own2 += isown ? x2 : 0.0f;
+          st.same2 += sm2 ? x2 : 0.0f;
+          st.diff2 += sm2 ? 0.0f : x2;
         }
       }
-    float o[3] = {own0, own1, own2}, sa[3] = {same0, same1, same2}, di[3] = {diff0, diff1, diff2};
+    }
+  }
+  __device__ inline void end(const State &st) const {
+    float o[3] = {st.own0, st.own1, st.own2}, sa[3] = {st.same0, st.same1, st.same2}, di[3] = {st.diff0, st.diff1, st.diff2};
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       const float ov = o[l] + __shfl_xor(o[l], 32);
       const float sv = sa[l] + __shfl_xor(sa[l], 32);
       const float dv = di[l] + __shfl_xor(di[l], 32);
-      if (h == 0 && valid) {
-        float *dst = part + (((int64_t)pb * N + row) * L + l) * 3;
+      if (st.h == 0 && st.valid) {
+        float *dst = part + (((int64_t)pb * N + st.row) * L + l) * 3;
         dst[0] = ov; dst[1] = sv; dst[2] = dv;
       }
     }
+  }
+  template <int MB>
+  __device__ inline void operator()(int tile, const f32x16 (&acc)[MB]) const {
+    State st;
+    begin(tile, st);
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      // (keeps the scheduler from hoisting all 32 x L label reads and exps of a tile: spills with L >= 2)
+      __builtin_amdgcn_sched_barrier(0);
+      if (m == 0) { piece<0, 0, 4>(st, acc[0]); __builtin_amdgcn_sched_barrier(0); piece<0, 4, 4>(st, acc[0]);
+                    __builtin_amdgcn_sched_barrier(0); piece<0, 8, 4>(st, acc[0]); __builtin_amdgcn_sched_barrier(0);
+                    piece<0, 12, 4>(st, acc[0]); }
+      else { piece<1, 0, 4>(st, acc[MB > 1 ? 1 : 0]); __builtin_amdgcn_sched_barrier(0); piece<1, 4, 4>(st, acc[MB > 1 ? 1 : 0]);
+             __builtin_amdgcn_sched_barrier(0); piece<1, 8, 4>(st, acc[MB > 1 ? 1 : 0]); __builtin_amdgcn_sched_barrier(0);
+             piece<1, 12, 4>(st, acc[MB > 1 ? 1 : 0]); }
+    }
+    end(st);
   }
 };
 
@@ -299,7 +329,7 @@ __global__ __launch_bounds__(NW * 64) void loss_tiles_kernel(
 // bf16x3 form, 16 significant bits, kept the loss within 1e-4 too but moved gradients by 2e-4 of their scale.)
 // The contract here is a tolerance, not bit-exactness; HSGK_LOSS=fp32 keeps the fp32 engine (needed for
 // values beyond fp16's range, |x| > 6e4).
-template <int NW, int DEPTH, class Epi, bool XPRE>
+template <int NW, int DEPTH, class Epi, bool XPRE, int NFULLC = 0>
 __global__ __launch_bounds__(NW * 64) void loss_tiles_split_kernel(
     const float *__restrict__ emb, int c, const float *__restrict__ proto, int64_t P, int64_t N,
     int split, Epi epi_proto) {
@@ -330,8 +360,8 @@ __global__ __launch_bounds__(NW * 64) void loss_tiles_split_kernel(
   epi.blab = blab;
   epi.blab_off = (int)split_lds_bytes<NW>(c);
   const int kvalid = (int)((P - (int64_t)pb * KB) < KB ? (P - (int64_t)pb * KB) : KB);
-  score_tiles_split<NW, DEPTH, Epi, false, true, XPRE>(emb, c, proto + (int64_t)pb * KB * c, kvalid, epi.crow0, nrows,
-                                                       lds_split, epi);
+  score_tiles_split<NW, DEPTH, Epi, false, true, XPRE, NFULLC>(emb, c, proto + (int64_t)pb * KB * c, kvalid, epi.crow0,
+                                                               nrows, lds_split, epi);
 }
 
 static bool loss_split_enabled(int c) {
@@ -412,13 +442,13 @@ static int launch_loss_tiles(const float *emb, int64_t N, int c, const float *pr
   const int nch = (int)((N + HSGK_CHUNK - 1) / HSGK_CHUNK);
   const int npb = (int)((P + 63) / 64);
   const bool even = (c & 1) == 0;
-  auto go = [&](auto kern, size_t lds, int tiles_per_chunk) -> int {
+  auto go = [&](auto kern, size_t lds, int tiles_per_chunk, int threads = 512) -> int {
     int split = 1;
     while (split < tiles_per_chunk && (int64_t)nch * npb * split < 1024) split *= 2;
     HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int rparts = nch * split;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(((rparts + 7) / 8) * 8 * npb)), dim3(512), lds, s, emb, c, proto, P, N,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(((rparts + 7) / 8) * 8 * npb)), dim3(threads), lds, s, emb, c, proto, P, N,
                        split, epi);
     HSGK_LAUNCH_CHECK();
     return 0;
@@ -429,6 +459,21 @@ static int launch_loss_tiles(const float *emb, int64_t N, int c, const float *pr
     if constexpr (exp2_type || !requires { Epi::kExp2; }) {
       if (xpre != nullptr && c % 32 == 0) {
         emb = xpre;
+        // HSGK_LOSS_PIPE=1 (experiment, 256 / 128 channels): the tile loop unrolled, the epilogue of a tile issued
+        // between the matrix instructions of the next one (sched_group_barrier pipeline).  Measured SLOWER: with eight
+        // waves the second tile of scores spills (2.13 against 1.34 ms at N = 200 704, P = 3 072), with four waves of
+        // 512 registers nothing spills but one wave per SIMD does not cover the LDS operand waits between the matrix
+        // instructions (1.58 ms).  The default stays the plain loop.
+        const char *pe = getenv("HSGK_LOSS_PIPE");
+        const bool pipe = pe && pe[0] == '1';
+        if constexpr (requires { typename Epi::State; }) {
+          // (four waves per workgroup, one per SIMD: the two tiles of scores a wave holds need more than the 256
+          //  registers two waves per SIMD leave each)
+          if (pipe && c == 256)
+            return go(loss_tiles_split_kernel<4, 4, Epi, true, 8>, split_lds_bytes<4>(c) + kLossBlockLabBytes, HSGK_CHUNK / 128, 256);
+          if (pipe && c == 128)
+            return go(loss_tiles_split_kernel<4, 4, Epi, true, 4>, split_lds_bytes<4>(c) + kLossBlockLabBytes, HSGK_CHUNK / 128, 256);
+        }
         return go(loss_tiles_split_kernel<8, 4, Epi, true>, split_lds_bytes<8>(c) + kLossBlockLabBytes, HSGK_CHUNK / 256);
       }
       return go(loss_tiles_split_kernel<8, 4, Epi, false>, split_lds_bytes<8>(c) + kLossBlockLabBytes, HSGK_CHUNK / 256);

@@ -95,7 +95,12 @@ __host__ __device__ constexpr size_t split_lds_bytes(int d) {
 // streamed once per prototype block, 48 times at P = 3 072: converting it each time was a third of that kernel's
 // vector work, staging it through LDS half of its LDS instructions).  The caller guarantees d % 32 == 0 (no tail
 // columns) and crow0 % 32 == 0; x points at the image of row 0.
-template <int NW, int DEPTH, class Epi, bool ROWS = false, bool F16S = false, bool XPRE = false>
+// NFULLC > 0 (XPRE only; the caller guarantees d == 32 NFULLC): the tile loop is unrolled and, when the epilogue has
+// the begin / piece / end form (loss.hip: LossFwdEpiFast), the per-score work of tile t - 1 is issued BETWEEN the
+// matrix instructions of tile t -- an MFMA occupies the matrix pipe for 32 cycles during which the wave would issue
+// nothing else; five vector instructions fit behind each one.  With two waves per SIMD (256 registers) the epilogue of
+// one wave and the MFMAs of the other overlapped only by chance.
+template <int NW, int DEPTH, class Epi, bool ROWS = false, bool F16S = false, bool XPRE = false, int NFULLC = 0>
 __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, int d,
                                          const float *__restrict__ table, int kvalid,
                                          int64_t crow0, int nrows, unsigned char *lds_raw,
@@ -389,6 +394,77 @@ __device__ __forceinline__ void score_tiles_split(const float *__restrict__ x, i
     u32x4 hA[2], lA[2], hB[2], lB[2], hC[2], lC[2], hD[2], lD[2];
     fetchx(hA, lA); fetchx(hB, lB); fetchx(hC, lC); fetchx(hD, lD);
     const float2 notail = {0.0f, 0.0f};
+    if constexpr (NFULLC > 0 && F16S && requires { typename Epi::State; }) {
+      static_assert(NFULLC == 4 || NFULLC == 8 || NFULLC == 16, "chunks per tile");
+      typedef typename Epi::State EState;
+      EState stp, stn;                      // rows of the tile whose scores are in `prev` / of the tile being scored
+      epi.begin(0, stp);
+      stp.valid = false; stp.pmax = 0;      // (nothing to fold before the first tile: scores of zero, nothing stored)
+      f32x16 prev[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) prev[m][r] = 0.0f;
+      auto xstep = [&]<int Q>(u32x4 (&h)[2], u32x4 (&l)[2]) {
+        computex(h, l, Q);
+        constexpr int P0 = Q * 8 / NFULLC, P1 = (Q + 1) * 8 / NFULLC;
+        if constexpr (P1 > P0) epi.template piece<P0 / 4, 4 * (P0 % 4), 4>(stp, prev[P0 / 4]);
+        if constexpr (P1 > P0 + 1) epi.template piece<(P0 + 1) / 4, 4 * ((P0 + 1) % 4), 4>(stp, prev[(P0 + 1) / 4]);
+        // one matrix instruction, then the vector work that fits behind it
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fetchx(h, l);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      for (int tile = 0; tile < ntile; ++tile) {
+        epi.begin(tile, stn);
+        xstep.template operator()<0>(hA, lA);
+        xstep.template operator()<1>(hB, lB);
+        xstep.template operator()<2>(hC, lC);
+        xstep.template operator()<3>(hD, lD);
+        if constexpr (NFULLC >= 8) {
+          xstep.template operator()<4>(hA, lA);
+          xstep.template operator()<5>(hB, lB);
+          xstep.template operator()<6>(hC, lC);
+          xstep.template operator()<7>(hD, lD);
+        }
+        if constexpr (NFULLC >= 16) {
+          xstep.template operator()<8>(hA, lA);
+          xstep.template operator()<9>(hB, lB);
+          xstep.template operator()<10>(hC, lC);
+          xstep.template operator()<11>(hD, lD);
+          xstep.template operator()<12>(hA, lA);
+          xstep.template operator()<13>(hB, lB);
+          xstep.template operator()<14>(hC, lC);
+          xstep.template operator()<15>(hD, lD);
+        }
+        epi.end(stp);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) prev[m][r] = fmaf(acc2[m][r], 0.00048828125f, acc[m][r]);
+        stp = stn;
+        zero_acc();
+      }
+      // the last tile's scores: nothing left to hide behind
+      epi.template piece<0, 0, 4>(stp, prev[0]);
+      epi.template piece<0, 4, 4>(stp, prev[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      epi.template piece<0, 8, 4>(stp, prev[0]);
+      epi.template piece<0, 12, 4>(stp, prev[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      epi.template piece<1, 0, 4>(stp, prev[1]);
+      epi.template piece<1, 4, 4>(stp, prev[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      epi.template piece<1, 8, 4>(stp, prev[1]);
+      epi.template piece<1, 12, 4>(stp, prev[1]);
+      epi.end(stp);
+      return;
+    }
 #define HSGK_SPLIT_XSTEP(H, L, QQ)                                            \
     computex(H, L, QQ);                                                       \
     __builtin_amdgcn_sched_barrier(0);                                        \
