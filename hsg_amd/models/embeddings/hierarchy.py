@@ -17,7 +17,6 @@ kernels (`hsgk_hier_assign` and its one-launch backward).
 """
 import ctypes
 import math
-import weakref
 
 import torch
 import torch.nn.functional as F
@@ -35,23 +34,14 @@ def _group_order(group_of_row):
   return torch.argsort(group_of_row, stable=True)
 
 
-_dense_memo = None                         # (weak reference to the last index tensor, its version, the result)
-
-
 def _dense_image_index(batch_indices):
-  """(rank of every pixel's image id among the distinct ids, the image-by-image permutation or None).
-  `generate_clusters` asks for it twice per step with the same tensor (fine and coarse level): the sorted
-  `unique` and the order check -- two host reads -- run once per tensor object and version.  (One immutable
-  tuple, replaced as a whole: threads driving different GPUs only ever evict each other's entry.)"""
-  global _dense_memo
-  memo = _dense_memo
-  if memo is not None and memo[0]() is batch_indices and memo[1] == batch_indices._version:
-    return memo[2]
+  """(rank of every pixel's image id among the distinct ids, the image-by-image permutation or None) -- the fallback
+  of collect_pixel_hierarchical_clustering_indices for index vectors that do not come from
+  calculate_kmeans_prototypes (which leaves both on its result, `ops.note`): a sorted `unique` and an order check,
+  two host reads per call.  (No memo: a cache keyed on tensor identity goes stale under out-of-band writes.)"""
   _, img = torch.unique(batch_indices.view(-1).long(), return_inverse=True)
   img = img.contiguous()
-  result = (img, _group_order(img))
-  _dense_memo = (weakref.ref(batch_indices), batch_indices._version, result)
-  return result
+  return img, _group_order(img)
 
 
 class _PlacedRows(torch.autograd.Function):

@@ -139,3 +139,33 @@ def test_bookkeeping_helpers_of_the_swapped_modules():
   got = list(mu.get_params(net, ['head'], ['weight']))
   assert len(got) == 1 and got[0] is net.head.weight
   assert [p is net.head.bias for p in mu.get_params(net, ['head', 'body'], ['bias'], exclude='body')] == [True]
+
+
+def test_notes_ride_on_the_tensor_object_and_die_with_in_place_writes():
+  """`ops.note` / `ops.noted` (host-side facts remembered on a tensor so that the next function needs no device read):
+  valid for that object and version only."""
+  import torch
+  from hsg_amd import ops
+  t = torch.arange(6)
+  assert ops.noted(t, 'index_count') is None
+  ops.note(t, 'index_count', 6)
+  assert ops.noted(t, 'index_count') == 6
+  assert ops.noted(t.long() if t.dtype != torch.int64 else t, 'index_count') == 6      # (.long() of an int64 tensor is the object itself)
+  assert ops.noted(t + 0, 'index_count') is None                                       # a new tensor carries nothing
+  t[0] = 5                                                                               # in-place write: the note is stale
+  assert ops.noted(t, 'index_count') is None
+  assert ops.noted(None, 'index_count') is None
+
+
+def test_process_group_key_is_the_c10d_name_not_the_object_id():
+  from hsg_amd.models import utils as mu
+
+  class Named:
+    group_name = '7'
+
+  class Anonymous:
+    pass
+  assert mu._group_key(None) is None
+  assert mu._group_key(Named()) == ('name', '7') == mu._group_key(Named())              # two objects, one group
+  a = Anonymous()
+  assert mu._group_key(a) == ('id', id(a))

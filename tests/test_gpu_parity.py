@@ -1974,3 +1974,70 @@ def test_exact_sum_mstep_full_and_incremental(dev, oracle, B, HW, C, K, route, m
       ref = oracle.calculate_prototypes_from_labels(x[b * HW:(b + 1) * HW], lab_np[b * HW:(b + 1) * HW].astype(np.int64),
                                                     K, exact_sums=True)
       assert np.array_equal(cent[b].cpu().numpy(), ref), 'centroids vs oracle (step %d, image %d)' % (step, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed,B,n,K,C,multiview,M', [(1, 3, 900, 7, 24, False, 32), (2, 4, 2500, 16, 64, True, 64),
+                                                      (3, 2, 300, 5, 130, True, None), (4, 5, 1200, 9, 16, False, None),
+                                                      (5, 1, 50, 3, 8, False, 8)])
+def test_padded_prototype_tables_one_pass_vs_aten(dev, seed, B, n, K, C, multiview, M):
+  """calculate_kmeans_prototypes on hsgk_pad_prototype_tables (one pass: scans, placement, masks, labels, per-pixel
+  rank / image) against the ATen formulation it replaced (sorted unique over (image, cluster, batch * div^2 + label),
+  per-image ranks, scatter into zero tables): every output identical, gradients of the prototypes too.  Views of one
+  image interleaved (multiview), images without pixels, dynamic table width (M=None)."""
+  import torch
+  from hsg_amd.models.embeddings import hierarchy as hz
+  g = torch.Generator().manual_seed(seed)
+  batch = torch.sort(torch.randint(0, B, (n,), generator=g)).values
+  if B > 2:
+    batch = batch[batch != 1]                                   # an image without pixels
+  n = batch.shape[0]
+  cluster = torch.randint(0, K, (n,), generator=g)
+  lab = (cluster * 7 + batch) % 5                                # one label per (batch, cluster)
+  emb = torch.nn.functional.normalize(torch.randn((n, C), generator=g), dim=1)
+  pos = torch.randn((n, 6), generator=g)
+  image_ids = (torch.arange(B) % 2) if multiview else None      # views 0, 2, 4 .. of image 0; 1, 3 .. of image 1
+  div = 16
+  T = lambda t: t.to(dev) if t is not None else None
+  e = T(emb).requires_grad_(True)
+  out = hz.calculate_kmeans_prototypes(e, T(cluster), T(batch), T(pos), T(lab), T(image_ids), label_divisor=div,
+                                       max_num_clusters=M)
+  # ---- ATen restatement
+  b, c, l = batch.long(), cluster.long(), lab.long()
+  img = b if image_ids is None else image_ids[b]
+  key2 = b * div * div + l
+  trip = torch.stack([img, c, key2], 1)
+  uniq, gid = torch.unique(trip, dim=0, return_inverse=True)
+  P = uniq.shape[0]
+  uimg = uniq[:, 0]
+  imgs, img_of_seg = torch.unique(uimg, return_inverse=True)
+  first = torch.ones(P, dtype=torch.bool); first[1:] = uimg[1:] != uimg[:-1]
+  seg = torch.arange(P)
+  local = seg - torch.cummax(torch.where(first, seg, torch.zeros_like(seg)), 0).values
+  Bp, most = imgs.shape[0], int(local.max())
+  Mm = M if M is not None else most + 1
+  slot = img_of_seg * Mm + local
+  e2 = emb.clone().requires_grad_(True)
+  sums = torch.zeros((P, C)).index_add(0, gid, e2)
+  protos = torch.nn.functional.normalize(sums, dim=1)
+  table = torch.zeros((Bp * Mm, C)).index_copy(0, slot, protos).view(Bp, Mm, C).permute(0, 2, 1)
+  cnt = torch.zeros(P).index_add(0, gid, torch.ones(n))
+  pmean = torch.zeros((P, 6)).index_add(0, gid, pos) / cnt.view(-1, 1)
+  ptab = torch.zeros((Bp * Mm, 6)).index_copy(0, slot, pmean).view(Bp, Mm, 6).permute(0, 2, 1)
+  masks = torch.ones(Bp * Mm, dtype=torch.bool); masks[slot] = False
+  plabs = torch.full((Bp * Mm,), -1, dtype=torch.long); plabs[slot] = uniq[:, 2] % (div * div)
+  pbatch = torch.full((Bp * Mm,), -1, dtype=torch.long); pbatch[slot] = uniq[:, 2] // (div * div)
+  by_image = local[gid]
+  order = torch.argsort(img_of_seg[gid], stable=True)
+  by_image = by_image[order]
+  assert tuple(out[0].shape) == (Bp, C, Mm)
+  assert torch.allclose(out[0].detach().cpu(), table.detach(), atol=2e-6)
+  assert torch.allclose(out[1].cpu(), ptab, atol=1e-5)
+  assert torch.equal(out[2].cpu(), masks.view(Bp, Mm))
+  assert torch.equal(out[3].cpu(), plabs.view(Bp, Mm))
+  assert torch.equal(out[4].cpu(), pbatch.view(Bp, Mm))
+  assert torch.equal(out[5].cpu(), by_image)
+  w = torch.randn((Bp, C, Mm), generator=g)
+  (out[0] * T(w)).sum().backward()
+  (table * w).sum().backward()
+  assert torch.allclose(e.grad.cpu(), e2.grad, atol=1e-5)
