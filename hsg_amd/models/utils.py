@@ -245,9 +245,9 @@ class HsgkExchangeBackend:
   def __init__(self, emb, emb_loc, c, b, sem, inst, cap_local, cap_total, world):
     ops.require_gpu(emb, 'embeddings')
     self.dev = emb.device
-    self.emb = emb.detach().reshape(-1, emb.shape[-1]).to(torch.float32).contiguous()
-    self.emb_loc = emb_loc.detach().reshape(-1, emb_loc.shape[-1]).to(torch.float32).contiguous()
-    self.keys_in = [t.detach().reshape(-1).to(device=self.dev, dtype=torch.int64).contiguous() for t in (c, b, sem, inst)]
+    self.emb = ops.as_rows(emb, torch.float32, 2)
+    self.emb_loc = ops.as_rows(emb_loc, torch.float32, 2)
+    self.keys_in = [ops.as_rows(t, torch.int64, 1, self.dev) for t in (c, b, sem, inst)]
     n, C = self.emb.shape
     D = self.emb_loc.shape[1]
     if self.emb_loc.shape[0] != n or any(k.shape[0] != n for k in self.keys_in):

@@ -100,21 +100,23 @@ def _nll_sets(embeddings, instance_labels, prototypes, label_sets, groups=None):
   ops.require_gpu(embeddings, 'embeddings')
   if not 1 <= len(label_sets) <= MAX_LABEL_SETS:
     raise ValueError('1..%d label sets per pass' % MAX_LABEL_SETS)
-  emb = embeddings.reshape(-1, embeddings.shape[-1]).to(torch.float32)
-  proto = prototypes.reshape(-1, prototypes.shape[-1]).to(torch.float32)
-  inst = instance_labels.reshape(-1).to(torch.int64).contiguous()
+  emb = embeddings if embeddings.dim() == 2 and embeddings.dtype is torch.float32 else \
+      embeddings.reshape(-1, embeddings.shape[-1]).to(torch.float32)              # (differentiable: no detach here)
+  proto = prototypes if prototypes.dim() == 2 and prototypes.dtype is torch.float32 else \
+      prototypes.reshape(-1, prototypes.shape[-1]).to(torch.float32)
+  inst = ops.as_rows(instance_labels, torch.int64, 1)
   sems, psems = [], []
   for ls in label_sets:
     words = (ls[3] >> 8) or 1                       # class-mask words per row (1 for plain labels)
-    a = ls[0].reshape(-1).to(torch.int64).contiguous()
-    b = ls[1].reshape(-1).to(torch.int64).contiguous()
+    a = ops.as_rows(ls[0], torch.int64, 1)
+    b = ops.as_rows(ls[1], torch.int64, 1)
     if a.shape[0] != emb.shape[0] * words or b.shape[0] != proto.shape[0] * words:
       raise ValueError('label vectors do not match the embeddings / prototypes')
     sems.append(a)
     psems.append(b)
   if groups is not None:
-    qg = groups[0].reshape(-1).to(torch.int64).contiguous()
-    pg = groups[1].reshape(-1).to(torch.int64).contiguous()
+    qg = ops.as_rows(groups[0], torch.int64, 1)
+    pg = ops.as_rows(groups[1], torch.int64, 1)
     if qg.shape[0] != emb.shape[0] or pg.shape[0] != proto.shape[0]:
       raise ValueError('group vectors do not match the embeddings / prototypes')
     groups = (qg, pg)
