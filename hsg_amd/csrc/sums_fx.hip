@@ -250,7 +250,10 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
   const int tw = d - tail0;
   const int tu = lane / max(tw, 1), tc = lane - tu * max(tw, 1);
   const bool tact = tw > 0 && tu < UNROLL;
-  constexpr int STRIP = 256, SPC = HSGK_CHUNK / STRIP;          // strips per chunk
+#ifndef HSGK_FX_STRIP
+#define HSGK_FX_STRIP 256
+#endif
+  constexpr int STRIP = HSGK_FX_STRIP, SPC = HSGK_CHUNK / STRIP, LPL = STRIP / 64;          // strips per chunk, labels per lane
   int c = c_begin;
   while (c < c_end) {
     // ---- the run of chunks [c, ce) of one image
@@ -305,9 +308,9 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
       const int n = min(chunk_rows[cc] - part * STRIP, STRIP);
       if (n <= 0) continue;
       const int64_t row0 = chunk_row0[cc] + (int64_t)part * STRIP;
-      int pl[4], cl[4];
+      int pl[LPL], cl[LPL];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < LPL; ++i) {
         const int r = 64 * i + lane;
         const int rr = min(r, n - 1);
         pl[i] = get_label(prev, row0 + rr);
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
       }
       int total = 0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < LPL; ++i) {
         // labels local to this workgroup's clusters, + 1 (0: not one of them / not added yet)
         const uint32_t ln = (uint32_t)(cl[i] - k0) < (uint32_t)kn ? (uint32_t)(cl[i] - k0 + 1) : 0u;
         const uint32_t lo = (uint32_t)(pl[i] - k0) < (uint32_t)kn ? (uint32_t)(pl[i] - k0 + 1) : 0u;
@@ -838,19 +841,27 @@ int launch_update_sums(const float *x, int d, const int32_t *prev, const int32_t
   {
     // persistent variant: the image's table in LDS, split by clusters over P <= 8 workgroups
     // when it does not fit one (every part re-scans the labels and reads the rows of its clusters)
-    constexpr int NWP = 8;
+    // Rows of up to 259 columns (one 16-byte vector per lane): SIXTEEN waves of four rows in flight each (102
+    // registers, four waves per SIMD) instead of eight waves of eight -- a wave's strips are a chain of dependent
+    // round trips (labels -> list -> rows -> LDS atomics), and twice the waves halve the chain: cfg2 3.55 -> 3.18 ms
+    // per call, K = 256 at 768^2 1.75 -> 1.49.  Longer rows (two vectors per lane, K split over workgroups) keep
+    // eight waves of eight (16 waves measured slower there: 1.28 -> 1.47 ms at K = 128, D = 386).
+    const bool narrow = d / 4 <= 64;
+    const int NWP = narrow ? 16 : 8;
     int P = 1;
     while (P < 8 && (size_t)((K + P - 1) / P) * d * 8 + 16 + (size_t)NWP * 256 * 4 + 32 > 150 * 1024) ++P;
     const size_t ldsp = (size_t)((K + P - 1) / P) * d * 8 + 16 + (size_t)NWP * 256 * 4 + 32;
     if (ldsp <= 150 * 1024 && d <= 515 && d >= 4) {
-      auto kp = d / 4 <= 64 ? update_sums_persistent_kernel<NWP, 8, 1> : update_sums_persistent_kernel<NWP, 8, 2>;
-      HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kp),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
-      const int nranges = max_chunks < n_cu / P ? max_chunks : (n_cu / P > 0 ? n_cu / P : 1);
-      hipLaunchKernelGGL(kp, dim3(nranges * P), dim3(NWP * 64), ldsp, s, x, d, prev, cur, t.chunk_row0,
-                         t.chunk_rows, t.chunk_img, K, P, reinterpret_cast<unsigned long long *>(sumq), meta);
-      HSGK_LAUNCH_CHECK();
-      return 0;
+      auto launch = [&](auto kp) -> int {
+        HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kp),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
+        const int nranges = max_chunks < n_cu / P ? max_chunks : (n_cu / P > 0 ? n_cu / P : 1);
+        hipLaunchKernelGGL(kp, dim3(nranges * P), dim3(NWP * 64), ldsp, s, x, d, prev, cur, t.chunk_row0,
+                           t.chunk_rows, t.chunk_img, K, P, reinterpret_cast<unsigned long long *>(sumq), meta);
+        HSGK_LAUNCH_CHECK();
+        return 0;
+      };
+      return narrow ? launch(update_sums_persistent_kernel<16, 4, 1>) : launch(update_sums_persistent_kernel<8, 8, 2>);
     }
   }
   constexpr int NW = 4, S = 12;
