@@ -435,12 +435,71 @@ __device__ __forceinline__ float exact_chain(const float *__restrict__ ck, const
 #ifdef HSGK_Q_STATS
 __device__ unsigned long long g_qstats[8];   // debug build: exact-queue entries by candidate count
 #endif
+// The same chain for all 64 lanes of a wave at once, lanes 4 g .. 4 g + 3 = the (up to four) candidates of entry g,
+// with the loads shared inside the group of four: exact_chain above makes every lane fetch its two rows in 16-byte
+// pieces -- 64 different cache lines per load instruction, and the texture addresser, not the bytes, bounds the
+// exact pass (K = 256 at 768^2: 0.32 GB in 0.18 ms, vector pipe 8 % busy).  Here the four lanes of a group fetch
+// 64 CONTIGUOUS bytes of one row per instruction (the pixel row once instead of four times, each candidate's
+// centroid row in turn), park them in a wave-private LDS window and every lane reads back ITS pair of rows: a
+// quarter of the line requests, the arithmetic and its order unchanged.  `kmine`: this lane's centroid (any valid
+// index on idle lanes); window: kExactStageFloats floats per wave.
+constexpr int kExactStride = 36;                                  // floats per staged 32-float piece (bank spread)
+constexpr int kExactStageFloats = (16 + 64) * kExactStride;
+__device__ __forceinline__ float exact_chain_coop(const float *__restrict__ ct, int kmine, const float *__restrict__ xr,
+                                                  int d, float *__restrict__ win) {
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));    // rows are 8-byte aligned
+  typedef float f4a __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, ci = lane & 3, g = lane >> 2;
+  const float *crow[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) crow[j] = ct + (int64_t)__shfl(kmine, (lane & ~3) + j) * d;
+  float *xs = win + g * kExactStride;
+  float *cs = win + (16 + 4 * g) * kExactStride;
+  float acc = 0.0f;
+  const int d4 = d & ~3;
+  int t0 = 0;
+  f4u xq[2], cq[4][2];
+  auto fetch = [&](int t) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int o = t + 4 * (ci + 4 * s2);
+      xq[s2] = *reinterpret_cast<const f4u *>(xr + o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cq[j][s2] = *reinterpret_cast<const f4u *>(crow[j] + o);
+    }
+  };
+  if (32 <= d4) fetch(0);
+  for (; t0 + 32 <= d4; t0 += 32) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      *reinterpret_cast<f4a *>(xs + 4 * (ci + 4 * s2)) = xq[s2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f4a *>(cs + j * kExactStride + 4 * (ci + 4 * s2)) = cq[j][s2];
+    }
+    if (t0 + 64 <= d4) fetch(t0 + 32);                   // (the next piece is on its way while this one is summed)
+    // (wave-private window: own writes are visible to own reads in order)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const f4a xv = *reinterpret_cast<const f4a *>(xs + 4 * u);
+      const f4a cv = *reinterpret_cast<const f4a *>(cs + ci * kExactStride + 4 * u);
+      acc = fmaf(cv.x, xv.x, acc);
+      acc = fmaf(cv.y, xv.y, acc);
+      acc = fmaf(cv.z, xv.z, acc);
+      acc = fmaf(cv.w, xv.w, acc);
+    }
+  }
+  const float *ck = ct + (int64_t)kmine * d;
+  for (int dd = t0; dd < d; ++dd) acc = fmaf(ck[dd], xr[dd], acc);
+  return acc;
+}
+
 // One batch of 16 exact-queue entries on a wave: lanes 4 g .. 4 g + 3 serve entry g (`ent`, `have`
 // and `img` are per-group values, identical on the four lanes); writes the exact label of the row.
+// win != nullptr: the shared-load chains (exact_chain_coop) through that wave-private LDS window.
 __device__ __forceinline__ void exact_rescore16(const SplitEntry ent, const bool have, const int img,
                                                 const float *__restrict__ x, int d,
                                                 const float *__restrict__ cent, int K,
-                                                int32_t *__restrict__ klab) {
+                                                int32_t *__restrict__ klab, float *__restrict__ win = nullptr) {
   const int lane = threadIdx.x & 63;
   const int ci = lane & 3;
   const int n = have ? (int)(ent.cand >> 24) : 0;
@@ -455,12 +514,20 @@ __device__ __forceinline__ void exact_rescore16(const SplitEntry ent, const bool
   const float *xr = x + (int64_t)ent.row * d;
   const float *ct = cent + (int64_t)img * K * d;
   float acc = -INFINITY;
-  if (act) acc = exact_chain(ct + (int64_t)ka * d, xr, d);
+  if (win) {
+    const float a = exact_chain_coop(ct, act ? ka : 0, xr, d, win);          // (all lanes take part in the loads)
+    if (act) acc = a;
+  } else if (act) {
+    acc = exact_chain(ct + (int64_t)ka * d, xr, d);
+  }
   float bv = (act && acc == acc) ? acc : -INFINITY;     // NaN never wins
   int bi = act ? ka : 0x7fffffff;
   if (__any(act2)) {
     float acc2 = -INFINITY;
-    if (act2) acc2 = exact_chain(ct + (int64_t)kb * d, xr, d);
+    if (win) {
+      const float a = exact_chain_coop(ct, act2 ? kb : 0, xr, d, win);
+      if (act2) acc2 = a;
+    } else if (act2) acc2 = exact_chain(ct + (int64_t)kb * d, xr, d);
     const float v2 = (act2 && acc2 == acc2) ? acc2 : -INFINITY;
     const int i2 = act2 ? kb : 0x7fffffff;
     if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
@@ -501,6 +568,7 @@ __global__ __launch_bounds__(256) void assign_requeue_rows_kernel(
     const float *__restrict__ x, int d, const float *__restrict__ cent, int K,
     int32_t *__restrict__ klab, const SplitEntry *__restrict__ gqueue,
     const int32_t *__restrict__ gcount, const int64_t *__restrict__ img_row0, int B) {
+  __shared__ __attribute__((aligned(16))) float exact_win[4 * kExactStageFloats];
   const int lane = threadIdx.x & 63;
   const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
@@ -519,7 +587,7 @@ __global__ __launch_bounds__(256) void assign_requeue_rows_kernel(
         if (img_row0[mid] <= (int64_t)ent.row) img = mid; else hi = mid;
       }
     }
-    exact_rescore16(ent, e < total, img, x, d, cent, K, klab);
+    exact_rescore16(ent, e < total, img, x, d, cent, K, klab, exact_win + (threadIdx.x >> 6) * kExactStageFloats);
   }
 }
 
@@ -2266,6 +2334,7 @@ __global__ __launch_bounds__(256) void assign_requeue_seg_kernel(
     const int64_t *__restrict__ img_row0, int B) {
   __shared__ int pre[1025];
   __shared__ int wsum[4];
+  __shared__ __attribute__((aligned(16))) float exact_win[4 * kExactStageFloats];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // exclusive prefix of the segment counts (four per thread)
   int c[4], tot = 0;
@@ -2307,7 +2376,7 @@ __global__ __launch_bounds__(256) void assign_requeue_seg_kernel(
         if (img_row0[mid] <= (int64_t)ent.row) img = mid; else hi = mid;
       }
     }
-    exact_rescore16(ent, e < total, img, x, d, cent, K, klab);
+    exact_rescore16(ent, e < total, img, x, d, cent, K, klab, exact_win + w * kExactStageFloats);
   }
 }
 

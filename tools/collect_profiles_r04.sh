@@ -34,9 +34,11 @@ for eng in split fp32; do
   rm -rf /tmp/prof_k; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k -o k -- python $GRAFT_REPO_ROOT/tools/probes/loss_prof.py 200704 256 3072 $eng > /dev/null 2>&1
   cp /tmp/prof_k/k_kernel_stats.csv $out/${tag}_loss_${eng}_kernel_stats.csv
 done
-for wl in train28 train14 reftrain cfg3 cfg4 cfg5; do
+for wl in train28 train14 reftrain cfg3 cfg5; do
   timeout 300 $B --workload $wl --steps 10 --warmup 3 --cpu-images 0 --no-extra 2>/dev/null | tail -1 > $out/${tag}_bench_${wl}.json
 done
+timeout 300 $B --workload cfg4 --steps 10 --warmup 3 --cpu-images 0 2>/dev/null | tail -1 > $out/${tag}_bench_cfg4.json      # (with extra_runs.hierarchy)
+timeout 400 python $GRAFT_REPO_ROOT/tests/checkers/fuzz_exchange.py 300 2>&1 | grep -v amdgpu | tail -4 > $out/${tag}_fuzz_exchange.txt
 timeout 600 python $GRAFT_REPO_ROOT/tools/bench_ops.py 2>/dev/null | tail -1 > $out/${tag}_ops.json
 { for p in train_step_wall train_step_gpu train_step_syncs train_step_gaps; do echo "== tools/probes/$p.py"; timeout 300 python -u $GRAFT_REPO_ROOT/tools/probes/$p.py 2>&1 | grep -v -i "amdgpu.ids\|warn"; done; } > $out/${tag}_train_step.txt
 for shp in "200704 256 3072" "50176 256 1568" "9408 128 1536"; do timeout 200 python $GRAFT_REPO_ROOT/tools/probes/loss_time.py $shp 2>&1 | tail -1; done > $out/${tag}_loss_time.txt
