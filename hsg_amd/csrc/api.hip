@@ -107,11 +107,16 @@ struct KmeansScratch {
   int m0_wt;           // prep workgroups per image
 };
 
-// HSGK_TLAYOUT=1 (experiment): the first E-step level reads a tile-ordered fp16 copy
-static bool tlayout_env() {
+// HSGK_TLAYOUT=1: the first E-step level reads a tile-ordered fp16 copy wherever an engine for it exists (K <= 64
+// and 128 < K <= 256 at 256 main columns), converted from the row-major copy when the prep kernel cannot write it
+// itself (+0.5 ms per call at 4 x 768^2).  Default (unset): only 128 < K <= 256, and only when the prep kernel
+// writes the tile order directly (no label compaction, H * W % 32 == 0) -- filter 0.49 -> 0.42 ms per launch with
+// no conversion.  HSGK_TLAYOUT=0: never.
+static int tlayout_mode() {
   const char *e = getenv("HSGK_TLAYOUT");
-  return e && e[0] == '1';
+  return !e ? -1 : e[0] == '1' ? 1 : 0;
 }
+static bool tlayout_env() { return tlayout_mode() == 1; }
 
 static int max_chunks_for(int B, int64_t rows_per_img) {
   return (int)(B * ((rows_per_img + HSGK_CHUNK - 1) / HSGK_CHUNK));
@@ -159,7 +164,8 @@ static void carve_kmeans(Carver &cv, int B, int64_t rows_per_img, int d, int K,
     // + slack rows: the fp16 engine reads past the end of a pass instead of clamping
     k->xh = cv.take<_Float16>(((size_t)B * rows_per_img + kHalfSlackRowsHost) * half_main_cols_host(d) + 8);
     k->xt = cv.take<uint2>((size_t)B * rows_per_img + kHalfSlackRowsHost);
-    if (tlayout_env() && (assign_half_eligible(d, K) || assign_half_wide2_eligible(d, K)) && d / 64 == 4 && rows_per_img % 32 == 0)
+    if (((tlayout_env() && assign_half_eligible(d, K)) || (tlayout_mode() != 0 && assign_half_wide2_eligible(d, K))) &&
+        d / 64 == 4 && rows_per_img % 32 == 0)
       k->xhT = cv.take<_Float16>(((size_t)B * rows_per_img + kHalfSlackRowsHost) * half_main_cols_host(d) + 8);
     k->q1 = cv.take<int32_t>((size_t)B * rows_per_img + 1);
     k->q1count = cv.take<int32_t>((size_t)B + 1);
@@ -206,7 +212,7 @@ static int assign_mode() {
 static int lloyd(const float *x, int d, int K, int B, int iterations,
                  const KmeansScratch &k, const hsgk_segkm_meta *meta, hipStream_t s,
                  bool unit_rows = false, bool half_ready = false, bool m0_ready = false,
-                 bool single_group = false, const int32_t **final_labels = nullptr) {
+                 bool single_group = false, const int32_t **final_labels = nullptr, bool tiles_ready = false) {
   const bool half_any = unit_rows && assign_mode() == 2 && k.xh && (half_ready || iterations >= 3);
   const bool half = half_any && assign_half_eligible(d, K);
   const bool wide = half_any && !half && assign_half_wide_eligible(d, K);
@@ -252,10 +258,11 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
   // as int32 (prep / the caller); the sums update reads either format, tagged per buffer.
   const bool u8 = label_u8_enabled() && fx && K <= 256 && (half || wide || wide2);
   const _Float16 *xhT = nullptr;
-  if ((half || wide2) && k.xhT && !single_group) {
+  if ((half || wide2) && k.xhT && !single_group && (tiles_ready || tlayout_env())) {
     // (experiment) every image holds rows_cap / B rows only when nothing was compacted away: the caller of the
     // experiment guarantees it
-    if (int rc = launch_rows_to_tiles(k.xh, d, (int64_t)k.rows_cap, k.xhT, s)) return rc;
+    if (!tiles_ready)
+      if (int rc = launch_rows_to_tiles(k.xh, d, (int64_t)k.rows_cap, k.xhT, s)) return rc;
     xhT = k.xhT;
   }
   for (int it = 0; it < iterations; ++it) {
@@ -471,7 +478,7 @@ int hsgk_segment_by_kmeans(const hsgk_segkm_args *a, hsgk_stream_t stream) {
 
   const bool compact = a->labels != nullptr && a->has_ignore;
   const bool want_half = assign_mode() == 2 && k.xh && a->iterations >= 1;
-  bool half_ready = false, m0_ready = false;
+  bool half_ready = false, m0_ready = false, tiles_ready = false;
   // HSGK_M0 = 0 / 1 (read per call, for the tests): never / whenever the shape allows
   const char *m0e = getenv("HSGK_M0");
   const bool m0_env = !(m0e && m0e[0] == '0'), m0_force = m0e && m0e[0] == '1';
@@ -486,14 +493,23 @@ int hsgk_segment_by_kmeans(const hsgk_segkm_args *a, hsgk_stream_t stream) {
                                     tile_cnt, a->meta, s)) return rc;
     if (int rc = launch_build_tables(compact ? tile_cnt : nullptr, a->B, HW, ntiles, tile_off,
                                      k.t, k.max_chunks, a->meta, s)) return rc;
+    // the fp16 copy in tile order straight from the prep kernel where the E-step has an engine for it (launch_prep
+    // declines when rows are compacted or H * W % 32 != 0); the row-major copy is left out when nothing would read it
+    const bool one_group = (a->flags & HSGK_SEGKM_ONE_GROUP) != 0;
+    const bool t_shape = k.xhT != nullptr && tlayout_mode() != 0 && !one_group &&
+                         (assign_half_wide2_eligible(D, a->K) || tlayout_env());
+    const bool tiles_only = t_shape && !compact && HW % 32 == 0 && assign_half_wide2_tiles(D, a->K, k.max_chunks) &&
+                            !assign_half_eligible(D, a->K);
     if (int rc = launch_prep(*a, compact ? tile_off : nullptr, k.t, k.klab, s,
-                             want_half ? k.xh : nullptr, k.xt, &half_ready,
-                             want_m0 ? &k.m0 : nullptr, &m0_ready)) return rc;
+                             want_half && !tiles_only ? k.xh : nullptr, k.xt, &half_ready,
+                             want_m0 ? &k.m0 : nullptr, &m0_ready, want_half && t_shape ? k.xhT : nullptr,
+                             &tiles_ready)) return rc;
+    if (tiles_only && !tiles_ready) half_ready = false;       // (declined: lloyd() makes the row-major copy itself)
   }
   const int32_t *final_labels = k.klab;      // int32 or byte labels (common.h), in either label buffer
   if (int rc = lloyd(a->out_embeddings_loc, D, a->K, a->B, a->iterations, k, a->meta, s,
                      /*unit_rows=*/true, half_ready, m0_ready, /*single_group=*/(a->flags & HSGK_SEGKM_ONE_GROUP) != 0,
-                     &final_labels)) return rc;
+                     &final_labels, tiles_ready)) return rc;
   {
     ProfScope p(HSGK_PROF_RELABEL, s);
     if (int rc = launch_relabel(*a, k.t, k.max_chunks, final_labels, table, scan_tmp, s)) return rc;

@@ -118,6 +118,9 @@ struct PrepM0 {
   int32_t *lab;
   unsigned long long *sumq;
   int K;
+  // (rides along: the 32-pixel prep kernel writes the fp16 copy of its rows in TILE order here -- score_tiles_f16t.h
+  //  -- when every image keeps all its pixels in place and H * W % 32 == 0: a half tile is one 32-row block)
+  _Float16 *tiles = nullptr;
 };
 int launch_m0_reduce(const PrepM0 &m0, int B, int WT, int d, hipStream_t s);
 
@@ -132,7 +135,9 @@ int launch_build_tables(const int32_t *tile_cnt, int B, int64_t HW, int ntiles,
 int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off,
                 const ChunkTable &t, int32_t *klab, hipStream_t s, _Float16 *xm = nullptr,
                 uint2 *xt = nullptr, bool *wrote_half = nullptr, const PrepM0 *m0 = nullptr,
-                bool *wrote_m0 = nullptr);
+                bool *wrote_m0 = nullptr, _Float16 *xmT = nullptr, bool *wrote_tiles = nullptr);
+// whether launch_assign_half_wide2 will take the tile-order kernel for this shape (then nothing reads the row-major copy)
+bool assign_half_wide2_tiles(int d, int K, int max_chunks);
 int launch_prep_bwd(const float *g_emb, const float *g_emb_loc, const float *emb,
                     const float *emb_loc, const float *norms, const int64_t *rowmap, int B, int C,
                     int H, int W, float eps, float *gx, hipStream_t s);

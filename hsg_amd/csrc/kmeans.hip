@@ -2387,6 +2387,20 @@ bool assign_half_wide2_eligible(int d, int K) {
          half_lds_bytes<8, 4, 1, 1>(d) + (size_t)kSplitLdsList * 6 <= 160 * 1024;
 }
 
+// (the conditions under which launch_assign_half_wide2 below runs assign_half_t256_kernel when it is handed a
+//  tile-ordered copy: api.hip then has the prep kernel write that copy only)
+bool assign_half_wide2_tiles(int d, int K, int max_chunks) {
+  if (!assign_half_wide2_eligible(d, K) || d / 64 != 4 || !wide1_fits(d) || max_chunks <= 0) return false;
+  const char *two = getenv("HSGK_WIDE2");
+  if (two) return false;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  (void)hipGetLastError();
+  const int64_t max_tiles = ((int64_t)max_chunks * HSGK_CHUNK + 255) / 256;
+  const int64_t grid = max_tiles < cus ? max_tiles : cus;
+  return grid <= 1024;
+}
+
 // state: [rows] 16-byte scratch records
 int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent,
                              float *errc, int K, int B, const ChunkTable &t, int max_chunks, int32_t *klab,

@@ -612,6 +612,8 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     float *__restrict__ norms_out, int64_t *__restrict__ rowmap_out,
     _Float16 *__restrict__ xh, uint2 *__restrict__ xt, PrepM0 m0) {
   const bool m0on = m0.part != nullptr;
+  _Float16 *const xhT = m0.tiles;
+  const bool tmode = xhT != nullptr;          // (host: no compaction, HW % 32 == 0 -> this half tile is one 32-row block)
 #ifdef HSGK_PREP_TIMING
   unsigned long long ts_ = __builtin_readcyclecounter();
 #endif
@@ -833,15 +835,17 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
         const long long f0 = to_fixed(a.x), f1 = to_fixed(a.y), f2 = to_fixed(c2.x), f3 = to_fixed(c2.y);
         cur[0] += f0; cur[1] += f1; cur[2] += f2; cur[3] += f3;     // (C <= 256 with the fusion on: one column pass)
       }
-      if (ho) {
+      if (ho || tmode) {
         const h4 hv = {(_Float16)a.x, (_Float16)a.y, (_Float16)c2.x, (_Float16)c2.y};
-        *reinterpret_cast<h4 *>(ho + 4 * q) = hv;
+        if (ho) *reinterpret_cast<h4 *>(ho + 4 * q) = hv;
+        // tile order: the four halves wait in the quad's own LDS slot (read above by this lane, by nobody else)
+        if (tmode) *reinterpret_cast<h4 *>(const_cast<float *>(r) + ((q ^ sj) << 2)) = hv;
         const float e0 = a.x - (float)hv[0], e1 = a.y - (float)hv[1];       // exact residuals
         const float e2b = c2.x - (float)hv[2], e3 = c2.y - (float)hv[3];
         e2 = fmaf(e0, e0, e2); e2 = fmaf(e1, e1, e2); e2 = fmaf(e2b, e2b, e2); e2 = fmaf(e3, e3, e2);
       }
     }
-    if (ho)
+    if (ho || tmode)
       for (int off = 32; off > 0; off >>= 1) e2 += __shfl_xor(e2, off);
     if (lane == 0) {
       float2 lv;
@@ -849,7 +853,7 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
       lv.y = locv[2 * j + 1] / n2;
       *reinterpret_cast<float2 *>(lo + C) = lv;
       if (m0on) { tcur[0] += to_fixed(lv.x); tcur[1] += to_fixed(lv.y); }
-      if (ho) {
+      if (ho || tmode) {
         const h2 hv = {(_Float16)lv.x, (_Float16)lv.y};
         const float e0 = lv.x - (float)hv[0], e1 = lv.y - (float)hv[1];
         e2 = fmaf(e0, e0, e2); e2 = fmaf(e1, e1, e2);
@@ -869,6 +873,21 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
       if (tid == 0) m0.lab[e0 + sidx] = m0l[sidx];
       unsigned long long *dst = m0.part + (e0 + sidx) * D;
       for (int i = tid; i < D; i += 256) dst[i] = mtab[sidx * D + i];
+    }
+  }
+  if (tmode) {
+    // the block's 16-byte pieces in operand order: piece (kb, lane = jj + 32 g) = row jj, columns 16 kb + 8 g .. + 7
+    // (two quads of four halves each, from their LDS slots); one KiB contiguous per wave instruction
+    __syncthreads();
+    const int jj = lane & 31, gg = lane >> 5;
+    const int64_t blk = (img_row0[b] + q0) >> 5;
+    uint2 *dst = reinterpret_cast<uint2 *>(xhT + blk * 32 * C);
+    for (int kb = w; kb < (C >> 4); kb += 4) {
+      const int qa = 4 * kb + 2 * gg;
+      const uint2 lo2 = *reinterpret_cast<const uint2 *>(tile + jj * C + ((qa ^ (jj & 15)) << 2));
+      const uint2 hi2 = *reinterpret_cast<const uint2 *>(tile + jj * C + (((qa + 1) ^ (jj & 15)) << 2));
+      uint4 pc = {lo2.x, lo2.y, hi2.x, hi2.y};
+      *reinterpret_cast<uint4 *>(dst + (kb * 64 + lane) * 2) = pc;
     }
   }
   HSGK_TS(7);
@@ -1156,9 +1175,10 @@ extern "C" __attribute__((visibility("default"))) int hsgk_debug_prep_timing(uns
 #endif
 int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTable &t,
                 int32_t *klab, hipStream_t s, _Float16 *xh, uint2 *xt, bool *wrote_half,
-                const PrepM0 *m0, bool *wrote_m0) {
+                const PrepM0 *m0, bool *wrote_m0, _Float16 *xmT, bool *wrote_tiles) {
   if (wrote_half) *wrote_half = false;
   if (wrote_m0) *wrote_m0 = false;
+  if (wrote_tiles) *wrote_tiles = false;
   PrepM0 m0v{nullptr, nullptr, nullptr, 0};
   const int64_t HW = (int64_t)a.H * a.W;
   const int ntiles = (int)((HW + kTilePix - 1) / kTilePix);
@@ -1188,7 +1208,14 @@ int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTa
       if (wrote_m0) *wrote_m0 = true;
     }
   }
-  if (fast && wrote_half) *wrote_half = xh != nullptr;      // both fast kernels write the fp16 copy
+  const char *pipe_env = getenv("HSGK_PREP");
+  if (fast && tile32 && xmT && tile_off == nullptr && HW % 32 == 0 && xt != nullptr && !(pipe_env && pipe_env[0] == 'p')) {
+    // the fp16 copy in tile order straight from this kernel (no labels to compact by: rows = pixels, a half tile =
+    // one 32-row block); the caller passes xh = null when nothing reads the row-major copy
+    m0v.tiles = xmT;
+    if (wrote_tiles) *wrote_tiles = true;
+  }
+  if (fast && wrote_half) *wrote_half = xh != nullptr || m0v.tiles != nullptr;      // both fast kernels write the fp16 copy
   {
     const char *pe = getenv("HSGK_PREP");            // "pipe": the persistent two-tile kernel (A/B; read per call)
     if (fast && tile32 && a.C <= 256 && pe && pe[0] == 'p') {

@@ -2041,3 +2041,35 @@ def test_padded_prototype_tables_one_pass_vs_aten(dev, seed, B, n, K, C, multivi
   (out[0] * T(w)).sum().backward()
   (table * w).sum().backward()
   assert torch.allclose(e.grad.cpu(), e2.grad, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tlayout', ['', '0', '1'])
+@pytest.mark.parametrize('shape', [(2, 256, 96, 96), (1, 256, 90, 70), (3, 256, 64, 48)])
+def test_k256_tile_order_copy_straight_from_prep_vs_oracle(dev, oracle, monkeypatch, tlayout, shape):
+  """K = 256 without a label map: by default the prep kernel writes the fp16 copy in tile order itself (H * W % 32 == 0)
+  and the register-resident-row filter runs on it, no row-major copy, no conversion; 90 x 70 (H * W % 32 != 0) keeps
+  the pair kernel; HSGK_TLAYOUT = 0 / 1: never / with the conversion kernel where prep declines.  All five outputs
+  bit-exact vs the oracle, every filtered label verified on the device."""
+  from hsg_amd import _lib
+  from hsg_amd.utils.segsort import common as sc
+  if tlayout:
+    monkeypatch.setenv('HSGK_TLAYOUT', tlayout)
+  else:
+    monkeypatch.delenv('HSGK_TLAYOUT', raising=False)
+  B, C, H, W = shape
+  iters = 6
+  x = synth.embeddings_nchw(synth.SEED_BASE + 41, shape, 'iid')
+  loc = (sc.generate_location_features((H, W), 'cpu', 'float') - 0.5).numpy()
+  _lib.verify_collect()
+  _lib.verify_enable(True)
+  try:
+    got = _run_segkm(dev, x, None, (16, 16), None, iters)
+    compared, differing = _lib.verify_collect()
+  finally:
+    _lib.verify_enable(False)
+  assert compared == got[0].shape[0] * iters and differing == 0, (compared, differing)
+  ref = oracle.segment_by_kmeans(x, None, (16, 16), loc, None, iters)
+  for nm, a, b in zip(('emb', 'emb_loc', 'labels', 'cluster', 'batch'), got, ref):
+    assert a.shape == b.shape, nm
+    assert np.array_equal(a, b), '%s: %d mismatching elements' % (nm, int((a != b).sum()))
