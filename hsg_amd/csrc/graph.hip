@@ -27,11 +27,12 @@ __global__ __launch_bounds__(256) void affinity_kernel(const float *__restrict__
   A[((int64_t)b * N + i) * N + j] = expf(acc * conc);
 }
 
-// grid (ceil(N / 16), B): 16 rows per workgroup, a wave per row (4 rows each)
+// grid (ceil(N / RPW), B): RPW rows per workgroup (4 when the whole launch has few rows -- 256 nodes of two images are
+// 128 workgroups instead of 32 -- else 16), a wave per row
 __global__ __launch_bounds__(256) void knn_graph_kernel(
     const float *__restrict__ A, int N, const uint8_t *__restrict__ pad,
     const int64_t *__restrict__ seg, int knn, int remove_self_loop, int binarize,
-    float *__restrict__ out) {
+    float *__restrict__ out, int rpw) {
   extern __shared__ unsigned char lds_raw[];
   int64_t *sl = reinterpret_cast<int64_t *>(lds_raw);                     // [N] segment label
   int *sid = reinterpret_cast<int *>(sl + N);                             // [N] first node with the same label, -1 = padded
@@ -73,8 +74,8 @@ __global__ __launch_bounds__(256) void knn_graph_kernel(
   float *row = rows + w * N;
   const float *Ab = A + (int64_t)b * N * N;
   float *ob = out + (int64_t)b * N * N;
-  const int i_end = min(N, ((int)blockIdx.x + 1) * 16);
-  for (int i = blockIdx.x * 16 + w; i < i_end; i += 4) {                  // wave per row
+  const int i_end = min(N, ((int)blockIdx.x + 1) * rpw);
+  for (int i = blockIdx.x * rpw + w; i < i_end; i += 4) {                 // wave per row
     const bool vi = sid[i] >= 0;
     for (int j = lane; j < N; j += 64) {
       float v = Ab[(int64_t)i * N + j];
@@ -279,8 +280,9 @@ int hsgk_knn_affinity(const float *x, const float *affinity_in, int B, int C, in
   }
   HSGK_REQUIRE(N <= 1024, "too many nodes for the k-NN graph kernel");
   const size_t lds = (size_t)N * 16 + (size_t)4 * N * 4 + 16;
-  hipLaunchKernelGGL(knn_graph_kernel, dim3((N + 15) / 16, B), dim3(256), lds, s, A, N, padding_mask,
-                     segment_labels, knn, remove_self_loop, binarize, out);
+  const int rpw = (int64_t)B * N <= 16384 ? 4 : 16;
+  hipLaunchKernelGGL(knn_graph_kernel, dim3((N + rpw - 1) / rpw, B), dim3(256), lds, s, A, N, padding_mask,
+                     segment_labels, knn, remove_self_loop, binarize, out, rpw);
   HSGK_LAUNCH_CHECK();
   return 0;
 }
