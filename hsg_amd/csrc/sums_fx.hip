@@ -774,15 +774,35 @@ __global__ __launch_bounds__(256) void m0_reduce_kernel(const long long *__restr
       __syncthreads();
       const int n = cnt;
       const int npass = min(4, (d - c0 + 255) / 256);       // column passes of this window that exist
+      if (npass == 2) {
+        // d = 258 and its kin: the second column pass holds a few columns only -- its loads ride in the first pass's
+        // round trips (threads whose second column exists) instead of walking the list a second time
+        const bool has2 = c0 + 256 + tid < d;
+        for (int i = 0; i < n; i += 16) {
+          long long v[16], v2[16];
 #pragma unroll
-      for (int p = 0; p < 4; ++p)
-        for (int i = 0; p < npass && i < n; i += 16) {       // 16 partial rows in flight per thread
-          long long v[16];
+          for (int u = 0; u < 16; ++u) {
+            const long long *rowp = pb + (int64_t)list[min(i + u, n - 1)] * d;
+            v[u] = rowp[col[0]];
+            v2[u] = has2 ? rowp[col[1]] : 0ll;
+          }
 #pragma unroll
-          for (int u = 0; u < 16; ++u) v[u] = pb[(int64_t)list[min(i + u, n - 1)] * d + col[p]];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) acc[p] += (i + u < n) ? v[u] : 0ll;
+          for (int u = 0; u < 16; ++u) {
+            acc[0] += (i + u < n) ? v[u] : 0ll;
+            acc[1] += (i + u < n) ? v2[u] : 0ll;
+          }
         }
+      } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          for (int i = 0; p < npass && i < n; i += 16) {       // 16 partial rows in flight per thread
+            long long v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = pb[(int64_t)list[min(i + u, n - 1)] * d + col[p]];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc[p] += (i + u < n) ? v[u] : 0ll;
+          }
+      }
       __syncthreads();
     }
 #pragma unroll
