@@ -143,13 +143,35 @@ __global__ __launch_bounds__(256) void segreduce_chunk_kernel(
   }
 }
 
+// lds_slots >= P: a workgroup counts in LDS and adds its non-zero slots to the global counters once (one global
+// atomic per row on ~1 K hot counters took 0.39 ms for 2.4 M rows); otherwise straight to global memory
 __global__ void count_labels_kernel(const int64_t *__restrict__ labels, int64_t n, int64_t P,
-                                    int32_t *__restrict__ counts) {
+                                    int32_t *__restrict__ counts, int lds_slots) {
+  extern __shared__ int cl_hist[];
+  const bool local = lds_slots >= P;
+  if (local) {
+    for (int i = threadIdx.x; i < (int)P; i += blockDim.x) cl_hist[i] = 0;
+    __syncthreads();
+  }
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n;
        r += (int64_t)gridDim.x * blockDim.x) {
     const int64_t l = labels[r];
-    if (l >= 0 && l < P) atomicAdd(&counts[l], 1);
+    if (l >= 0 && l < P) atomicAdd(local ? &cl_hist[l] : &counts[l], 1);
   }
+  if (local) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < (int)P; i += blockDim.x) {
+      const int v = cl_hist[i];
+      if (v) atomicAdd(&counts[i], v);
+    }
+  }
+}
+static void launch_count_labels(const int64_t *labels, int64_t n, int64_t P, int32_t *counts, hipStream_t s) {
+  const int64_t g = (n + 255) / 256;
+  const bool local = P <= 8192 && n >= 16 * P;
+  const int64_t cap = local ? 512 : 2048;
+  hipLaunchKernelGGL(count_labels_kernel, dim3((unsigned)(g > cap ? cap : g)), dim3(256), local ? (size_t)P * 4 : 0, s,
+                     labels, n, P, counts, local ? (int)P : 0);
 }
 
 // One workgroup per segment: chunk partials in chunk order (C2), then the
@@ -412,8 +434,7 @@ int hsgk_segment_reduce(const float *x, int64_t n, int d, const int64_t *labels,
     if (mode == 1) {
       HSGK_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)P * 4, s));
       if (n > 0) {
-        int64_t g = (n + 255) / 256;
-        hipLaunchKernelGGL(count_labels_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, s, labels, n, P, counts);
+        launch_count_labels(labels, n, P, counts, s);
         HSGK_LAUNCH_CHECK();
       }
     }
@@ -462,9 +483,7 @@ int hsgk_segment_reduce(const float *x, int64_t n, int d, const int64_t *labels,
   if (mode == 1) {
     HSGK_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)P * 4, s));
     if (n > 0) {
-      int64_t g = (n + 255) / 256;
-      hipLaunchKernelGGL(count_labels_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, s,
-                         labels, n, P, counts);
+      launch_count_labels(labels, n, P, counts, s);
       HSGK_LAUNCH_CHECK();
     }
   }
