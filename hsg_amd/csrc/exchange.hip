@@ -195,11 +195,19 @@ __global__ __launch_bounds__(256) void xk_sort_tile_kernel(long long *__restrict
   // (merging an ascending tile with padding leaves it in place)
   const int64_t nk = ctrl->n_keys;
   if (kglobal ? nk <= kSortTile : g0 >= nk) return;
+  // with all keys inside the first tile, its sort only has to order the first m = 2^ceil(log2(keys)) entries: the
+  // padding behind them sorts last and already sits there (a training step's exchange sorts ~100 keys: 28 network
+  // steps instead of 66)
+  int m = kSortTile;
+  if (!kglobal && nk <= kSortTile) {           // (all keys in tile 0, which sorts ascending; later tiles alternate)
+    m = 2;
+    while (m < (int)nk) m <<= 1;
+  }
   for (int i = tid; i < kSortTile; i += 256) { sk[i] = keys[g0 + i]; sv[i] = vals[g0 + i]; }
   __syncthreads();
-  for (int k = kglobal ? kSortTile : 2; k <= kSortTile; k <<= 1) {
+  for (int k = kglobal ? kSortTile : 2; k <= m; k <<= 1) {
     for (int j = (kglobal ? kSortTile : k) >> 1; j > 0; j >>= 1) {
-      for (int p = tid; p < kSortTile / 2; p += 256) {
+      for (int p = tid; p < m / 2; p += 256) {
         const int i = 2 * j * (p / j) + (p % j);
         const int64_t gi = g0 + i;
         const bool asc = ((gi & (kglobal ? (int64_t)kglobal : (int64_t)k)) == 0);
