@@ -14,9 +14,35 @@ namespace hsgk {
 
 // --------------------------------------------------------------------------
 // Row L2 normalisation of an [n,d] matrix (normalize_embedding,
-// general/common.py:101-120).  One wave per row is pointless for a serial
-// chain, so one THREAD owns one row and waves stream 64 rows at a time; this
-// entry point serves small tables (prototypes, tests), not the pixel stream.
+// general/common.py:101-120); this entry point serves small tables (prototypes, centroid rows, tests), not the
+// pixel stream.  One WAVE per row: the lanes fetch the row coalesced into a wave-private LDS window, lane 0 walks
+// the C1 chain from there (a thread per row walked its own strided global loads: 22 us for sixteen rows of 128),
+// all lanes divide and store coalesced.  Rows longer than the window: the thread-per-row form.
+constexpr int kNormRowWindow = 4096;                 // floats per wave
+__global__ __launch_bounds__(256) void normalize_rows_wave_kernel(const float *__restrict__ x, int64_t n, int d,
+                                                                  float eps, float *__restrict__ out,
+                                                                  float *__restrict__ norms) {
+  extern __shared__ float nr_win[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * 4 + w;
+  if (r >= n) return;
+  float *row = nr_win + (size_t)w * d;
+  const float *xr = x + r * d;
+  for (int i = lane; i < d; i += 64) row[i] = xr[i];
+  // (wave-private window: own writes are visible to own reads in order)
+  float nrm = 0.0f;
+  if (lane == 0) {
+    float ss = 0.0f;
+    for (int i = 0; i < d; ++i) ss = fmaf(row[i], row[i], ss);
+    nrm = sqrtf(ss);
+    if (!(nrm >= eps)) nrm = eps;
+    if (norms) norms[r] = nrm;
+  }
+  nrm = __shfl(nrm, 0);
+  float *yr = out + r * d;
+  for (int i = lane; i < d; i += 64) yr[i] = row[i] / nrm;
+}
+
 __global__ void normalize_rows_kernel(const float *__restrict__ x, int64_t n, int d,
                                       float eps, float *__restrict__ out,
                                       float *__restrict__ norms) {
@@ -35,6 +61,12 @@ __global__ void normalize_rows_kernel(const float *__restrict__ x, int64_t n, in
 int launch_normalize_rows(const float *x, int64_t n, int d, float eps, float *out,
                           float *norms, hipStream_t s) {
   if (n <= 0) return 0;
+  if (d <= kNormRowWindow && n <= (int64_t)1 << 22) {
+    hipLaunchKernelGGL(normalize_rows_wave_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)4 * d * 4, s, x, n, d,
+                       eps, out, norms);
+    HSGK_LAUNCH_CHECK();
+    return 0;
+  }
   int64_t blocks = (n + 63) / 64;
   hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)blocks), dim3(64), 0, s, x,
                      n, d, eps, out, norms);
