@@ -621,7 +621,9 @@ int hsgk_lloyd_estep(const float *x, int B, int64_t rows_per_image, int d, int K
   if (unit_rows == 2 && k.xh) {              // fp16 filter first (the copy is made here)
     if (int rc = launch_to_half_rows(x, k.t, k.max_chunks, d, k.xh, k.xt, meta, s)) return rc;
     const _Float16 *xhT = nullptr;
-    if (k.xhT) {                              // (tile-ordered copy: every image here holds rows_per_image rows)
+    // (tile-ordered copy: every image here holds rows_per_image rows.  A single E-step would pay the
+    //  conversion for one filter pass, so only the explicit switch takes it; the Lloyd loop amortises it.)
+    if (k.xhT && tlayout_env()) {
       if (int rc = launch_rows_to_tiles(k.xh, d, (int64_t)k.rows_cap, k.xhT, s)) return rc;
       xhT = k.xhT;
     }

@@ -33,5 +33,5 @@ print('device kernels: %d launches, %.3f ms total' % (len(ks), tot))
 c = collections.defaultdict(lambda: [0, 0.0])
 for e in ks:
   c[e.name][0] += 1; c[e.name][1] += (e.time_range.end - e.time_range.start) / 1e3
-for n, (k, t) in sorted(c.items(), key=lambda kv: -kv[1][1])[:25]:
+for n, (k, t) in sorted(c.items(), key=lambda kv: -kv[1][1])[:60]:
   print('%8.3f ms %4d  %s' % (t, k, n[:110]))
