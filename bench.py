@@ -318,22 +318,34 @@ def main():
     fence()
     return time.perf_counter() - t0, out
 
-  for _ in range(args.warmup):
+  profiled = args.workload.startswith('cfg')
+  for i in range(args.warmup):
+    # the LAST warm-up step already runs with the in-library events on: the runtime's first timed event record on a
+    # stream is a one-time set-up (measured 9 ... 60 ms, in about one process of four) that belongs to the warm-up,
+    # not to step 1 of the timed region; its records are discarded by the profile_collect() below
+    if profiled and i == args.warmup - 1:
+      _lib.profile_enable(True)
     out = run(x, labels)
     del out
   fence()
   # in-library HIP events around the kernel groups (the rooflines below); not for the training-resolution
   # workloads (train28 / train14 / reftrain), where ten event pairs per call would be a tenth of the 0.3 ms
   # step and no roofline is reported
-  profiled = args.workload.startswith('cfg')
   _lib.profile_enable(profiled)
   _lib.profile_collect()
+  step_times = [] if os.environ.get('HSGK_BENCH_STEP_TIMES') else None    # (diagnostic: a fence per step, stderr)
   t0 = time.perf_counter()
   out = None
   for _ in range(args.steps):
     del out
     out = run(x, labels)
+    if step_times is not None:
+      torch.cuda.synchronize(dev)
+      step_times.append(time.perf_counter())
   torch.cuda.synchronize(dev)
+  if step_times:
+    print('step ms:', ' '.join('%.2f' % (1e3 * (b - a)) for a, b in zip([t0] + step_times, step_times)),
+          file=sys.stderr)
   own_elapsed = time.perf_counter() - t0       # this rank's own K steps (before it waits for the others)
   fence()
   elapsed = time.perf_counter() - t0

@@ -275,9 +275,12 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
           return rc;
         std::swap(cur, prev); }
       { ProfScope p(HSGK_PROF_FINALIZE, s);
-        counters_zeroed = half;
+        // (the queue counters of the E-step that follows, and for the hi-plane filters of K > 64 the table's fp16
+        //  rounding errors, come out of this launch instead of memsets / a kernel of their own per iteration)
+        counters_zeroed = half || ((wide || wide2) && k.errc);
         if (int rc = launch_finalize_fx(k.sumq, d, K, B, HSGK_EPS, k.cent, s, half ? k.q1count : nullptr, B,
-                                        half ? k.qcount : nullptr)) return rc; }
+                                        counters_zeroed ? k.qcount : nullptr,
+                                        (wide || wide2) ? k.errc : nullptr)) return rc; }
     } else {
       { ProfScope p(HSGK_PROF_ACCUMULATE, s);
         if (int rc = launch_accumulate(x, d, cur, k.t, k.max_chunks, K, k.partial, k.pmask, meta, s)) return rc; }
@@ -289,9 +292,9 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
       if (int rc = half ? launch_assign_half(x, k.xh, k.xt, d, k.cent, K, B, k.t, k.max_chunks, cur, k.q1,
                                              k.q1count, k.q1cap, k.qrows, k.qcount, meta, s, counters_zeroed, xhT)
                : wide ? launch_assign_half_wide(x, k.xh, k.xt, d, k.cent, k.errc, K, B, k.t, k.max_chunks, cur,
-                                                k.qrows, k.qcount, meta, s)
+                                                k.qrows, k.qcount, meta, s, counters_zeroed)
                : wide2 ? launch_assign_half_wide2(x, k.xh, k.xt, d, k.cent, k.errc, K, B, k.t, k.max_chunks,
-                                                  cur, k.state, k.qrows, k.qcount, meta, s, xhT)
+                                                  cur, k.state, k.qrows, k.qcount, meta, s, xhT, counters_zeroed)
                : unit_rows && assign_mode() >= 1
                    ? launch_assign_fast(x, d, k.cent, K, B, k.t, k.max_chunks, cur, k.best,
                                         k.qrows, k.qcount, meta, s)

@@ -170,9 +170,11 @@ int launch_update_sums(const float *x, int d, const int32_t *prev, const int32_t
 // (unit_cols: leading columns the caller guarantees within [-1, 1] -- the normalised embedding columns; they may
 //  take the matrix-core route of the update, sums_fx.hip)
 // zero_a[0 .. na) and zero_b[0] (optional): queue counters of the E-step that follows, reset
-// here instead of by two memsets per iteration
+// here instead of by two memsets per iteration; errc (optional) [B * K]: the fp16 rounding error of every centroid
+// row it writes (what the hi-plane filters of K > 64 otherwise measure with a launch of their own)
 int launch_finalize_fx(const long long *sumq, int d, int K, int B, float eps, float *cent,
-                       hipStream_t s, int32_t *zero_a = nullptr, int na = 0, int32_t *zero_b = nullptr);
+                       hipStream_t s, int32_t *zero_a = nullptr, int na = 0, int32_t *zero_b = nullptr,
+                       float *errc = nullptr);
 
 // three-level E-step (fp16 copy -> bf16x3 on the undecided rows -> exact chains)
 inline int half_main_cols_host(int d) { return d & ~63; }
@@ -184,12 +186,13 @@ int launch_to_half_rows(const float *x, const ChunkTable &t, int max_chunks, int
 bool assign_half_wide_eligible(int d, int K);          // 64 < K <= 128: hi-plane fp16 filter -> exact chains
 int launch_assign_half_wide(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent,
                             float *errc, int K, int B, const ChunkTable &t, int max_chunks, int32_t *klab,
-                            void *qrows, int32_t *qcount, const hsgk_segkm_meta *meta, hipStream_t s);
+                            void *qrows, int32_t *qcount, const hsgk_segkm_meta *meta, hipStream_t s,
+                            bool table_ready = false);   // errc measured and qcount zeroed by launch_finalize_fx
 bool assign_half_wide2_eligible(int d, int K);         // 128 < K <= 256: two table halves per pass
 int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent,
                              float *errc, int K, int B, const ChunkTable &t, int max_chunks, int32_t *klab,
                              void *state, void *qrows, int32_t *qcount, const hsgk_segkm_meta *meta,
-                             hipStream_t s, const _Float16 *xmT = nullptr);
+                             hipStream_t s, const _Float16 *xmT = nullptr, bool table_ready = false);
 int launch_assign_half(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent, int K, int B,
                        const ChunkTable &t, int max_chunks, int32_t *klab, int32_t *q1,
                        int32_t *q1count, int64_t q1cap, void *qrows, int32_t *qcount,

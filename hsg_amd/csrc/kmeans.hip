@@ -1031,7 +1031,8 @@ bool assign_half_wide_eligible(int d, int K) {
 // errc: [B][K] scratch for the measured table rounding errors
 int launch_assign_half_wide(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent,
                             float *errc, int K, int B, const ChunkTable &t, int max_chunks, int32_t *klab,
-                            void *qrows, int32_t *qcount, const hsgk_segkm_meta *meta, hipStream_t s) {
+                            void *qrows, int32_t *qcount, const hsgk_segkm_meta *meta, hipStream_t s,
+                            bool table_ready) {
   if (max_chunks <= 0 || B <= 0) return 0;
   constexpr int NW = 8, TPX = NW * 32, MB = 4;
   static const int n_cu = [] {
@@ -1042,10 +1043,12 @@ int launch_assign_half_wide(const float *x, const _Float16 *xm, const uint2 *xt,
   }();
   const int64_t max_tiles = ((int64_t)max_chunks * HSGK_CHUNK + TPX - 1) / TPX;
   const int grid = (int)(max_tiles < n_cu ? max_tiles : n_cu);
-  HSGK_CHECK_HIP(hipMemsetAsync(qcount, 0, sizeof(int32_t), s));
-  hipLaunchKernelGGL(centroid_half_err_kernel, dim3((unsigned)(((int64_t)B * K + 3) / 4)), dim3(256), 0, s,
-                     cent, d, (int64_t)B * K, errc);
-  HSGK_LAUNCH_CHECK();
+  if (!table_ready) {                      // (inside the Lloyd loop launch_finalize_fx has done both)
+    HSGK_CHECK_HIP(hipMemsetAsync(qcount, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(centroid_half_err_kernel, dim3((unsigned)(((int64_t)B * K + 3) / 4)), dim3(256), 0, s,
+                       cent, d, (int64_t)B * K, errc);
+    HSGK_LAUNCH_CHECK();
+  }
   {
     const bool deep = ((d / 64) & 3) == 0;
     auto kern = deep ? assign_half_wide_kernel<NW, 4, MB> : assign_half_wide_kernel<NW, 2, MB>;
@@ -2405,7 +2408,7 @@ bool assign_half_wide2_tiles(int d, int K, int max_chunks) {
 int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent,
                              float *errc, int K, int B, const ChunkTable &t, int max_chunks, int32_t *klab,
                              void *state, void *qrows, int32_t *qcount, const hsgk_segkm_meta *meta,
-                             hipStream_t s, const _Float16 *xmT) {
+                             hipStream_t s, const _Float16 *xmT, bool table_ready) {
   if (max_chunks <= 0 || B <= 0) return 0;
   constexpr int NW = 8, TPX = NW * 32, MB = 4;
   static const int n_cu = [] {
@@ -2416,9 +2419,11 @@ int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt
   }();
   const int64_t max_tiles = ((int64_t)max_chunks * HSGK_CHUNK + TPX - 1) / TPX;
   const int grid = (int)(max_tiles < n_cu ? max_tiles : n_cu);
-  hipLaunchKernelGGL(centroid_half_err_kernel, dim3((unsigned)(((int64_t)B * K + 3) / 4)), dim3(256), 0, s,
-                     cent, d, (int64_t)B * K, errc);
-  HSGK_LAUNCH_CHECK();
+  if (!table_ready) {                      // (inside the Lloyd loop launch_finalize_fx has measured errc and zeroed qcount)
+    hipLaunchKernelGGL(centroid_half_err_kernel, dim3((unsigned)(((int64_t)B * K + 3) / 4)), dim3(256), 0, s,
+                       cent, d, (int64_t)B * K, errc);
+    HSGK_LAUNCH_CHECK();
+  }
   const char *two = getenv("HSGK_WIDE2");               // "two": the two-half kernel (A/B; read per call)
   if (wide1_fits(d) && !(two && two[0] == 't') && grid <= 1024 &&
       (int64_t)max_chunks * HSGK_CHUNK * 16 >= (int64_t)grid * 16) {
@@ -2478,7 +2483,7 @@ int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt
     HSGK_LAUNCH_CHECK();
     return 0;
   }
-  HSGK_CHECK_HIP(hipMemsetAsync(qcount, 0, sizeof(int32_t), s));
+  if (!table_ready) HSGK_CHECK_HIP(hipMemsetAsync(qcount, 0, sizeof(int32_t), s));
   {
     const bool deep = ((d / 64) & 3) == 0;
     auto kern = deep ? assign_half_wide2_kernel<NW, 4, MB> : assign_half_wide2_kernel<NW, 2, MB>;

@@ -702,8 +702,9 @@ __global__ __launch_bounds__(512) void update_sums_mfma_kernel(
 __global__ __launch_bounds__(256) void finalize_fx_kernel(const long long *__restrict__ sumq, int d,
                                                           int K, float eps, float *__restrict__ cent,
                                                           int32_t *__restrict__ zero_a, int na,
-                                                          int32_t *__restrict__ zero_b) {
+                                                          int32_t *__restrict__ zero_b, float *__restrict__ errc) {
   extern __shared__ float row[];    // [d] + 1
+  __shared__ float esum[4];
   const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   if (k == 0 && b == 0) {           // queue counters of the E-step that follows
     for (int i = tid; i < na; i += 256) zero_a[i] = 0;
@@ -732,7 +733,21 @@ __global__ __launch_bounds__(256) void finalize_fx_kernel(const long long *__res
   __syncthreads();
   const float nrm = row[d];
   float *out = cent + ((int64_t)b * K + k) * d;
-  for (int i = tid; i < d; i += 256) out[i] = row[i] / nrm;
+  float e2 = 0.0f;
+  for (int i = tid; i < d; i += 256) {
+    const float v = row[i] / nrm;
+    out[i] = v;
+    const float e = v - (float)(_Float16)v;                  // exact residual
+    e2 = fmaf(e, e, e2);
+  }
+  // errc(k) = |c_k - fp16(c_k)|_2 (x 1.0001): the hi-plane filters' table error bound, measured here instead of by a
+  // launch of its own per iteration (kmeans.hip, centroid_half_err_kernel: a bound, so the summation order is free)
+  if (errc) {
+    for (int off = 32; off > 0; off >>= 1) e2 += __shfl_xor(e2, off);
+    if ((tid & 63) == 0) esum[tid >> 6] = e2;
+    __syncthreads();
+    if (tid == 0) errc[(int64_t)b * K + k] = sqrtf((esum[0] + esum[1]) + (esum[2] + esum[3])) * 1.0001f;
+  }
 }
 
 // sumq[b][k][:] += the prep workgroups' partial sums whose label is k.  Workgroup per (k, image):
@@ -898,10 +913,10 @@ int launch_update_sums(const float *x, int d, const int32_t *prev, const int32_t
 }
 
 int launch_finalize_fx(const long long *sumq, int d, int K, int B, float eps, float *cent, hipStream_t s,
-                       int32_t *zero_a, int na, int32_t *zero_b) {
+                       int32_t *zero_a, int na, int32_t *zero_b, float *errc) {
   if (B <= 0 || K <= 0) return 0;
   hipLaunchKernelGGL(finalize_fx_kernel, dim3(K, B), dim3(256), (size_t)(d + 1) * 4, s, sumq, d, K, eps,
-                     cent, zero_a, zero_a ? na : 0, zero_b);
+                     cent, zero_a, zero_a ? na : 0, zero_b, errc);
   HSGK_LAUNCH_CHECK();
   return 0;
 }
