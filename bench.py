@@ -35,6 +35,7 @@ Prints ONE JSON line on rank 0, including
                 map + 4-row ignore band, N=1 only.
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -310,13 +311,17 @@ def main():
       out = run(xin, lab)
       del out
     fence()
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     out = None
     for _ in range(steps):
       del out
       out = run(xin, lab)
     fence()
-    return time.perf_counter() - t0, out
+    dt = time.perf_counter() - t0
+    gc.enable()
+    return dt, out
 
   profiled = args.workload.startswith('cfg')
   for i in range(args.warmup):
@@ -334,13 +339,21 @@ def main():
   _lib.profile_enable(profiled)
   _lib.profile_collect()
   step_times = [] if os.environ.get('HSGK_BENCH_STEP_TIMES') else None    # (diagnostic: a fence per step, stderr)
+  if os.environ.get('HSGK_BENCH_NOPROF'):
+    _lib.profile_enable(False)
+  # No cyclic-GC pass inside a timed region (as timeit does): a generation-2 collection of a torch process is a
+  # 34-74 ms host stall that landed in about one run of eight (tools/probes/bench_stall.sh: the stalled step is a
+  # CPU-side one, at a random step, gone with the collector off) -- a quarter of cfg3's ten steps.
+  gc.collect()
+  gc.disable()
   t0 = time.perf_counter()
   out = None
   for _ in range(args.steps):
     del out
     out = run(x, labels)
     if step_times is not None:
-      torch.cuda.synchronize(dev)
+      if os.environ['HSGK_BENCH_STEP_TIMES'] != 'nosync':
+        torch.cuda.synchronize(dev)
       step_times.append(time.perf_counter())
   torch.cuda.synchronize(dev)
   if step_times:
@@ -349,6 +362,7 @@ def main():
   own_elapsed = time.perf_counter() - t0       # this rank's own K steps (before it waits for the others)
   fence()
   elapsed = time.perf_counter() - t0
+  gc.enable()
   prof = _lib.profile_collect()
   _lib.profile_enable(False)
 

@@ -1045,11 +1045,26 @@ static XWs carve_from(const hsgk_exchange_args *a, int world) {
   return w;
 }
 
+// the per-call fills in ONE launch (four memsets before: empty hash slots = -1, unused sort keys = 0x7F.. (sort last),
+// control block and meta = 0); small exchanges are launch-bound and run several times per training step
+__global__ __launch_bounds__(256) void xk_init_kernel(XCtrl *__restrict__ ctrl, long long *__restrict__ table,
+                                                      int64_t hsize, long long *__restrict__ ckeys, int64_t capp,
+                                                      int64_t *__restrict__ meta) {
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, step = (int64_t)gridDim.x * 256;
+  for (int64_t i = i0; i < hsize; i += step) table[i] = -1ll;
+  for (int64_t i = i0; i < capp; i += step) ckeys[i] = 0x7F7F7F7F7F7F7F7Fll;
+  if (i0 < (int64_t)(sizeof(XCtrl) / 4)) reinterpret_cast<int32_t *>(ctrl)[i0] = 0;
+  if (i0 < 8) meta[i0] = 0;
+}
+
 static int launch_keys(const hsgk_exchange_args *a, const XWs &w, hipStream_t s) {
-  HSGK_CHECK_HIP(hipMemsetAsync(w.ctrl, 0, sizeof(XCtrl), s));
-  HSGK_CHECK_HIP(hipMemsetAsync(w.table, 0xFF, (size_t)w.hsize * 8, s));
-  HSGK_CHECK_HIP(hipMemsetAsync(w.ckeys, 0x7F, (size_t)w.capp * 8, s));
-  HSGK_CHECK_HIP(hipMemsetAsync(a->meta, 0, 8 * sizeof(int64_t), s));
+  {
+    const int64_t most = (int64_t)w.hsize > (int64_t)w.capp ? (int64_t)w.hsize : (int64_t)w.capp;
+    const int64_t g = (most + 256 * 4 - 1) / (256 * 4);
+    hipLaunchKernelGGL(xk_init_kernel, dim3((unsigned)(g < 1 ? 1 : g > 2048 ? 2048 : g)), dim3(256), 0, s, w.ctrl,
+                       w.table, (int64_t)w.hsize, w.ckeys, (int64_t)w.capp, a->meta);
+    HSGK_LAUNCH_CHECK();
+  }
   if (a->n > 0) {
     const int64_t g = (a->n + 256 * 8 - 1) / (256 * 8);
     hipLaunchKernelGGL(xk_ranges_kernel, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, s, a->cluster, a->batch,
