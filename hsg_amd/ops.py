@@ -1,6 +1,7 @@
 """torch.autograd glue over the libhsgk C ABI (internal; the public surface is
 the reference-shaped modules under hsg_amd/utils and hsg_amd/models)."""
 import ctypes
+import os
 import threading
 
 import torch
@@ -14,7 +15,15 @@ EPS = 1e-12
 # host anyway (an exchange knows its table length, the image-id gather its id list) and read back by the next
 # function that would otherwise fetch them from the device with a stalling read.  Valid for that object and its
 # current version only: any op makes a new object without the note, an in-place write bumps `_version`.
+# NOT covered (the caveat of every `_version` check): writes through `.data`, `set_()` or a foreign kernel writing
+# through `data_ptr()` -- this package only notes tensors it has just produced and hands them straight to the next
+# function of the same step.  HSGK_NO_NOTES=1 turns the notes off (every consumer then reads the device).
+_notes_on = os.environ.get('HSGK_NO_NOTES', '') in ('', '0')
+
+
 def note(t, name, value):
+  if not _notes_on:
+    return t
   try:
     setattr(t, '_hsg_' + name, (value, t._version))
   except (AttributeError, RuntimeError):

@@ -146,6 +146,8 @@ def test_notes_ride_on_the_tensor_object_and_die_with_in_place_writes():
   valid for that object and version only."""
   import torch
   from hsg_amd import ops
+  if not ops._notes_on:
+    pytest.skip('HSGK_NO_NOTES is set')
   t = torch.arange(6)
   assert ops.noted(t, 'index_count') is None
   ops.note(t, 'index_count', 6)
