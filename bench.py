@@ -243,6 +243,56 @@ def main():
     os.environ.setdefault('WORLD_SIZE', '1')
     torch.cuda.set_device(local)
     backend = os.environ.get('HSGK_BENCH_BACKEND', 'nccl')
+
+    def startup_failed(e, from_thread=False):
+      # One retry in a fresh process image with the other IPC mode (the variable is read when the HSA runtime
+      # starts, so it cannot be changed in place).  Every rank that fails does the same; a rank that did not fail
+      # sits in the collective until its watchdog below sends it after the others.  The line reports which setting
+      # worked.
+      what = ('%s: %s' % (type(e).__name__, str(e)))[:300]
+      if os.environ.get('HSGK_BENCH_RETRIED') is None and backend == 'nccl' and world > 1:
+        sys.stderr.write('[bench rank %d] RCCL start-up failed (%s); retrying without HSA_ENABLE_IPC_MODE_LEGACY\n'
+                         % (rank, what[:200]))
+        sys.stderr.flush()
+        env = dict(os.environ)
+        env['HSGK_BENCH_RETRIED'] = '1'
+        env['HSGK_BENCH_FIRST_ERROR'] = what
+        env.pop('HSA_ENABLE_IPC_MODE_LEGACY', None)
+        env['HSGK_BENCH_NO_IPC_DEFAULT'] = '1'
+        os.execve(sys.executable, [sys.executable] + sys.argv, env)
+      # Both RCCL start-ups failed: the k-means path itself has no collective (images shard across the ranks), so the
+      # metric is still measurable -- barrier and max over ranks through gloo; the line then says `dist_backend: gloo`,
+      # `rccl_ranks: 0` and carries both RCCL errors, and the prototype exchange is timed over gloo.
+      if os.environ.get('HSGK_BENCH_RETRIED') == '1' and backend == 'nccl' and world > 1:
+        sys.stderr.write('[bench rank %d] RCCL start-up failed again (%s); barrier / max over gloo\n'
+                         % (rank, what[:200]))
+        sys.stderr.flush()
+        env = dict(os.environ)
+        env['HSGK_BENCH_RETRIED'] = '2'
+        env['HSGK_BENCH_SECOND_ERROR'] = what
+        env['HSGK_BENCH_BACKEND'] = 'gloo'
+        os.execve(sys.executable, [sys.executable] + sys.argv, env)
+      if rank == 0:
+        print(json.dumps({'metric': 'pixel-embeddings clustered/sec', 'value': None, 'unit': 'pixels/s',
+                          'n_gpus': world, 'error': 'process-group start-up failed: %s' % what,
+                          'first_error': os.environ.get('HSGK_BENCH_FIRST_ERROR'),
+                          'second_error': os.environ.get('HSGK_BENCH_SECOND_ERROR')}), flush=True)
+      if from_thread:
+        os._exit(1)
+      sys.exit(1)
+
+    # A rank whose peers have failed (and left for the retry) hangs in its first collective until RCCL's own
+    # time-out, which ends the process instead of raising: this watchdog sends it after the others well before the
+    # rendezvous of the retry (300 s) gives up on it.
+    import threading
+    started = threading.Event()
+
+    def startup_watchdog():
+      if not started.wait(float(os.environ.get('HSGK_BENCH_STARTUP_S', '200'))):
+        startup_failed(TimeoutError('the first collective did not finish in time'), from_thread=True)
+
+    if world > 1:
+      threading.Thread(target=startup_watchdog, daemon=True).start()
     try:
       if backend == 'nccl':
         dist.init_process_group('nccl', device_id=torch.device('cuda', local),
@@ -256,25 +306,12 @@ def main():
       torch.cuda.synchronize(torch.device('cuda', local))
       if int(probe.item()) != world:
         raise RuntimeError('first all_reduce returned %r for %d ranks' % (probe.item(), world))
+      if backend == 'nccl' and os.environ.get('HSGK_BENCH_FAKE_RCCL_FAILURE') == '1':     # (fault injection, tests)
+        raise RuntimeError('injected RCCL start-up failure')
+      started.set()
     except Exception as e:                      # noqa: BLE001
-      # One retry in a fresh process image with the other IPC mode (the variable is read when the HSA runtime
-      # starts, so it cannot be changed in place).  Every rank that fails does the same; a rank that did not fail
-      # runs into the collective's time-out and follows.  The line reports which setting worked.
-      if os.environ.get('HSGK_BENCH_RETRIED') != '1' and backend == 'nccl' and world > 1:
-        sys.stderr.write('[bench rank %d] RCCL start-up failed (%s: %s); retrying without HSA_ENABLE_IPC_MODE_LEGACY\n'
-                         % (rank, type(e).__name__, str(e)[:200]))
-        sys.stderr.flush()
-        env = dict(os.environ)
-        env['HSGK_BENCH_RETRIED'] = '1'
-        env['HSGK_BENCH_FIRST_ERROR'] = ('%s: %s' % (type(e).__name__, str(e)))[:300]
-        env.pop('HSA_ENABLE_IPC_MODE_LEGACY', None)
-        env['HSGK_BENCH_NO_IPC_DEFAULT'] = '1'
-        os.execve(sys.executable, [sys.executable] + sys.argv, env)
-      if rank == 0:
-        print(json.dumps({'metric': 'pixel-embeddings clustered/sec', 'value': None, 'unit': 'pixels/s',
-                          'n_gpus': world, 'error': 'RCCL start-up failed: %s: %s' % (type(e).__name__, str(e)[:300]),
-                          'first_error': os.environ.get('HSGK_BENCH_FIRST_ERROR')}), flush=True)
-      sys.exit(1)
+      started.set()
+      startup_failed(e)
   dev = torch.device('cuda', local)
   torch.cuda.set_device(dev)
 
@@ -565,8 +602,10 @@ def main():
         # rank 0's own rate over its K steps before the closing barrier (at N = 1 it equals `value`), and every rank's
         'n1_value': round(own_rates[0], 1), 'per_rank_pixels_per_s': [round(v, 1) for v in own_rates],
         'hsa_ipc_mode_legacy_env': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'),
-        'rccl_startup_retried': os.environ.get('HSGK_BENCH_RETRIED') == '1',
+        'rccl_startup_retried': os.environ.get('HSGK_BENCH_RETRIED') in ('1', '2'),
         'rccl_startup_first_error': os.environ.get('HSGK_BENCH_FIRST_ERROR'),
+        'rccl_startup_second_error': os.environ.get('HSGK_BENCH_SECOND_ERROR'),
+        'rccl_fell_back_to_gloo': os.environ.get('HSGK_BENCH_RETRIED') == '2',
         'roofline': roofline, 'roofline_mstep': roofline_mstep, 'roofline_prep': roofline_prep,
         'roofline_iteration': roofline_iteration, 'cpu_baseline': cpu, 'extra_runs': extra}), flush=True)
 
