@@ -344,12 +344,12 @@ def main():
 
   def timed(xin, lab, warmup, steps):
     out = None
+    gc.collect()              # (before the warm-up, which also re-warms the caches the collector's heap walk evicted)
+    gc.disable()
     for _ in range(warmup):
       out = run(xin, lab)
       del out
     fence()
-    gc.collect()
-    gc.disable()
     t0 = time.perf_counter()
     out = None
     for _ in range(steps):
@@ -361,6 +361,13 @@ def main():
     return dt, out
 
   profiled = args.workload.startswith('cfg')
+  # No cyclic-GC pass inside a timed region (as timeit does): a generation-2 collection of a torch process is a
+  # 34-74 ms host stall that landed in about one run of eight (tools/probes/bench_stall.sh: the stalled step is a
+  # CPU-side one, at a random step, gone with the collector off) -- a quarter of cfg3's ten steps.  Collected BEFORE
+  # the warm-up: the collector's walk over the heap leaves the caches cold, and the first step after it paid 0.3-0.4
+  # ms of host time for that (a tenth of ten 0.3 ms training-resolution steps).
+  gc.collect()
+  gc.disable()
   for i in range(args.warmup):
     # the LAST warm-up step already runs with the in-library events on: the runtime's first timed event record on a
     # stream is a one-time set-up (measured 9 ... 60 ms, in about one process of four) that belongs to the warm-up,
@@ -378,11 +385,6 @@ def main():
   step_times = [] if os.environ.get('HSGK_BENCH_STEP_TIMES') else None    # (diagnostic: a fence per step, stderr)
   if os.environ.get('HSGK_BENCH_NOPROF'):
     _lib.profile_enable(False)
-  # No cyclic-GC pass inside a timed region (as timeit does): a generation-2 collection of a torch process is a
-  # 34-74 ms host stall that landed in about one run of eight (tools/probes/bench_stall.sh: the stalled step is a
-  # CPU-side one, at a random step, gone with the collector off) -- a quarter of cfg3's ten steps.
-  gc.collect()
-  gc.disable()
   t0 = time.perf_counter()
   out = None
   for _ in range(args.steps):
