@@ -222,15 +222,18 @@ def _transport(group):
 _pin_pool = threading.local()
 
 
-def _pinned_meta():
-  free = getattr(_pin_pool, 'free', None)
-  if free is None:
-    free = _pin_pool.free = []
-  return free.pop() if free else torch.empty((8,), dtype=torch.int64).pin_memory()
+def _pinned_meta(dev_index):
+  """(pinned [8] int64, its event or None) of this thread and device: the buffer travels with the event that guards
+  it (an event belongs to the device it was first recorded on; creating one per exchange was ~5 us of host time)."""
+  pools = getattr(_pin_pool, 'free', None)
+  if pools is None:
+    pools = _pin_pool.free = {}
+  free = pools.setdefault(dev_index, [])
+  return free.pop() if free else (torch.empty((8,), dtype=torch.int64).pin_memory(), None)
 
 
-def _pinned_release(t):
-  _pin_pool.free.append(t)
+def _pinned_release(dev_index, pin, ev):
+  _pin_pool.free[dev_index].append((pin, ev))
 
 
 early_meta = os.environ.get('HSGK_EXCHANGE_EARLY_META', '1') != '0'     # (A/B switch of read_meta_begin)
@@ -315,10 +318,11 @@ class HsgkExchangeBackend:
   def read_meta_begin(self):
     """After `merge`: the meta block (complete from there on) starts its way to pinned host memory, so that the
     one host read of the exchange waits for keys + merge only and the sums run behind it."""
-    pin = _pinned_meta()
+    pin, ev = _pinned_meta(self.dev.index)
     with torch.cuda.device(self.dev):
       pin.copy_(self.meta, non_blocking=True)
-      ev = torch.cuda.Event()
+      if ev is None:
+        ev = torch.cuda.Event()
       ev.record()
     self._pending = (pin, ev)
 
@@ -328,7 +332,7 @@ class HsgkExchangeBackend:
       pin, ev = pending
       ev.synchronize()
       m = pin.tolist()
-      _pinned_release(pin)
+      _pinned_release(self.dev.index, pin, ev)
       self._pending = None
     else:
       m = self.meta.cpu().tolist()

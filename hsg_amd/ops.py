@@ -42,18 +42,21 @@ _pin_pool = threading.local()
 def read_i64(dev_tensor):
   """Host list of a small int64 device vector through pinned memory (a pageable `.cpu()` stages the copy and costs
   ~50 us more); the stream is waited for up to the copy only."""
-  free = getattr(_pin_pool, 'free', None)
-  if free is None:
-    free = _pin_pool.free = []
+  pools = getattr(_pin_pool, 'free', None)
+  if pools is None:
+    pools = _pin_pool.free = {}
+  free = pools.setdefault(dev_tensor.device.index, [])      # (an event belongs to the device it was first recorded on)
   n = dev_tensor.numel()
-  pin = free.pop() if free else torch.empty((64,), dtype=torch.int64).pin_memory()
+  # (the pinned buffer travels with its event: creating one per read was ~5 us of the read)
+  pin, ev = free.pop() if free else (torch.empty((64,), dtype=torch.int64).pin_memory(), None)
   with torch.cuda.device(dev_tensor.device):
     pin[:n].copy_(dev_tensor.view(-1), non_blocking=True)
-    ev = torch.cuda.Event()
+    if ev is None:
+      ev = torch.cuda.Event()
     ev.record()
   ev.synchronize()
   out = pin[:n].tolist()
-  free.append(pin)
+  free.append((pin, ev))
   return out
 
 
