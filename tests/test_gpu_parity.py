@@ -1442,8 +1442,8 @@ def test_whole_train_step_vs_reference(dev):
             'finehrchy_mapping_index', 'coarsehrchy_mapping_index', 'n_prototypes'):
     assert np.array_equal(out[k].cpu().numpy(), g[k]), k
   for k in ('img_sim_loss', 'hrchy_group_loss', 'clustering_loss'):
-    assert abs(float(out[k]) - float(g[k])) <= 1e-4, (k, float(out[k]), float(g[k]))
-  assert abs(float(out['accuracy']) - float(g['accuracy'])) <= 1e-6
+    assert abs(float(out[k].detach()) - float(g[k])) <= 1e-4, (k, float(out[k].detach()), float(g[k]))
+  assert abs(float(out['accuracy'].detach()) - float(g['accuracy'])) <= 1e-6
   for k in ('grad', 'g_fine_logits', 'g_coarse_logits', 'g_cent_f'):
     ref = g[k]
     scale = max(float(np.abs(ref).max()), 1e-6)
@@ -1666,8 +1666,8 @@ def test_segsort_model_predictions_losses_multiset_vs_reference(dev):
   assert np.array_equal(out['semantic_prediction'].cpu().numpy(), g['pred'])
   assert np.array_equal(out['semantic_score'].cpu().numpy(), g['topk'])
   for k, ref in (('sem_ann_loss', 'sem_ann'), ('sem_occ_loss', 'sem_occ'), ('img_sim_loss', 'img_sim')):
-    assert abs(float(out[k]) - float(g[ref])) <= 1e-4, (k, float(out[k]), float(g[ref]))
-  assert abs(float(out['accuracy']) - float(g['acc'])) <= 1e-6
+    assert abs(float(out[k].detach()) - float(g[ref])) <= 1e-4, (k, float(out[k].detach()), float(g[ref]))
+  assert abs(float(out['accuracy'].detach()) - float(g['acc'])) <= 1e-6
   (out['sem_ann_loss'] + out['sem_occ_loss'] + out['img_sim_loss']).backward()
   for got, ref in ((datas['cluster_embedding'].grad, g['g_emb']), (targets['prototype'].grad, g['g_protos'])):
     scale = float(np.abs(ref).max())
