@@ -1799,7 +1799,7 @@ __global__ __launch_bounds__(512) void assign_half_pair_kernel(
 // shared-window kernel pays (assign_half_pair_kernel: twelve per tile, matrix pipe 28 % busy): 2 x 64 row registers
 // (this tile + the next one in flight), 32 accumulators, two waves per SIMD, every wave on its own.
 // After a pass the 32 scores of a lane collapse to the pass's tagged top-3 (position among the lane's 32 scores
-// in the low five mantissa bits: <= 31 ulp <= 3.7e-6, in the gap), five v_med3 per score, and the accumulators are
+// in the low five mantissa bits: <= 31 ulp <= 3.7e-6, in the gap), the tag and three v_med3 per score, and the accumulators are
 // free for the next pass.  At the end of the tile the row's best / second best come out of the 4 x 2 kept values of
 // both lane halves; an undecided row's candidate set {k : score >= best - gap} is exactly the kept values above
 // the threshold, unless some pass's THIRD value reaches it too -- then the entry asks for all K centroids (the
@@ -1940,10 +1940,11 @@ __global__ __launch_bounds__(512) void assign_half_t256_kernel(
           for (int rr = 0; rr < 16; ++rr) {
             float v = __uint_as_float((__float_as_uint(acc[m][rr]) & ~31u) | (uint32_t)(m * 16 + rr));
             if (!full) v = mg * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h < K ? v : NINF;
-            const float drop = __builtin_amdgcn_fmed3f(a2, v, NINF);            // min(a2, v): what leaves the top 2
+            // (a3 <= a2 <= a1 throughout: the median of {a2, v, a3} IS the new third -- a2 when v displaces it, v when
+            //  v lands between a3 and a2, a3 otherwise; one instruction instead of min(a2, v) + max(a3, .))
+            a3 = __builtin_amdgcn_fmed3f(a2, v, a3);
             a2 = __builtin_amdgcn_fmed3f(a1, a2, v);
             a1 = __builtin_amdgcn_fmed3f(a1, v, PINF);                          // max
-            a3 = __builtin_amdgcn_fmed3f(a3, drop, PINF);
           }
         }
         g1[g] = a1; g2[g] = a2; g3[g] = a3;
