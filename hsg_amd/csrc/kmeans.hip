@@ -26,6 +26,17 @@ static_assert(hsgk::kHalfSlackRows == hsgk::kHalfSlackRowsHost, "fp16 copy slack
 
 namespace hsgk {
 
+// max(a, b) in ONE instruction for a bit-tagged score: fmaxf makes the compiler canonicalise an operand whose bits
+// came out of integer arithmetic first (v_max_f32 x, x, x -- a fourth instruction per score in the tagged top-2
+// loops, a quarter of their work); v_med3_f32(a, b, +inf) takes raw inputs, and the +inf sits in a scalar register
+// the compiler cannot see through (a visible constant is folded back to fmax).  NaN operands are ignored like fmaxf's.
+__device__ __forceinline__ float max_raw(float a, float b) {
+  float pinf;
+  asm("s_mov_b32 %0, 0x7f800000" : "=s"(pinf));
+  return __builtin_amdgcn_fmed3f(a, b, pinf);
+}
+
+
 
 // ===========================================================================
 // M-step, stage 1: chunk partial sums.
@@ -290,7 +301,7 @@ struct SplitEpi {
         sc[m][r] = v;
         b2 = fmaxf(b2, fminf(b1, v));
         bi = v > b1 ? k : bi;
-        b1 = fmaxf(b1, v);
+        b1 = max_raw(b1, v);
       }
     const float o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
     const int oi = __shfl_xor(bi, 32);
@@ -681,7 +692,7 @@ struct HalfEpi {
         for (int r = 0; r < 16; ++r) {
           const float v = __uint_as_float((__float_as_uint(sacc[m][r]) & ~31u) | (uint32_t)(m * 16 + r));
           t2 = __builtin_amdgcn_fmed3f(t1, t2, v);
-          t1 = fmaxf(t1, v);
+          t1 = max_raw(t1, v);
         }
       } else {
 #pragma unroll
@@ -690,7 +701,7 @@ struct HalfEpi {
           float v = __uint_as_float((__float_as_uint(sacc[m][r]) & ~31u) | (uint32_t)(m * 16 + r));
           v = k < K ? v : -INFINITY;
           t2 = __builtin_amdgcn_fmed3f(t1, t2, v);
-          t1 = fmaxf(t1, v);
+          t1 = max_raw(t1, v);
         }
       }
     }
@@ -888,7 +899,7 @@ struct HalfWideEpi {
           for (int r = 0; r < 16; ++r) {
             const float v = __uint_as_float((__float_as_uint(sacc[m][r]) & ~15u) | (uint32_t)r);
             b2 = __builtin_amdgcn_fmed3f(b1, b2, v);
-            b1 = fmaxf(b1, v);
+            b1 = max_raw(b1, v);
           }
         } else {
 #pragma unroll
@@ -897,7 +908,7 @@ struct HalfWideEpi {
             float v = __uint_as_float((__float_as_uint(sacc[m][r]) & ~15u) | (uint32_t)r);
             v = k < K ? v : -INFINITY;
             b2 = __builtin_amdgcn_fmed3f(b1, b2, v);
-            b1 = fmaxf(b1, v);
+            b1 = max_raw(b1, v);
           }
         }
       }
@@ -1098,7 +1109,7 @@ struct HalfStateEpi {
         const float v = k < K ? sacc[m][r] : -INFINITY;
         b2 = fmaxf(b2, fminf(b1, v));
         bi = v > b1 ? k : bi;
-        b1 = fmaxf(b1, v);
+        b1 = max_raw(b1, v);
       }
     const float o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
     const int oi = __shfl_xor(bi, 32);
@@ -1165,7 +1176,7 @@ struct HalfMergeEpi {
         const float v = k < K2 ? sacc[m][r] : -INFINITY;
         b2 = fmaxf(b2, fminf(b1, v));
         bi = v > b1 ? k : bi;
-        b1 = fmaxf(b1, v);
+        b1 = max_raw(b1, v);
       }
     const float o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
     const int oi = __shfl_xor(bi, 32);
@@ -1320,7 +1331,7 @@ struct HalfWide1Epi {
           for (int r = 0; r < 16; ++r) {
             const float v = __uint_as_float((__float_as_uint(sacc[m][r]) & ~15u) | (uint32_t)r);
             b2 = __builtin_amdgcn_fmed3f(b1, b2, v);
-            b1 = fmaxf(b1, v);
+            b1 = max_raw(b1, v);
           }
         } else {
 #pragma unroll
@@ -1329,7 +1340,7 @@ struct HalfWide1Epi {
             float v = __uint_as_float((__float_as_uint(sacc[m][r]) & ~15u) | (uint32_t)r);
             v = k < K ? v : -INFINITY;
             b2 = __builtin_amdgcn_fmed3f(b1, b2, v);
-            b1 = fmaxf(b1, v);
+            b1 = max_raw(b1, v);
           }
         }
       }
@@ -1680,7 +1691,7 @@ __global__ __launch_bounds__(512) void assign_half_pair_kernel(
             for (int rr = 0; rr < 16; ++rr) {
               const float v = __uint_as_float((__float_as_uint(acc[m][rr]) & ~15u) | (uint32_t)rr);
               b2 = __builtin_amdgcn_fmed3f(b1, b2, v);
-              b1 = fmaxf(b1, v);
+              b1 = max_raw(b1, v);
             }
           } else {
 #pragma unroll
@@ -1689,7 +1700,7 @@ __global__ __launch_bounds__(512) void assign_half_pair_kernel(
               float v = __uint_as_float((__float_as_uint(acc[m][rr]) & ~15u) | (uint32_t)rr);
               v = k < K ? v : -INFINITY;
               b2 = __builtin_amdgcn_fmed3f(b1, b2, v);
-              b1 = fmaxf(b1, v);
+              b1 = max_raw(b1, v);
             }
           }
         }
@@ -2211,7 +2222,7 @@ __global__ __launch_bounds__(512, 2) void assign_half_regs_kernel(
             for (int rr = 0; rr < 16; ++rr) {
               const float v = __uint_as_float((__float_as_uint(acc[u][rr]) & ~15u) | (uint32_t)rr);
               b2 = __builtin_amdgcn_fmed3f(b1, b2, v);
-              b1 = fmaxf(b1, v);
+              b1 = max_raw(b1, v);
             }
           } else {
 #pragma unroll
@@ -2220,7 +2231,7 @@ __global__ __launch_bounds__(512, 2) void assign_half_regs_kernel(
               float v = __uint_as_float((__float_as_uint(acc[u][rr]) & ~15u) | (uint32_t)rr);
               v = k < K ? v : -INFINITY;
               b2 = __builtin_amdgcn_fmed3f(b1, b2, v);
-              b1 = fmaxf(b1, v);
+              b1 = max_raw(b1, v);
             }
           }
           bm1[u] = b1;
