@@ -1947,15 +1947,30 @@ __global__ __launch_bounds__(512) void assign_half_t256_kernel(
           const int mg = 2 * g + m;
           if (mg * 32 >= K) continue;                                // (uniform)
           const bool full = (mg + 1) * 32 <= K;
+          // (a3 <= a2 <= a1 throughout: the median of {a2, v, a3} IS the new third -- a2 when v displaces it, v when
+          //  v lands between a3 and a2, a3 otherwise; one instruction instead of min(a2, v) + max(a3, .))
+          // Two loops under a REAL branch: written as one loop with `if (!full) v = k < K ? v : -inf` the compiler
+          // if-converted the mask into every block -- two v_cndmask per score, their 128 lane masks spilled to
+          // VGPR lanes and read back with two v_readlane each: eight vector instructions per score instead of four.
+          if (full) {
 #pragma unroll
-          for (int rr = 0; rr < 16; ++rr) {
-            float v = __uint_as_float((__float_as_uint(acc[m][rr]) & ~31u) | (uint32_t)(m * 16 + rr));
-            if (!full) v = mg * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h < K ? v : NINF;
-            // (a3 <= a2 <= a1 throughout: the median of {a2, v, a3} IS the new third -- a2 when v displaces it, v when
-            //  v lands between a3 and a2, a3 otherwise; one instruction instead of min(a2, v) + max(a3, .))
-            a3 = __builtin_amdgcn_fmed3f(a2, v, a3);
-            a2 = __builtin_amdgcn_fmed3f(a1, a2, v);
-            a1 = __builtin_amdgcn_fmed3f(a1, v, PINF);                          // max
+            for (int rr = 0; rr < 16; ++rr) {
+              const float v = __uint_as_float((__float_as_uint(acc[m][rr]) & ~31u) | (uint32_t)(m * 16 + rr));
+              a3 = __builtin_amdgcn_fmed3f(a2, v, a3);
+              a2 = __builtin_amdgcn_fmed3f(a1, a2, v);
+              a1 = __builtin_amdgcn_fmed3f(a1, v, PINF);                          // max
+            }
+          } else {
+            asm volatile("" ::: "memory");                            // (keeps the ragged last block a branch of its own)
+            const int rem = K - mg * 32 - 4 * h;                       // score rr exists iff (rr & 3) + 8 (rr >> 2) < rem
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+              float v = __uint_as_float((__float_as_uint(acc[m][rr]) & ~31u) | (uint32_t)(m * 16 + rr));
+              v = (rr & 3) + 8 * (rr >> 2) < rem ? v : NINF;
+              a3 = __builtin_amdgcn_fmed3f(a2, v, a3);
+              a2 = __builtin_amdgcn_fmed3f(a1, a2, v);
+              a1 = __builtin_amdgcn_fmed3f(a1, v, PINF);
+            }
           }
         }
         g1[g] = a1; g2[g] = a2; g3[g] = a3;
