@@ -200,15 +200,21 @@ struct LossFwdEpiFast {
     st.pmax = (int)((P - kb0) < 64 ? (P - kb0) : 64);
     st.own0 = st.same0 = st.diff0 = st.own1 = st.same1 = st.diff1 = st.own2 = st.same2 = st.diff2 = 0.f;
   }
-  template <int M, int R0, int NR>
+  // ALL (wave-uniform, decided per tile by operator()): the block holds 64 prototypes and there are no groups, so
+  // every score is live -- no group word read from LDS, no 64-bit compare, no column compare, no select per score
+  // (five of the ~22 instructions a score costs here; the usual case: only the last block of a table is ragged).
+  template <int M, int R0, int NR, bool ALL = false>
   __device__ inline void piece(State &st, const f32x16 &accm) const {
     const int64_t *bl = st.bl;
 #pragma unroll
     for (int r = R0; r < R0 + NR; ++r) {
       const int pl = (M * 32 + (r & 3) + 8 * (r >> 2)) | (st.h << 2);
       // (no branches in a piece: it has to stay ONE scheduling region with the matrix instructions it hides behind)
-      const int64_t grp = bl[kLabSlots * 64 + pl];                   // (always a staged word: pl < 64)
-      const bool live = (pl < st.pmax) & (!st.grouped | (grp == st.gj));
+      bool live = true;
+      if constexpr (!ALL) {
+        const int64_t grp = bl[kLabSlots * 64 + pl];                 // (always a staged word: pl < 64)
+        live = (pl < st.pmax) & (!st.grouped | (grp == st.gj));
+      }
       const float a = accm[r];
       float x0 = EXP2 ? __builtin_amdgcn_exp2f(a * st.kl0) : expf(a * st.k0);
       x0 = live ? x0 : 0.0f;
@@ -250,21 +256,27 @@ struct LossFwdEpiFast {
       }
     }
   }
-  template <int MB>
-  __device__ inline void operator()(int tile, const f32x16 (&acc)[MB]) const {
-    State st;
-    begin(tile, st);
+  template <int MB, bool ALL>
+  __device__ inline void pieces(State &st, const f32x16 (&acc)[MB]) const {
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
       // (keeps the scheduler from hoisting all 32 x L label reads and exps of a tile: spills with L >= 2)
       __builtin_amdgcn_sched_barrier(0);
-      if (m == 0) { piece<0, 0, 4>(st, acc[0]); __builtin_amdgcn_sched_barrier(0); piece<0, 4, 4>(st, acc[0]);
-                    __builtin_amdgcn_sched_barrier(0); piece<0, 8, 4>(st, acc[0]); __builtin_amdgcn_sched_barrier(0);
-                    piece<0, 12, 4>(st, acc[0]); }
-      else { piece<1, 0, 4>(st, acc[MB > 1 ? 1 : 0]); __builtin_amdgcn_sched_barrier(0); piece<1, 4, 4>(st, acc[MB > 1 ? 1 : 0]);
-             __builtin_amdgcn_sched_barrier(0); piece<1, 8, 4>(st, acc[MB > 1 ? 1 : 0]); __builtin_amdgcn_sched_barrier(0);
-             piece<1, 12, 4>(st, acc[MB > 1 ? 1 : 0]); }
+      if (m == 0) { piece<0, 0, 4, ALL>(st, acc[0]); __builtin_amdgcn_sched_barrier(0); piece<0, 4, 4, ALL>(st, acc[0]);
+                    __builtin_amdgcn_sched_barrier(0); piece<0, 8, 4, ALL>(st, acc[0]); __builtin_amdgcn_sched_barrier(0);
+                    piece<0, 12, 4, ALL>(st, acc[0]); }
+      else { piece<1, 0, 4, ALL>(st, acc[MB > 1 ? 1 : 0]); __builtin_amdgcn_sched_barrier(0);
+             piece<1, 4, 4, ALL>(st, acc[MB > 1 ? 1 : 0]); __builtin_amdgcn_sched_barrier(0);
+             piece<1, 8, 4, ALL>(st, acc[MB > 1 ? 1 : 0]); __builtin_amdgcn_sched_barrier(0);
+             piece<1, 12, 4, ALL>(st, acc[MB > 1 ? 1 : 0]); }
     }
+  }
+  template <int MB>
+  __device__ inline void operator()(int tile, const f32x16 (&acc)[MB]) const {
+    State st;
+    begin(tile, st);
+    if (st.pmax == 64 && !st.grouped) pieces<MB, true>(st, acc);     // (wave-uniform)
+    else pieces<MB, false>(st, acc);
     end(st);
   }
 };
