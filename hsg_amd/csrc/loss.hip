@@ -203,7 +203,10 @@ struct LossFwdEpiFast {
   // ALL (wave-uniform, decided per tile by operator()): the block holds 64 prototypes and there are no groups, so
   // every score is live -- no group word read from LDS, no 64-bit compare, no column compare, no select per score
   // (five of the ~22 instructions a score costs here; the usual case: only the last block of a table is ragged).
-  template <int M, int R0, int NR, bool ALL = false>
+  // OWN (wave-uniform too): some row of the wave's tile has its own prototype inside this block.  A row's own
+  // prototype sits in ONE of the table's blocks, so with 48 blocks about half of the 32-row tiles have none here and
+  // skip the compare / select / add per score that collects it.
+  template <int M, int R0, int NR, bool ALL = false, bool OWN = true>
   __device__ inline void piece(State &st, const f32x16 &accm) const {
     const int64_t *bl = st.bl;
 #pragma unroll
@@ -218,10 +221,10 @@ struct LossFwdEpiFast {
       const float a = accm[r];
       float x0 = EXP2 ? __builtin_amdgcn_exp2f(a * st.kl0) : expf(a * st.k0);
       x0 = live ? x0 : 0.0f;
-      const bool isown = pl == st.ij;
+      const bool isown = OWN && pl == st.ij;
       {
         const bool sm = bl[pl] == st.s0;
-        st.own0 += isown ? x0 : 0.0f;
+        if constexpr (OWN) st.own0 += isown ? x0 : 0.0f;
         st.same0 += sm ? x0 : 0.0f;
         st.diff0 += sm ? 0.0f : x0;
       }
@@ -229,14 +232,14 @@ struct LossFwdEpiFast {
         float x1 = EXP2 ? __builtin_amdgcn_exp2f(a * st.kl1) : expf(a * st.k1);
         x1 = st.e1 ? (live ? x1 : 0.0f) : x0;
         const bool sm = bl[kMaskWords * 64 + pl] == st.s1;
-        st.own1 += isown ? x1 : 0.0f;
+        if constexpr (OWN) st.own1 += isown ? x1 : 0.0f;
         st.same1 += sm ? x1 : 0.0f;
         st.diff1 += sm ? 0.0f : x1;
         if constexpr (L > 2) {
           float x2 = EXP2 ? __builtin_amdgcn_exp2f(a * st.kl2) : expf(a * st.k2);
           x2 = st.e2 ? (live ? x2 : 0.0f) : x1;
           const bool sm2 = bl[(kMaskWords + 1) * 64 + pl] == st.s2;
-          st.own2 += isown ? x2 : 0.0f;
+          if constexpr (OWN) st.own2 += isown ? x2 : 0.0f;
           st.same2 += sm2 ? x2 : 0.0f;
           st.diff2 += sm2 ? 0.0f : x2;
         }
@@ -256,27 +259,31 @@ struct LossFwdEpiFast {
       }
     }
   }
-  template <int MB, bool ALL>
+  template <int MB, bool ALL, bool OWN = true>
   __device__ inline void pieces(State &st, const f32x16 (&acc)[MB]) const {
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
       // (keeps the scheduler from hoisting all 32 x L label reads and exps of a tile: spills with L >= 2)
       __builtin_amdgcn_sched_barrier(0);
-      if (m == 0) { piece<0, 0, 4, ALL>(st, acc[0]); __builtin_amdgcn_sched_barrier(0); piece<0, 4, 4, ALL>(st, acc[0]);
-                    __builtin_amdgcn_sched_barrier(0); piece<0, 8, 4, ALL>(st, acc[0]); __builtin_amdgcn_sched_barrier(0);
-                    piece<0, 12, 4, ALL>(st, acc[0]); }
-      else { piece<1, 0, 4, ALL>(st, acc[MB > 1 ? 1 : 0]); __builtin_amdgcn_sched_barrier(0);
-             piece<1, 4, 4, ALL>(st, acc[MB > 1 ? 1 : 0]); __builtin_amdgcn_sched_barrier(0);
-             piece<1, 8, 4, ALL>(st, acc[MB > 1 ? 1 : 0]); __builtin_amdgcn_sched_barrier(0);
-             piece<1, 12, 4, ALL>(st, acc[MB > 1 ? 1 : 0]); }
+      if (m == 0) { piece<0, 0, 4, ALL, OWN>(st, acc[0]); __builtin_amdgcn_sched_barrier(0); piece<0, 4, 4, ALL, OWN>(st, acc[0]);
+                    __builtin_amdgcn_sched_barrier(0); piece<0, 8, 4, ALL, OWN>(st, acc[0]); __builtin_amdgcn_sched_barrier(0);
+                    piece<0, 12, 4, ALL, OWN>(st, acc[0]); }
+      else { piece<1, 0, 4, ALL, OWN>(st, acc[MB > 1 ? 1 : 0]); __builtin_amdgcn_sched_barrier(0);
+             piece<1, 4, 4, ALL, OWN>(st, acc[MB > 1 ? 1 : 0]); __builtin_amdgcn_sched_barrier(0);
+             piece<1, 8, 4, ALL, OWN>(st, acc[MB > 1 ? 1 : 0]); __builtin_amdgcn_sched_barrier(0);
+             piece<1, 12, 4, ALL, OWN>(st, acc[MB > 1 ? 1 : 0]); }
     }
   }
   template <int MB>
   __device__ inline void operator()(int tile, const f32x16 (&acc)[MB]) const {
     State st;
     begin(tile, st);
-    if (st.pmax == 64 && !st.grouped) pieces<MB, true>(st, acc);     // (wave-uniform)
-    else pieces<MB, false>(st, acc);
+    if (st.pmax == 64 && !st.grouped) {                              // (wave-uniform branches)
+      if (__any(st.ij >= 0)) pieces<MB, true, true>(st, acc);
+      else pieces<MB, true, false>(st, acc);
+    } else {
+      pieces<MB, false, true>(st, acc);
+    }
     end(st);
   }
 };
