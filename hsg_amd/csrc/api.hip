@@ -189,7 +189,7 @@ static void carve_kmeans(Carver &cv, int B, int64_t rows_per_img, int d, int K,
         d / 64 == 4 && rows_per_img % 32 == 0)
       k->xhT = cv.take<_Float16>(((size_t)B * rows_per_img + kHalfSlackRowsHost) * half_main_cols_host(d) + 8);
     k->q1 = cv.take<int32_t>((size_t)B * rows_per_img + 1);
-    k->q1count = cv.take<int32_t>((size_t)B + 1);
+    k->q1count = cv.take<int32_t>(2 * ((size_t)B + 1));   // [B] lengths (+ [B] of the previous iteration: all-K lists)
   }
   k->cent_multi = nullptr;
   if (k->sumq && assign_half_eligible(d, K) && rows_per_img <= 16 * 1024)       // small maps only (lloyd_small_groups)
@@ -300,9 +300,12 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
         // (the queue counters of the E-step that follows, and for the hi-plane filters of K > 64 the table's fp16
         //  rounding errors, come out of this launch instead of memsets / a kernel of their own per iteration)
         counters_zeroed = half || ((wide || wide2) && k.errc);
-        if (int rc = launch_finalize_fx(k.sumq, d, K, B, HSGK_EPS, k.cent, s, half ? k.q1count : nullptr, B,
+        // (k.q1 / k.q1count: the fp16 level's row queues when K <= 64, the all-K row lists of the wider filters)
+        if (int rc = launch_finalize_fx(k.sumq, d, K, B, HSGK_EPS, k.cent, s,
+                                        (half || counters_zeroed) ? k.q1count : nullptr, B,
                                         counters_zeroed ? k.qcount : nullptr,
-                                        (wide || wide2) ? k.errc : nullptr)) return rc; }
+                                        (wide || wide2) ? k.errc : nullptr,
+                                        (!half && counters_zeroed) ? k.q1count + B + 1 : nullptr, it > 0)) return rc; }
     } else {
       { ProfScope p(HSGK_PROF_ACCUMULATE, s);
         if (int rc = launch_accumulate(x, d, cur, k.t, k.max_chunks, K, k.partial, k.pmask, meta, s)) return rc; }
@@ -314,9 +317,10 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
       if (int rc = half ? launch_assign_half(x, k.xh, k.xt, d, k.cent, K, B, k.t, k.max_chunks, cur, k.q1,
                                              k.q1count, k.q1cap, k.qrows, k.qcount, meta, s, counters_zeroed, xhT)
                : wide ? launch_assign_half_wide(x, k.xh, k.xt, d, k.cent, k.errc, K, B, k.t, k.max_chunks, cur,
-                                                k.qrows, k.qcount, meta, s, counters_zeroed)
+                                                k.qrows, k.qcount, meta, s, counters_zeroed, k.q1, k.q1count, k.q1cap)
                : wide2 ? launch_assign_half_wide2(x, k.xh, k.xt, d, k.cent, k.errc, K, B, k.t, k.max_chunks,
-                                                  cur, k.state, k.qrows, k.qcount, meta, s, xhT, counters_zeroed)
+                                                  cur, k.state, k.qrows, k.qcount, meta, s, xhT, counters_zeroed,
+                                                  k.q1, k.q1count, k.q1cap)
                : unit_rows && assign_mode() >= 1
                    ? launch_assign_fast(x, d, k.cent, K, B, k.t, k.max_chunks, cur, k.best,
                                         k.qrows, k.qcount, meta, s)
@@ -661,9 +665,9 @@ int hsgk_lloyd_estep(const float *x, int B, int64_t rows_per_image, int d, int K
                                 k.q1count, k.q1cap, k.qrows, k.qcount, meta, s, false, xhT);
     if (assign_half_wide_eligible(d, K))
       return launch_assign_half_wide(x, k.xh, k.xt, d, centroids, k.errc, K, B, k.t, k.max_chunks, labels_out,
-                                     k.qrows, k.qcount, meta, s);
+                                     k.qrows, k.qcount, meta, s, false, k.q1, k.q1count, k.q1cap);
     return launch_assign_half_wide2(x, k.xh, k.xt, d, centroids, k.errc, K, B, k.t, k.max_chunks, labels_out,
-                                    k.state, k.qrows, k.qcount, meta, s, xhT);
+                                    k.state, k.qrows, k.qcount, meta, s, xhT, false, k.q1, k.q1count, k.q1cap);
   }
   if (unit_rows)
     return launch_assign_fast(x, d, centroids, K, B, k.t, k.max_chunks, labels_out, k.best, k.qrows,

@@ -174,7 +174,8 @@ int launch_update_sums(const float *x, int d, const int32_t *prev, const int32_t
 // row it writes (what the hi-plane filters of K > 64 otherwise measure with a launch of their own)
 int launch_finalize_fx(const long long *sumq, int d, int K, int B, float eps, float *cent,
                        hipStream_t s, int32_t *zero_a = nullptr, int na = 0, int32_t *zero_b = nullptr,
-                       float *errc = nullptr);
+                       float *errc = nullptr, int32_t *keep_a = nullptr,
+                       bool keep_valid = false);   // keep_a[i] = keep_valid ? zero_a[i] : 0 before the zeroing
 
 // three-level E-step (fp16 copy -> bf16x3 on the undecided rows -> exact chains)
 inline int half_main_cols_host(int d) { return d & ~63; }
@@ -187,12 +188,17 @@ bool assign_half_wide_eligible(int d, int K);          // 64 < K <= 128: hi-plan
 int launch_assign_half_wide(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent,
                             float *errc, int K, int B, const ChunkTable &t, int max_chunks, int32_t *klab,
                             void *qrows, int32_t *qcount, const hsgk_segkm_meta *meta, hipStream_t s,
-                            bool table_ready = false);   // errc measured and qcount zeroed by launch_finalize_fx
+                            bool table_ready = false,    // errc measured and the counters zeroed by launch_finalize_fx
+                            int32_t *hard_rows = nullptr, int32_t *hard_count = nullptr, int64_t hard_cap = 0);
+// hard_rows [B][hard_cap] / hard_count [B]: the rows whose exact-queue entry asks for all K centroids are listed
+// per image and scored by the dense fp32 matrix-pipe pass (kmeans.hip: assign_hard_rows_kernel); null: one entry
+// at a time inside the exact pass
 bool assign_half_wide2_eligible(int d, int K);         // 128 < K <= 256: two table halves per pass
 int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent,
                              float *errc, int K, int B, const ChunkTable &t, int max_chunks, int32_t *klab,
                              void *state, void *qrows, int32_t *qcount, const hsgk_segkm_meta *meta,
-                             hipStream_t s, const _Float16 *xmT = nullptr, bool table_ready = false);
+                             hipStream_t s, const _Float16 *xmT = nullptr, bool table_ready = false,
+                             int32_t *hard_rows = nullptr, int32_t *hard_count = nullptr, int64_t hard_cap = 0);
 int launch_assign_half(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent, int K, int B,
                        const ChunkTable &t, int max_chunks, int32_t *klab, int32_t *q1,
                        int32_t *q1count, int64_t q1cap, void *qrows, int32_t *qcount,

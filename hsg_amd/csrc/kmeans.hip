@@ -507,10 +507,21 @@ __device__ __forceinline__ float exact_chain_coop(const float *__restrict__ ct, 
 // One batch of 16 exact-queue entries on a wave: lanes 4 g .. 4 g + 3 serve entry g (`ent`, `have`
 // and `img` are per-group values, identical on the four lanes); writes the exact label of the row.
 // win != nullptr: the shared-load chains (exact_chain_coop) through that wave-private LDS window.
+// hl.rows != nullptr: an entry that asks for ALL K centroids is not scored here (one entry at a time on a whole
+// wave, K chains from K different table rows: 2 - 2.7 ms per iteration at K = 256 when a few per cent of the rows
+// sit between many near-duplicate centroids -- the 'mixture' input at 768^2, profiles/r05_cfg4_mixture_before.txt);
+// its row goes on the image's list for assign_hard_rows_kernel, the same C1 chains on the fp32 matrix pipe.
+// The first `skip` such entries of an image stay on the whole-wave path below (a few hundred per iteration on i.i.d.
+// rows: cheaper than the dense pass's start-up), list positions [skip, count) go to the dense pass.
+// prev (nullable): the images' counts of the previous Lloyd iteration -- an image that had more than `skip` such
+// rows then will have them again and the dense pass will run anyway, so all of its entries go to the list (the
+// whole-wave path costs ~0.1 us per entry: 2 048 of them 0.2 ms per iteration at 4 x 768^2, mixture input).
+struct HardList { int32_t *rows; int32_t *count; int64_t cap; int skip; const int32_t *prev; };   // [B][cap] ids, [B] lengths
 __device__ __forceinline__ void exact_rescore16(const SplitEntry ent, const bool have, const int img,
                                                 const float *__restrict__ x, int d,
                                                 const float *__restrict__ cent, int K,
-                                                int32_t *__restrict__ klab, float *__restrict__ win = nullptr) {
+                                                int32_t *__restrict__ klab, float *__restrict__ win = nullptr,
+                                                const HardList hl = HardList{nullptr, nullptr, 0, 0, nullptr}) {
   const int lane = threadIdx.x & 63;
   const int ci = lane & 3;
   const int n = have ? (int)(ent.cand >> 24) : 0;
@@ -550,8 +561,26 @@ __device__ __forceinline__ void exact_rescore16(const SplitEntry ent, const bool
     if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
   }
   if (ci == 0 && n >= 1 && n <= 7) put_label(klab, ent.row, bi == 0x7fffffff ? 0 : bi);
-  // rare: entries that need all K centroids, one at a time on the whole wave
+  // entries that need all K centroids
   unsigned long long hard = __ballot(ci == 0 && n == 255);
+  if (hl.rows) {
+    if (hard) {
+      const bool mine = ci == 0 && n == 255;
+      const int lead = __builtin_ctzll(hard);
+      const int limg = __builtin_amdgcn_readlane(img, lead);
+      int pos;
+      if (__ballot(mine && img != limg) == 0ull) {          // (usual case) one image: one atomic for the wave's batch
+        int base = 0;
+        if (lane == lead) base = atomicAdd(&hl.count[limg], __popcll(hard));
+        pos = __shfl(base, lead) + __popcll(hard & ((1ull << lane) - 1ull));
+      } else {
+        pos = mine ? atomicAdd(&hl.count[img], 1) : 0;
+      }
+      const int skip = (mine && hl.prev && hl.prev[img] > hl.skip) ? 0 : hl.skip;
+      if (mine && pos >= skip) hl.rows[(int64_t)img * hl.cap + pos] = ent.row;
+      hard = __ballot(mine && pos < skip);
+    }
+  }
   while (hard) {
     const int src = __builtin_ctzll(hard);
     hard &= hard - 1;
@@ -578,7 +607,8 @@ __device__ __forceinline__ void exact_rescore16(const SplitEntry ent, const bool
 __global__ __launch_bounds__(256) void assign_requeue_rows_kernel(
     const float *__restrict__ x, int d, const float *__restrict__ cent, int K,
     int32_t *__restrict__ klab, const SplitEntry *__restrict__ gqueue,
-    const int32_t *__restrict__ gcount, const int64_t *__restrict__ img_row0, int B) {
+    const int32_t *__restrict__ gcount, const int64_t *__restrict__ img_row0, int B,
+    const HardList hl = HardList{nullptr, nullptr, 0, 0, nullptr}) {
   __shared__ __attribute__((aligned(16))) float exact_win[4 * kExactStageFloats];
   const int lane = threadIdx.x & 63;
   const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -598,9 +628,124 @@ __global__ __launch_bounds__(256) void assign_requeue_rows_kernel(
         if (img_row0[mid] <= (int64_t)ent.row) img = mid; else hi = mid;
       }
     }
-    exact_rescore16(ent, e < total, img, x, d, cent, K, klab, exact_win + (threadIdx.x >> 6) * kExactStageFloats);
+    exact_rescore16(ent, e < total, img, x, d, cent, K, klab, exact_win + (threadIdx.x >> 6) * kExactStageFloats, hl);
   }
 }
+
+// ---------------------------------------------------------------------------
+// Dense exact pass over the rows that asked for all K centroids (HardList, filled by the exact pass above): units
+// of NW * 32 listed rows of one image against the image's whole table in blocks of 64 centroids on the fp32 matrix
+// pipe -- v_mfma_f32_32x32x2_f32 IS the canonical C1 chain (score_tiles.h), so the label is the exact engine's
+// (first maximum) by construction, no bound involved.  A wave keeps its 32 rows' running best across the table
+// blocks in two registers; the rows are gathered once per block (1 KB each, from L2 after the first).  Work: the
+// grid strides over the units of all images; a workgroup without a unit reads the B counters and leaves.
+struct HardEpi {
+  int kb0, K, first;
+  float *sv;             // LDS [rows of the unit] running best score ...
+  int *si;               // ... and its centroid
+  template <int MB>
+  __device__ inline void operator()(int tile, const f32x16 (&acc)[MB]) const {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const int TPX = (int)(blockDim.x >> 1);
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = kb0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = acc[m][r];
+        if (k < K && v > bv) { bv = v; bi = k; }           // ascending k, strict >: first maximum; NaN never wins
+      }
+    const float ov = __shfl_xor(bv, 32);
+    const int oi = __shfl_xor(bi, 32);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    if (h == 0) {                                          // (a row's state is touched by its own wave only)
+      const int p = tile * TPX + w * 32 + j;
+      if (first || bv > sv[p]) { sv[p] = bv; si[p] = bi; }  // later blocks win only strictly
+    }
+  }
+};
+
+constexpr int kHardMaxTiles = 8;           // tiles of NW * 32 rows per unit at most
+
+template <int NW, int KC, bool EVEN_D>
+__global__ __launch_bounds__(NW * 64) void assign_hard_rows_kernel(
+    const float *__restrict__ x, int d, const float *__restrict__ cent, int K, int B, const HardList hl,
+    int32_t *__restrict__ klab) {
+  constexpr int TPX = NW * 32;
+  extern __shared__ float lds[];
+  float *sv = lds + score_tiles_lds_bytes<64, NW, KC>(d) / 4;
+  int *si = reinterpret_cast<int *>(sv + kHardMaxTiles * TPX);
+  // rows on the lists; the unit grows with them so that a table block is staged once for several tiles
+  auto skip_of = [&](int b) { return (hl.prev && hl.prev[b] > hl.skip) ? 0 : hl.skip; };
+  int64_t total = 0;
+  for (int b = 0; b < B; ++b) total += max(hl.count[b] - skip_of(b), 0);
+  if (total == 0) return;
+  const int64_t tiles_all = (total + TPX - 1) / TPX;
+  const int ut = (int)min((int64_t)kHardMaxTiles, max((int64_t)1, (tiles_all + gridDim.x - 1) / gridDim.x));
+  const int U = ut * TPX;
+  int b = 0, ub = 0;                       // image under the cursor, units before it
+  for (int u = blockIdx.x;; u += gridDim.x) {
+    int nu = 0;
+    while (b < B && u >= ub + (nu = (max(hl.count[b] - skip_of(b), 0) + U - 1) / U)) { ub += nu; ++b; }
+    if (b >= B) return;
+    const int lu = u - ub, skip = skip_of(b);
+    const int nrows = min(hl.count[b] - skip - lu * U, U);
+    const int32_t *list = hl.rows + (int64_t)b * hl.cap + skip + (int64_t)lu * U;
+    for (int kb0 = 0; kb0 < K; kb0 += 64) {
+      __syncthreads();                     // nobody still reads the previous table block (or the previous unit's)
+      HardEpi epi{kb0, K, kb0 == 0, sv, si};
+      score_tiles<64, NW, KC, EVEN_D, HardEpi, int32_t>(x, d, cent + ((int64_t)b * K + kb0) * d, min(64, K - kb0),
+                                                        0, nrows, lds, epi, list);
+    }
+    // (own rows only: the wave that wrote a row's state reads it)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane < 32)
+      for (int t = 0; t * TPX < nrows; ++t) {
+        const int p = t * TPX + w * 32 + lane;
+        if (p < nrows) put_label(klab, list[p], si[p] == 0x7fffffff ? 0 : si[p]);
+      }
+  }
+}
+
+static int hard_skip(int B) {               // HSGK_HARD_SKIP=n: entries per image that stay on the whole-wave path
+  const char *e = getenv("HSGK_HARD_SKIP");
+  if (e) return atoi(e) > 0 ? atoi(e) : 0;
+  return 2048 / B > 64 ? 2048 / B : 64;
+}
+static bool hard_rows_enabled() {          // HSGK_HARD=0: the whole-wave chains inside the exact pass (A/B)
+  const char *e = getenv("HSGK_HARD");
+  return !(e && e[0] == '0');
+}
+
+// the launch that follows an exact pass which was handed `hl`; returns 1 when no configuration fits the row length
+static int launch_assign_hard_rows(const float *x, int d, const float *cent, int K, int B, const HardList hl,
+                                   int32_t *klab, hipStream_t s) {
+  if (!hl.rows || B <= 0) return 0;
+  static const int n_cu = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess)
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus > 0 ? cus : 256;
+  }();
+  const bool even = (d & 1) == 0;
+  auto go = [&](auto kern, size_t lds) -> int {
+    HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(n_cu), dim3(512), lds, s, x, d, cent, K, B, hl, klab);
+    HSGK_LAUNCH_CHECK();
+    return 0;
+  };
+  const size_t st = (size_t)kHardMaxTiles * 256 * 8;
+  const size_t l32 = score_tiles_lds_bytes<64, 8, 32>(d) + st, l16 = score_tiles_lds_bytes<64, 8, 16>(d) + st;
+  if (l32 <= 160 * 1024)
+    return even ? go(assign_hard_rows_kernel<8, 32, true>, l32) : go(assign_hard_rows_kernel<8, 32, false>, l32);
+  if (l16 <= 160 * 1024)
+    return even ? go(assign_hard_rows_kernel<8, 16, true>, l16) : go(assign_hard_rows_kernel<8, 16, false>, l16);
+  return 1;
+}
+static bool hard_rows_fit(int d) { return score_tiles_lds_bytes<64, 8, 16>(d) + (size_t)kHardMaxTiles * 256 * 8 <= 160 * 1024; }
 
 static int launch_assign_split(const float *x, int d, const float *cent, int K, int B,
                                const ChunkTable &t, int max_chunks, int32_t *klab,
@@ -1043,8 +1188,13 @@ bool assign_half_wide_eligible(int d, int K) {
 int launch_assign_half_wide(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent,
                             float *errc, int K, int B, const ChunkTable &t, int max_chunks, int32_t *klab,
                             void *qrows, int32_t *qcount, const hsgk_segkm_meta *meta, hipStream_t s,
-                            bool table_ready) {
+                            bool table_ready, int32_t *hard_rows, int32_t *hard_count, int64_t hard_cap) {
   if (max_chunks <= 0 || B <= 0) return 0;
+  HardList hl{nullptr, nullptr, 0, 0, nullptr};
+  if (hard_rows && hard_count && hard_rows_enabled() && hard_rows_fit(d)) {
+    hl = HardList{hard_rows, hard_count, hard_cap, hard_skip(B), table_ready ? hard_count + B + 1 : nullptr};
+    if (!table_ready) HSGK_CHECK_HIP(hipMemsetAsync(hard_count, 0, sizeof(int32_t) * (size_t)B, s));
+  }
   constexpr int NW = 8, TPX = NW * 32, MB = 4;
   static const int n_cu = [] {
     int dev = 0, cus = 256;
@@ -1071,9 +1221,9 @@ int launch_assign_half_wide(const float *x, const _Float16 *xm, const uint2 *xt,
     HSGK_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(assign_requeue_rows_kernel, dim3(2048), dim3(256), 0, s, x, d, cent, K, klab,
-                     reinterpret_cast<const SplitEntry *>(qrows), qcount, t.img_row0, B);
+                     reinterpret_cast<const SplitEntry *>(qrows), qcount, t.img_row0, B, hl);
   HSGK_LAUNCH_CHECK();
-  return 0;
+  return launch_assign_hard_rows(x, d, cent, K, B, hl, klab, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -2361,7 +2511,7 @@ __global__ __launch_bounds__(512, 2) void assign_half_regs_kernel(
 __global__ __launch_bounds__(256) void assign_requeue_seg_kernel(
     const float *__restrict__ x, int d, const float *__restrict__ cent, int K,
     int32_t *__restrict__ klab, const SplitEntry *__restrict__ gqueue, SegQueue seg, int nseg,
-    const int64_t *__restrict__ img_row0, int B) {
+    const int64_t *__restrict__ img_row0, int B, const HardList hl) {
   __shared__ int pre[1025];
   __shared__ int wsum[4];
   __shared__ __attribute__((aligned(16))) float exact_win[4 * kExactStageFloats];
@@ -2406,7 +2556,7 @@ __global__ __launch_bounds__(256) void assign_requeue_seg_kernel(
         if (img_row0[mid] <= (int64_t)ent.row) img = mid; else hi = mid;
       }
     }
-    exact_rescore16(ent, e < total, img, x, d, cent, K, klab, exact_win + w * kExactStageFloats);
+    exact_rescore16(ent, e < total, img, x, d, cent, K, klab, exact_win + w * kExactStageFloats, hl);
   }
 }
 
@@ -2435,8 +2585,14 @@ bool assign_half_wide2_tiles(int d, int K, int max_chunks) {
 int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt, int d, const float *cent,
                              float *errc, int K, int B, const ChunkTable &t, int max_chunks, int32_t *klab,
                              void *state, void *qrows, int32_t *qcount, const hsgk_segkm_meta *meta,
-                             hipStream_t s, const _Float16 *xmT, bool table_ready) {
+                             hipStream_t s, const _Float16 *xmT, bool table_ready, int32_t *hard_rows,
+                             int32_t *hard_count, int64_t hard_cap) {
   if (max_chunks <= 0 || B <= 0) return 0;
+  HardList hl{nullptr, nullptr, 0, 0, nullptr};
+  if (hard_rows && hard_count && hard_rows_enabled() && hard_rows_fit(d)) {
+    hl = HardList{hard_rows, hard_count, hard_cap, hard_skip(B), table_ready ? hard_count + B + 1 : nullptr};
+    if (!table_ready) HSGK_CHECK_HIP(hipMemsetAsync(hard_count, 0, sizeof(int32_t) * (size_t)B, s));
+  }
   constexpr int NW = 8, TPX = NW * 32, MB = 4;
   static const int n_cu = [] {
     int dev = 0, cus = 256;
@@ -2471,8 +2627,9 @@ int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt
                          klab, reinterpret_cast<SplitEntry *>(qrows), seg, meta);
       HSGK_LAUNCH_CHECK();
       hipLaunchKernelGGL(assign_requeue_seg_kernel, dim3(2048), dim3(256), 0, s, x, d, cent, K, klab,
-                         reinterpret_cast<const SplitEntry *>(qrows), seg, gridt, t.img_row0, B);
+                         reinterpret_cast<const SplitEntry *>(qrows), seg, gridt, t.img_row0, B, hl);
       HSGK_LAUNCH_CHECK();
+      if (int rc = launch_assign_hard_rows(x, d, cent, K, B, hl, klab, s)) return rc;
       return 0;
     }
     if (d / 64 == 4 && two && two[0] == 'r') {
@@ -2487,8 +2644,9 @@ int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt
                          klab, reinterpret_cast<SplitEntry *>(qrows), seg, meta);
       HSGK_LAUNCH_CHECK();
       hipLaunchKernelGGL(assign_requeue_seg_kernel, dim3(2048), dim3(256), 0, s, x, d, cent, K, klab,
-                         reinterpret_cast<const SplitEntry *>(qrows), seg, gridr, t.img_row0, B);
+                         reinterpret_cast<const SplitEntry *>(qrows), seg, gridr, t.img_row0, B, hl);
       HSGK_LAUNCH_CHECK();
+      if (int rc = launch_assign_hard_rows(x, d, cent, K, B, hl, klab, s)) return rc;
       return 0;
     }
     if (two && two[0] == 'o') {                       // "one": the four-wave kernel (one wave per SIMD)
@@ -2506,8 +2664,9 @@ int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt
     }
     HSGK_LAUNCH_CHECK();
     hipLaunchKernelGGL(assign_requeue_seg_kernel, dim3(2048), dim3(256), 0, s, x, d, cent, K, klab,
-                       reinterpret_cast<const SplitEntry *>(qrows), seg, grid1, t.img_row0, B);
+                       reinterpret_cast<const SplitEntry *>(qrows), seg, grid1, t.img_row0, B, hl);
     HSGK_LAUNCH_CHECK();
+    if (int rc = launch_assign_hard_rows(x, d, cent, K, B, hl, klab, s)) return rc;
     return 0;
   }
   if (!table_ready) HSGK_CHECK_HIP(hipMemsetAsync(qcount, 0, sizeof(int32_t), s));
@@ -2523,9 +2682,9 @@ int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt
     HSGK_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(assign_requeue_rows_kernel, dim3(2048), dim3(256), 0, s, x, d, cent, K, klab,
-                     reinterpret_cast<const SplitEntry *>(qrows), qcount, t.img_row0, B);
+                     reinterpret_cast<const SplitEntry *>(qrows), qcount, t.img_row0, B, hl);
   HSGK_LAUNCH_CHECK();
-  return 0;
+  return launch_assign_hard_rows(x, d, cent, K, B, hl, klab, s);
 }
 
 // Level 2: grid (T, B); workgroup (t, b) takes a contiguous slice of image b's queue.

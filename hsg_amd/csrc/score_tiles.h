@@ -40,12 +40,14 @@ __host__ __device__ constexpr size_t score_tiles_lds_bytes(int d) {
 
 // rowlist (nullable): when given, logical row r of the range is the physical
 // row crow0 + rowlist[r] (used by the exact re-scoring pass of the bf16-split
-// E-step, which only visits the queued rows of a chunk).
-template <int KB, int NW, int KC, bool EVEN_D, class Epi>
+// E-step, which only visits the queued rows of a chunk).  RL = int32_t with
+// crow0 = 0: a list of absolute row ids (the dense pass over the rows that ask
+// for all K centroids, kmeans.hip: assign_hard_rows_kernel).
+template <int KB, int NW, int KC, bool EVEN_D, class Epi, class RL = uint16_t>
 __device__ inline void score_tiles(const float *__restrict__ x, int d,
                                    const float *__restrict__ table, int kvalid,
                                    int64_t crow0, int nrows, float *lds, Epi &epi,
-                                   const uint16_t *__restrict__ rowlist = nullptr) {
+                                   const RL *__restrict__ rowlist = nullptr) {
   constexpr int NT = NW * 64;
   constexpr int TPX = NW * 32;
   constexpr int XS = KC + 1;

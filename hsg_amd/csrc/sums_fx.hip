@@ -702,12 +702,16 @@ __global__ __launch_bounds__(512) void update_sums_mfma_kernel(
 __global__ __launch_bounds__(256) void finalize_fx_kernel(const long long *__restrict__ sumq, int d,
                                                           int K, float eps, float *__restrict__ cent,
                                                           int32_t *__restrict__ zero_a, int na,
-                                                          int32_t *__restrict__ zero_b, float *__restrict__ errc) {
+                                                          int32_t *__restrict__ zero_b, float *__restrict__ errc,
+                                                          int32_t *__restrict__ keep_a, int keep_valid) {
   extern __shared__ float row[];    // [d] + 1
   __shared__ float esum[4];
   const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   if (k == 0 && b == 0) {           // queue counters of the E-step that follows
-    for (int i = tid; i < na; i += 256) zero_a[i] = 0;
+    for (int i = tid; i < na; i += 256) {
+      if (keep_a) keep_a[i] = keep_valid ? zero_a[i] : 0;   // (the all-K row lists: last iteration's lengths steer this one's routing)
+      zero_a[i] = 0;
+    }
     if (zero_b && tid == 0) zero_b[0] = 0;
   }
   const long long *src = sumq + ((int64_t)b * K + k) * d;
@@ -913,10 +917,10 @@ int launch_update_sums(const float *x, int d, const int32_t *prev, const int32_t
 }
 
 int launch_finalize_fx(const long long *sumq, int d, int K, int B, float eps, float *cent, hipStream_t s,
-                       int32_t *zero_a, int na, int32_t *zero_b, float *errc) {
+                       int32_t *zero_a, int na, int32_t *zero_b, float *errc, int32_t *keep_a, bool keep_valid) {
   if (B <= 0 || K <= 0) return 0;
   hipLaunchKernelGGL(finalize_fx_kernel, dim3(K, B), dim3(256), (size_t)(d + 1) * 4, s, sumq, d, K, eps,
-                     cent, zero_a, zero_a ? na : 0, zero_b, errc);
+                     cent, zero_a, zero_a ? na : 0, zero_b, errc, zero_a ? keep_a : nullptr, keep_valid ? 1 : 0);
   HSGK_LAUNCH_CHECK();
   return 0;
 }

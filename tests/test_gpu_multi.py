@@ -86,9 +86,10 @@ def _dist_worker(rank, world, port, result_dir, backend, same_device, library_co
     part = util.exchange_inputs(int(g['seed']))[rank]
     T = lambda k: torch.from_numpy(part[k]).to(dev)
     emb = T('emb').requires_grad_(True)
+    emb_loc = T('emb_loc').requires_grad_(True)
     before = mu.collective_calls
     protos, protos_loc, psem, pinst, pbatch, upd = mu.gather_clustering_and_update_prototypes(
-        emb, T('emb_loc'), T('cluster'), T('batch'), T('sem'), T('inst'))
+        emb, emb_loc, T('cluster'), T('batch'), T('sem'), T('inst'))
     assert mu.collective_calls - before == 2
     assert np.array_equal(psem.cpu().numpy(), g['psem'])
     assert np.array_equal(pinst.cpu().numpy(), g['pinst'])
@@ -101,8 +102,8 @@ def _dist_worker(rank, world, port, result_dir, backend, same_device, library_co
     want = orc.exchange_prototypes(util.exchange_inputs(int(g['seed'])))
     assert np.array_equal(protos.detach().cpu().numpy().view(np.uint32), want[0].view(np.uint32))
     assert np.array_equal(protos_loc.detach().cpu().numpy().view(np.uint32), want[1].view(np.uint32))
-    protos.sum().backward()
-    assert emb.grad is not None and torch.isfinite(emb.grad).all() and float(emb.grad.abs().sum()) > 0
+    # the gradient that crosses the collective, against the reference's own autograd (f8: gemb / gloc)
+    util.check_exchange_grads(g, rank, protos, protos_loc, emb, emb_loc)
     # too small tuple blocks: every rank regrows from the gathered header counts and repeats
     mu._capacity.clear()
     saved, mu._CAP_START = mu._CAP_START, 8

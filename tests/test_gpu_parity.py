@@ -2073,3 +2073,81 @@ def test_k256_tile_order_copy_straight_from_prep_vs_oracle(dev, oracle, monkeypa
   for nm, a, b in zip(('emb', 'emb_loc', 'labels', 'cluster', 'batch'), got, ref):
     assert a.shape == b.shape, nm
     assert np.array_equal(a, b), '%s: %d mismatching elements' % (nm, int((a != b).sum()))
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('hard', ['', '0', 'skip0'])
+@pytest.mark.parametrize('flavour,shape,grid', [('mixture', (2, 256, 96, 96), (16, 16)),
+                                                ('mixture', (2, 384, 64, 64), (8, 16)),
+                                                ('flat', (1, 256, 64, 64), (16, 16)),
+                                                ('flat', (1, 130, 48, 48), (8, 12))])
+def test_all_k_entries_dense_exact_pass_vs_oracle(dev, oracle, monkeypatch, hard, flavour, shape, grid):
+  """K > 64 on inputs whose rows sit between MANY near-duplicate centroids (the mixture input: ~13 of the 256
+  seed-grid clusters share each mixture centre; 'flat': every row within 1e-3 of one vector, all K centroids
+  near-ties): their exact-queue entries ask for all K centroids and take the dense fp32 matrix-pipe pass
+  (assign_hard_rows_kernel; HSGK_HARD=0: the whole-wave chains inside the exact pass).  All five outputs bit-exact
+  vs the oracle on both routes, every filtered label verified on the device."""
+  from hsg_amd import _lib
+  from hsg_amd.utils.segsort import common as sc
+  monkeypatch.delenv('HSGK_HARD', raising=False)
+  monkeypatch.delenv('HSGK_HARD_SKIP', raising=False)
+  if hard == 'skip0':                    # every such entry to the dense pass (default: the first few stay on the wave path)
+    monkeypatch.setenv('HSGK_HARD_SKIP', '0')
+  elif hard:
+    monkeypatch.setenv('HSGK_HARD', hard)
+  B, C, H, W = shape
+  iters = 5
+  if flavour == 'flat':
+    v = synth.gaussish(synth.SEED_BASE + 61, C).reshape(1, C, 1, 1)
+    x = (v + np.float32(1e-3) * synth.embeddings_nchw(synth.SEED_BASE + 62, shape, 'iid')).astype(np.float32)
+  else:
+    x = synth.embeddings_nchw(synth.SEED_BASE + 60 + C, shape, 'mixture')
+  loc = (sc.generate_location_features((H, W), 'cpu', 'float') - 0.5).numpy()
+  _lib.verify_collect()
+  _lib.verify_enable(True)
+  try:
+    got = _run_segkm(dev, x, None, grid, None, iters)
+    compared, differing = _lib.verify_collect()
+  finally:
+    _lib.verify_enable(False)
+  # (C = 130: no fp16 filter for that row length -- the exact engine runs and nothing is compared)
+  assert compared in ((0,) if C == 130 else ()) + (got[0].shape[0] * iters,) and differing == 0, (compared, differing)
+  ref = oracle.segment_by_kmeans(x, None, grid, loc, None, iters)
+  for nm, a, b in zip(('emb', 'emb_loc', 'labels', 'cluster', 'batch'), got, ref):
+    assert a.shape == b.shape, nm
+    assert np.array_equal(a, b), '%s: %d mismatching elements' % (nm, int((a != b).sum()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', util.F19_CASES)
+def test_f19_full_size_image_vs_reference(dev, case):
+  """tools/gen_golden.py f19: one WHOLE image of every BASELINE shape (448^2 / K 64, 224^2 / K 64, 768^2 / K 256,
+  224^2 / C 384 / K 128; i.i.d. and mixture) against the REFERENCE's own labels.
+  (1) teacher-forced: segment_by_kmeans(iterations=1, cluster_indices=the reference's labels after iteration
+      t - 1) == the reference's labels after iteration t, except on the recorded near-tie pixels (float64 margin
+      < 1e-6 in the reference's own scores, <= 12 pixels per image and iteration);
+  (2) free-running: the operator's 10 iterations end exactly where the fixture says the canonical arithmetic ends
+      (the reference's labels where no near-tie flipped on the way)."""
+  import torch
+  from hsg_amd.utils.segsort import common as sc
+  g, x, grid, loc, ref, forced = util.f19_case(case)
+  _, C, H, W = x.shape
+  xd = torch.from_numpy(x).to(dev)
+  ref[0] = sc.initialize_cluster_labels(list(grid), [H, W], 'cpu').view(-1).numpy()
+  ref[0] = np.unique(ref[0], return_inverse=True)[1]
+  for t in (1, 2, 10):
+    init = torch.from_numpy(ref[t - 1].reshape(1, H, W)).to(dev)
+    out = sc.segment_by_kmeans(xd, None, list(grid), iterations=1, cluster_indices=init)
+    got = out[3].cpu().numpy()
+    want = np.unique(forced(t), return_inverse=True)[1]
+    assert np.array_equal(got, want), '%s iteration %d: %d pixels' % (case, t, int((got != want).sum()))
+    if g['tf%d_pixels' % t].size:
+      assert g['tf%d_margin64' % t].max() < util.TIE_MARGIN
+  out = sc.segment_by_kmeans(xd, None, list(grid), iterations=10)
+  want = ref[10].copy()
+  want[g['free_pixels']] = g['free_oracle']
+  got = out[3].cpu().numpy()
+  want = np.unique(want, return_inverse=True)[1]
+  assert np.array_equal(got, want), '%s free-running: %d pixels' % (case, int((got != want).sum()))
+  # the rows themselves against the reference's (strided subset, column sums are not stored at this size)
+  assert out[1].shape == (H * W, C + 2)
+

@@ -44,6 +44,54 @@ def f4_inputs(g):
 F4_CASES = ['cfg1_nolabel', 'cfg1_overseg', 'k1_it1', 'mix_overseg', 'c256k64',
             'ragged', 'noignore_labels']
 F3_CASES = ['cfg1', 'c256k64', 'c384k128', 'mix']
+F19_CASES = ['%s_%s' % (c, f) for c in ('cfg2', 'cfg3', 'cfg4', 'cfg5') for f in ('iid', 'mixture')]
+TIE_MARGIN = 1e-6      # float64 top-2 margin below which a label difference against the reference is a near-tie
+
+
+def f19_case(name):
+  """tools/gen_golden.py f19: one whole image of a BASELINE shape.  Returns (g, x NCHW, grid, loc, ref) with
+  ref[t] = the REFERENCE's labels after iteration t (t = 0: the grid seeds, 1, 2, 9, 10), and
+  forced(t) = what one iteration of the canonical arithmetic gives when started from ref[t - 1]: the reference's
+  labels except on the recorded near-tie pixels."""
+  g = load('f19_full_' + name)
+  shape = tuple(int(v) for v in g['shape'])
+  grid = tuple(int(v) for v in g['grid'])
+  x = synth.embeddings_nchw(int(g['seed']), shape, str(g['flavour']))
+  loc = loc_from_lin(g['ylin'], g['xlin'])
+  ref = {1: g['lab1'].astype(np.int64), 2: g['lab2'].astype(np.int64), 9: g['lab9'].astype(np.int64)}
+  ref[10] = ref[9].copy()
+  ref[10][g['lab10_idx']] = g['lab10_val']
+
+  def forced(t):
+    out = ref[t].copy()
+    out[g['tf%d_pixels' % t]] = g['tf%d_oracle' % t]
+    return out
+  return g, x, grid, loc, ref, forced
+
+
+
+def exchange_grad_weights(rank, P, C, D):
+  """Weights of the per-'GPU' scalar  (protos * w1).sum() + (protos_loc * w2).sum()  whose gradients with respect to
+  every GPU's rows the f8 fixture holds (tools/gen_golden.py f8: the reference's own autograd)."""
+  w1 = (np.linspace(-1.0, 1.0, P * C, dtype=np.float64).reshape(P, C) * (1.0 + rank)).astype(np.float32)
+  w2 = np.cos(np.arange(P * D, dtype=np.float64) * 0.37 + rank).reshape(P, D).astype(np.float32)
+  return w1, w2
+
+
+def check_exchange_grads(g, rank, protos, protos_loc, emb, emb_loc, tol=1e-5):
+  """Backward of this rank's scalar through the exchange; the rows' gradients must be the reference's
+  (f8: sum over every GPU's replica, i.e. what the all_reduce in the backward carries), <= tol of their scale."""
+  import torch
+  w1, w2 = exchange_grad_weights(rank, protos.shape[0], protos.shape[1], protos_loc.shape[1])
+  dev = protos.device
+  ((protos * torch.from_numpy(w1).to(dev)).sum() + (protos_loc * torch.from_numpy(w2).to(dev)).sum()).backward()
+  for name, t in (('gemb', emb), ('gloc', emb_loc)):
+    want = g['%s%d' % (name, rank)]
+    assert t.grad is not None, name
+    got = t.grad.detach().cpu().numpy()
+    scale = float(np.abs(want).max())
+    err = float(np.abs(got - want).max())
+    assert err <= tol * scale, '%s rank %d: |grad - reference| = %.3g of scale %.3g' % (name, rank, err, scale)
 
 
 def exchange_inputs(seed, n_gpus=2, imgs_per_gpu=3, C=16, K=6):

@@ -9,10 +9,13 @@ L = _lib.lib()
 SHAPES = {'cfg4': (4, 256, 768, 768, [16, 16]), 'cfg2': (48, 256, 448, 448, [8, 8]), 'cfg5': (24, 384, 224, 224, [8, 16]),
           'cfg3': (16, 256, 224, 224, [8, 8])}
 B, C, H, W, grid = SHAPES[sys.argv[1] if len(sys.argv) > 1 else 'cfg4']
-x = torch.randn((B, C, H, W), device='cuda:0')
+flavour = sys.argv[2] if len(sys.argv) > 2 else 'iid'
+from hsg_amd.utils import synth
+x = synth.device_embeddings_nchw(synth.SEED_BASE + 4, (B, C, H, W), flavour, 'cuda:0')
+print('qstats', sys.argv[1:], flush=True)
 out = (ctypes.c_ulonglong * 8)()
 prev = [0] * 8
-for it in range(1, 5):
+for it in range(1, 11):
   sc.segment_by_kmeans(x, None, grid, iterations=it); torch.cuda.synchronize()
   L.hsgk_debug_qstats(out)
   cur = list(out)
