@@ -66,43 +66,64 @@ WORKLOADS = {
     'reftrain': (8, 4, 128, 56, 56, (4, 4), 15),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
-PMC_FILES = ('r04_cfg2_pmc.txt', 'r03_cfg2_pmc.txt', 'r02_pmc.txt', 'r01_pmc.txt')
 
 
-def pmc_traffic(kernels, files=None):
-  """HBM bytes per launch of the given kernels from the committed rocprofv3 counter passes
-  (profiles/rNN_pmc.txt, collected by tools/collect_profiles.sh with one --pmc pass per
-  counter group), corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE (KB)
-  tallies 128-byte requests at 64 B, so it is doubled; WRITE_SIZE (KB) is taken as is (it
-  matches the expected bytes of the prep and label writes within 2 %).  Calibration on these
-  very access patterns: 2 x FETCH_SIZE of assign_half_kernel = 5.07 GB for 5.05 GB streamed,
-  of the M-step's full pass 10.2 GB for 9.98 GB.  (None, None) when no file has them."""
-  for fname in (files or PMC_FILES):
+def pmc_files(workload):
+  """Committed counter passes of one workload, newest round first (tools/collect_profiles_rNN.sh)."""
+  names = ['r%02d_%s_pmc.txt' % (r, workload) for r in range(9, 2, -1)]
+  if workload == 'cfg2':
+    names += ['r02_pmc.txt', 'r01_pmc.txt']
+  return names
+
+
+# launch groups by what the kernels are NAMED in the library (the E-step kernels are all `assign_*`, plus the table's
+# rounding-error pass; the M-step `update_sums*` / `m0_reduce*` / `xk_sums*`; the prep kernel `prep_*`), so that a
+# renamed or new filter kernel cannot leave a stale list here
+PMC_GROUPS = {'assign': ('assign_', 'centroid_half_err'), 'accumulate': ('update_sums', 'm0_reduce', 'xk_sums'),
+              'prep': ('prep_',)}
+
+
+def pmc_traffic(group, workload):
+  """HBM bytes of one launch group from the committed rocprofv3 counter passes of `workload`
+  (profiles/rNN_<workload>_pmc.txt: one --pmc pass per counter group, means per dispatch and dispatch counts),
+  corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE (KB) tallies 128-byte requests at 64 B, so
+  it is doubled; WRITE_SIZE (KB) is taken as is.  The group's kernels are found by name prefix (PMC_GROUPS);
+  bytes per group instance = sum over its kernels of mean x dispatches / dispatches of the group's most frequent
+  kernel (one instance = one E-step of one Lloyd iteration, one M-step launch, one prep launch).
+  Returns (bytes, source, kernels, commit) or (None, None, None, None)."""
+  import re
+  for fname in pmc_files(workload):
     path = os.path.join(ROOT, 'profiles', fname)
     try:
       lines = open(path).read().splitlines()
     except OSError:
       continue
-    vals, kern = {}, None
+    vals, kern, commit = {}, None, None
     for ln in lines:
       if ln.startswith('#'):
+        m = re.search(r'commit ([0-9a-f]{7,40})', ln)
+        if m:
+          commit = m.group(1)
         continue
       if ln and not ln.startswith(' '):
         kern = ln.strip()
         continue
       parts = ln.split()
       if len(parts) >= 2 and parts[0] in ('FETCH_SIZE', 'WRITE_SIZE') and kern:
-        vals.setdefault(kern, {})[parts[0]] = float(parts[1]) * 1024.0      # KB -> B
-    total, ok = 0.0, True
-    for k in kernels:
-      hit = [v for name, v in vals.items() if k in name]
-      if not hit:
-        ok = False
-        break
-      total += 2.0 * hit[0].get('FETCH_SIZE', 0.0) + hit[0].get('WRITE_SIZE', 0.0)
-    if ok:
-      return int(total), 'profiles/' + fname
-  return None, None
+        m = re.search(r'n=(\d+)', ln)
+        vals.setdefault(kern, {})[parts[0]] = (float(parts[1]) * 1024.0, int(m.group(1)) if m else 1)   # KB -> B
+    hits = {k: v for k, v in vals.items() if any(pre in k for pre in PMC_GROUPS[group])}
+    hits = {k: v for k, v in hits.items() if 'FETCH_SIZE' in v and 'WRITE_SIZE' in v}
+    if not hits:
+      continue
+    # (an E-step instance launches every kernel of its group; an M-step instance ONE of its group's kernels)
+    counts = [v['FETCH_SIZE'][1] for v in hits.values()]
+    n_ref = sum(counts) if group == 'accumulate' else max(counts)
+    total = 0.0
+    for v in hits.values():
+      total += (2.0 * v['FETCH_SIZE'][0] * v['FETCH_SIZE'][1] + v['WRITE_SIZE'][0] * v['WRITE_SIZE'][1]) / n_ref
+    return int(total), 'profiles/' + fname, sorted(hits), commit
+  return None, None, None, None
 
 
 def free_port():
@@ -482,76 +503,67 @@ def main():
   a_ms, a_n = prof['assign']
   headline = args.workload == 'cfg2' and B == 48 and args.flavour == 'iid' and not args.labels
 
-  def rl(kernel, algorithmic, moved, moved_source, ms, n, **extra):
-    """achieved / frac: the bytes the launch moves through HBM over its duration; algorithmic_*:
-    SURVEY 8(d)'s per-pixel figure over the same duration."""
+  def rl(kernel, algorithmic, moved, moved_source, ms, n, commit=None, **extra):
+    """achieved / frac: the bytes the launch group moves through HBM (committed PMC counters of this workload, or a
+    by-construction count) over its duration measured in THIS run; both are null when neither source exists --
+    SURVEY 8(d)'s algorithmic bytes over the same time are reported next to them but are not a bandwidth (the
+    filter level reads a half-size copy, the update kernel only the changed rows)."""
     if not n:
       return None
     avg_s = ms / n * 1e-3
-    ach = moved / avg_s / 1e9
     alg = algorithmic / avg_s / 1e9
-    res = {'bound': 'hbm', 'kernel': kernel, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
-           'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-           'traffic': int(moved) if moved_source.startswith('profiles/') else None,
-           'bytes_source': moved_source, 'traffic_measured_in_this_run': False,
+    ach = moved / avg_s / 1e9 if moved else None
+    res = {'bound': 'hbm', 'kernel': kernel, 'achieved': round(ach, 1) if ach else None, 'peak': HBM_PEAK_GBS,
+           'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4) if ach else None,
+           'traffic': int(moved) if moved and moved_source.startswith('profiles/') else None,
+           'bytes_source': moved_source, 'traffic_measured_in_this_run': False, 'traffic_counters_commit': commit,
            'avg_launch_ms': round(ms / n, 4), 'launches': int(n),
            'algorithmic_bytes_per_launch': int(algorithmic),
-           # SURVEY 8(d)'s per-pixel bytes over the same time: NOT a roofline fraction (the filter level reads a
-           # half-size copy of the rows, so this rate can exceed what the memory system delivers)
            'algorithmic_bytes_over_time_GBps': round(alg, 1)}
     res.update(extra)
     return res
 
+  # counters apply to the workload's own per-GPU batch on the i.i.d. input without a label map (what was profiled)
+  profiled = args.flavour == 'iid' and not args.labels and B == WORKLOADS[args.workload][1]
   half_ok = (D % 64 == 2 and 128 <= D <= 322 and (D // 64) % 2 == 0 and K <= 64)
   e_alg = (4 * D + 8) * npx
-  e_moved, e_src = e_alg, 'algorithmic (the exact engine reads every fp32 row once)'
-  if half_ok:
+  e_moved, e_src, e_names, e_commit = None, 'no counter pass committed for this workload / input', None, None
+  if profiled:
+    tr, src, names, commit = pmc_traffic('assign', args.workload)
+    if tr:
+      e_moved, e_names, e_commit = tr, names, commit
+      e_src = src + ': 2 x FETCH_SIZE + WRITE_SIZE summed over the group (gfx950 correction of MI355X_MICROARCH.md)'
+  if e_moved is None and half_ok:
     e_moved = (2 * (D - 2) + 8 + 4 + 0.015 * 4 * D) * npx
     e_src = 'by construction: fp16 row copy 2(D-2)+8 B + 4 B label per pixel + the fp32 rows of ~1.5 % undecided pixels'
-  if headline and half_ok:
-    tr, src = pmc_traffic(['assign_half_kernel', 'assign_split_rows_kernel', 'assign_requeue_rows_kernel'])
-    if tr:
-      e_moved, e_src = tr, src + ': 2 x FETCH_SIZE + WRITE_SIZE summed over the group (gfx950 correction of MI355X_MICROARCH.md)'
-  # the other per-GPU configs at their default batch: counters of profiles/r03_<workload>_pmc.txt (same passes)
-  group = {'cfg3': ['assign_half_wide_kernel', 'assign_requeue_rows_kernel'],
-           'cfg4': ['assign_half_pair_kernel', 'assign_requeue_seg_kernel', 'centroid_half_err_kernel'],
-           'cfg5': ['assign_half_wide_kernel', 'assign_requeue_rows_kernel', 'centroid_half_err_kernel']}.get(args.workload)
-  e_kernel = None
-  if group and args.flavour == 'iid' and not args.labels and B == WORKLOADS[args.workload][1]:
-    tr, src = pmc_traffic(group, ['r03_%s_pmc.txt' % args.workload])
-    if tr:
-      e_moved, e_src = tr, src + ': 2 x FETCH_SIZE + WRITE_SIZE summed over the group (gfx950 correction of MI355X_MICROARCH.md)'
-      e_kernel = 'E-step launch group (dominant by time): ' + ' + '.join(group)
   roofline = rl(
-      'E-step launch group (dominant by time): assign_half_kernel (fp16 filter over the fp16 row '
-      'copy) + assign_split_rows_kernel (bf16x3 on the undecided rows) + assign_requeue_rows_kernel '
-      '(exact fp32 chains)' if half_ok and not e_kernel else (e_kernel or 'E-step launch group (dominant by time)'),
-      e_alg, e_moved, e_src, a_ms, a_n,
+      'E-step launch group (dominant by time)' + (': ' + ' + '.join(e_names) if e_names else ''),
+      e_alg, e_moved, e_src, a_ms, a_n, e_commit,
       mfma_tflops=round(2.0 * D * K * npx / (a_ms / max(a_n, 1) * 1e-3) / 1e12, 2) if a_n else None)
 
   m_alg = 4 * D * npx
-  m_moved, m_src = m_alg, 'algorithmic upper bound (one read of every fp32 row; the update reads only changed rows)'
+  m_moved, m_src, m_commit = None, 'no counter pass committed for this workload / input', None
   pr_alg = (8 * C + 4 * D + 24) * npx
-  pr_moved, pr_src = pr_alg + (2 * C + 12) * npx, 'by construction: input + both float outputs + labels + the fp16 row copy'
-  if headline:
-    t_u, s_u = pmc_traffic(['update_sums_persistent_kernel'])
-    t_r, _ = pmc_traffic(['m0_reduce_kernel'])
-    if t_u and t_r and iters >= 1:          # per call: one reduce + (iterations - 1) updates
-      m_moved, m_src = ((iters - 1) * t_u + t_r) / iters, s_u + ': 2 x FETCH_SIZE + WRITE_SIZE, averaged over the call\'s M-step launches'
-    t_p, s_p = pmc_traffic(['prep_fast32_kernel'])
+  pr_moved, pr_src, pr_commit = pr_alg + (2 * C + 12) * npx, 'by construction: input + both float outputs + labels + the fp16 row copy', None
+  if profiled:
+    t_m, s_m, _, c_m = pmc_traffic('accumulate', args.workload)
+    if t_m:        # (mean over the call's M-step launches: one m0_reduce / first update + (iterations - 1) updates)
+      m_moved, m_src, m_commit = t_m, s_m + ': 2 x FETCH_SIZE + WRITE_SIZE, mean over the call\'s M-step launches', c_m
+    t_p, s_p, _, c_p = pmc_traffic('prep', args.workload)
     if t_p:
-      pr_moved, pr_src = t_p, s_p + ': 2 x FETCH_SIZE + WRITE_SIZE'
+      pr_moved, pr_src, pr_commit = t_p, s_p + ': 2 x FETCH_SIZE + WRITE_SIZE', c_p
   roofline_mstep = rl(
       'M-step: exact fixed-point segment sums.  The first M-step of a call is summed inside the prep '
-      'kernel (seed-grid labels) and folded by m0_reduce_kernel; the other launches are the update_sums '
-      'kernel, which reads only the rows whose label changed', m_alg, m_moved, m_src, m_ms, m_n)
+      'kernel (seed-grid labels) and folded by m0_reduce_kernel where the prep kernel can; the other launches are the '
+      'update_sums kernel, which reads only the rows whose label changed', m_alg, m_moved, m_src, m_ms, m_n, m_commit)
   roofline_prep = rl('prep kernel (NCHW -> normalised rows, both float outputs, labels, fp16 copy, first M-step)',
-                     pr_alg, pr_moved, pr_src, p_ms, p_n)
+                     pr_alg, pr_moved, pr_src, p_ms, p_n, pr_commit)
   roofline_iteration = None
   if m_n and a_n and f_n:
     it_ms = m_ms / m_n + f_ms / f_n + a_ms / a_n
-    roofline_iteration = rl('one Lloyd iteration = sums update + finalize + E-step group',
-                            e_alg, e_moved + m_moved, 'sum of the E-step and M-step figures above', it_ms, 1)
+    roofline_iteration = rl('one Lloyd iteration = sums update + finalize + E-step group', e_alg,
+                            (e_moved + m_moved) if (e_moved and m_moved) else None,
+                            'sum of the E-step and M-step figures above', it_ms, 1, e_commit)
     roofline_iteration['launches'] = int(a_n)
   phases = {k: round(v[0] / max(1, args.steps), 3) for k, v in prof.items()}
 

@@ -189,7 +189,9 @@ static void carve_kmeans(Carver &cv, int B, int64_t rows_per_img, int d, int K,
         d / 64 == 4 && rows_per_img % 32 == 0)
       k->xhT = cv.take<_Float16>(((size_t)B * rows_per_img + kHalfSlackRowsHost) * half_main_cols_host(d) + 8);
     k->q1 = cv.take<int32_t>((size_t)B * rows_per_img + 1);
-    k->q1count = cv.take<int32_t>(2 * ((size_t)B + 1));   // [B] lengths (+ [B] of the previous iteration: all-K lists)
+    // K <= 64: [B] lengths of the fp16 level's row queues; wider filters: the all-K row lists' lengths, one 128-byte
+    // line per image (kmeans.hip: kHardStride), followed by the previous iteration's
+    k->q1count = cv.take<int32_t>(2 * ((size_t)B + 1) * 32);
   }
   k->cent_multi = nullptr;
   if (k->sumq && assign_half_eligible(d, K) && rows_per_img <= 16 * 1024)       // small maps only (lloyd_small_groups)
@@ -302,10 +304,10 @@ static int lloyd(const float *x, int d, int K, int B, int iterations,
         counters_zeroed = half || ((wide || wide2) && k.errc);
         // (k.q1 / k.q1count: the fp16 level's row queues when K <= 64, the all-K row lists of the wider filters)
         if (int rc = launch_finalize_fx(k.sumq, d, K, B, HSGK_EPS, k.cent, s,
-                                        (half || counters_zeroed) ? k.q1count : nullptr, B,
+                                        (half || counters_zeroed) ? k.q1count : nullptr, half ? B : B * 32,
                                         counters_zeroed ? k.qcount : nullptr,
                                         (wide || wide2) ? k.errc : nullptr,
-                                        (!half && counters_zeroed) ? k.q1count + B + 1 : nullptr, it > 0)) return rc; }
+                                        (!half && counters_zeroed) ? k.q1count + (size_t)(B + 1) * 32 : nullptr, it > 0)) return rc; }
     } else {
       { ProfScope p(HSGK_PROF_ACCUMULATE, s);
         if (int rc = launch_accumulate(x, d, cur, k.t, k.max_chunks, K, k.partial, k.pmask, meta, s)) return rc; }
@@ -699,7 +701,9 @@ int hsgk_lloyd_requeued_rows(int B, int64_t rows_per_image, int d, int K, void *
   hipLaunchKernelGGL(sum_qcount_kernel, dim3(1), dim3(256), 0, s, k.qcount, 1, out);
   HSGK_LAUNCH_CHECK();
   if (k.q1count) {                 // rows the fp16 level left to the bf16x3 level (unit_rows = 2)
-    hipLaunchKernelGGL(sum_qcount_kernel, dim3(1), dim3(256), 0, s, k.q1count, B, out + 1);
+    // (K > 64: the all-K row lists' lengths, one 128-byte line per image)
+    hipLaunchKernelGGL(sum_qcount_kernel, dim3(1), dim3(256), 0, s, k.q1count, assign_half_eligible(d, K) ? B : B * 32,
+                       out + 1);
     HSGK_LAUNCH_CHECK();
   } else {
     HSGK_CHECK_HIP(hipMemsetAsync(out + 1, 0, sizeof(int64_t), s));

@@ -514,14 +514,72 @@ __device__ __forceinline__ float exact_chain_coop(const float *__restrict__ ct, 
 // The first `skip` such entries of an image stay on the whole-wave path below (a few hundred per iteration on i.i.d.
 // rows: cheaper than the dense pass's start-up), list positions [skip, count) go to the dense pass.
 // prev (nullable): the images' counts of the previous Lloyd iteration -- an image that had more than `skip` such
-// rows then will have them again and the dense pass will run anyway, so all of its entries go to the list (the
-// whole-wave path costs ~0.1 us per entry: 2 048 of them 0.2 ms per iteration at 4 x 768^2, mixture input).
-struct HardList { int32_t *rows; int32_t *count; int64_t cap; int skip; const int32_t *prev; };   // [B][cap] ids, [B] lengths
+// rows then will have them again and the dense pass will run anyway, so all of its entries go to the list.
+// Counters sit kHardStride ints apart (one 128-byte line per image, `prev` in lines of its own): a line that takes
+// atomics serialises everything else that touches it (profiles/r05_hard_routing_ab.txt: a plain load of `prev`
+// from the counters' line made the exact pass 2.5 x slower).
+constexpr int kHardStride = 32;
+struct HardList { int32_t *rows; int32_t *count; int64_t cap; int skip; const int32_t *prev; };   // [B][cap] ids
+// A wave collects its all-K rows in a wave-private LDS buffer and publishes them 48 - 64 at a time: one global
+// atomic per flush and image instead of one per batch of 16 entries (31 k -> 2 k per iteration at 4 x 768^2).
+constexpr int kHardBuf = 64;
+struct HardBuf { int32_t *row; int32_t *img; int n; };
+
+// one row against all K centroids on the whole wave: lane = centroid k0 + lane, first maximum wins
+__device__ __forceinline__ void exact_all_k(const int row, const int himg, const float *__restrict__ x, int d,
+                                            const float *__restrict__ cent, int K, int32_t *__restrict__ klab) {
+  const int lane = threadIdx.x & 63;
+  float hv = -INFINITY;
+  int hi = 0x7fffffff;
+  for (int k0 = 0; k0 < K; k0 += 64) {
+    const int k = k0 + lane;
+    float a = -INFINITY;
+    if (k < K) a = exact_chain(cent + ((int64_t)himg * K + k) * d, x + (int64_t)row * d, d);
+    if (k < K && a == a && a > hv) { hv = a; hi = k; }
+  }
+  if (hi == 0x7fffffff) hi = lane;                         // (all NaN: lowest lane index, as before)
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(hv, off);
+    const int oi = __shfl_xor(hi, off);
+    if (ov > hv || (ov == hv && oi < hi)) { hv = ov; hi = oi; }
+  }
+  if (lane == 0) put_label(klab, row, hi < K ? hi : 0);
+}
+
+__device__ __forceinline__ void hard_flush(HardBuf &hb, const HardList hl, const float *__restrict__ x, int d,
+                                           const float *__restrict__ cent, int K, int32_t *__restrict__ klab) {
+  const int lane = threadIdx.x & 63;
+  const bool have = lane < hb.n;
+  const int row = have ? hb.row[lane] : 0, img = have ? hb.img[lane] : 0;
+  unsigned long long todo = __ballot(have), inkernel = 0ull;
+  while (todo) {
+    const int lead = __builtin_ctzll(todo);
+    const int limg = __builtin_amdgcn_readlane(img, lead);
+    const unsigned long long grp = __ballot(have && img == limg) & todo;
+    int base = 0;
+    if (lane == lead) base = atomicAdd(&hl.count[limg * kHardStride], __popcll(grp));
+    base = __shfl(base, lead);
+    const bool in = (grp >> lane) & 1ull;
+    const int pos = base + __popcll(grp & ((1ull << lane) - 1ull));
+    const int skip = (hl.prev && hl.prev[limg * kHardStride] > hl.skip) ? 0 : hl.skip;
+    if (in && pos >= skip) hl.rows[(int64_t)limg * hl.cap + pos] = row;
+    inkernel |= __ballot(in && pos < skip);
+    todo &= ~grp;
+  }
+  hb.n = 0;
+  while (inkernel) {
+    const int src = __builtin_ctzll(inkernel);
+    inkernel &= inkernel - 1;
+    exact_all_k(__builtin_amdgcn_readlane(row, src), __builtin_amdgcn_readlane(img, src), x, d, cent, K, klab);
+  }
+}
+
 __device__ __forceinline__ void exact_rescore16(const SplitEntry ent, const bool have, const int img,
                                                 const float *__restrict__ x, int d,
                                                 const float *__restrict__ cent, int K,
                                                 int32_t *__restrict__ klab, float *__restrict__ win = nullptr,
-                                                const HardList hl = HardList{nullptr, nullptr, 0, 0, nullptr}) {
+                                                const HardList hl = HardList{nullptr, nullptr, 0, 0, nullptr},
+                                                HardBuf *hb = nullptr) {
   const int lane = threadIdx.x & 63;
   const int ci = lane & 3;
   const int n = have ? (int)(ent.cand >> 24) : 0;
@@ -563,44 +621,23 @@ __device__ __forceinline__ void exact_rescore16(const SplitEntry ent, const bool
   if (ci == 0 && n >= 1 && n <= 7) put_label(klab, ent.row, bi == 0x7fffffff ? 0 : bi);
   // entries that need all K centroids
   unsigned long long hard = __ballot(ci == 0 && n == 255);
-  if (hl.rows) {
+  if (hl.rows && hb) {
     if (hard) {
       const bool mine = ci == 0 && n == 255;
-      const int lead = __builtin_ctzll(hard);
-      const int limg = __builtin_amdgcn_readlane(img, lead);
-      int pos;
-      if (__ballot(mine && img != limg) == 0ull) {          // (usual case) one image: one atomic for the wave's batch
-        int base = 0;
-        if (lane == lead) base = atomicAdd(&hl.count[limg], __popcll(hard));
-        pos = __shfl(base, lead) + __popcll(hard & ((1ull << lane) - 1ull));
-      } else {
-        pos = mine ? atomicAdd(&hl.count[img], 1) : 0;
+      if (mine) {
+        const int p = hb->n + __popcll(hard & ((1ull << lane) - 1ull));
+        hb->row[p] = ent.row;
+        hb->img[p] = img;
       }
-      const int skip = (mine && hl.prev && hl.prev[img] > hl.skip) ? 0 : hl.skip;
-      if (mine && pos >= skip) hl.rows[(int64_t)img * hl.cap + pos] = ent.row;
-      hard = __ballot(mine && pos < skip);
+      hb->n += __popcll(hard);
+      if (hb->n > kHardBuf - 16) hard_flush(*hb, hl, x, d, cent, K, klab);
     }
+    return;
   }
   while (hard) {
     const int src = __builtin_ctzll(hard);
     hard &= hard - 1;
-    const int row = __builtin_amdgcn_readlane(ent.row, src);
-    const int himg = __builtin_amdgcn_readlane(img, src);
-    float hv = -INFINITY;
-    int hi = 0x7fffffff;
-    for (int k0 = 0; k0 < K; k0 += 64) {                    // lane = centroid k0 + lane, first maximum wins
-      const int k = k0 + lane;
-      float a = -INFINITY;
-      if (k < K) a = exact_chain(cent + ((int64_t)himg * K + k) * d, x + (int64_t)row * d, d);
-      if (k < K && a == a && a > hv) { hv = a; hi = k; }
-    }
-    if (hi == 0x7fffffff) hi = lane;                         // (all NaN: lowest lane index, as before)
-    for (int off = 32; off > 0; off >>= 1) {
-      const float ov = __shfl_xor(hv, off);
-      const int oi = __shfl_xor(hi, off);
-      if (ov > hv || (ov == hv && oi < hi)) { hv = ov; hi = oi; }
-    }
-    if (lane == 0) put_label(klab, row, hi < K ? hi : 0);
+    exact_all_k(__builtin_amdgcn_readlane(ent.row, src), __builtin_amdgcn_readlane(img, src), x, d, cent, K, klab);
   }
 }
 
@@ -610,6 +647,8 @@ __global__ __launch_bounds__(256) void assign_requeue_rows_kernel(
     const int32_t *__restrict__ gcount, const int64_t *__restrict__ img_row0, int B,
     const HardList hl = HardList{nullptr, nullptr, 0, 0, nullptr}) {
   __shared__ __attribute__((aligned(16))) float exact_win[4 * kExactStageFloats];
+  __shared__ int32_t hard_buf[4][2][kHardBuf];
+  HardBuf hb{hard_buf[threadIdx.x >> 6][0], hard_buf[threadIdx.x >> 6][1], 0};
   const int lane = threadIdx.x & 63;
   const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
@@ -628,8 +667,10 @@ __global__ __launch_bounds__(256) void assign_requeue_rows_kernel(
         if (img_row0[mid] <= (int64_t)ent.row) img = mid; else hi = mid;
       }
     }
-    exact_rescore16(ent, e < total, img, x, d, cent, K, klab, exact_win + (threadIdx.x >> 6) * kExactStageFloats, hl);
+    exact_rescore16(ent, e < total, img, x, d, cent, K, klab, exact_win + (threadIdx.x >> 6) * kExactStageFloats, hl,
+                    &hb);
   }
+  if (hl.rows && hb.n) hard_flush(hb, hl, x, d, cent, K, klab);
 }
 
 // ---------------------------------------------------------------------------
@@ -678,9 +719,10 @@ __global__ __launch_bounds__(NW * 64) void assign_hard_rows_kernel(
   float *sv = lds + score_tiles_lds_bytes<64, NW, KC>(d) / 4;
   int *si = reinterpret_cast<int *>(sv + kHardMaxTiles * TPX);
   // rows on the lists; the unit grows with them so that a table block is staged once for several tiles
-  auto skip_of = [&](int b) { return (hl.prev && hl.prev[b] > hl.skip) ? 0 : hl.skip; };
+  auto skip_of = [&](int b) { return (hl.prev && hl.prev[b * kHardStride] > hl.skip) ? 0 : hl.skip; };
+  auto count_of = [&](int b) { return hl.count[b * kHardStride]; };
   int64_t total = 0;
-  for (int b = 0; b < B; ++b) total += max(hl.count[b] - skip_of(b), 0);
+  for (int b = 0; b < B; ++b) total += max(count_of(b) - skip_of(b), 0);
   if (total == 0) return;
   const int64_t tiles_all = (total + TPX - 1) / TPX;
   const int ut = (int)min((int64_t)kHardMaxTiles, max((int64_t)1, (tiles_all + gridDim.x - 1) / gridDim.x));
@@ -688,10 +730,10 @@ __global__ __launch_bounds__(NW * 64) void assign_hard_rows_kernel(
   int b = 0, ub = 0;                       // image under the cursor, units before it
   for (int u = blockIdx.x;; u += gridDim.x) {
     int nu = 0;
-    while (b < B && u >= ub + (nu = (max(hl.count[b] - skip_of(b), 0) + U - 1) / U)) { ub += nu; ++b; }
+    while (b < B && u >= ub + (nu = (max(count_of(b) - skip_of(b), 0) + U - 1) / U)) { ub += nu; ++b; }
     if (b >= B) return;
     const int lu = u - ub, skip = skip_of(b);
-    const int nrows = min(hl.count[b] - skip - lu * U, U);
+    const int nrows = min(count_of(b) - skip - lu * U, U);
     const int32_t *list = hl.rows + (int64_t)b * hl.cap + skip + (int64_t)lu * U;
     for (int kb0 = 0; kb0 < K; kb0 += 64) {
       __syncthreads();                     // nobody still reads the previous table block (or the previous unit's)
@@ -709,10 +751,143 @@ __global__ __launch_bounds__(NW * 64) void assign_hard_rows_kernel(
   }
 }
 
+// The same pass with the rows gathered ONCE: a wave pulls its 32 listed rows through a wave-private LDS window in
+// 32-column chunks (128 contiguous bytes of a row per 16 lanes) straight into the registers the matrix instruction
+// takes its B operand from -- NFULL * 16 + 1 of them per lane (d = 32 NFULL + 2: 66, 130, 258) -- and keeps them
+// there while the image's table streams through LDS in blocks of 64 centroids; the next block is on its way into
+// registers while this one is scored.  The pass above re-gathers every row once per table block, and the gather
+// (1 KB rows from all over the image, 128 bytes at a time) is what bounds it: 100 k rows of 4 x 768^2 took 0.35 ms
+// per iteration, the matrix work alone is 0.09.  Running best per lane in two registers, first maximum wins.
+template <int NFULL>
+__global__ __launch_bounds__(512) void assign_hard_regs_kernel(
+    const float *__restrict__ x, const float *__restrict__ cent, int K, int B, const HardList hl,
+    int32_t *__restrict__ klab) {
+  constexpr int NW = 8, TPX = NW * 32, D = 32 * NFULL + 2, NS = 16 * NFULL + 1, DP = D | 1, XS = 33;
+  constexpr int F2 = 64 * (D / 2), TB = (F2 + 511) / 512;        // float2 elements of a table block, per thread
+  extern __shared__ float lds[];
+  float *cent_s = lds;                                            // [64][DP]
+  float *xw = lds + 64 * DP + (threadIdx.x >> 6) * (32 * XS);     // this wave's window [32][XS]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, h = lane >> 5;
+  auto skip_of = [&](int b) { return (hl.prev && hl.prev[b * kHardStride] > hl.skip) ? 0 : hl.skip; };
+  auto count_of = [&](int b) { return hl.count[b * kHardStride]; };
+  int64_t total = 0;
+  for (int b = 0; b < B; ++b) total += max(count_of(b) - skip_of(b), 0);
+  if (total == 0) return;
+  float2 tb[TB];
+  auto prefetch = [&](const float *src, int kvalid) {             // table block -> registers (rows >= kvalid: zero)
+#pragma unroll
+    for (int u = 0; u < TB; ++u) {
+      const int f = tid + 512 * u;
+      const int k = f / (D / 2);
+      tb[u] = (f < F2 && k < kvalid) ? *reinterpret_cast<const float2 *>(src + 2 * (int64_t)f) : make_float2(0.0f, 0.0f);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < TB; ++u) {
+      const int f = tid + 512 * u;
+      if (f < F2) {
+        const int k = f / (D / 2), col = 2 * (f - k * (D / 2));
+        cent_s[k * DP + col] = tb[u].x;
+        cent_s[k * DP + col + 1] = tb[u].y;
+      }
+    }
+  };
+  int b = 0, ub = 0;
+  for (int u = blockIdx.x;; u += gridDim.x) {
+    int nu = 0;
+    while (b < B && u >= ub + (nu = (max(count_of(b) - skip_of(b), 0) + TPX - 1) / TPX)) { ub += nu; ++b; }
+    if (b >= B) return;
+    const int lu = u - ub, skip = skip_of(b);
+    const int nrows = min(count_of(b) - skip - lu * TPX, TPX);
+    const int32_t *list = hl.rows + (int64_t)b * hl.cap + skip + (int64_t)lu * TPX;
+    const float *ct = cent + (int64_t)b * K * D;
+    prefetch(ct, min(64, K));
+    // ---- gather: rows of this wave -> xr (B operand of k-step st: column 2 st + h of row j)
+    float xr[NS];
+    {
+      const int n = nrows - w * 32;                               // rows this wave owns (<= 0: it idles along)
+      const int lpx = lane >> 4, lf2 = lane & 15;
+      const float *rp[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int px = max(min(lpx + 4 * i, n - 1), -(w * 32));   // rows past the end re-read a valid one
+        rp[i] = x + (int64_t)list[w * 32 + px] * D + 2 * lf2;
+      }
+      float2 pre[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) pre[i] = *reinterpret_cast<const float2 *>(rp[i]);
+#pragma unroll
+      for (int q = 0; q < NFULL; ++q) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          xw[(lpx + 4 * i) * XS + 2 * lf2] = pre[i].x;
+          xw[(lpx + 4 * i) * XS + 2 * lf2 + 1] = pre[i].y;
+        }
+        if (q + 1 < NFULL) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) pre[i] = *reinterpret_cast<const float2 *>(rp[i] + 32 * (q + 1));
+        }
+        // (wave-private window: LDS operations of a wave execute in order)
+#pragma unroll
+        for (int st = 0; st < 16; ++st) xr[16 * q + st] = xw[j * XS + 2 * st + h];
+      }
+      const int jc = max(min(j, n - 1), -(w * 32));
+      xr[NS - 1] = x[(int64_t)list[w * 32 + jc] * D + 32 * NFULL + h];
+    }
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    __syncthreads();                       // the previous unit's last table block is not read any more
+    commit();
+    __syncthreads();
+    for (int kb0 = 0; kb0 < K; kb0 += 64) {
+      if (kb0 + 64 < K) prefetch(ct + (int64_t)(kb0 + 64) * D, min(64, K - kb0 - 64));
+      f32x16 acc[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+      const float *cb = cent_s + j * DP + h;
+      float a0 = cb[0], a1 = cb[32 * DP];
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        float n0 = 0.0f, n1 = 0.0f;
+        if (st + 1 < NS) { n0 = cb[2 * st + 2]; n1 = cb[32 * DP + 2 * st + 2]; }
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, xr[st], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, xr[st], acc[1], 0, 0, 0);
+        a0 = n0;
+        a1 = n1;
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = kb0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float v = acc[m][r];
+          if (k < K && v > bv) { bv = v; bi = k; }           // ascending k, strict >: first maximum; NaN never wins
+        }
+      if (kb0 + 64 < K) {
+        __syncthreads();                   // every wave is done with this block
+        commit();
+        __syncthreads();
+      }
+    }
+    const float ov = __shfl_xor(bv, 32);
+    const int oi = __shfl_xor(bi, 32);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    const int px = w * 32 + j;
+    if (h == 0 && px < nrows) put_label(klab, list[px], bi == 0x7fffffff ? 0 : bi);
+  }
+}
+
 static int hard_skip(int B) {               // HSGK_HARD_SKIP=n: entries per image that stay on the whole-wave path
   const char *e = getenv("HSGK_HARD_SKIP");
   if (e) return atoi(e) > 0 ? atoi(e) : 0;
   return 2048 / B > 64 ? 2048 / B : 64;
+}
+static bool hard_prev_enabled() {          // HSGK_HARD_PREV=0: the skip budget regardless of the last iteration's counts (A/B)
+  const char *e = getenv("HSGK_HARD_PREV");
+  return !(e && e[0] == '0');
 }
 static bool hard_rows_enabled() {          // HSGK_HARD=0: the whole-wave chains inside the exact pass (A/B)
   const char *e = getenv("HSGK_HARD");
@@ -729,6 +904,23 @@ static int launch_assign_hard_rows(const float *x, int d, const float *cent, int
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     return cus > 0 ? cus : 256;
   }();
+  {
+    // rows gathered once into registers (d = 66 / 130 / 258); HSGK_HARD=lds: the pass that streams them per block
+    const char *e = getenv("HSGK_HARD");
+    auto regs = [&](auto kern, int nfull) -> int {
+      const size_t lds = ((size_t)64 * ((32 * nfull + 2) | 1) + (size_t)8 * 32 * 33) * 4;
+      HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, dim3(n_cu), dim3(512), lds, s, x, cent, K, B, hl, klab);
+      HSGK_LAUNCH_CHECK();
+      return 0;
+    };
+    if (!(e && e[0] == 'l')) {
+      if (d == 258) return regs(assign_hard_regs_kernel<8>, 8);
+      if (d == 130) return regs(assign_hard_regs_kernel<4>, 4);
+      if (d == 66) return regs(assign_hard_regs_kernel<2>, 2);
+    }
+  }
   const bool even = (d & 1) == 0;
   auto go = [&](auto kern, size_t lds) -> int {
     HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -1192,8 +1384,8 @@ int launch_assign_half_wide(const float *x, const _Float16 *xm, const uint2 *xt,
   if (max_chunks <= 0 || B <= 0) return 0;
   HardList hl{nullptr, nullptr, 0, 0, nullptr};
   if (hard_rows && hard_count && hard_rows_enabled() && hard_rows_fit(d)) {
-    hl = HardList{hard_rows, hard_count, hard_cap, hard_skip(B), table_ready ? hard_count + B + 1 : nullptr};
-    if (!table_ready) HSGK_CHECK_HIP(hipMemsetAsync(hard_count, 0, sizeof(int32_t) * (size_t)B, s));
+    hl = HardList{hard_rows, hard_count, hard_cap, hard_skip(B), table_ready && hard_prev_enabled() ? hard_count + (size_t)(B + 1) * kHardStride : nullptr};
+    if (!table_ready) HSGK_CHECK_HIP(hipMemsetAsync(hard_count, 0, sizeof(int32_t) * (size_t)B * kHardStride, s));
   }
   constexpr int NW = 8, TPX = NW * 32, MB = 4;
   static const int n_cu = [] {
@@ -2515,7 +2707,9 @@ __global__ __launch_bounds__(256) void assign_requeue_seg_kernel(
   __shared__ int pre[1025];
   __shared__ int wsum[4];
   __shared__ __attribute__((aligned(16))) float exact_win[4 * kExactStageFloats];
+  __shared__ int32_t hard_buf[4][2][kHardBuf];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  HardBuf hb{hard_buf[w][0], hard_buf[w][1], 0};
   // exclusive prefix of the segment counts (four per thread)
   int c[4], tot = 0;
 #pragma unroll
@@ -2556,8 +2750,9 @@ __global__ __launch_bounds__(256) void assign_requeue_seg_kernel(
         if (img_row0[mid] <= (int64_t)ent.row) img = mid; else hi = mid;
       }
     }
-    exact_rescore16(ent, e < total, img, x, d, cent, K, klab, exact_win + w * kExactStageFloats, hl);
+    exact_rescore16(ent, e < total, img, x, d, cent, K, klab, exact_win + w * kExactStageFloats, hl, &hb);
   }
+  if (hl.rows && hb.n) hard_flush(hb, hl, x, d, cent, K, klab);
 }
 
 static bool wide1_fits(int d) { return (d / 64 == 4 || d / 64 == 2) && half_lds_bytes<4, 8, 1, 1>(d) + 64 <= 160 * 1024; }
@@ -2590,8 +2785,8 @@ int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt
   if (max_chunks <= 0 || B <= 0) return 0;
   HardList hl{nullptr, nullptr, 0, 0, nullptr};
   if (hard_rows && hard_count && hard_rows_enabled() && hard_rows_fit(d)) {
-    hl = HardList{hard_rows, hard_count, hard_cap, hard_skip(B), table_ready ? hard_count + B + 1 : nullptr};
-    if (!table_ready) HSGK_CHECK_HIP(hipMemsetAsync(hard_count, 0, sizeof(int32_t) * (size_t)B, s));
+    hl = HardList{hard_rows, hard_count, hard_cap, hard_skip(B), table_ready && hard_prev_enabled() ? hard_count + (size_t)(B + 1) * kHardStride : nullptr};
+    if (!table_ready) HSGK_CHECK_HIP(hipMemsetAsync(hard_count, 0, sizeof(int32_t) * (size_t)B * kHardStride, s));
   }
   constexpr int NW = 8, TPX = NW * 32, MB = 4;
   static const int n_cu = [] {
