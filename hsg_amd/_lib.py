@@ -198,19 +198,31 @@ def verify_collect():
   return int(a.value), int(b.value)
 
 
-# ---- deferred device-side error flags ---------------------------------------
-# Data-dependent errors (a label outside [0, P)) are detected by the kernels.  Reading the
-# flag right away would cost a host sync per call, so the flag is copied to pinned host
-# memory behind the kernels and looked at by later libhsgk calls once its event has
-# completed -- the error surfaces asynchronously, like a device-side assert of the
-# reference on a GPU.  HSGK_SYNC_ERRORS=1 checks immediately (one sync per call).
+# ---- device-side error flags ------------------------------------------------
+# Data-dependent errors (a label outside [0, P)) are detected by the kernels.
+# * The reference-shaped functional entry points (calculate_prototypes_from_labels with an explicit max_label)
+#   read the flag AT THE CALL and raise there, as the reference does on CPU inside scatter_add_ (one host sync per
+#   call; HSGK_SYNC_ERRORS=0 opts out).
+# * The model-internal callers (labels in range by construction) and everything under HSGK_SYNC_ERRORS=0 keep the
+#   host out of it: the flag is copied to pinned host memory behind the kernels and looked at by later libhsgk calls
+#   once its event has completed -- the error surfaces asynchronously, like the reference's device-side assert on
+#   a GPU.  HSGK_SYNC_ERRORS=1 checks immediately everywhere.
 _deferred_lock = threading.Lock()
 _deferred = []          # (event, pinned int32[1], message)
 
 
-def defer_status(status_dev, message):
+def sync_errors_default():
+  """Whether the reference-shaped functional entry points read their error flag AT the call (the reference on CPU
+  raises inside `scatter_add_`): yes unless HSGK_SYNC_ERRORS=0."""
+  return os.environ.get('HSGK_SYNC_ERRORS') != '0'
+
+
+def defer_status(status_dev, message, at_call=False):
+  """at_call: read the flag now (one host sync) unless HSGK_SYNC_ERRORS=0; otherwise the flag travels behind the
+  kernels and a later libhsgk call raises (at once with HSGK_SYNC_ERRORS=1)."""
   import torch
-  if os.environ.get('HSGK_SYNC_ERRORS') == '1':
+  env = os.environ.get('HSGK_SYNC_ERRORS')
+  if env == '1' or (at_call and env != '0'):
     if int(status_dev.item()) != 0:
       raise HsgkError(message)
     return

@@ -3557,6 +3557,11 @@ int launch_lloyd_small(const float *x, const _Float16 *xm, const uint2 *xt, int 
   const bool deep = ((d / 64) & 3) == 0;
   const size_t lds = (size_t)small_layout(d, K).total;
   int G = (cent_multi && !single_group) ? lloyd_small_groups(B, rows_per_image) : 1;   // (no scratch for private centroids: one workgroup per image)
+  // Under stream capture the two-in-flight admission below cannot be applied (a graph may replay on any number of
+  // streams at once): one workgroup per image where the map allows it, else the co-operative launch, whose grid the
+  // runtime itself checks for co-residency.
+  const bool capturing = G > 1 && stream_capturing(s);
+  if (capturing && rows_per_image <= kSmallRowsMax) G = 1;
   auto go = [&](auto kern) -> int {
     HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -3581,7 +3586,7 @@ int launch_lloyd_small(const float *x, const _Float16 *xm, const uint2 *xt, int 
       return 0;
     };
     if (G <= 1) return plain();                // one workgroup per image waits for nobody
-    if (small_coop_enabled()) {
+    if (small_coop_enabled() || capturing) {
       // (the runtime rejects a grid that cannot be resident at once -- hipErrorCooperativeLaunchTooLarge)
       return small_admit(s, [&]() -> int {
         const int64_t *img_row0 = t.img_row0;

@@ -206,7 +206,10 @@ struct LossFwdEpiFast {
   // OWN (wave-uniform too): some row of the wave's tile has its own prototype inside this block.  A row's own
   // prototype sits in ONE of the table's blocks, so with 48 blocks about half of the 32-row tiles have none here and
   // skip the compare / select / add per score that collects it.
-  template <int M, int R0, int NR, bool ALL = false, bool OWN = true>
+  // BRANCH (the default engine's call through pieces()): a label set whose kappa equals the previous set's -- the
+  // usual case -- reuses that set's exponential behind a wave-uniform branch; the pipelined engine keeps the
+  // branch-free form (one scheduling region) and evaluates it regardless.
+  template <int M, int R0, int NR, bool ALL = false, bool OWN = true, bool BRANCH = false>
   __device__ inline void piece(State &st, const f32x16 &accm) const {
     const int64_t *bl = st.bl;
 #pragma unroll
@@ -229,15 +232,31 @@ struct LossFwdEpiFast {
         st.diff0 += sm ? 0.0f : x0;
       }
       if constexpr (L > 1) {
-        float x1 = EXP2 ? __builtin_amdgcn_exp2f(a * st.kl1) : expf(a * st.k1);
-        x1 = st.e1 ? (live ? x1 : 0.0f) : x0;
+        float x1 = x0;
+        if constexpr (BRANCH) {
+          if (st.e1) {
+            x1 = EXP2 ? __builtin_amdgcn_exp2f(a * st.kl1) : expf(a * st.k1);
+            x1 = live ? x1 : 0.0f;
+          }
+        } else {
+          x1 = EXP2 ? __builtin_amdgcn_exp2f(a * st.kl1) : expf(a * st.k1);
+          x1 = st.e1 ? (live ? x1 : 0.0f) : x0;
+        }
         const bool sm = bl[kMaskWords * 64 + pl] == st.s1;
         if constexpr (OWN) st.own1 += isown ? x1 : 0.0f;
         st.same1 += sm ? x1 : 0.0f;
         st.diff1 += sm ? 0.0f : x1;
         if constexpr (L > 2) {
-          float x2 = EXP2 ? __builtin_amdgcn_exp2f(a * st.kl2) : expf(a * st.k2);
-          x2 = st.e2 ? (live ? x2 : 0.0f) : x1;
+          float x2 = x1;
+          if constexpr (BRANCH) {
+            if (st.e2) {
+              x2 = EXP2 ? __builtin_amdgcn_exp2f(a * st.kl2) : expf(a * st.k2);
+              x2 = live ? x2 : 0.0f;
+            }
+          } else {
+            x2 = EXP2 ? __builtin_amdgcn_exp2f(a * st.kl2) : expf(a * st.k2);
+            x2 = st.e2 ? (live ? x2 : 0.0f) : x1;
+          }
           const bool sm2 = bl[(kMaskWords + 1) * 64 + pl] == st.s2;
           if constexpr (OWN) st.own2 += isown ? x2 : 0.0f;
           st.same2 += sm2 ? x2 : 0.0f;
@@ -265,13 +284,13 @@ struct LossFwdEpiFast {
     for (int m = 0; m < MB; ++m) {
       // (keeps the scheduler from hoisting all 32 x L label reads and exps of a tile: spills with L >= 2)
       __builtin_amdgcn_sched_barrier(0);
-      if (m == 0) { piece<0, 0, 4, ALL, OWN>(st, acc[0]); __builtin_amdgcn_sched_barrier(0); piece<0, 4, 4, ALL, OWN>(st, acc[0]);
-                    __builtin_amdgcn_sched_barrier(0); piece<0, 8, 4, ALL, OWN>(st, acc[0]); __builtin_amdgcn_sched_barrier(0);
-                    piece<0, 12, 4, ALL, OWN>(st, acc[0]); }
-      else { piece<1, 0, 4, ALL, OWN>(st, acc[MB > 1 ? 1 : 0]); __builtin_amdgcn_sched_barrier(0);
-             piece<1, 4, 4, ALL, OWN>(st, acc[MB > 1 ? 1 : 0]); __builtin_amdgcn_sched_barrier(0);
-             piece<1, 8, 4, ALL, OWN>(st, acc[MB > 1 ? 1 : 0]); __builtin_amdgcn_sched_barrier(0);
-             piece<1, 12, 4, ALL, OWN>(st, acc[MB > 1 ? 1 : 0]); }
+      if (m == 0) { piece<0, 0, 4, ALL, OWN, true>(st, acc[0]); __builtin_amdgcn_sched_barrier(0); piece<0, 4, 4, ALL, OWN, true>(st, acc[0]);
+                    __builtin_amdgcn_sched_barrier(0); piece<0, 8, 4, ALL, OWN, true>(st, acc[0]); __builtin_amdgcn_sched_barrier(0);
+                    piece<0, 12, 4, ALL, OWN, true>(st, acc[0]); }
+      else { piece<1, 0, 4, ALL, OWN, true>(st, acc[MB > 1 ? 1 : 0]); __builtin_amdgcn_sched_barrier(0);
+             piece<1, 4, 4, ALL, OWN, true>(st, acc[MB > 1 ? 1 : 0]); __builtin_amdgcn_sched_barrier(0);
+             piece<1, 8, 4, ALL, OWN, true>(st, acc[MB > 1 ? 1 : 0]); __builtin_amdgcn_sched_barrier(0);
+             piece<1, 12, 4, ALL, OWN, true>(st, acc[MB > 1 ? 1 : 0]); }
     }
   }
   template <int MB>

@@ -634,6 +634,34 @@ __device__ unsigned long long g_prep_ts[8];
 #else
 #define HSGK_TS(i) do { } while (0)
 #endif
+// HSGK_PREP_NT (build-time A/B, tools/probes/ab_prep_nt.sh): the three row streams as nontemporal stores
+#ifdef HSGK_PREP_NT
+__device__ __forceinline__ void nt_store(float4 *p, float4 v) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(f4v{v.x, v.y, v.z, v.w}, reinterpret_cast<f4v *>(p));
+}
+__device__ __forceinline__ void nt_store(float2 *p, float2 v) {
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  __builtin_nontemporal_store(f2v{v.x, v.y}, reinterpret_cast<f2v *>(p));
+}
+template <class T> __device__ __forceinline__ void nt_store(T *p, T v) { __builtin_nontemporal_store(v, p); }
+#define HSGK_ROW_STORE(p, v) nt_store(p, v)
+#else
+#define HSGK_ROW_STORE(p, v) (*(p) = (v))
+#endif
+// HSGK_PREP_MARKSTEIN (build-time A/B): x / n as q0 = x * r, q = fma(fma(-q0, n, x), r, q0) with r = 1 / n correctly
+// rounded once per row (Markstein's correction step) instead of the ~11-instruction IEEE division sequence
+#ifdef HSGK_PREP_MARKSTEIN
+#define HSGK_DIV_SETUP(n, r) const float r = 1.0f / (n);
+__device__ __forceinline__ float div_markstein(float x, float n, float r) {
+  const float q0 = x * r;
+  return fmaf(fmaf(-q0, n, x), r, q0);
+}
+#define HSGK_DIV(x, n, r) div_markstein(x, n, r)
+#else
+#define HSGK_DIV_SETUP(n, r)
+#define HSGK_DIV(x, n, r) ((x) / (n))
+#endif
 __global__ __launch_bounds__(256) void prep_fast32_kernel(
     const float *__restrict__ in, int C, int64_t HW, int ntiles,
     const float *__restrict__ loc, int64_t loc_sb, const int64_t *__restrict__ labels,
@@ -783,11 +811,12 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
   // phase 2b
   {
     const float n1 = nrm1[jl];
+    HSGK_DIV_SETUP(n1, r1)
     float *r = tile + jl * C;
     for (int q = 2 * w + sub; q < NQ; q += 8) {
       float4 *pv = reinterpret_cast<float4 *>(r + ((q ^ sw) << 2));
       float4 v = *pv;
-      v.x = v.x / n1; v.y = v.y / n1; v.z = v.z / n1; v.w = v.w / n1;
+      v.x = HSGK_DIV(v.x, n1, r1); v.y = HSGK_DIV(v.y, n1, r1); v.z = HSGK_DIV(v.z, n1, r1); v.w = HSGK_DIV(v.w, n1, r1);
       *pv = v;
     }
   }
@@ -837,6 +866,7 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     const int64_t row = rowi[j];
     if (row < 0) continue;
     const float n2 = nrm2[j];
+    HSGK_DIV_SETUP(n2, r2)
     if (norms_out && lane == 0) { norms_out[2 * row] = nrm1[j]; norms_out[2 * row + 1] = n2; }
     const float *r = tile + j * C;
     float *eo = emb + row * C;
@@ -858,18 +888,18 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     }
     for (int q = lane; q < NQ; q += 64) {
       const float4 v = *reinterpret_cast<const float4 *>(r + ((q ^ sj) << 2));
-      *reinterpret_cast<float4 *>(eo + 4 * q) = v;
+      HSGK_ROW_STORE(reinterpret_cast<float4 *>(eo + 4 * q), v);
       float2 a, c2;
-      a.x = v.x / n2; a.y = v.y / n2; c2.x = v.z / n2; c2.y = v.w / n2;
-      *reinterpret_cast<float2 *>(lo + 4 * q) = a;
-      *reinterpret_cast<float2 *>(lo + 4 * q + 2) = c2;
+      a.x = HSGK_DIV(v.x, n2, r2); a.y = HSGK_DIV(v.y, n2, r2); c2.x = HSGK_DIV(v.z, n2, r2); c2.y = HSGK_DIV(v.w, n2, r2);
+      HSGK_ROW_STORE(reinterpret_cast<float2 *>(lo + 4 * q), a);
+      HSGK_ROW_STORE(reinterpret_cast<float2 *>(lo + 4 * q + 2), c2);
       if (m0on) {                            // (uniform)
         const long long f0 = to_fixed(a.x), f1 = to_fixed(a.y), f2 = to_fixed(c2.x), f3 = to_fixed(c2.y);
         cur[0] += f0; cur[1] += f1; cur[2] += f2; cur[3] += f3;     // (C <= 256 with the fusion on: one column pass)
       }
       if (ho || tmode) {
         const h4 hv = {(_Float16)a.x, (_Float16)a.y, (_Float16)c2.x, (_Float16)c2.y};
-        if (ho) *reinterpret_cast<h4 *>(ho + 4 * q) = hv;
+        if (ho) HSGK_ROW_STORE(reinterpret_cast<h4 *>(ho + 4 * q), hv);
         // tile order: the four halves wait in the quad's own LDS slot (read above by this lane, by nobody else)
         if (tmode) *reinterpret_cast<h4 *>(const_cast<float *>(r) + ((q ^ sj) << 2)) = hv;
         const float e0 = a.x - (float)hv[0], e1 = a.y - (float)hv[1];       // exact residuals

@@ -112,6 +112,14 @@ def calculate_kmeans_prototypes(cluster_embeddings, cluster_indices, cluster_bat
     B, most = torch.stack([first.sum(), run.max()]).tolist()           # the shape of the tables: one host read
   if M is None:
     M = most + 1                                     # (a cluster carries one label: segments == distinct clusters)
+  if P == 0 and M <= 0:
+    # no kept pixel at all and no fixed table width (the Cityscapes twin): the reference's loop runs zero times and
+    # its stacks are empty -- empty tables, no library call
+    C = cluster_embeddings.shape[-1]
+    e = cluster_embeddings.new_zeros((0, C, 0))
+    el = torch.zeros((0, 0), dtype=torch.long, device=dev)
+    return (e, e.clone() if cluster_pos_embeddings is not None else None, torch.zeros((0, 0), dtype=torch.bool, device=dev),
+            el, el.clone(), torch.zeros((0,), dtype=torch.long, device=dev))
   if most >= M:
     raise IndexError('an image has more than max_num_clusters=%d segments' % M)
   # One pass (hsgk_pad_prototype_tables) places every segment at (dense image number, rank inside its image) of the
@@ -158,7 +166,7 @@ def calculate_kmeans_prototypes(cluster_embeddings, cluster_indices, cluster_bat
     order = _group_order(pixel_image)
   if order is not None:
     cluster_indices_by_image = cluster_indices_by_image[order]
-  ops.note(cluster_indices_by_image, 'pixel_image', (pixel_image, order))
+  ops.note(cluster_indices_by_image, 'pixel_image', (pixel_image, order, object()))
   prototypes = table.view(B, M, C).permute(0, 2, 1)
   pos_prototypes = ptab.view(B, M, -1).permute(0, 2, 1) if ptab is not None else None
   return (prototypes, pos_prototypes, masks.view(B, M), plabs.view(B, M), pbatch.view(B, M),
@@ -301,6 +309,15 @@ def collect_nd_coarser_prototype(prototypes, prototype_grouping_labels,
 
 
 # ---------------------------------------------------------------------------
+def vouch_pixel_images(cluster_indices_by_image, pixel_image_indices):
+  """The caller states that `pixel_image_indices` is the per-pixel image-id vector `cluster_indices_by_image` (a
+  result of calculate_kmeans_prototypes) was built from: collect_pixel_hierarchical_clustering_indices may then use
+  the dense image numbers found there instead of deriving them again."""
+  known = ops.noted(cluster_indices_by_image, 'pixel_image')
+  if known is not None:
+    ops.note(pixel_image_indices, 'pixel_image_token', known[2])
+
+
 def collect_pixel_hierarchical_clustering_indices(cluster_indices_by_batch,
                                                   cluster_batch_indices,
                                                   finehrchy_prototype_grouping_labels):
@@ -310,8 +327,16 @@ def collect_pixel_hierarchical_clustering_indices(cluster_indices_by_batch,
   concatenated image by image, exactly as the reference's loop does."""
   ops.require_gpu(cluster_indices_by_batch, 'cluster_indices_by_batch')
   seg = cluster_indices_by_batch.view(-1).long().contiguous()
-  known = ops.noted(cluster_indices_by_batch, 'pixel_image')       # left by calculate_kmeans_prototypes
-  img, order = known if known is not None and known[0].shape[0] == seg.shape[0] else _dense_image_index(cluster_batch_indices)
+  # The dense image numbers calculate_kmeans_prototypes left on its result are used only when the caller has
+  # vouched (vouch_pixel_images) that `cluster_batch_indices` is the id vector they were derived from; ids of any
+  # other origin (view ids, ids of another batch) go through the reference's own lookup (:751-780).
+  known = ops.noted(cluster_indices_by_batch, 'pixel_image')
+  token = ops.noted(cluster_batch_indices, 'pixel_image_token')
+  if (known is not None and token is not None and token is known[2] and known[0].shape[0] == seg.shape[0]
+      and cluster_batch_indices.shape[0] == seg.shape[0]):
+    img, order = known[0], known[1]
+  else:
+    img, order = _dense_image_index(cluster_batch_indices)
   table = finehrchy_prototype_grouping_labels.long().contiguous()
   out = torch.empty_like(seg)
   if seg.numel() == 0:

@@ -127,7 +127,10 @@ def _generate_clusters(self, embeddings, semantic_labels, instance_labels, image
   else:
     pixel_image_indices = cluster_batch_indices
   # (the dense image number of every pixel and the image-by-image order were found while the prototype tables
-  #  were built; they ride on `cluster_indices_by_image` -- ops.note -- instead of a second `unique` + order check)
+  #  were built; they ride on `cluster_indices_by_image` -- ops.note -- instead of a second `unique` + order check.
+  #  This caller vouches that `pixel_image_indices` is the id vector those tables were built from; any other
+  #  caller of the method gets the reference's lookup from the ids it passes)
+  hierarchy.vouch_pixel_images(cluster_indices_by_image, pixel_image_indices)
   finehrchy_cluster_indices = self._collect_pixel_hierarchical_clustering_indices(
       cluster_indices_by_image, pixel_image_indices, fine_labels)
   coarsehrchy_cluster_indices = self._collect_pixel_hierarchical_clustering_indices(

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 import hsg_amd.utils.segsort.common as segsort_common
+from hsg_amd import ops
 import hsg_amd.utils.segsort.eval as segsort_eval
 import hsg_amd.utils.segsort.loss as segsort_loss
 
@@ -56,8 +57,8 @@ class Segsort(nn.Module):
       return None, None
     _, cluster_indices = torch.unique(cluster_indices, return_inverse=True)
     num_prototypes = int(cluster_indices.max()) + 1
-    prototypes = segsort_common.calculate_prototypes_from_labels(cluster_embeddings, cluster_indices,
-                                                                 num_prototypes)
+    # (labels dense by construction: the functional entry point's at-the-call error read is not needed)
+    prototypes = ops.segment_reduce(cluster_embeddings, cluster_indices, num_prototypes, 0)
     idx, _ = segsort_eval.top_k_indices(prototypes, memory_prototypes, 20)
     top_k_labels = memory_prototype_labels.view(-1)[idx.view(-1)].view(-1, 20)
     pred = segsort_eval.majority_label_from_topk(top_k_labels)

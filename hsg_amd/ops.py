@@ -93,8 +93,8 @@ def _segment_reduce_fwd(x, labels, P, mode, strict=False):
     _lib.check(L.hsgk_segment_reduce(
         x.data_ptr(), n, d, labels.data_ptr(), P, mode, ctypes.c_float(EPS), out.data_ptr(),
         aux.data_ptr(), status.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr()))
-    if strict:      # the reference's scatter_add_ rejects such labels; reported asynchronously
-      _lib.defer_status(status, 'segment_reduce: a label lies outside [0, %d)' % P)
+    if strict:      # the reference's scatter_add_ rejects such labels: raised here ('call') or by a later call
+      _lib.defer_status(status, 'segment_reduce: a label lies outside [0, %d)' % P, at_call=(strict == 'call'))
   return out, aux
 
 
@@ -125,8 +125,9 @@ class SegmentReduce(torch.autograd.Function):
 
 
 def segment_reduce(x, labels, P, mode, strict=False):
-  """Rows whose label lies outside [0, P) are skipped; with `strict` that is an error (raised by a
-  later libhsgk call once the kernels have run, or at once with HSGK_SYNC_ERRORS=1)."""
+  """Rows whose label lies outside [0, P) are skipped; with `strict` that is an error: strict='call' raises at this
+  call (one host read; HSGK_SYNC_ERRORS=0: as True), strict=True by a later libhsgk call once the kernels have run
+  (at once with HSGK_SYNC_ERRORS=1)."""
   require_gpu(x, 'x')
   if x.dtype != torch.float32:
     raise TypeError('x must be float32')
@@ -134,7 +135,7 @@ def segment_reduce(x, labels, P, mode, strict=False):
   lab = labels.reshape(-1).to(torch.int64).contiguous()
   if lab.shape[0] != x2.shape[0]:
     raise ValueError('labels and rows disagree: %d vs %d' % (lab.shape[0], x2.shape[0]))
-  return SegmentReduce.apply(x2, lab, int(P), int(mode), bool(strict))
+  return SegmentReduce.apply(x2, lab, int(P), int(mode), strict if strict == 'call' else bool(strict))
 
 
 class NormalizeRows(torch.autograd.Function):

@@ -407,8 +407,16 @@ def calculate_prototypes_from_labels(embeddings, labels, max_label=None):
   scatter_add_ -> normalize_embedding.  Differentiable w.r.t. `embeddings`
   (prototypes carry gradient in the reference's training step)."""
   if max_label is None:
-    max_label = int(labels.max()) + 1
-  return ops.segment_reduce(embeddings, labels, int(max_label), 0, strict=True)
+    # one host read, as the reference's `labels.max() + 1` (:33); the smallest label rides along, so a negative
+    # label raises here and nothing is left to report later
+    lo, hi = torch.aminmax(labels)
+    lo, hi = (int(v) for v in torch.stack([lo, hi]).tolist())
+    if lo < 0:
+      raise _lib.HsgkError('calculate_prototypes_from_labels: negative label %d' % lo)
+    return ops.segment_reduce(embeddings, labels, hi + 1, 0)
+  # an explicit max_label: a label outside [0, max_label) raises AT THIS CALL, as scatter_add_ does on the
+  # reference's CPU path (one host read of the kernel's flag; HSGK_SYNC_ERRORS=0: reported by a later call)
+  return ops.segment_reduce(embeddings, labels, int(max_label), 0, strict='call')
 
 
 def prepare_prototype_labels(semantic_labels, instance_labels, offset=256):

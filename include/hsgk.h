@@ -177,8 +177,13 @@ HSGK_API int hsgk_lloyd_mstep(const float *x, int B, int64_t rows_per_image, int
                               const int32_t *labels, float *centroids, void *workspace,
                               size_t workspace_bytes, hsgk_stream_t stream);
 /* M-step with EXACT segment sums (canonical order C2x: fixed point, quantum 2^-40, 64-bit
- * integer sums, one rounding to fp32; rows must be bounded, |x| <= 1 for unit rows), the
- * arithmetic of the Lloyd loop inside hsgk_segment_by_kmeans.  sums [B,K,d] int64 is the
+ * integer sums, one rounding to fp32), the arithmetic of the Lloyd loop inside
+ * hsgk_segment_by_kmeans.  PRECONDITION: every element satisfies |x| <= 1 (true for the
+ * L2-normalised rows this path is built for; 2^22 rows of such elements per segment stay
+ * inside int64).  Larger magnitudes are not checked: the default kernels then only risk
+ * int64 overflow of a sum beyond 2^23 in magnitude, but the opt-in matrix-core variant
+ * (environment HSGK_MSTEP=mfma, an experiment kept for A/B) cuts the fixed
+ * point value into digits that ASSUME |x| <= 1 and returns wrong sums otherwise.  sums [B,K,d] int64 is the
  * caller-owned state: labels_prev == NULL computes it from scratch for `labels`; otherwise
  * sums must hold the exact sums of labels_prev and is UPDATED from the rows whose label
  * differs (identical to a from-scratch pass over `labels`).  centroids [B,K,d].          */

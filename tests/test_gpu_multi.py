@@ -62,7 +62,7 @@ def test_bench_line_single_rank_process_group():
   r = _bench(['--workload', 'cfg1', '--steps', '2', '--warmup', '1', '--cpu-images', '0', '--no-extra'],
              {'HSGK_BENCH_FORCE_DIST': '1'})
   assert r['n_gpus'] == 1 and r['steps'] == 2 and r['scaling'] == 'weak'
-  assert r['value'] > 0 and r['roofline']['frac'] <= 1.0
+  assert r['value'] > 0 and (r['roofline']['frac'] is None or r['roofline']['frac'] <= 1.0)   # (no counter pass for cfg1)
   assert 'error' not in r['prototype_exchange'], r['prototype_exchange']
   assert r['exchange_ms'] > 0
 

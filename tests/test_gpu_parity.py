@@ -291,22 +291,36 @@ def test_segment_reduce_arbitrary_ids_vs_oracle(dev, oracle, n, d, P, pattern):
 
 
 def test_segment_reduce_out_of_range_label_is_reported(dev, monkeypatch):
-  """calculate_prototypes_from_labels mirrors the reference's scatter_add_: a label outside
-  [0, max_label) is an error -- raised at once with HSGK_SYNC_ERRORS=1, otherwise by a later call."""
+  """calculate_prototypes_from_labels mirrors the reference's scatter_add_: a label outside [0, max_label) is an
+  error raised BY THE OFFENDING CALL with no environment switch set (SURVEY 8b: Python exceptions at the call);
+  HSGK_SYNC_ERRORS=0 keeps the host out of it and a later call reports."""
   import torch
-  from hsg_amd import _lib
+  from hsg_amd import _lib, ops
   from hsg_amd.utils.segsort import common as sc
   x = torch.randn((100, 8), device=dev)
   lab = torch.arange(100, device=dev) % 7
   lab[13] = 9
-  monkeypatch.setenv('HSGK_SYNC_ERRORS', '1')
+  monkeypatch.delenv('HSGK_SYNC_ERRORS', raising=False)
   with pytest.raises(_lib.HsgkError):
-    sc.calculate_prototypes_from_labels(x, lab, max_label=7)
-  monkeypatch.delenv('HSGK_SYNC_ERRORS')
+    sc.calculate_prototypes_from_labels(x, lab, max_label=7)        # at the call
+  _lib.poll_deferred(wait=True)                                     # nothing left to report
+  neg = lab.clone()
+  neg[13] = -1
+  with pytest.raises(_lib.HsgkError):
+    sc.calculate_prototypes_from_labels(x, neg)                     # default max_label: the read it does anyway
+  assert sc.calculate_prototypes_from_labels(x, lab).shape == (10, 8)
+  monkeypatch.setenv('HSGK_SYNC_ERRORS', '0')
   sc.calculate_prototypes_from_labels(x, lab, max_label=7)          # flag travels behind the kernels
   with pytest.raises(_lib.HsgkError):
     _lib.poll_deferred(wait=True)
   _lib.poll_deferred(wait=True)                                     # reported once
+  monkeypatch.delenv('HSGK_SYNC_ERRORS')
+  ops.segment_reduce(x, lab, 7, 0, strict=True)                     # the library-level op: deferred unless asked
+  with pytest.raises(_lib.HsgkError):
+    _lib.poll_deferred(wait=True)
+  monkeypatch.setenv('HSGK_SYNC_ERRORS', '1')
+  with pytest.raises(_lib.HsgkError):
+    ops.segment_reduce(x, lab, 7, 0, strict=True)
 
 
 def test_prototype_gradients_match_torch_autograd(dev):
