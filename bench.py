@@ -232,6 +232,7 @@ def hierarchy_run(torch, dev, out, B, C, K):
   res['hier_assign_ms'], (flab, _, clab, _) = best(lambda: hz.hierarchical_grouping_from_logits(fl, cl))
   res['group_mean_fine_ms'], fine_pos = best(lambda: hz.collect_nd_coarser_prototype(
       pos_prototypes, flab, masks, num_groups=KF, normalized=False))
+  hz.vouch_pixel_images(by_image, bidx)       # (as generate_clusters does: `bidx` is the id vector the tables were built from)
   res['gather_labels_fine_ms'], _ = best(lambda: hz.collect_pixel_hierarchical_clustering_indices(by_image, bidx, flab))
   res['gather_labels_coarse_ms'], _ = best(lambda: hz.collect_pixel_hierarchical_clustering_indices(by_image, bidx, clab))
   res['hierarchy_ms'] = round(sum(v for k, v in res.items() if k.endswith('_ms')), 3)

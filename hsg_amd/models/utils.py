@@ -38,7 +38,7 @@ import threading
 import torch
 import torch.distributed as dist
 
-from hsg_amd import _lib, ops
+from hsg_amd import _lib, _torch_ops, ops
 
 HDR = 8                      # int64 words in front of a tuple block (hsg_amd/csrc/exchange.hip kXHdr)
 ERR_NEGATIVE, ERR_CAPACITY, ERR_OVERFLOW, ERR_ROWS = 1, 2, 4, 8
@@ -469,6 +469,24 @@ def exchange_prototypes(embeddings, embeddings_with_loc, cluster_indices, batch_
   of predictions/segsort.py:224-244)."""
   C = embeddings.shape[-1]
   D = embeddings_with_loc.shape[-1]
+  tops = _torch_ops.ops() if backend_class is HsgkExchangeBackend else None
+  if tops is not None and (local or _world(group) == 1):
+    # one rank: the whole exchange is ONE op of the torch-extension binding (hsg_amd/csrc/torch_ops.cpp: keys ->
+    # merge -> meta on its way to the host -> sums -> finish, backward as a C++ autograd node) instead of the ~25
+    # dispatches of the phase-by-phase mirror below, which the multi-rank exchange needs for its two collectives
+    ops.require_gpu(embeddings, 'embeddings')
+    while True:
+      cap = _cap_get(group, tag)
+      pa, pb, psem, pinst, pbatch, upd, meta = tops.exchange_local(
+          embeddings, embeddings_with_loc, cluster_indices, batch_indices, semantic_labels, instance_labels, cap)
+      m = meta.tolist()
+      last_exchange.image_stats = (m[4], m[5])
+      if m[2] & (ERR_CAPACITY | ERR_ROWS):
+        _cap_set(group, tag, _pow2(max(m[3], 2 * cap)))
+        continue
+      if m[2]:
+        _raise_for(m[2])
+      return pa, pb, psem, pinst, pbatch, upd
   return _Exchange.apply(embeddings.reshape(-1, C), embeddings_with_loc.reshape(-1, D), cluster_indices,
                          batch_indices, semantic_labels, instance_labels, group, tag, bool(local))
 

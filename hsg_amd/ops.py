@@ -6,7 +6,7 @@ import threading
 
 import torch
 
-from hsg_amd import _lib
+from hsg_amd import _lib, _torch_ops
 
 EPS = 1e-12
 
@@ -135,6 +135,13 @@ def segment_reduce(x, labels, P, mode, strict=False):
   lab = labels.reshape(-1).to(torch.int64).contiguous()
   if lab.shape[0] != x2.shape[0]:
     raise ValueError('labels and rows disagree: %d vs %d' % (lab.shape[0], x2.shape[0]))
+  tops = _torch_ops.ops()
+  if tops is not None:                 # the torch-extension binding: one dispatch, C++ autograd node
+    _lib.poll_deferred()
+    out, status = tops.segment_reduce(x2, lab, int(P), int(mode))
+    if strict:
+      _lib.defer_status(status, 'segment_reduce: a label lies outside [0, %d)' % P, at_call=(strict == 'call'))
+    return out
   return SegmentReduce.apply(x2, lab, int(P), int(mode), strict if strict == 'call' else bool(strict))
 
 

@@ -30,6 +30,21 @@ def test_header_symbols_exported_and_bound():
   assert set(_lib.SIGNATURES) == set(names)
 
 
+def test_torch_extension_binding_loads_and_registers_its_ops():
+  """hsg_amd/csrc/torch_ops.cpp (TORCH_LIBRARY(hsgk, ...) + C++ autograd nodes): the library loads next
+  to libhsgk.so, binds the same ABI version, registers the op schemas -- and refuses CPU tensors (no compute here)."""
+  import torch
+  from hsg_amd import _lib, _torch_ops
+  tops = _torch_ops.ops()
+  assert tops is not None, 'libhsgk_torch.so is not built (make -C hsg_amd/csrc torch)'
+  assert int(tops.abi_version()) == _lib.ABI_VERSION
+  for name in ('segment_reduce', 'exchange_local'):
+    schema = str(getattr(tops, name).default._schema)
+    assert schema.startswith('hsgk::' + name), schema
+  with pytest.raises(RuntimeError, match='no CPU path'):
+    tops.segment_reduce(torch.zeros(3, 4), torch.zeros(3, dtype=torch.long), 2, 0)
+
+
 def test_workspace_queries_run_on_cpu():
   from hsg_amd import _lib
   L = _lib.lib()

@@ -2165,3 +2165,54 @@ def test_f19_full_size_image_vs_reference(dev, case):
   # the rows themselves against the reference's (strided subset, column sums are not stored at this size)
   assert out[1].shape == (H * W, C + 2)
 
+
+@pytest.mark.gpu
+def test_torch_extension_binding_matches_the_ctypes_mirror_bit_for_bit(dev, monkeypatch):
+  """The two host bindings drive the same kernels: segment_reduce (prototypes / means / sums, forward and the
+  gradient of the rows) and the single-rank prototype exchange (six results, gradients of both row sets) through
+  torch.ops.hsgk.* (hsg_amd/csrc/torch_ops.cpp, C++ autograd nodes) and through ctypes give identical bits;
+  the exchange also reproduces the reference's f8 tables and regrows its capacity the same way."""
+  import torch
+  from hsg_amd import _lib, _torch_ops, ops
+  from hsg_amd.models import utils as mu
+  assert _torch_ops.ops() is not None, 'libhsgk_torch.so is not built'
+  x = torch.from_numpy(synth.gaussish(11, 5000 * 66).reshape(5000, 66).copy()).to(dev)
+  lab = torch.from_numpy((synth.hash_u64(12, 5000) % np.uint64(37)).astype(np.int64)).to(dev)
+  w = torch.from_numpy(synth.gaussish(13, 40 * 66).reshape(40, 66).copy()).to(dev)
+  res = {}
+  for binding in ('torch', 'ctypes'):
+    if binding == 'ctypes':
+      monkeypatch.setenv('HSGK_BINDING', 'ctypes')
+    else:
+      monkeypatch.delenv('HSGK_BINDING', raising=False)
+    outs = []
+    for mode in (0, 1, 2):
+      xr = x.clone().requires_grad_(True)
+      o = ops.segment_reduce(xr, lab, 40, mode)
+      (o * w).sum().backward()
+      outs += [o.detach().cpu().numpy(), xr.grad.cpu().numpy()]
+    g = util.load('f8_exchange')
+    parts = util.exchange_inputs(int(g['seed']))
+    cat = {k: np.concatenate([p[k] for p in parts]) for k in ('emb', 'emb_loc', 'cluster', 'sem', 'inst')}
+    # one device holding both 'GPUs' pixel sets: batch ids of the second shifted as the reference does (B * gpu)
+    nb = int(parts[0]['batch'].max()) + 1
+    cat['batch'] = np.concatenate([parts[0]['batch'], parts[1]['batch'] + nb * 0])
+    T = lambda k: torch.from_numpy(cat[k]).to(dev)
+    for cap_start in (mu._CAP_START, 8):
+      mu._capacity.clear()
+      saved, mu._CAP_START = mu._CAP_START, cap_start
+      try:
+        e, el = T('emb').requires_grad_(True), T('emb_loc').requires_grad_(True)
+        r = mu.exchange_prototypes(e, el, T('cluster'), T('batch'), T('sem'), T('inst'), local=True, tag='bind_test')
+        w1, w2 = util.exchange_grad_weights(0, r[0].shape[0], r[0].shape[1], r[1].shape[1])
+        ((r[0] * torch.from_numpy(w1).to(dev)).sum() + (r[1] * torch.from_numpy(w2).to(dev)).sum()).backward()
+        outs += [t.detach().cpu().numpy() for t in r] + [e.grad.cpu().numpy(), el.grad.cpu().numpy()]
+      finally:
+        mu._CAP_START = saved
+    res[binding] = outs
+  assert len(res['torch']) == len(res['ctypes'])
+  for i, (a, b) in enumerate(zip(res['torch'], res['ctypes'])):
+    assert a.shape == b.shape and a.dtype == b.dtype, i
+    assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b), \
+        'result %d differs between the bindings' % i
+
