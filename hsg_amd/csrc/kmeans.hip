@@ -2176,6 +2176,19 @@ __global__ __launch_bounds__(512) void assign_half_t256_kernel(
   int64_t r = (int64_t)blockIdx.x * per;
   const int64_t r_end = min(N, r + per);
   if (tid == 0) { seg.count[blockIdx.x] = 0; seg.row0[blockIdx.x] = r < r_end ? r : 0; qnp[0] = 0; }
+#ifdef HSGK_T256_TURNS
+  // EXPERIMENT (build with -DHSGK_T256_TURNS; measured neutral, profiles/r05_turns_ab.txt: 9.16 / 9.36 ms against
+  // 9.13 / 9.11 at 4 x 768^2): the two waves of a SIMD take TURNS on the matrix pipe -- a wave holds its SIMD's turn
+  // for the matrix instructions of a pass and gives it up before the pass's epilogue, so that one wave's ~1 100
+  // cycles of MFMA would always run beside the other's ~700 cycles of vector work.  The counters had suggested the
+  // two pipes idle in turn (matrix 43 %, vector 45 % busy: their SUM fills the kernel, profiles/r05_cfg4_pmc.txt);
+  // enforcing the alternation changes nothing, so the waves already interleave and the rest of the time is the
+  // LDS operand stream (one ds_read_b128 per MFMA: 1 MB per CU and round of tiles) and the row loads.
+  int *turn = qnp + 8;                                       // [4] one word per SIMD (0: free)
+  if (tid < 4) turn[tid] = 0;
+  // HW_ID bits 5:4 = SIMD the wave runs on (s_getreg_b32 hwreg(HW_REG_HW_ID, 4, 2))
+  const int simd = __builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11)) & 3);
+#endif
   if (r >= r_end) return;
   SplitEntry *slice = gqueue + r;
   int b = image_of_row(img_row0, B, r);
@@ -2272,6 +2285,12 @@ __global__ __launch_bounds__(512) void assign_half_t256_kernel(
         // operands TWO k-blocks ahead (three sets): with one set ahead every k-block's first MFMA waited for the
         // LDS reads issued just before it (two MFMAs = 64 cycles of matrix work do not cover an LDS round trip)
         Ops o[3];
+#ifdef HSGK_T256_TURNS
+        __builtin_amdgcn_sched_barrier(0);
+        if (lane == 0)
+          while (atomicCAS(turn + simd, 0, 1) != 0) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         ld(0, o[0]);
         ld(16, o[1]);
 #pragma unroll
@@ -2282,6 +2301,11 @@ __global__ __launch_bounds__(512) void assign_half_t256_kernel(
         }
         __builtin_amdgcn_sched_barrier(0);
         if (has_tail) mm(o[NKB % 3], tv, false);
+#ifdef HSGK_T256_TURNS
+        __builtin_amdgcn_sched_barrier(0);
+        if (lane == 0) __hip_atomic_store(turn + simd, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         // ---- tagged top-3 of the lane's 32 scores of this pass
         float a1 = NINF, a2 = NINF, a3 = NINF;
 #pragma unroll
