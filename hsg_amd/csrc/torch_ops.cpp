@@ -9,6 +9,10 @@
 //   hsgk::segment_reduce(x, labels, P, mode) -> (out, status)
 //       hsg/utils/segsort/common.py:11-41 calculate_prototypes_from_labels (mode 0), general/common.py:123-147
 //       segment_mean (mode 1), raw sums (mode 2); status int32[1] != 0: a label outside [0, P).
+//   hsgk::segsort_nll(emb, inst, proto, sems[], psems[], kappas[], modes[], pixel_groups?, proto_groups?) -> nll [L, n]
+//       hsg/utils/segsort/loss.py:15-82 (:85-130 with class-mask labels), up to three label sets in one pass.
+//   hsgk::segment_by_kmeans(x, labels?, loc, ...) -> (emb, emb_loc, labels, cluster, batch, meta_host, meta)
+//       hsg/utils/segsort/common.py:270-408, one attempt of the library call; backward = hsgk_segment_by_kmeans_bwd.
 //   hsgk::exchange_local(emb, emb_loc, cluster, batch, sem, inst, cap) ->
 //       (prototypes, prototypes_with_loc, proto_sem, proto_inst, proto_batch, updated_cluster, meta_host)
 //       hsg/models/utils.py:127-217 gather_clustering_and_update_prototypes for ONE rank / one device (no collective:
@@ -237,6 +241,205 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> exchange_loca
   return {r[0], r[1], r[2], r[3], r[4], r[5], r[6]};
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// hsg/utils/segsort/loss.py:15-82 (and :85-130): per-pixel negative log-likelihood of up to three label sets over
+// the same embeddings / own-prototype indices / prototype table in one pass over E P^T -> nll [L, n].
+struct SegsortNllFn : public torch::autograd::Function<SegsortNllFn> {
+  static Tensor forward(AutogradContext *ctx, const Tensor &emb, const Tensor &inst, const Tensor &proto,
+                        std::vector<Tensor> sems, std::vector<Tensor> psems, std::vector<double> kappas,
+                        std::vector<int64_t> modes, const c10::optional<Tensor> &qg, const c10::optional<Tensor> &pg) {
+    TORCH_CHECK(emb.is_cuda(), "hsgk::segsort_nll: tensors must be on a ROCm device (there is no CPU path)");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(emb.device());
+    const int64_t L = (int64_t)kappas.size(), n = emb.size(0), c = emb.size(1), P = proto.size(0);
+    TORCH_CHECK(L >= 1 && L <= HSGK_LOSS_MAX_SETS && (int64_t)sems.size() == L && (int64_t)psems.size() == L &&
+                    (int64_t)modes.size() == L, "1..3 label sets per pass");
+    auto f32 = emb.options().dtype(at::kFloat);
+    Tensor nll = at::empty({L, n}, f32), num = at::empty({L, n}, f32), den = at::empty({L, n}, f32);
+    Tensor use_same = at::empty({L, n}, emb.options().dtype(at::kInt));
+    const size_t wsb = hsgk_segsort_loss_workspace_bytes(n, (int)c, P, (int)L);
+    Tensor ws = at::empty({(int64_t)wsb}, emb.options().dtype(at::kByte));
+    hsgk_loss_set sets[HSGK_LOSS_MAX_SETS];
+    for (int64_t l = 0; l < L; ++l)
+      sets[l] = hsgk_loss_set{sems[l].data_ptr<int64_t>(), psems[l].data_ptr<int64_t>(), (float)kappas[l], (int32_t)modes[l]};
+    const bool grouped = qg.has_value() && qg->defined();
+    check(hsgk_segsort_loss_fwd(emb.data_ptr<float>(), n, (int)c, inst.data_ptr<int64_t>(), proto.data_ptr<float>(), P,
+                                (int)L, sets, grouped ? qg->data_ptr<int64_t>() : nullptr,
+                                grouped ? pg->data_ptr<int64_t>() : nullptr, nll.data_ptr<float>(), num.data_ptr<float>(),
+                                den.data_ptr<float>(), use_same.data_ptr<int32_t>(), ws.data_ptr(), wsb, stream_of(emb)),
+          "hsgk_segsort_loss_fwd");
+    variable_list keep = {emb, proto, inst, num, den, use_same};
+    for (auto &t : sems) keep.push_back(t);
+    for (auto &t : psems) keep.push_back(t);
+    if (grouped) { keep.push_back(*qg); keep.push_back(*pg); }
+    ctx->save_for_backward(keep);
+    ctx->saved_data["kappas"] = kappas;
+    ctx->saved_data["modes"] = modes;
+    ctx->saved_data["grouped"] = grouped;
+    return nll;
+  }
+  static variable_list backward(AutogradContext *ctx, variable_list grads) {
+    auto sv = ctx->get_saved_variables();
+    const Tensor &emb = sv[0], &proto = sv[1], &inst = sv[2], &num = sv[3], &den = sv[4], &use_same = sv[5];
+    const auto kappas = ctx->saved_data["kappas"].toDoubleVector();
+    const auto modes = ctx->saved_data["modes"].toIntVector();
+    const bool grouped = ctx->saved_data["grouped"].toBool();
+    const int64_t L = (int64_t)kappas.size(), n = emb.size(0), c = emb.size(1), P = proto.size(0);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(emb.device());
+    const bool want_e = ctx->needs_input_grad(0), want_p = ctx->needs_input_grad(2);
+    Tensor g_emb, g_proto;
+    if (want_e || want_p) {
+      Tensor gscale = grads[0].to(at::kFloat).contiguous();
+      if (want_e) g_emb = at::empty({n, c}, emb.options());
+      if (want_p) g_proto = at::empty({P, c}, emb.options());
+      const size_t wsb = hsgk_segsort_loss_bwd_workspace_bytes(n, (int)c, P, (int)L);
+      Tensor ws = at::empty({(int64_t)wsb}, emb.options().dtype(at::kByte));
+      hsgk_loss_set sets[HSGK_LOSS_MAX_SETS];
+      for (int64_t l = 0; l < L; ++l)
+        sets[l] = hsgk_loss_set{sv[6 + l].data_ptr<int64_t>(), sv[6 + L + l].data_ptr<int64_t>(), (float)kappas[l],
+                                (int32_t)modes[l]};
+      check(hsgk_segsort_loss_bwd(emb.data_ptr<float>(), n, (int)c, inst.data_ptr<int64_t>(), proto.data_ptr<float>(), P,
+                                  (int)L, sets, grouped ? sv[6 + 2 * L].data_ptr<int64_t>() : nullptr,
+                                  grouped ? sv[7 + 2 * L].data_ptr<int64_t>() : nullptr, num.data_ptr<float>(),
+                                  den.data_ptr<float>(), use_same.data_ptr<int32_t>(), gscale.data_ptr<float>(),
+                                  want_e ? g_emb.data_ptr<float>() : nullptr, want_p ? g_proto.data_ptr<float>() : nullptr,
+                                  ws.data_ptr(), wsb, stream_of(emb)),
+            "hsgk_segsort_loss_bwd");
+    }
+    return {g_emb, Tensor(), g_proto, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+Tensor segsort_nll(const Tensor &emb, const Tensor &inst, const Tensor &proto, at::TensorList sems, at::TensorList psems,
+                   at::ArrayRef<double> kappas, at::IntArrayRef modes, const c10::optional<Tensor> &qg,
+                   const c10::optional<Tensor> &pg) {
+  Tensor e = rows_f32(emb), p = rows_f32(proto);
+  const at::Device dev = e.device();
+  std::vector<Tensor> a, b;
+  for (size_t l = 0; l < sems.size(); ++l) {
+    a.push_back(vec_i64(sems[l], dev));
+    b.push_back(vec_i64(psems[l], dev));
+    const int64_t words = std::max<int64_t>(modes[l] >> 8, 1);            // class-mask words per row (1: plain labels)
+    TORCH_CHECK(a.back().size(0) == e.size(0) * words && b.back().size(0) == p.size(0) * words,
+                "label vectors do not match the embeddings / prototypes");
+  }
+  c10::optional<Tensor> q, g;
+  if (qg.has_value() && qg->defined()) {
+    TORCH_CHECK(pg.has_value() && pg->defined(), "pixel and prototype groups come together");
+    q = vec_i64(*qg, dev);
+    g = vec_i64(*pg, dev);
+    TORCH_CHECK(q->size(0) == e.size(0) && g->size(0) == p.size(0), "group vectors do not match the embeddings / prototypes");
+  }
+  return SegsortNllFn::apply(e, vec_i64(inst, dev), p, a, b, kappas.vec(), modes.vec(), q, g);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// hsg/utils/segsort/common.py:270-408 segment_by_kmeans: ONE attempt of the library call (the rare repeats -- a
+// label range the presence table cannot hold, a timed-out small-map wait -- are decided by the Python mirror from
+// meta_host).  x [B,C,H,W] f32; labels [B,H,W] i64 or undefined; loc / seed_map as hsgk_segkm_args describes them.
+// Returns the five outputs cut to the kept rows and meta_host int64[8] (n_rows, n_segments, label_min, label_max,
+// n_chunks, error, ...).  Without a label map nothing is read from the device (the row count is B H W).
+struct SegmentByKmeansFn : public torch::autograd::Function<SegmentByKmeansFn> {
+  static variable_list forward(AutogradContext *ctx, const Tensor &x, const c10::optional<Tensor> &lab, const Tensor &loc,
+                               int64_t loc_sb, const Tensor &seed_map, int64_t seed_sb, int64_t K, bool has_ignore,
+                               int64_t ign, int64_t iterations, int64_t batch_offset, int64_t table_cap, int64_t flags,
+                               bool want_grad) {
+    TORCH_CHECK(x.is_cuda(), "hsgk::segment_by_kmeans: embeddings must be on a ROCm device (there is no CPU path)");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+    const int64_t B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3), n_max = B * H * W;
+    const bool labelled = lab.has_value() && lab->defined();
+    auto f32 = x.options().dtype(at::kFloat);
+    auto i64 = x.options().dtype(at::kLong);
+    Tensor emb = at::empty({n_max, C}, f32), eloc = at::empty({n_max, C + 2}, f32);
+    Tensor out_lab = at::empty({n_max}, i64), cluster = at::empty({n_max}, i64), batch = at::empty({n_max}, i64);
+    Tensor meta = at::empty({8}, i64);
+    Tensor norms, rowmap;
+    if (want_grad) {
+      norms = at::empty({n_max, 2}, f32);
+      if (has_ignore) rowmap = at::empty({n_max}, i64);
+    }
+    const size_t wsb = hsgk_segment_by_kmeans_workspace_bytes((int)B, (int)C, (int)H, (int)W, (int)K, table_cap);
+    Tensor ws = at::empty({(int64_t)wsb}, x.options().dtype(at::kByte));
+    hsgk_segkm_args a{};
+    a.embeddings = x.data_ptr<float>();
+    a.labels = labelled ? lab->data_ptr<int64_t>() : nullptr;
+    a.loc = loc.data_ptr<float>();
+    a.loc_batch_stride = loc_sb;
+    a.seed_map = seed_map.data_ptr<int32_t>();
+    a.B = (int32_t)B; a.C = (int32_t)C; a.H = (int32_t)H; a.W = (int32_t)W; a.K = (int32_t)K;
+    a.iterations = (int32_t)iterations;
+    a.has_ignore = has_ignore ? 1 : 0;
+    a.ignore_index = ign;
+    a.batch_offset = batch_offset;
+    a.table_cap = table_cap;
+    a.out_embeddings = emb.data_ptr<float>();
+    a.out_embeddings_loc = eloc.data_ptr<float>();
+    a.out_labels = out_lab.data_ptr<int64_t>();
+    a.out_cluster = cluster.data_ptr<int64_t>();
+    a.out_batch = batch.data_ptr<int64_t>();
+    a.meta = reinterpret_cast<hsgk_segkm_meta *>(meta.data_ptr<int64_t>());
+    a.out_norms = norms.defined() ? norms.data_ptr<float>() : nullptr;
+    a.out_rowmap = rowmap.defined() ? rowmap.data_ptr<int64_t>() : nullptr;
+    a.workspace = ws.data_ptr();
+    a.workspace_bytes = wsb;
+    a.seed_batch_stride = seed_sb;
+    a.flags = (int32_t)flags;
+    hsgk_stream_t st = stream_of(x);
+    check(hsgk_segment_by_kmeans(&a, st), "hsgk_segment_by_kmeans");
+    Tensor meta_host = at::zeros({8}, at::TensorOptions().dtype(at::kLong));
+    int64_t n = n_max;
+    if (labelled) {                          // the operator's single host read
+      hipStream_t hst = reinterpret_cast<hipStream_t>(st);
+      PinnedMeta &pm = pinned_meta(x.device().index());
+      TORCH_CHECK(hipMemcpyAsync(pm.pin.data_ptr(), meta.data_ptr(), 8 * sizeof(int64_t), hipMemcpyDeviceToHost, hst) ==
+                      hipSuccess, "hipMemcpyAsync(meta)");
+      TORCH_CHECK(hipEventRecord(pm.ev, hst) == hipSuccess, "hipEventRecord");
+      TORCH_CHECK(hipEventSynchronize(pm.ev) == hipSuccess, "hipEventSynchronize");
+      std::memcpy(meta_host.data_ptr(), pm.pin.data_ptr(), 8 * sizeof(int64_t));
+      n = meta_host.data_ptr<int64_t>()[5] ? 0 : meta_host.data_ptr<int64_t>()[0];
+    } else {
+      meta_host.data_ptr<int64_t>()[0] = n_max;
+    }
+    Tensor e = emb.narrow(0, 0, n), el = eloc.narrow(0, 0, n);
+    Tensor l = out_lab.narrow(0, 0, n), c = cluster.narrow(0, 0, n), bt = batch.narrow(0, 0, n);
+    if (want_grad) {
+      ctx->save_for_backward({e, el, norms, rowmap.defined() ? rowmap : Tensor()});
+      ctx->saved_data["shape"] = std::vector<int64_t>{B, C, H, W};
+    }
+    // (the device meta block rides along for the deferred small-map time-out flag of the unlabelled call)
+    ctx->mark_non_differentiable({l, c, bt, meta_host, meta});
+    return {e, el, l, c, bt, meta_host, meta};
+  }
+  static variable_list backward(AutogradContext *ctx, variable_list grads) {
+    auto sv = ctx->get_saved_variables();
+    const Tensor &emb = sv[0], &eloc = sv[1], &norms = sv[2], &rowmap = sv[3];
+    const auto shape = ctx->saved_data["shape"].toIntVector();
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(emb.device());
+    Tensor ge, gl;
+    if (grads[0].defined()) ge = grads[0].to(at::kFloat).contiguous();
+    if (grads[1].defined()) gl = grads[1].to(at::kFloat).contiguous();
+    Tensor gx = at::empty({shape[0], shape[1], shape[2], shape[3]}, emb.options());
+    check(hsgk_segment_by_kmeans_bwd(ge.defined() ? ge.data_ptr<float>() : nullptr, gl.defined() ? gl.data_ptr<float>() : nullptr,
+                                     emb.data_ptr<float>(), eloc.data_ptr<float>(), norms.data_ptr<float>(),
+                                     rowmap.defined() ? rowmap.data_ptr<int64_t>() : nullptr, (int)shape[0], (int)shape[1],
+                                     (int)shape[2], (int)shape[3], kEps, gx.data_ptr<float>(), stream_of(emb)),
+          "hsgk_segment_by_kmeans_bwd");
+    variable_list out(14);
+    out[0] = gx;
+    return out;
+  }
+};
+
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> segment_by_kmeans(
+    const Tensor &x, const c10::optional<Tensor> &labels, const Tensor &loc, int64_t loc_sb, const Tensor &seed_map,
+    int64_t seed_sb, int64_t K, bool has_ignore, int64_t ign, int64_t iterations, int64_t batch_offset, int64_t table_cap,
+    int64_t flags) {
+  TORCH_CHECK(x.dim() == 4 && x.scalar_type() == at::kFloat, "embeddings must be float32 [B, C, H, W]");
+  Tensor xc = x.contiguous();
+  auto r = SegmentByKmeansFn::apply(xc, labels, loc, loc_sb, seed_map, seed_sb, K, has_ignore, ign, iterations,
+                                    batch_offset, table_cap, flags, x.requires_grad() && at::GradMode::is_enabled());
+  return {r[0], r[1], r[2], r[3], r[4], r[5], r[6]};
+}
+
 int64_t abi_version() { return hsgk_version(); }
 
 }  // namespace
@@ -246,4 +449,9 @@ TORCH_LIBRARY(hsgk, m) {
   m.def("segment_reduce(Tensor x, Tensor labels, int P, int mode) -> (Tensor, Tensor)", &segment_reduce);
   m.def("exchange_local(Tensor emb, Tensor emb_loc, Tensor cluster, Tensor batch, Tensor sem, Tensor inst, int cap)"
         " -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)", &exchange_local);
+  m.def("segsort_nll(Tensor emb, Tensor inst, Tensor proto, Tensor[] sems, Tensor[] psems, float[] kappas, int[] modes,"
+        " Tensor? pixel_groups, Tensor? proto_groups) -> Tensor", &segsort_nll);
+  m.def("segment_by_kmeans(Tensor x, Tensor? labels, Tensor loc, int loc_batch_stride, Tensor seed_map,"
+        " int seed_batch_stride, int K, bool has_ignore, int ignore_index, int iterations, int batch_offset,"
+        " int table_cap, int flags) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)", &segment_by_kmeans);
 }

@@ -18,7 +18,7 @@ import threading
 
 import torch
 
-from hsg_amd import _lib, ops
+from hsg_amd import _lib, _torch_ops, ops
 from hsg_amd.utils.general import common as common_utils
 
 _cache_lock = threading.Lock()
@@ -243,6 +243,60 @@ class _SegmentByKmeans(torch.autograd.Function):
     return gx, None, None, None, None, None, None, None, None, None, None
 
 
+def _segment_by_kmeans_torch(tops, x, lab, loc, loc_sb, seed_map, K, has_ignore, ign, iterations, batch_offset, seed_sb):
+  """The same call through the torch-extension binding (hsg_amd/csrc/torch_ops.cpp: hsgk::segment_by_kmeans, C++
+  autograd node): one dispatch per attempt; the rare repeats are decided here exactly as in _SegmentByKmeans."""
+  dev = x.device
+  B, C, H, W = x.shape
+  table_cap = B * K if lab is None else max(B * K, min(B * K * 4096, _TABLE_CAP_MAX))
+
+  def run(lab, ign, table_cap, flags=0):
+    r = tops.segment_by_kmeans(x, lab, loc, int(loc_sb), seed_map, int(seed_sb), int(K), bool(has_ignore), int(ign),
+                               int(iterations), int(batch_offset), int(table_cap), int(flags))
+    if lab is None and flags == 0 and _lib.lib().hsgk_small_map_groups(B, C, H, W, K) > 1:
+      _lib.defer_status(r[6].view(torch.int32)[10:11],
+                        'segment_by_kmeans: the co-operating workgroups of an image waited 10 s for each '
+                        'other (labels invalid); set HSGK_SMALL_GROUPS=1')
+    return r[5].tolist(), r[:5]
+
+  m, outs = run(lab, ign, table_cap)
+  if m[5] == 3:
+    m, outs = run(lab, ign, table_cap, flags=1)
+  if m[5] == 2:
+    kept = lab[lab != ign] if has_ignore else lab
+    if kept.numel() and int(kept.min()) < 0:
+      raise ValueError('segment_by_kmeans: negative labels are not supported')
+    uniq, inv = torch.unique(lab, return_inverse=True)
+    D = int(uniq.numel())
+    ign_rank = D
+    if has_ignore:
+      pos = int(torch.searchsorted(uniq, torch.tensor([ign], dtype=uniq.dtype, device=dev)))
+      if pos < D and int(uniq[pos]) == ign:
+        ign_rank = pos
+    m, outs = run(inv.view(B, H, W).contiguous(), ign_rank, max(table_cap, B * K * (D + 1)))
+    if m[5] == 0:
+      outs = outs[:2] + (uniq[outs[2].clamp(0, D - 1)],) + outs[3:]
+  err = m[5]
+  if err == 1:
+    raise ValueError('segment_by_kmeans: negative labels are not supported')
+  if err == 3:
+    raise _lib.HsgkError('segment_by_kmeans: the cooperating workgroups of an image were not co-resident '
+                         '(inter-workgroup wait timed out); set HSGK_SMALL_GROUPS=1')
+  if err == 2:
+    raise _lib.HsgkError('segment_by_kmeans: label range too large for the relabel '
+                         'table (label_max=%d)' % m[3])
+  return tuple(outs)
+
+
+def _segment_by_kmeans_any(x, lab, loc, loc_sb, seed_map, K, has_ignore, ign, iterations, batch_offset, seed_sb):
+  tops = _torch_ops.ops()
+  if tops is not None:
+    return _segment_by_kmeans_torch(tops, x, lab, loc, loc_sb, seed_map, K, has_ignore, ign, iterations, batch_offset,
+                                    seed_sb)
+  return _SegmentByKmeans.apply(x, lab, loc, loc_sb, seed_map, K, has_ignore, ign, int(iterations), int(batch_offset),
+                                int(seed_sb))
+
+
 def segment_by_kmeans(embeddings,
                       labels=None,
                       num_clusters=[5, 5],
@@ -302,8 +356,8 @@ def segment_by_kmeans(embeddings,
     batch_offset = _batch_offset(B, dev)
   if isinstance(K, list):
     return _segment_by_kmeans_grouped(x, lab, loc, loc_sb, seed_map, K, has_ignore, ign, iterations, batch_offset)
-  out = _SegmentByKmeans.apply(x, lab, loc, loc_sb, seed_map, K, has_ignore, ign,
-                               int(iterations), int(batch_offset), int(seed_sb))
+  out = _segment_by_kmeans_any(x, lab, loc, loc_sb, seed_map, K, has_ignore, ign, int(iterations), int(batch_offset),
+                               int(seed_sb))
   ops.note(out[4], 'ascending', True)          # rows leave image by image: downstream order checks need no read
   return out
 
@@ -326,7 +380,7 @@ def _segment_by_kmeans_grouped(x, lab, loc, loc_sb, dense, counts, has_ignore, i
     labs = lab.index_select(0, it).contiguous() if lab is not None else None
     locs = loc if loc_sb == 0 else loc.index_select(0, it).contiguous()
     seeds = dense.index_select(0, it).contiguous()
-    emb, eloc, labels, cluster, batch = _SegmentByKmeans.apply(
+    emb, eloc, labels, cluster, batch = _segment_by_kmeans_any(
         xs, labs, locs, loc_sb, seeds, K, has_ignore, ign, int(iterations), 0, HW)
     bounds = torch.searchsorted(batch, torch.arange(len(idx) + 1, device=dev)).cpu().tolist()
     for j, b in enumerate(idx):

@@ -15,7 +15,7 @@ import ctypes
 import torch
 from torch.nn.modules.loss import _Loss
 
-from hsg_amd import _lib, ops
+from hsg_amd import _lib, _torch_ops, ops
 
 
 MAX_LABEL_SETS = 3
@@ -120,6 +120,11 @@ def _nll_sets(embeddings, instance_labels, prototypes, label_sets, groups=None):
     if qg.shape[0] != emb.shape[0] or pg.shape[0] != proto.shape[0]:
       raise ValueError('group vectors do not match the embeddings / prototypes')
     groups = (qg, pg)
+  tops = _torch_ops.ops()
+  if tops is not None:                 # the torch-extension binding: one dispatch, C++ autograd node
+    return tops.segsort_nll(emb, inst, proto, sems, psems, [float(ls[2]) for ls in label_sets],
+                            [int(ls[3]) for ls in label_sets], groups[0] if groups is not None else None,
+                            groups[1] if groups is not None else None)
   return _SegSortNLL.apply(emb, inst, proto, tuple(ls[2] for ls in label_sets),
                            tuple(ls[3] for ls in label_sets), groups, *sems, *psems)
 

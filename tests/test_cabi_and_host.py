@@ -38,7 +38,7 @@ def test_torch_extension_binding_loads_and_registers_its_ops():
   tops = _torch_ops.ops()
   assert tops is not None, 'libhsgk_torch.so is not built (make -C hsg_amd/csrc torch)'
   assert int(tops.abi_version()) == _lib.ABI_VERSION
-  for name in ('segment_reduce', 'exchange_local'):
+  for name in ('segment_reduce', 'exchange_local', 'segsort_nll', 'segment_by_kmeans'):
     schema = str(getattr(tops, name).default._schema)
     assert schema.startswith('hsgk::' + name), schema
   with pytest.raises(RuntimeError, match='no CPU path'):

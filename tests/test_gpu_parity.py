@@ -2169,7 +2169,9 @@ def test_f19_full_size_image_vs_reference(dev, case):
 @pytest.mark.gpu
 def test_torch_extension_binding_matches_the_ctypes_mirror_bit_for_bit(dev, monkeypatch):
   """The two host bindings drive the same kernels: segment_reduce (prototypes / means / sums, forward and the
-  gradient of the rows) and the single-rank prototype exchange (six results, gradients of both row sets) through
+  gradient of the rows), segment_by_kmeans (five outputs and the gradient of the NCHW input, with and without a
+  label map), the contrastive loss (three label sets in one pass, pixel / prototype groups; both gradients) and the
+  single-rank prototype exchange (six results, gradients of both row sets) through
   torch.ops.hsgk.* (hsg_amd/csrc/torch_ops.cpp, C++ autograd nodes) and through ctypes give identical bits;
   the exchange also reproduces the reference's f8 tables and regrows its capacity the same way."""
   import torch
@@ -2191,6 +2193,34 @@ def test_torch_extension_binding_matches_the_ctypes_mirror_bit_for_bit(dev, monk
       o = ops.segment_reduce(xr, lab, 40, mode)
       (o * w).sum().backward()
       outs += [o.detach().cpu().numpy(), xr.grad.cpu().numpy()]
+    # segment_by_kmeans: with a label map + ignore band (one host read) and without (none), forward and backward
+    from hsg_amd.utils.segsort import common as sc
+    from hsg_amd.utils.segsort import loss as sl
+    xs = synth.embeddings_nchw(synth.SEED_BASE + 71, (2, 64, 24, 40), 'mixture')
+    lb = synth.overseg_labels(synth.SEED_BASE + 72, 2, 24, 40, regions=7, ignore_rows=2)
+    for labelled in (True, False):
+      xt = torch.from_numpy(xs).to(dev).requires_grad_(True)
+      o = sc.segment_by_kmeans(xt, torch.from_numpy(lb).to(dev) if labelled else None, [3, 4],
+                               ignore_index=255 if labelled else None, iterations=4)
+      w1 = torch.from_numpy(synth.gaussish(73, o[0].numel()).reshape(o[0].shape).copy()).to(dev)
+      w2 = torch.from_numpy(synth.gaussish(74, o[1].numel()).reshape(o[1].shape).copy()).to(dev)
+      ((o[0] * w1).sum() + (o[1] * w2).sum()).backward()
+      outs += [t.detach().cpu().numpy() for t in o] + [xt.grad.cpu().numpy()]
+    # the contrastive loss: three label sets in one pass (two kappas), then one grouped set; both gradients
+    n, c, P = 700, 64, 53
+    e = torch.from_numpy(synth.gaussish(75, n * c).reshape(n, c).copy()).to(dev)
+    e = (e / e.norm(dim=1, keepdim=True)).requires_grad_(True)
+    inst = torch.from_numpy((synth.hash_u64(76, n) % np.uint64(P)).astype(np.int64)).to(dev)
+    pr = ops.segment_reduce(e.detach(), inst, P, 0).requires_grad_(True)
+    psems = [torch.from_numpy((synth.hash_u64(77 + i, P) % np.uint64(5 + i)).astype(np.int64)).to(dev) for i in range(3)]
+    sets = [(ps[inst], ps, k, 'segsort+' if i != 1 else 'segsort') for i, (ps, k) in enumerate(zip(psems, (16.0, 16.0, 10.0)))]
+    vals = sl.segsort_losses(e, inst, pr, sets)
+    (vals[0] + 2 * vals[1] + 3 * vals[2]).backward()
+    outs += [v.detach().cpu().numpy().reshape(1) for v in vals] + [e.grad.cpu().numpy(), pr.grad.cpu().numpy()]
+    qg = torch.from_numpy((synth.hash_u64(81, n) % np.uint64(2)).astype(np.int64)).to(dev)
+    pg = torch.from_numpy((np.arange(P) % 2).astype(np.int64)).to(dev)
+    nl = sl.segsort_nll(e.detach(), psems[0][inst], inst, pr.detach(), psems[0], 12.0, 'segsort+', qg, pg)
+    outs.append(torch.nan_to_num(nl, nan=-1.0, posinf=-2.0, neginf=-3.0).cpu().numpy())
     g = util.load('f8_exchange')
     parts = util.exchange_inputs(int(g['seed']))
     cat = {k: np.concatenate([p[k] for p in parts]) for k in ('emb', 'emb_loc', 'cluster', 'sem', 'inst')}
