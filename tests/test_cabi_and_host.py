@@ -3,6 +3,7 @@ include/hsgk.h declares (no compute calls without a GPU), and the host-side
 helpers of the Python mirror agree with the oracle / golden tables."""
 import ctypes
 import os
+import sys
 import re
 
 import numpy as np
@@ -186,3 +187,29 @@ def test_process_group_key_is_the_c10d_name_not_the_object_id():
   assert mu._group_key(Named()) == ('name', '7') == mu._group_key(Named())              # two objects, one group
   a = Anonymous()
   assert mu._group_key(a) == ('id', id(a))
+
+
+def test_bench_roofline_byte_sources_come_from_the_newest_counter_pass():
+  """bench.py prices each workload's launch groups with the moved bytes of that workload's newest committed
+  rocprofv3 counter pass, kernels found by name prefix (no stale kernel lists, no fraction above 1
+  from an algorithmic stand-in)."""
+  import importlib.util
+  spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+  bench = importlib.util.module_from_spec(spec)
+  argv, sys.argv = sys.argv, ['bench.py']
+  try:
+    spec.loader.exec_module(bench)
+  finally:
+    sys.argv = argv
+  rows = {'cfg2': 48 * 448 * 448, 'cfg3': 16 * 224 * 224, 'cfg4': 4 * 768 * 768, 'cfg5': 24 * 224 * 224}
+  for wl, n in rows.items():
+    for group in ('assign', 'accumulate', 'prep'):
+      traffic, src, names, commit = bench.pmc_traffic(group, wl)
+      assert traffic and src.startswith('profiles/r05_%s_pmc' % wl), (wl, group, src)
+      assert commit, 'the counter file names the commit it was taken at'
+      assert all(any(pre in k for pre in bench.PMC_GROUPS[group]) for k in names)
+      assert 50 <= traffic / n <= 6000, (wl, group, traffic / n)      # bytes per pixel row and group instance (prep at C = 384: 5.4 KB)
+    d = 258 if wl != 'cfg5' else 386
+    e_bytes = bench.pmc_traffic('assign', wl)[0] / n
+    assert e_bytes < 4 * d + 8, 'the filtered E-step moves less than one fp32 read of every row'
+  assert bench.pmc_traffic('assign', 'cfg1') == (None, None, None, None)
