@@ -773,6 +773,10 @@ __global__ __launch_bounds__(512) void assign_hard_regs_kernel(
   int64_t total = 0;
   for (int b = 0; b < B; ++b) total += max(count_of(b) - skip_of(b), 0);
   if (total == 0) return;
+  // rows per unit: as many as keep every workgroup of the grid busy, 32 (one wave) to 256 (all eight) -- a short
+  // list (the first iteration of an i.i.d. batch: ~4 k rows) then runs one wave per SIMD on many CUs instead of
+  // two on a few (the matrix instructions of a unit take the same time for one wave as for four)
+  const int UR = (int)min((int64_t)TPX, max((int64_t)32, ((total + gridDim.x - 1) / gridDim.x + 31) / 32 * 32));
   float2 tb[TB];
   auto prefetch = [&](const float *src, int kvalid) {             // table block -> registers (rows >= kvalid: zero)
 #pragma unroll
@@ -796,11 +800,11 @@ __global__ __launch_bounds__(512) void assign_hard_regs_kernel(
   int b = 0, ub = 0;
   for (int u = blockIdx.x;; u += gridDim.x) {
     int nu = 0;
-    while (b < B && u >= ub + (nu = (max(count_of(b) - skip_of(b), 0) + TPX - 1) / TPX)) { ub += nu; ++b; }
+    while (b < B && u >= ub + (nu = (max(count_of(b) - skip_of(b), 0) + UR - 1) / UR)) { ub += nu; ++b; }
     if (b >= B) return;
     const int lu = u - ub, skip = skip_of(b);
-    const int nrows = min(count_of(b) - skip - lu * TPX, TPX);
-    const int32_t *list = hl.rows + (int64_t)b * hl.cap + skip + (int64_t)lu * TPX;
+    const int nrows = min(count_of(b) - skip - lu * UR, UR);
+    const int32_t *list = hl.rows + (int64_t)b * hl.cap + skip + (int64_t)lu * UR;
     const float *ct = cent + (int64_t)b * K * D;
     prefetch(ct, min(64, K));
     // ---- gather: rows of this wave -> xr (B operand of k-step st: column 2 st + h of row j)
@@ -842,6 +846,7 @@ __global__ __launch_bounds__(512) void assign_hard_regs_kernel(
     __syncthreads();
     for (int kb0 = 0; kb0 < K; kb0 += 64) {
       if (kb0 + 64 < K) prefetch(ct + (int64_t)(kb0 + 64) * D, min(64, K - kb0 - 64));
+      if (w * 32 < nrows) {                 // (wave-uniform: a wave without rows only helps with the table blocks)
       f32x16 acc[2];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
@@ -866,6 +871,7 @@ __global__ __launch_bounds__(512) void assign_hard_regs_kernel(
           const float v = acc[m][r];
           if (k < K && v > bv) { bv = v; bi = k; }           // ascending k, strict >: first maximum; NaN never wins
         }
+      }
       if (kb0 + 64 < K) {
         __syncthreads();                   // every wave is done with this block
         commit();
