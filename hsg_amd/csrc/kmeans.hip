@@ -721,8 +721,14 @@ __global__ __launch_bounds__(NW * 64) void assign_hard_rows_kernel(
   // rows on the lists; the unit grows with them so that a table block is staged once for several tiles
   auto skip_of = [&](int b) { return (hl.prev && hl.prev[b * kHardStride] > hl.skip) ? 0 : hl.skip; };
   auto count_of = [&](int b) { return hl.count[b * kHardStride]; };
+  // (one image per lane: a loop over the images is one dependent round trip per image -- 13 us before an EMPTY
+  //  launch returned at B = 24)
   int64_t total = 0;
-  for (int b = 0; b < B; ++b) total += max(count_of(b) - skip_of(b), 0);
+  {
+    const int ln = threadIdx.x & 63;
+    for (int b0 = 0; b0 < B; b0 += 64) total += (b0 + ln < B) ? max(count_of(b0 + ln) - skip_of(b0 + ln), 0) : 0;
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+  }
   if (total == 0) return;
   const int64_t tiles_all = (total + TPX - 1) / TPX;
   const int ut = (int)min((int64_t)kHardMaxTiles, max((int64_t)1, (tiles_all + gridDim.x - 1) / gridDim.x));
@@ -770,8 +776,14 @@ __global__ __launch_bounds__(512) void assign_hard_regs_kernel(
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, h = lane >> 5;
   auto skip_of = [&](int b) { return (hl.prev && hl.prev[b * kHardStride] > hl.skip) ? 0 : hl.skip; };
   auto count_of = [&](int b) { return hl.count[b * kHardStride]; };
+  // (one image per lane: a loop over the images is one dependent round trip per image -- 13 us before an EMPTY
+  //  launch returned at B = 24)
   int64_t total = 0;
-  for (int b = 0; b < B; ++b) total += max(count_of(b) - skip_of(b), 0);
+  {
+    const int ln = threadIdx.x & 63;
+    for (int b0 = 0; b0 < B; b0 += 64) total += (b0 + ln < B) ? max(count_of(b0 + ln) - skip_of(b0 + ln), 0) : 0;
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+  }
   if (total == 0) return;
   // rows per unit: as many as keep every workgroup of the grid busy, 32 (one wave) to 256 (all eight) -- a short
   // list (the first iteration of an i.i.d. batch: ~4 k rows) then runs one wave per SIMD on many CUs instead of
