@@ -220,6 +220,28 @@ __global__ __launch_bounds__(NW * 64) void update_sums_kernel(
 // columns of a whole batch of rows share one atomic per side, and consecutive changed rows
 // of one cluster add up in registers first (run-length carries; pixels are in raster order).
 // NV: 16-byte vectors per lane and row (1: d <= 259, 2: d <= 515)
+// elimination builds (tools/probes/ab_cfg.sh with ab_libs built by make EXTRA=-DHSGK_FX_ELIM=n): 1 no LDS atomics,
+// 2 no row loads, 3 neither -- WRONG sums, timing only
+#ifndef HSGK_FX_ELIM
+#define HSGK_FX_ELIM 0
+#endif
+#if HSGK_FX_ELIM & 1
+#define HSGK_FX_ATOMIC(p, v) do { if ((v) == 0x123456789abcull) atomicAdd(p, v); } while (0)
+#else
+#define HSGK_FX_ATOMIC(p, v) atomicAdd(p, v)
+#endif
+#if HSGK_FX_ELIM & 2
+#define HSGK_FX_LOADV(p) (gvec_t{(float)((uintptr_t)(p) & 1023) * 1e-4f, 0.25f, -0.125f, 0.0625f})
+#define HSGK_FX_LOADT(p) ((float)((uintptr_t)(p) & 255) * 1e-3f)
+#else
+#define HSGK_FX_LOADV(p) (*reinterpret_cast<const gvec_t *>(p))
+#define HSGK_FX_LOADT(p) (*(p))
+#endif
+#ifdef HSGK_FX_TIMING
+__device__ unsigned long long g_fx_ts[8];
+#define HSGK_FXT(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_fx_ts[i], now_ - fx_ts); fx_ts = now_; } while (0)
+#endif
 template <int NW, int UNROLL, int NV>
 __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
     const float *__restrict__ x, int d, const int32_t *__restrict__ prev,
@@ -227,6 +249,9 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
     const int32_t *__restrict__ chunk_rows, const int32_t *__restrict__ chunk_img, int K, int P,
     unsigned long long *__restrict__ sumq, const hsgk_segkm_meta *__restrict__ meta) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+#ifdef HSGK_FX_TIMING
+  unsigned long long fx_ts = __builtin_readcyclecounter();
+#endif
   // P workgroups share one chunk range, each owning the clusters [k0, k0 + kn) (P = 1 when the
   // whole table fits LDS): a workgroup reads the rows that leave or join ITS clusters
   const int KP = (K + P - 1) / P;
@@ -292,7 +317,7 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
           const int nh = min(64, nq - 64 * h);
           if (q4 < nq) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) atomicAdd(rowp + 256 * h + j * nh + lane, (unsigned long long)cq[side][h][j]);
+            for (int j = 0; j < 4; ++j) HSGK_FX_ATOMIC(rowp + 256 * h + j * nh + lane, (unsigned long long)cq[side][h][j]);
           }
         }
       }
@@ -304,6 +329,9 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
     // ---- strips of the run, dealt to the waves round robin; no barrier inside
     const int nstrips = (ce - c) * SPC;
     for (int st = w; st < nstrips; st += NW) {
+#ifdef HSGK_FX_TIMING
+      fx_ts = __builtin_readcyclecounter();
+#endif
       const int cc = c + st / SPC, part = st - (st / SPC) * SPC;
       const int n = min(chunk_rows[cc] - part * STRIP, STRIP);
       if (n <= 0) continue;
@@ -334,15 +362,24 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
       const float *xr = x + row0 * d;
       auto entry = [&](int i) { return list[min(i, total - 1)]; };
       auto issue = [&](int i0, gvec_t (&v)[UNROLL][NV], float &t) {
+#ifdef HSGK_FX_TIMING
+        {   // (probe) the list entries alone: LDS reads that queue behind the other waves' atomics
+          uint32_t es = 0;
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u) es += entry(i0 + u);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(es)::"memory");
+          HSGK_FXT(5);
+        }
+#endif
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
           const int r = (int)(entry(i0 + u) >> 22);
           const float *src = xr + (int64_t)r * d;
 #pragma unroll
           for (int h = 0; h < NV; ++h)    // unconditional (d >= 4 here): a branch around a load costs the counted waits
-            v[u][h] = *reinterpret_cast<const gvec_t *>(src + 4 * min(lane + 64 * h, nq - 1));
+            v[u][h] = HSGK_FX_LOADV(src + 4 * min(lane + 64 * h, nq - 1));
         }
-        t = xr[(int64_t)(entry(i0 + min(tu, UNROLL - 1)) >> 22) * d + min(tail0 + tc, d - 1)];
+        t = HSGK_FX_LOADT(xr + (int64_t)(entry(i0 + min(tu, UNROLL - 1)) >> 22) * d + min(tail0 + tc, d - 1));
       };
       auto fold = [&](int i0, const gvec_t (&v)[UNROLL][NV], const float &t) {
 #pragma unroll
@@ -371,12 +408,42 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
           const uint32_t e = entry(i0 + tu);
           const long long qt = to_fixed(t);
           const int ln = (int)((e >> 11) & 2047u) - 1, lo = (int)(e & 2047u) - 1;
-          if (ln >= 0) atomicAdd(tab + (size_t)ln * d + tail0 + tc, (unsigned long long)qt);
-          if (lo >= 0) atomicAdd(tab + (size_t)lo * d + tail0 + tc, (unsigned long long)(-qt));
+          if (ln >= 0) HSGK_FX_ATOMIC(tab + (size_t)ln * d + tail0 + tc, (unsigned long long)qt);
+          if (lo >= 0) HSGK_FX_ATOMIC(tab + (size_t)lo * d + tail0 + tc, (unsigned long long)(-qt));
         }
       };
       gvec_t va[UNROLL][NV], vb[UNROLL][NV];
       float ta, tb;
+#ifdef HSGK_FX_TIMING
+      // probe build (tools/probes/fx_timing.py): where a wave's time goes -- [0] labels + list, [1] waiting for a
+      // batch of rows (explicit s_waitcnt vmcnt with the NEXT batch still in flight), [2] conversion + issuing the
+      // LDS atomics, [3] waiting for those atomics to drain (s_waitcnt lgkmcnt(0)), [4] issuing loads
+      HSGK_FXT(0);
+      issue(0, va, ta);
+      HSGK_FXT(4);
+      for (int i0 = 0; i0 < total; i0 += 2 * UNROLL) {
+        issue(i0 + UNROLL, vb, tb);
+        __builtin_amdgcn_sched_barrier(0);
+        HSGK_FXT(4);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UNROLL * NV + 1) : "memory");
+        HSGK_FXT(1);
+        fold(i0, va, ta);
+        __builtin_amdgcn_sched_barrier(0);
+        HSGK_FXT(2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        HSGK_FXT(3);
+        issue(i0 + 2 * UNROLL, va, ta);
+        __builtin_amdgcn_sched_barrier(0);
+        HSGK_FXT(4);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UNROLL * NV + 1) : "memory");
+        HSGK_FXT(1);
+        fold(i0 + UNROLL, vb, tb);
+        __builtin_amdgcn_sched_barrier(0);
+        HSGK_FXT(2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        HSGK_FXT(3);
+      }
+#else
       issue(0, va, ta);
       for (int i0 = 0; i0 < total; i0 += 2 * UNROLL) {
         issue(i0 + UNROLL, vb, tb);
@@ -388,6 +455,7 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
         fold(i0 + UNROLL, vb, tb);
         __builtin_amdgcn_sched_barrier(0);
       }
+#endif
     }
     flush_run(0);
     flush_run(1);
@@ -926,3 +994,14 @@ int launch_finalize_fx(const long long *sumq, int d, int K, int B, float eps, fl
 }
 
 }  // namespace hsgk
+
+#ifdef HSGK_FX_TIMING
+extern "C" __attribute__((visibility("default"))) int hsgk_debug_fx_timing(unsigned long long *out) {
+  unsigned long long h[8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(hsgk::g_fx_ts), sizeof(h)) != hipSuccess) return -1;
+  for (int i = 0; i < 8; ++i) out[i] = h[i];
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(hsgk::g_fx_ts), z, sizeof(z));
+  return 0;
+}
+#endif
