@@ -242,12 +242,15 @@ __device__ unsigned long long g_fx_ts[8];
 #define HSGK_FXT(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
     if ((threadIdx.x & 63) == 0) atomicAdd(&g_fx_ts[i], now_ - fx_ts); fx_ts = now_; } while (0)
 #endif
-template <int NW, int UNROLL, int NV>
+// DC > 0: the row length as a compile-time constant (258: the headline shape) -- strides, quad counts and the
+// lane tests fold away (the loop body shrinks by about a fifth); 0: from the argument
+template <int NW, int UNROLL, int NV, int DC = 0>
 __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
-    const float *__restrict__ x, int d, const int32_t *__restrict__ prev,
+    const float *__restrict__ x, int d_arg, const int32_t *__restrict__ prev,
     const int32_t *__restrict__ cur, const int64_t *__restrict__ chunk_row0,
     const int32_t *__restrict__ chunk_rows, const int32_t *__restrict__ chunk_img, int K, int P,
     unsigned long long *__restrict__ sumq, const hsgk_segkm_meta *__restrict__ meta) {
+    const int d = DC > 0 ? DC : d_arg;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 #ifdef HSGK_FX_TIMING
   unsigned long long fx_ts = __builtin_readcyclecounter();
@@ -360,7 +363,10 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
       if (total == 0) continue;
       // (wave-private list: own LDS writes are visible to own reads in order)
       const float *xr = x + row0 * d;
-      auto entry = [&](int i) { return list[min(i, total - 1)]; };
+      // (wave-uniform by construction; readfirstlane puts the row number and both labels on the scalar unit: the run
+      //  tests become scalar branches instead of v_cmp + saveexec pairs and the row address a scalar multiply)
+      auto entry = [&](int i) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)list[min(i, total - 1)]); };
+      auto entry_v = [&](int i) { return list[min(i, total - 1)]; };      // (per-lane index: the tail columns' lanes)
       auto issue = [&](int i0, gvec_t (&v)[UNROLL][NV], float &t) {
 #ifdef HSGK_FX_TIMING
         {   // (probe) the list entries alone: LDS reads that queue behind the other waves' atomics
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
           for (int h = 0; h < NV; ++h)    // unconditional (d >= 4 here): a branch around a load costs the counted waits
             v[u][h] = HSGK_FX_LOADV(src + 4 * min(lane + 64 * h, nq - 1));
         }
-        t = HSGK_FX_LOADT(xr + (int64_t)(entry(i0 + min(tu, UNROLL - 1)) >> 22) * d + min(tail0 + tc, d - 1));
+        t = HSGK_FX_LOADT(xr + (int64_t)(entry_v(i0 + min(tu, UNROLL - 1)) >> 22) * d + min(tail0 + tc, d - 1));
       };
       auto fold = [&](int i0, const gvec_t (&v)[UNROLL][NV], const float &t) {
 #pragma unroll
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(NW * 64) void update_sums_persistent_kernel(
           }
         }
         if (tact && i0 + tu < total) {
-          const uint32_t e = entry(i0 + tu);
+          const uint32_t e = entry_v(i0 + tu);
           const long long qt = to_fixed(t);
           const int ln = (int)((e >> 11) & 2047u) - 1, lo = (int)(e & 2047u) - 1;
           if (ln >= 0) HSGK_FX_ATOMIC(tab + (size_t)ln * d + tail0 + tc, (unsigned long long)qt);
@@ -914,6 +920,10 @@ bool sums_fx_eligible(int d) { return d >= 1; }
 // kernel -- first update launch of a 48 x 448 x 448 call 1.85 ms against 1.24 ms, the sparse launches 0.16-0.31
 // against 0.15-0.31 ms; elimination table in profiles/r04_mstep_mfma.txt: the digit cut costs as many vector
 // instructions per element as the 64-bit adds it replaces).  Read per call.
+static bool fx_const_d() {                  // HSGK_FX_CONST_D=0: the generic instance whatever the row length (A/B)
+  const char *e = getenv("HSGK_FX_CONST_D");
+  return !(e && e[0] == '0');
+}
 static bool mstep_mfma_enabled() {
   const char *e = getenv("HSGK_MSTEP");
   return e && e[0] == 'm';
@@ -968,6 +978,8 @@ int launch_update_sums(const float *x, int d, const int32_t *prev, const int32_t
         HSGK_LAUNCH_CHECK();
         return 0;
       };
+      if (d == 258 && fx_const_d()) return launch(update_sums_persistent_kernel<16, 4, 1, 258>);
+      if (d == 130 && fx_const_d()) return launch(update_sums_persistent_kernel<16, 4, 1, 130>);
       return narrow ? launch(update_sums_persistent_kernel<16, 4, 1>) : launch(update_sums_persistent_kernel<8, 8, 2>);
     }
   }
