@@ -14,9 +14,17 @@ SO_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libh
 
 
 def ops():
-  """torch.ops.hsgk once libhsgk_torch.so is loaded, else None (not built, or HSGK_BINDING=ctypes)."""
+  """torch.ops.hsgk once libhsgk_torch.so is loaded, else None (not built, or HSGK_BINDING=ctypes).
+
+  Every call site fetches the namespace through here right before it dispatches an op, so this is also where the
+  torch-bound route drains the deferred device flags (`_lib.check` does it for the ctypes route): a small-map
+  time-out raises from the next libhsgk call of either binding, and the pinned words do not pile up."""
   if os.environ.get('HSGK_BINDING') == 'ctypes':
     return None
+  if _state['tried']:
+    from hsg_amd import _lib
+    if _lib._deferred:
+      _lib.poll_deferred()
   if not _state['tried']:
     with _lock:
       if not _state['tried']:

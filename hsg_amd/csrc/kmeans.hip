@@ -1403,8 +1403,9 @@ int launch_assign_half_wide(const float *x, const _Float16 *xm, const uint2 *xt,
   HardList hl{nullptr, nullptr, 0, 0, nullptr};
   if (hard_rows && hard_count && hard_rows_enabled() && hard_rows_fit(d)) {
     hl = HardList{hard_rows, hard_count, hard_cap, hard_skip(B), table_ready && hard_prev_enabled() ? hard_count + (size_t)(B + 1) * kHardStride : nullptr};
-    if (!table_ready) HSGK_CHECK_HIP(hipMemsetAsync(hard_count, 0, sizeof(int32_t) * (size_t)B * kHardStride, s));
   }
+  // (also with the lists switched off: hsgk_lloyd_requeued_rows sums these counters)
+  if (!table_ready && hard_count) HSGK_CHECK_HIP(hipMemsetAsync(hard_count, 0, sizeof(int32_t) * (size_t)B * kHardStride, s));
   constexpr int NW = 8, TPX = NW * 32, MB = 4;
   static const int n_cu = [] {
     int dev = 0, cus = 256;
@@ -2828,8 +2829,9 @@ int launch_assign_half_wide2(const float *x, const _Float16 *xm, const uint2 *xt
   HardList hl{nullptr, nullptr, 0, 0, nullptr};
   if (hard_rows && hard_count && hard_rows_enabled() && hard_rows_fit(d)) {
     hl = HardList{hard_rows, hard_count, hard_cap, hard_skip(B), table_ready && hard_prev_enabled() ? hard_count + (size_t)(B + 1) * kHardStride : nullptr};
-    if (!table_ready) HSGK_CHECK_HIP(hipMemsetAsync(hard_count, 0, sizeof(int32_t) * (size_t)B * kHardStride, s));
   }
+  // (also with the lists switched off: hsgk_lloyd_requeued_rows sums these counters)
+  if (!table_ready && hard_count) HSGK_CHECK_HIP(hipMemsetAsync(hard_count, 0, sizeof(int32_t) * (size_t)B * kHardStride, s));
   constexpr int NW = 8, TPX = NW * 32, MB = 4;
   static const int n_cu = [] {
     int dev = 0, cus = 256;

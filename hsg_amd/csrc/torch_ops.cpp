@@ -114,7 +114,12 @@ struct PinnedMeta {
   hipEvent_t ev = nullptr;
 };
 PinnedMeta &pinned_meta(int dev) {
-  thread_local std::vector<PinnedMeta> pool;
+  // one heap-allocated pool per thread, never freed: its pinned blocks and events would otherwise be released by
+  // thread_local destructors at thread / process exit, in an unspecified order against torch's host allocator and
+  // the HIP runtime (64 bytes + one event per thread and device).  A block is used by one op at a time: the ops
+  // wait for their read before they return, so a thread cannot re-enter with the block in flight.
+  thread_local std::vector<PinnedMeta> *pool_p = new std::vector<PinnedMeta>();
+  std::vector<PinnedMeta> &pool = *pool_p;
   if ((int)pool.size() <= dev) pool.resize(dev + 1);
   PinnedMeta &p = pool[dev];
   if (!p.pin.defined()) {

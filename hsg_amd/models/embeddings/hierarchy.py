@@ -114,11 +114,14 @@ def calculate_kmeans_prototypes(cluster_embeddings, cluster_indices, cluster_bat
     M = most + 1                                     # (a cluster carries one label: segments == distinct clusters)
   if P == 0 and M <= 0:
     # no kept pixel at all and no fixed table width (the Cityscapes twin): the reference's loop runs zero times and
-    # its stacks are empty -- empty tables, no library call
+    # its `torch.stack([])` RAISES; a deliberate divergence -- empty tables (each with its own channel width), no
+    # library call, so that a batch whose every pixel is ignored costs a step and not the run
     C = cluster_embeddings.shape[-1]
     e = cluster_embeddings.new_zeros((0, C, 0))
     el = torch.zeros((0, 0), dtype=torch.long, device=dev)
-    return (e, e.clone() if cluster_pos_embeddings is not None else None, torch.zeros((0, 0), dtype=torch.bool, device=dev),
+    pe = (cluster_pos_embeddings.new_zeros((0, cluster_pos_embeddings.shape[-1], 0))
+          if cluster_pos_embeddings is not None else None)
+    return (e, pe, torch.zeros((0, 0), dtype=torch.bool, device=dev),
             el, el.clone(), torch.zeros((0,), dtype=torch.long, device=dev))
   if most >= M:
     raise IndexError('an image has more than max_num_clusters=%d segments' % M)
