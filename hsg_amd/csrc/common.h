@@ -121,6 +121,9 @@ struct PrepM0 {
   // (rides along: the 32-pixel prep kernel writes the fp16 copy of its rows in TILE order here -- score_tiles_f16t.h
   //  -- when every image keeps all its pixels in place and H * W % 32 == 0: a half tile is one 32-row block)
   _Float16 *tiles = nullptr;
+  // (rides along too) 1: workgroup ids of an image -- which the dispatcher deals round-robin over the 8 XCDs -- are
+  // mapped to half tiles so that each XCD walks one CONTIGUOUS eighth of the image (prep_fast32_kernel)
+  int xcd_order = 0;
 };
 int launch_m0_reduce(const PrepM0 &m0, int B, int WT, int d, hipStream_t s);
 

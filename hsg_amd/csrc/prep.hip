@@ -627,6 +627,7 @@ __global__ __launch_bounds__(256) void prep_fast_kernel(
 // produces the first M-step of the Lloyd loop: the exact fixed-point sums of its rows
 // under their seed-grid labels (PrepM0, common.h).
 // Phase timers for tools/probes/prep_timing.py: make EXTRA=-DHSGK_PREP_TIMING.
+constexpr int kPrep32TilePad = 72;      // floats after the [32][C] tile: room for its rows as [32][C + 2] + a 16-byte phase
 #ifdef HSGK_PREP_TIMING
 __device__ unsigned long long g_prep_ts[8];
 #define HSGK_TS(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
@@ -662,6 +663,15 @@ __device__ __forceinline__ float div_markstein(float x, float n, float r) {
 #define HSGK_DIV_SETUP(n, r)
 #define HSGK_DIV(x, n, r) ((x) / (n))
 #endif
+// FLAT (round 6; C <= 256, one 16-byte quad per lane): phase 3 keeps a wave's eight rows in registers, and the
+// emb_loc rows -- 1 032 bytes each, so that a lane's quad is only 8-byte aligned and used to leave as two half-density
+// 8-byte stores per lane plus a tail store per row -- go back to LDS in their final layout (the half tile's rows are
+// one contiguous byte range of the output) and leave as full 16-byte pieces, 1 KiB contiguous per wave instruction;
+// the per-row tail work (location columns, xt word, norms) is done once for all 32 rows with lane = row instead of on
+// lane 0 of 32 wave-wide passes.  The kernel runs at the speed of its memory side (tools/probes/prep_mem.hip:
+// the same access pattern without any arithmetic takes the kernel's time), and this is what the memory side
+// gains: 6.38 -> 6.02 ms next to the XCD-contiguous order (profiles/r06_prep_mem.txt).  Same arithmetic, same bits.
+template <bool FLAT>
 __global__ __launch_bounds__(256) void prep_fast32_kernel(
     const float *__restrict__ in, int C, int64_t HW, int ntiles,
     const float *__restrict__ loc, int64_t loc_sb, const int64_t *__restrict__ labels,
@@ -678,17 +688,30 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
   unsigned long long ts_ = __builtin_readcyclecounter();
 #endif
   extern __shared__ float lds[];
-  float *tile = lds;                       // [32][C] swizzled
-  float *nrm1 = lds + 32 * C;              // [32]
+  float *tile = lds;                       // [32][C] swizzled; FLAT: later the rows of emb_loc, [<= 32][C + 2] + phase
+  float *nrm1 = lds + 32 * C + kPrep32TilePad;   // [32]
   float *nrm2 = nrm1 + 32;                 // [32]
   float *locv = nrm2 + 32;                 // [32][2]
   int64_t *rowi = reinterpret_cast<int64_t *>(locv + 64);   // [32]
   int *seedl = reinterpret_cast<int *>(rowi + 32);          // [32] seed label of the kept pixels (-1: dropped)
-  int *m0l = seedl + 32;                                    // [2] the (at most) two labels with an LDS slot, [2..3] pad
-  unsigned long long *mtab = reinterpret_cast<unsigned long long *>(m0l + 4);   // [2][D] exact sums (fused first M-step)
+  int *m0l = seedl + 32;                                    // [2] the (at most) two labels with an LDS slot, [2] rows kept in this half
+  float *e2s = reinterpret_cast<float *>(m0l + 4);          // [32] squared fp16 rounding error of the rows' main columns
+  int64_t *hrow0 = reinterpret_cast<int64_t *>(e2s + 32);   // [1] output row of this half's first kept pixel
+  unsigned long long *mtab = reinterpret_cast<unsigned long long *>(hrow0 + 1);   // [2][D] exact sums (fused first M-step)
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int t = blockIdx.x >> 1, sh = blockIdx.x & 1, b = blockIdx.y;
+  // Half tile of this workgroup.  Workgroup ids are dealt round-robin over the 8 XCDs; with ids taken as they come,
+  // neighbouring half tiles land on different XCDs, i.e. different L2s: the 128-byte lines that two neighbours
+  // share (rows of 1 032 bytes, the 8-byte words per row) reach HBM as two partial writes, and no XCD streams a
+  // contiguous range.  Round 6: id x + 8 i -> half tile start(x) + i, start(x) = x q + min(x, r) for gridDim.x =
+  // 8 q + r -- one contiguous eighth of the image per XCD.  The kernel's memory side alone: 6.70 -> 6.38 ms,
+  // tools/probes/prep_mem.hip, profiles/r06_prep_mem.txt.
+  unsigned bx = blockIdx.x;
+  if (m0.xcd_order) {
+    const unsigned q8 = gridDim.x >> 3, r8 = gridDim.x & 7u, x8 = bx & 7u;
+    bx = x8 * q8 + (x8 < r8 ? x8 : r8) + (bx >> 3);
+  }
+  const int t = (int)(bx >> 1), sh = (int)(bx & 1u), b = blockIdx.y;
   const int64_t p0 = (int64_t)t * kTilePix;        // start of the 64-pixel compaction tile
   const int64_t q0 = p0 + 32 * sh;                 // start of this half
   const int D = C + 2;
@@ -736,7 +759,11 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
       }
     }
     const unsigned long long mh = sh ? (m >> 32) : (m & 0xffffffffull);
-    if (lane == 0) nrm1[0] = mh ? 1.0f : 0.0f;
+    if (lane == 0) {
+      nrm1[0] = mh ? 1.0f : 0.0f;
+      m0l[2] = __popcll(mh);
+      *hrow0 = base + (sh ? __popcll(m & 0xffffffffull) : 0);
+    }
     if (m0on && (lane >> 5) == sh) seedl[lane & 31] = keep ? seed_map[(int64_t)b * seed_sb + pix] : -1;   // (fused first M-step)
   }
   __syncthreads();
@@ -862,6 +889,149 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     }
     cur[0] = cur[1] = cur[2] = cur[3] = 0; tcur[0] = tcur[1] = 0;
   };
+  if constexpr (FLAT) {
+    // ---- (NQ <= 64) this wave's eight rows -> registers; emb, the fp16 copy and the first M-step straight from them
+    const bool act = lane < NQ;
+    float4 rv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = w + 4 * i;
+      rv[i] = *reinterpret_cast<const float4 *>(tile + j * C + (((act ? lane : 0) ^ (j & 15)) << 2));
+    }
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = w + 4 * i;
+      const long long rr = rowi[j];           // (wave-uniform: the row's addresses on the scalar unit)
+      const int64_t row = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rr >> 32)) << 32) |
+                                    (unsigned)__builtin_amdgcn_readfirstlane((int)rr));
+      if (row < 0) continue;
+      const float n2 = nrm2[j];
+      HSGK_DIV_SETUP(n2, r2)
+      if (m0on) {
+        const int L = __builtin_amdgcn_readfirstlane(seedl[j]);
+        const int L0 = __builtin_amdgcn_readfirstlane(m0l[0]), L1 = __builtin_amdgcn_readfirstlane(m0l[1]);
+        const int slot = L < 0 ? -1 : L == L0 ? 0 : L == L1 ? 1 : L < m0.K ? 2 : -1;
+        unsigned long long *g = slot == 2 ? m0.sumq + ((int64_t)b * m0.K + L) * D : nullptr;
+        if (slot != cslot || g != cg) { m0_flush(); cslot = slot; cg = g; }
+      }
+      float e2 = 0.0f;                         // |row - fp16(row)|^2, this lane's columns
+      if (act) {
+        const float4 v = rv[i];
+        HSGK_ROW_STORE(reinterpret_cast<float4 *>(emb + row * C + 4 * lane), v);
+        float4 a;
+        a.x = HSGK_DIV(v.x, n2, r2); a.y = HSGK_DIV(v.y, n2, r2); a.z = HSGK_DIV(v.z, n2, r2); a.w = HSGK_DIV(v.w, n2, r2);
+        rv[i] = a;                             // (kept: the emb_loc row leaves through LDS below)
+        if (m0on) {                            // (uniform)
+          cur[0] += to_fixed(a.x); cur[1] += to_fixed(a.y); cur[2] += to_fixed(a.z); cur[3] += to_fixed(a.w);
+        }
+        if (xh || tmode) {
+          const h4 hv = {(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w};
+          if (xh) HSGK_ROW_STORE(reinterpret_cast<h4 *>(xh + row * C + 4 * lane), hv);
+          // tile order: the four halves wait in the quad's own LDS slot (read above by this lane, by nobody else)
+          if (tmode) *reinterpret_cast<h4 *>(tile + j * C + ((lane ^ (j & 15)) << 2)) = hv;
+          const float e0 = a.x - (float)hv[0], e1 = a.y - (float)hv[1];       // exact residuals
+          const float e2b = a.z - (float)hv[2], e3 = a.w - (float)hv[3];
+          e2 = fmaf(e0, e0, e2); e2 = fmaf(e1, e1, e2); e2 = fmaf(e2b, e2b, e2); e2 = fmaf(e3, e3, e2);
+        }
+      }
+      if (xh || tmode) {
+        for (int off = 32; off > 0; off >>= 1) e2 += __shfl_xor(e2, off);
+        if (lane == 0) e2s[j] = e2;
+      }
+    }
+    if (m0on) m0_flush();
+    if (tmode) {
+      // the block's 16-byte pieces in operand order: piece (kb, lane = jj + 32 g) = row jj, columns 16 kb + 8 g .. + 7
+      // (two quads of four halves each, from their LDS slots); one KiB contiguous per wave instruction
+      __syncthreads();
+      const int jj = lane & 31, gg = lane >> 5;
+      const int64_t blk = (img_row0[b] + q0) >> 5;
+      uint2 *dst = reinterpret_cast<uint2 *>(xhT + blk * 32 * C);
+      for (int kb = w; kb < (C >> 4); kb += 4) {
+        const int qa = 4 * kb + 2 * gg;
+        const uint2 lo2 = *reinterpret_cast<const uint2 *>(tile + jj * C + ((qa ^ (jj & 15)) << 2));
+        const uint2 hi2 = *reinterpret_cast<const uint2 *>(tile + jj * C + (((qa + 1) ^ (jj & 15)) << 2));
+        uint4 pc = {lo2.x, lo2.y, hi2.x, hi2.y};
+        *reinterpret_cast<uint4 *>(dst + (kb * 64 + lane) * 2) = pc;
+      }
+    }
+    __syncthreads();                           // nobody reads the tile any more: it becomes the rows of emb_loc
+    HSGK_TS(6);
+    const int64_t h0 = *hrow0;
+    const int hc = m0l[2];
+    float *const gl = emb_loc + h0 * D;        // this half's rows: [gl, gl + hc * D), 8-byte aligned
+    // same 16-byte phase in LDS as in HBM, so that aligned pieces of one are aligned pieces of the other
+    float *const flat = tile + ((reinterpret_cast<uintptr_t>(gl) >> 2) & 2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = w + 4 * i;
+      const long long rr = rowi[j];
+      const int64_t row = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rr >> 32)) << 32) |
+                                    (unsigned)__builtin_amdgcn_readfirstlane((int)rr));
+      if (row < 0) continue;
+      if (act) {
+        float *fr = flat + (int)(row - h0) * D + 4 * lane;
+        *reinterpret_cast<float2 *>(fr) = make_float2(rv[i].x, rv[i].y);
+        *reinterpret_cast<float2 *>(fr + 2) = make_float2(rv[i].z, rv[i].w);
+      }
+    }
+    // the per-row tail, lane = row: location columns, their share of the first M-step, norms, the xt word
+    if (w == 3 && lane < 32) {
+      const int64_t row = rowi[lane];
+      if (row >= 0) {
+        const float n2 = nrm2[lane];
+        float2 lv;
+        lv.x = locv[2 * lane] / n2;
+        lv.y = locv[2 * lane + 1] / n2;
+        *reinterpret_cast<float2 *>(flat + (int)(row - h0) * D + C) = lv;
+        if (norms_out) { norms_out[2 * row] = nrm1[lane]; norms_out[2 * row + 1] = n2; }
+        if (m0on) {
+          const int L = seedl[lane];
+          unsigned long long *t2 = L < 0 ? nullptr : L == m0l[0] ? mtab : L == m0l[1] ? mtab + D
+                                   : L < m0.K ? m0.sumq + ((int64_t)b * m0.K + L) * D : nullptr;
+          if (t2) {                            // (exact integer sums: any order; LDS or global atomic by address space)
+            atomicAdd(t2 + C, (unsigned long long)to_fixed(lv.x));
+            atomicAdd(t2 + C + 1, (unsigned long long)to_fixed(lv.y));
+          }
+        }
+        if (xh || tmode) {
+          const h2 hv = {(_Float16)lv.x, (_Float16)lv.y};
+          const float e0 = lv.x - (float)hv[0], e1 = lv.y - (float)hv[1];
+          float e2 = e2s[lane];
+          e2 = fmaf(e0, e0, e2); e2 = fmaf(e1, e1, e2);
+          // measured rounding error of the copy of this row, inflated against the rounding
+          // of this very sum (bound: score_tiles_f16.h)
+          xt[row] = make_uint2(__builtin_bit_cast(uint32_t, hv), __float_as_uint(sqrtf(e2) * 1.0001f));
+        }
+      }
+    }
+    __syncthreads();
+    {
+      // [gl, gl + hc * D) as 16-byte pieces (an 8-byte head / tail where the range starts / ends mid-piece)
+      char *gb = reinterpret_cast<char *>(gl);
+      const char *lb = reinterpret_cast<const char *>(flat);
+      const int total = hc * D * 4;
+      const int head = (int)((16 - (reinterpret_cast<uintptr_t>(gb) & 15)) & 15);     // 0 or 8
+      const int n16 = (total - head) >> 4;
+      if (head && tid == 64) *reinterpret_cast<float2 *>(gb) = *reinterpret_cast<const float2 *>(lb);
+      float4 *gd = reinterpret_cast<float4 *>(gb + head);
+      const float4 *ls = reinterpret_cast<const float4 *>(lb + head);
+      for (int i = tid; i < n16; i += 256) HSGK_ROW_STORE(gd + i, ls[i]);
+      if (total - head - 16 * n16 && tid == 128)
+        *reinterpret_cast<float2 *>(gb + head + 16 * n16) = *reinterpret_cast<const float2 *>(lb + head + 16 * n16);
+    }
+    if (m0on) {                             // this workgroup's two partial sums
+      const int64_t e0 = ((int64_t)b * gridDim.x + bx) * 2;
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        if (m0l[sidx] < 0) continue;
+        if (tid == 0) m0.lab[e0 + sidx] = m0l[sidx];
+        unsigned long long *dst = m0.part + (e0 + sidx) * D;
+        for (int i = tid; i < D; i += 256) dst[i] = mtab[sidx * D + i];
+      }
+    }
+  } else {
   for (int j = w; j < 32; j += 4) {
     const int64_t row = rowi[j];
     if (row < 0) continue;
@@ -929,7 +1099,7 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     m0_flush();
     __syncthreads();
   HSGK_TS(6);
-    const int64_t e0 = ((int64_t)b * gridDim.x + blockIdx.x) * 2;
+    const int64_t e0 = ((int64_t)b * gridDim.x + bx) * 2;
     for (int sidx = 0; sidx < 2; ++sidx) {
       if (m0l[sidx] < 0) continue;
       if (tid == 0) m0.lab[e0 + sidx] = m0l[sidx];
@@ -951,6 +1121,7 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
       uint4 pc = {lo2.x, lo2.y, hi2.x, hi2.y};
       *reinterpret_cast<uint4 *>(dst + (kb * 64 + lane) * 2) = pc;
     }
+  }
   }
   HSGK_TS(7);
 }
@@ -1257,8 +1428,9 @@ int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTa
   auto kern = fast ? prep_fast_kernel : prep_kernel;
   dim3 grid(ntiles, a.B);
   if (fast && tile32) {
-    kern = prep_fast32_kernel;
-    lds = ((size_t)32 * a.C + 32 + 32 + 64) * 4 + 32 * 8 + 36 * 4;
+    const char *fe = getenv("HSGK_PREP_FLAT");        // "0": phase 3 as in rounds 2-5 (A/B; read per call)
+    kern = (a.C <= 256 && !(fe && fe[0] == '0')) ? prep_fast32_kernel<true> : prep_fast32_kernel<false>;
+    lds = ((size_t)32 * a.C + kPrep32TilePad + 32 + 32 + 64) * 4 + 32 * 8 + (32 + 4 + 32 + 2) * 4;
 #ifdef HSGK_PREP_PAD_LDS
     lds += HSGK_PREP_PAD_LDS;
 #endif
@@ -1276,6 +1448,10 @@ int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTa
     // one 32-row block); the caller passes xh = null when nothing reads the row-major copy
     m0v.tiles = xmT;
     if (wrote_tiles) *wrote_tiles = true;
+  }
+  {
+    const char *oe = getenv("HSGK_PREP_ORDER");      // "0": workgroup ids as they come (A/B; read per call)
+    m0v.xcd_order = !(oe && oe[0] == '0');
   }
   if (fast && wrote_half) *wrote_half = xh != nullptr || m0v.tiles != nullptr;      // both fast kernels write the fp16 copy
   {

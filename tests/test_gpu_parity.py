@@ -2136,9 +2136,9 @@ def test_all_k_entries_dense_exact_pass_vs_oracle(dev, oracle, monkeypatch, hard
 def test_f19_full_size_image_vs_reference(dev, case):
   """tools/gen_golden.py f19: one WHOLE image of every BASELINE shape (448^2 / K 64, 224^2 / K 64, 768^2 / K 256,
   224^2 / C 384 / K 128; i.i.d. and mixture) against the REFERENCE's own labels.
-  (1) teacher-forced: segment_by_kmeans(iterations=1, cluster_indices=the reference's labels after iteration
-      t - 1) == the reference's labels after iteration t, except on the recorded near-tie pixels (float64 margin
-      < 1e-6 in the reference's own scores, <= 12 pixels per image and iteration);
+  (1) teacher-forced, all ten iterations: segment_by_kmeans(iterations=1, cluster_indices=the reference's labels
+      after iteration t - 1) == the reference's labels after iteration t, except on the recorded near-tie pixels
+      (float64 margin < 1e-6 in the reference's own scores, <= 12 pixels per image and iteration);
   (2) free-running: the operator's 10 iterations end exactly where the fixture says the canonical arithmetic ends
       (the reference's labels where no near-tie flipped on the way)."""
   import torch
@@ -2148,7 +2148,7 @@ def test_f19_full_size_image_vs_reference(dev, case):
   xd = torch.from_numpy(x).to(dev)
   ref[0] = sc.initialize_cluster_labels(list(grid), [H, W], 'cpu').view(-1).numpy()
   ref[0] = np.unique(ref[0], return_inverse=True)[1]
-  for t in (1, 2, 10):
+  for t in range(1, 11):                 # every iteration (round 6: f20 holds the reference's labels after 3 .. 8)
     init = torch.from_numpy(ref[t - 1].reshape(1, H, W)).to(dev)
     out = sc.segment_by_kmeans(xd, None, list(grid), iterations=1, cluster_indices=init)
     got = out[3].cpu().numpy()

@@ -50,7 +50,7 @@ TIE_MARGIN = 1e-6      # float64 top-2 margin below which a label difference aga
 
 def f19_case(name):
   """tools/gen_golden.py f19: one whole image of a BASELINE shape.  Returns (g, x NCHW, grid, loc, ref) with
-  ref[t] = the REFERENCE's labels after iteration t (t = 0: the grid seeds, 1, 2, 9, 10), and
+  ref[t] = the REFERENCE's labels after iteration t (t = 0: the grid seeds -- filled in by the caller --, 1 .. 10), and
   forced(t) = what one iteration of the canonical arithmetic gives when started from ref[t - 1]: the reference's
   labels except on the recorded near-tie pixels."""
   g = load('f19_full_' + name)
@@ -61,6 +61,11 @@ def f19_case(name):
   ref = {1: g['lab1'].astype(np.int64), 2: g['lab2'].astype(np.int64), 9: g['lab9'].astype(np.int64)}
   ref[10] = ref[9].copy()
   ref[10][g['lab10_idx']] = g['lab10_val']
+  # iterations 3 .. 8 of the same reference run: deltas in f20 (tools/ref_vs_ref.py, its `base` setting)
+  f20 = load('f20_ref_vs_ref')
+  for t in range(3, 9):
+    ref[t] = ref[t - 1].copy()
+    ref[t][f20['%s_lab%d_idx' % (name, t)]] = f20['%s_lab%d_val' % (name, t)]
 
   def forced(t):
     out = ref[t].copy()

@@ -725,9 +725,80 @@ def f19(only=None):
       save('f19_full_%s_%s' % (tag, flav), **rec)
 
 
+def f21():
+  """Full-size LABELLED input with an ignore band through the reference's own operator (round 6, review item 2: the
+  compaction / double-`unique` path of common.py:355-405 at BASELINE size, pinned to the reference and not only to
+  the oracle): images 0 and 1 of the cfg2 batch (2 x 256 x 448 x 448, grid 8 x 8), a 48-region over-segmentation
+  label map with a 4-row ignore band.
+
+  Stored: (a) the reference's 3 integer outputs of the full 10-iteration call (the drift of a free-running run is
+  f19's subject; here they pin the bookkeeping: which pixels are kept, their labels, the image partition);
+  (b) TEACHER-FORCED: the reference's k-means labels after 9 iterations, scattered back to the full images as a
+  `cluster_indices` map, and the reference's own operator started from that map for ONE iteration -- its 5-tuple is
+  what ours must give from the same start, except at near-ties of the reference's own scores, which are recorded
+  the way f19 records them (pixels where the oracle's k-means label differs + their float64 margins)."""
+  from oracle import oracle as orc
+  seed, shape, grid = synth.SEED_BASE + 2, (2, 256, 448, 448), (8, 8)
+  B, C, H, W = shape
+  K = grid[0] * grid[1]
+  x = synth.embeddings_nchw(seed, shape, 'iid')
+  lab = synth.overseg_labels(seed + 0x100, B, H, W, regions=48, ignore_rows=4, ignore_index=255)
+  xt, lt = torch.from_numpy(x), torch.from_numpy(lab)
+  full = ref_segment_by_kmeans(xt, lt, list(grid), ignore_index=255, iterations=10)
+  # the reference's labels after 9 iterations, per image, on the kept pixels (its own functions, common.py:337-369)
+  rows = _prep(x)
+  init = ref_common.initialize_cluster_labels(list(grid), (H, W), 'cpu').view(-1)
+  _, init = torch.unique(init, return_inverse=True)
+  ci = np.zeros((B, H * W), np.int64)
+  lab9, keep = [], []
+  for b in range(B):
+    valid = torch.ne(lt[b].view(-1), 255).nonzero().view(-1)
+    r = torch.index_select(rows[b], 0, valid)
+    l9 = ref_common.kmeans_with_initial_labels(r, torch.index_select(init, 0, valid), K, 9)
+    ci[b] = int(l9[0])              # (ignored pixels: a label the kept ones have, so the per-image `unique` of
+    ci[b, valid.numpy()] = l9.numpy()    #  common.py:341-345 sees the same set of values)
+    lab9.append(l9)
+    keep.append(valid)
+  ci = ci.reshape(B, H, W)
+  tf = ref_segment_by_kmeans(xt, lt, list(grid), ignore_index=255, iterations=1,
+                             cluster_indices=torch.from_numpy(ci))
+  assert all(torch.equal(a, b) for a, b in zip(full[2:], tf[2:])), 'chained iterations differ from the 10-iteration call'
+  loc = (ref_common.generate_location_features((H, W), 'cpu', 'float') - 0.5).numpy()
+  o = orc.segment_by_kmeans(x, lab, grid, loc, 255, 1, cluster_indices=ci)
+  assert np.array_equal(np.asarray(o[2]), tf[2].numpy()) and np.array_equal(np.asarray(o[4]), tf[4].numpy())
+  # near-ties: the k-means label of one iteration, oracle against reference, per image
+  pix, margins, off = [], [], 0
+  for b in range(B):
+    r = torch.index_select(rows[b], 0, keep[b])
+    ref10 = ref_common.kmeans_with_initial_labels(r, lab9[b], K, 1).numpy()
+    got = orc.kmeans_with_initial_labels(np.asarray(o[1])[off:off + r.shape[0]], lab9[b].numpy(), K, 1, exact_sums=True)
+    d = np.nonzero(got != ref10)[0]
+    if d.size:
+      cen = ref_common.calculate_prototypes_from_labels(r, lab9[b], K).double()
+      top2 = (r[torch.from_numpy(d)].double() @ cen.t()).topk(2, 1).values
+      margins.append((top2[:, 0] - top2[:, 1]).numpy())
+      pix.append(d + off)
+    off += r.shape[0]
+  pix = np.concatenate(pix) if pix else np.zeros((0,), np.int64)
+  margins = np.concatenate(margins) if margins else np.zeros((0,), np.float64)
+  oc, rc = np.asarray(o[3]), tf[3].numpy()
+  didx = np.nonzero(oc != rc)[0]
+  print('  f21: %d kept pixels, %d segments; oracle k-means labels differ from the reference on %d pixels (max margin %.2g); '
+        'final ids differ on %d' % (rc.shape[0], int(rc.max()) + 1, pix.size, margins.max() if margins.size else 0.0,
+                                    didx.size))
+  es, ec = sub_rows(tf[0])
+  ls, lc = sub_rows(tf[1])
+  save('f21_full_labelled_cfg2', seed=seed, label_seed=seed + 0x100, shape=np.array(shape), grid=np.array(grid),
+       ignore=255, ylin=lin01(H), xlin=lin01(W), start=ci.astype(np.uint8),
+       labels=tf[2].numpy().astype(np.uint8), cluster=rc.astype(np.int32), batch=tf[4].numpy().astype(np.uint8),
+       n_segments=np.int64(int(rc.max()) + 1), emb_rows=es, emb_colsum=ec, emb_loc_rows=ls, emb_loc_colsum=lc,
+       tie_pixels=pix.astype(np.int32), tie_margin64=margins,
+       oracle_cluster_idx=didx.astype(np.int32), oracle_cluster_val=oc[didx].astype(np.int32))
+
+
 if __name__ == '__main__':
   os.makedirs(OUT, exist_ok=True)
-  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13', 'f14', 'f15', 'f16', 'f17', 'f18', 'f19']
+  which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13', 'f14', 'f15', 'f16', 'f17', 'f18', 'f19', 'f21']
   for w in which:
     if w.startswith('f19:'):
       f19(w[4:].split(','))

@@ -106,6 +106,12 @@ def main():
         if name == 'base':
           # the same run as the f19 fixture's (labels after iterations 1, 2, 9)
           assert np.array_equal(r['free'][1], f19['lab1']) and np.array_equal(r['free'][9], f19['lab9']), key
+          # the reference's labels after iterations 3 .. 8 (f19 holds 1, 2, 9, 10), each as a delta against the
+          # iteration before: with them the GPU test teacher-forces ALL ten iterations (tests/util.py: f19_case)
+          for t in range(3, 9):
+            idx = np.nonzero(r['free'][t] != r['free'][t - 1])[0]
+            fix['%s_lab%d_idx' % (key, t)] = idx.astype(np.int32)
+            fix['%s_lab%d_val' % (key, t)] = r['free'][t][idx].astype(np.uint8)
           continue
         fix['%s_%s_tf' % (key, name)] = r['tf_counts']
         fix['%s_%s_free' % (key, name)] = r['free_counts']
