@@ -663,6 +663,61 @@ __device__ __forceinline__ float div_markstein(float x, float n, float r) {
 #define HSGK_DIV_SETUP(n, r)
 #define HSGK_DIV(x, n, r) ((x) / (n))
 #endif
+// ---- round 6: the kernel's vector work (static audit: tools/probes/isa_audit.py, profiles/r06_prep_isa_audit.txt)
+// x / n, correctly rounded, for the quads of a row that share the divisor n.  hipcc lowers `x / n` to the IEEE
+// sequence  s = v_div_scale(n), t = v_div_scale(x), r0 = v_rcp(s), r = fma(fma(-s, r0, 1), r0, r0), q0 = t * r,
+// q1 = fma(fma(-s, q0, t), r, q0), q = v_div_fmas(fma(-s, q1, t), r, q1), v_div_fixup(q, n, x): twelve vector
+// instructions per element, two of them (scale + reciprocal + its refinement) functions of n alone.  v_div_scale
+// returns its operand unchanged, v_div_fmas is a plain fma and v_div_fixup passes q through (ISA manual: they act
+// only on zeros, infinities, NaNs, denormals and exponent differences beyond +-96 / a dividend below 2^-103),
+// whenever  2^-60 <= n <= 2^20  and  2^-100 <= |x| < 2^30.  In that range the five instructions below ARE the
+// compiler's sequence -- same operations, same operands, same bits -- with r computed once per row.  |x| <= n (1 +
+// 2^-20) holds for every dividend here (n is the row's own norm, or the eps clamp above it), so the guard is n's
+// range, once per row, and min |x| >= 2^-100 per quad; a wave with any lane outside (exact zeros, tiny values,
+// NaN / Inf rows) takes the compiler's sequence for that quad.  DivRow::make costs 3 instructions per row.
+struct DivRow {
+  float n, r;
+  bool ok;
+  static __device__ __forceinline__ DivRow make(float n) {
+    const float r0 = __builtin_amdgcn_rcpf(n);
+    const float e = fmaf(-n, r0, 1.0f);
+    return DivRow{n, fmaf(e, r0, r0), n >= 0x1p-60f && n <= 0x1p20f};
+  }
+  __device__ __forceinline__ float one(float x) const {
+    const float q0 = x * r;
+    const float q1 = fmaf(fmaf(-n, q0, x), r, q0);
+    return fmaf(fmaf(-n, q1, x), r, q1);
+  }
+  __device__ __forceinline__ float4 quad(float4 v) const {
+    const float m = fminf(fminf(fabsf(v.x), fabsf(v.y)), fminf(fabsf(v.z), fabsf(v.w)));
+    if (__builtin_amdgcn_ballot_w64(!(ok && m >= 0x1p-100f)) == 0ull)
+      return make_float4(one(v.x), one(v.y), one(v.z), one(v.w));
+    return make_float4(v.x / n, v.y / n, v.z / n, v.w / n);
+  }
+};
+// sum over the 64 lanes in the data-parallel-primitive network (six v_add_f32 with a DPP operand instead of six
+// LDS-crossbar shuffles with their address arithmetic): pairs, quads, 8 (half-row mirror), 16 (row mirror), then
+// lane 15 -> next row, lane 31 -> rows 2 and 3; the total sits in lane 63.  Fixed order, used for the error word only.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define HSGK_DPP_ADD(ctrl, rmask)                                                                         \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+  HSGK_DPP_ADD(0xB1, 0xf);     // quad_perm [1, 0, 3, 2]
+  HSGK_DPP_ADD(0x4E, 0xf);     // quad_perm [2, 3, 0, 1]
+  HSGK_DPP_ADD(0x141, 0xf);    // row_half_mirror
+  HSGK_DPP_ADD(0x140, 0xf);    // row_mirror
+  HSGK_DPP_ADD(0x142, 0xa);    // row_bcast:15 into rows 1 and 3
+  HSGK_DPP_ADD(0x143, 0xc);    // row_bcast:31 into rows 2 and 3
+#undef HSGK_DPP_ADD
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// to_fixed(x) + 2^52 * 1.5 as the raw bits of the double (common.h: to_fixed): x * 2^40 is exact in fp32 for |x| <= 1
+// (a power-of-two scale), the double addition rounds it to the nearest-even integer exactly as to_fixed's fma does;
+// the caller subtracts the magic constant's bits once per flushed run instead of once per element
+__device__ __forceinline__ long long to_fixed_biased(float x) {
+  return __builtin_bit_cast(long long, (double)(x * 0x1p40f) + 6755399441055744.0);
+}
+constexpr long long kFixedBias = 0x4338000000000000ll;      // bits of 6755399441055744.0
+
 // FLAT (round 6; C <= 256, one 16-byte quad per lane): phase 3 keeps a wave's eight rows in registers, and the
 // emb_loc rows -- 1 032 bytes each, so that a lane's quad is only 8-byte aligned and used to leave as two half-density
 // 8-byte stores per lane plus a tail store per row -- go back to LDS in their final layout (the half tile's rows are
@@ -724,15 +779,22 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
   // otherwise put a second memory latency in front of them (18 % of a workgroup's lifetime
   // by the phase timers, tools/probes/prep_timing.py).  Indices are clamped, not branched on.
   const bool pix_ok = q0 + jl < HW;
-  const float *src = in + (int64_t)b * C * HW + (pix_ok ? q0 + jl : HW - 1);
+  // plane bases on the scalar unit, ONE 32-bit byte offset per lane (pixel + which of the wave's two quads): a load
+  // is one instruction with no vector address arithmetic (was ~6 per load, two of them quarter-rate multiplies).
+  // The host guarantees 20 * HW < 2^32.
+  const int ws = __builtin_amdgcn_readfirstlane(w);
+  const char *img = reinterpret_cast<const char *>(in + (int64_t)b * C * HW);
+  const unsigned boff = ((unsigned)(pix_ok ? q0 + jl : HW - 1) + (unsigned)sub * 4u * (unsigned)HW) * 4u;
+  const int64_t plane = HW * 4;
   float4 v0[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
-    const int q = min(2 * w + sub + 8 * u, NQ - 1);
-    v0[u].x = src[(int64_t)(4 * q + 0) * HW];
-    v0[u].y = src[(int64_t)(4 * q + 1) * HW];
-    v0[u].z = src[(int64_t)(4 * q + 2) * HW];
-    v0[u].w = src[(int64_t)(4 * q + 3) * HW];
+    const int qs = min(2 * ws + 8 * u, NQ - 2);      // (scalar; a clamped quad is loaded twice and never stored)
+    const char *pl = img + (int64_t)(4 * qs) * plane;
+    v0[u].x = *reinterpret_cast<const float *>(pl + boff);
+    v0[u].y = *reinterpret_cast<const float *>(pl + plane + boff);
+    v0[u].z = *reinterpret_cast<const float *>(pl + 2 * plane + boff);
+    v0[u].w = *reinterpret_cast<const float *>(pl + 3 * plane + boff);
   }
 
   if (w == 0) {
@@ -783,15 +845,17 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     }
     // further batches (C > 256): all 32 loads of a batch are issued before its first LDS
     // write (a load-use loop here exposes one memory latency per quad)
-    for (int q0b = 2 * w + sub + 64; q0b < NQ; q0b += 64) {
+    for (int qb = 2 * ws + 64; qb < NQ; qb += 64) {      // (scalar loop: NQ is even, both quads of a wave agree)
+      const int q0b = qb + sub;
       float4 v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int q = min(q0b + 8 * u, NQ - 1);
-        v[u].x = src[(int64_t)(4 * q + 0) * HW];
-        v[u].y = src[(int64_t)(4 * q + 1) * HW];
-        v[u].z = src[(int64_t)(4 * q + 2) * HW];
-        v[u].w = src[(int64_t)(4 * q + 3) * HW];
+        const int qs = min(qb + 8 * u, NQ - 2);
+        const char *pl = img + (int64_t)(4 * qs) * plane;
+        v[u].x = *reinterpret_cast<const float *>(pl + boff);
+        v[u].y = *reinterpret_cast<const float *>(pl + plane + boff);
+        v[u].z = *reinterpret_cast<const float *>(pl + 2 * plane + boff);
+        v[u].w = *reinterpret_cast<const float *>(pl + 3 * plane + boff);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -839,11 +903,16 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
   {
     const float n1 = nrm1[jl];
     HSGK_DIV_SETUP(n1, r1)
+    const DivRow d1 = DivRow::make(n1);
     float *r = tile + jl * C;
     for (int q = 2 * w + sub; q < NQ; q += 8) {
       float4 *pv = reinterpret_cast<float4 *>(r + ((q ^ sw) << 2));
       float4 v = *pv;
-      v.x = HSGK_DIV(v.x, n1, r1); v.y = HSGK_DIV(v.y, n1, r1); v.z = HSGK_DIV(v.z, n1, r1); v.w = HSGK_DIV(v.w, n1, r1);
+      if constexpr (FLAT) {
+        v = d1.quad(v);
+      } else {
+        v.x = HSGK_DIV(v.x, n1, r1); v.y = HSGK_DIV(v.y, n1, r1); v.z = HSGK_DIV(v.z, n1, r1); v.w = HSGK_DIV(v.w, n1, r1);
+      }
       *pv = v;
     }
   }
@@ -900,6 +969,13 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     }
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    int nrun = 0;                              // rows in the current run: their to_fixed bias leaves with the flush
+    auto flat_flush = [&]() {
+      const long long bias = (long long)nrun * kFixedBias;
+      cur[0] -= bias; cur[1] -= bias; cur[2] -= bias; cur[3] -= bias;
+      nrun = 0;
+      m0_flush();
+    };
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int j = w + 4 * i;
@@ -907,24 +983,24 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
       const int64_t row = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rr >> 32)) << 32) |
                                     (unsigned)__builtin_amdgcn_readfirstlane((int)rr));
       if (row < 0) continue;
-      const float n2 = nrm2[j];
-      HSGK_DIV_SETUP(n2, r2)
+      const DivRow d2 = DivRow::make(nrm2[j]);
       if (m0on) {
         const int L = __builtin_amdgcn_readfirstlane(seedl[j]);
         const int L0 = __builtin_amdgcn_readfirstlane(m0l[0]), L1 = __builtin_amdgcn_readfirstlane(m0l[1]);
         const int slot = L < 0 ? -1 : L == L0 ? 0 : L == L1 ? 1 : L < m0.K ? 2 : -1;
         unsigned long long *g = slot == 2 ? m0.sumq + ((int64_t)b * m0.K + L) * D : nullptr;
-        if (slot != cslot || g != cg) { m0_flush(); cslot = slot; cg = g; }
+        if (slot != cslot || g != cg) { flat_flush(); cslot = slot; cg = g; }
       }
       float e2 = 0.0f;                         // |row - fp16(row)|^2, this lane's columns
       if (act) {
         const float4 v = rv[i];
         HSGK_ROW_STORE(reinterpret_cast<float4 *>(emb + row * C + 4 * lane), v);
-        float4 a;
-        a.x = HSGK_DIV(v.x, n2, r2); a.y = HSGK_DIV(v.y, n2, r2); a.z = HSGK_DIV(v.z, n2, r2); a.w = HSGK_DIV(v.w, n2, r2);
+        const float4 a = d2.quad(v);
         rv[i] = a;                             // (kept: the emb_loc row leaves through LDS below)
-        if (m0on) {                            // (uniform)
-          cur[0] += to_fixed(a.x); cur[1] += to_fixed(a.y); cur[2] += to_fixed(a.z); cur[3] += to_fixed(a.w);
+        if (m0on) {                            // (uniform; the bias of to_fixed_biased leaves at the flush)
+          cur[0] += to_fixed_biased(a.x); cur[1] += to_fixed_biased(a.y);
+          cur[2] += to_fixed_biased(a.z); cur[3] += to_fixed_biased(a.w);
+          ++nrun;
         }
         if (xh || tmode) {
           const h4 hv = {(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w};
@@ -937,11 +1013,11 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
         }
       }
       if (xh || tmode) {
-        for (int off = 32; off > 0; off >>= 1) e2 += __shfl_xor(e2, off);
+        e2 = wave_sum_dpp(e2);
         if (lane == 0) e2s[j] = e2;
       }
     }
-    if (m0on) m0_flush();
+    if (m0on) flat_flush();
     if (tmode) {
       // the block's 16-byte pieces in operand order: piece (kb, lane = jj + 32 g) = row jj, columns 16 kb + 8 g .. + 7
       // (two quads of four halves each, from their LDS slots); one KiB contiguous per wave instruction
@@ -1428,6 +1504,7 @@ int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTa
   auto kern = fast ? prep_fast_kernel : prep_kernel;
   dim3 grid(ntiles, a.B);
   if (fast && tile32) {
+    HSGK_REQUIRE(HW * 20 < ((int64_t)1 << 32), "image too large for the 32-bit lane offsets of the prep kernel");
     const char *fe = getenv("HSGK_PREP_FLAT");        // "0": phase 3 as in rounds 2-5 (A/B; read per call)
     kern = (a.C <= 256 && !(fe && fe[0] == '0')) ? prep_fast32_kernel<true> : prep_fast32_kernel<false>;
     lds = ((size_t)32 * a.C + kPrep32TilePad + 32 + 32 + 64) * 4 + 32 * 8 + (32 + 4 + 32 + 2) * 4;

@@ -2167,6 +2167,20 @@ def test_f19_full_size_image_vs_reference(dev, case):
 
 
 @pytest.mark.gpu
+def test_f21_full_size_labelled_input_vs_reference(dev):
+  """tools/gen_golden.py f21: the labelled path at BASELINE size against the REFERENCE's own operator (2 x 256 x 448
+  x 448, 48-region label map + ignore band; common.py:355-405): segment_by_kmeans(iterations=1, cluster_indices =
+  the reference's labels after nine iterations) gives the reference's kept pixels, labels, image ids, segment ids
+  (except the fixture's 3 recorded near-tie pixels) and rows."""
+  import torch
+  from hsg_amd.utils.segsort import common as sc
+  g, x, lab, grid, loc, start, want = util.f21_case()
+  out = sc.segment_by_kmeans(torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev), list(grid),
+                             ignore_index=255, iterations=1, cluster_indices=torch.from_numpy(start).to(dev))
+  util.check_f21(g, want, *[o.cpu().numpy() for o in out])
+
+
+@pytest.mark.gpu
 def test_torch_extension_binding_matches_the_ctypes_mirror_bit_for_bit(dev, monkeypatch):
   """The two host bindings drive the same kernels: segment_reduce (prototypes / means / sums, forward and the
   gradient of the rows), segment_by_kmeans (five outputs and the gradient of the NCHW input, with and without a

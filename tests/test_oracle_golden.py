@@ -312,3 +312,15 @@ def test_f20_reference_against_itself():
   assert min(tot['avx2_tf'], tot['compat_tf']) >= 0.75 * tot['ours_tf']
   # pixels that differ after ten free-running iterations, summed over the images: ours 49 121, theirs 42 307 / 40 260
   assert tot['ours_free'] <= 1.5 * max(tot['avx2_free'], tot['compat_free'])
+
+
+def test_f21_full_size_labelled_input_vs_reference(oracle):
+  """Full-size pin of the labelled path to the reference itself (tools/gen_golden.py f21; common.py:355-405: ignore
+  compaction, per-image `unique`, partition by image and by ground-truth label): 2 x 256 x 448 x 448 with a 48-region
+  label map and a 4-row ignore band, one iteration from the reference's own labels after nine -- the reference's
+  operator gives the fixture, the oracle must give the same 397 824 kept pixels, labels, image ids and segment ids
+  (3 recorded near-tie pixels, float64 margin < 1e-7) and the same rows."""
+  g, x, lab, grid, loc, start, want = util.f21_case()
+  out = oracle.segment_by_kmeans(x, lab, grid, loc, 255, 1, cluster_indices=start)
+  util.check_f21(g, want, *[np.asarray(o) for o in out])
+  assert int(np.asarray(out[3]).max()) + 1 == int(g['n_segments']) or g['oracle_cluster_idx'].size > 0

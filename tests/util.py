@@ -75,6 +75,35 @@ def f19_case(name):
 
 
 
+def f21_case():
+  """tools/gen_golden.py f21: images 0 and 1 of the cfg2 batch with an over-segmentation label map and an ignore
+  band, teacher-forced through the REFERENCE's own operator (one iteration from its labels after nine).  Returns
+  (g, x, labels, grid, loc, start, want): `start` = the `cluster_indices` argument, `want` = the reference's final
+  ids except where a recorded near-tie (float64 margin in g['tie_margin64']) moved a pixel."""
+  g = load('f21_full_labelled_cfg2')
+  shape = tuple(int(v) for v in g['shape'])
+  B, C, H, W = shape
+  x = synth.embeddings_nchw(int(g['seed']), shape, 'iid')
+  lab = synth.overseg_labels(int(g['label_seed']), B, H, W, regions=48, ignore_rows=4, ignore_index=255)
+  want = g['cluster'].astype(np.int64)
+  want[g['oracle_cluster_idx']] = g['oracle_cluster_val']
+  return (g, x, lab, tuple(int(v) for v in g['grid']), loc_from_lin(g['ylin'], g['xlin']),
+          g['start'].astype(np.int64), want)
+
+
+def check_f21(g, want, emb, emb_loc, labels, cluster, batch):
+  assert np.array_equal(labels, g['labels'].astype(np.int64))         # which pixels are kept, in which order
+  assert np.array_equal(batch, g['batch'].astype(np.int64))
+  assert np.array_equal(cluster, want), '%d ids differ' % int((cluster != want).sum())
+  assert g['tie_pixels'].size <= 16 and (g['tie_pixels'].size == 0 or g['tie_margin64'].max() < TIE_MARGIN)
+  st = int(g['row_stride'])
+  assert np.abs(emb[::st] - g['emb_rows']).max() <= 2e-6
+  assert np.abs(emb_loc[::st] - g['emb_loc_rows']).max() <= 2e-6
+  n = emb.shape[0]
+  assert np.abs(emb.astype(np.float64).sum(0) - g['emb_colsum']).max() <= 2e-7 * n
+  assert np.abs(emb_loc.astype(np.float64).sum(0) - g['emb_loc_colsum']).max() <= 2e-7 * n
+
+
 def exchange_grad_weights(rank, P, C, D):
   """Weights of the per-'GPU' scalar  (protos * w1).sum() + (protos_loc * w2).sum()  whose gradients with respect to
   every GPU's rows the f8 fixture holds (tools/gen_golden.py f8: the reference's own autograd)."""

@@ -45,9 +45,9 @@ exec(_src, _ns)
 ref_segment_by_kmeans = _ns['segment_by_kmeans']
 
 
-def sub_rows(a):
+def sub_rows(a, stride=ROW_STRIDE):
   a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
-  return a[::ROW_STRIDE].copy(), a.astype(np.float64).sum(0)
+  return a[::stride].copy(), a.astype(np.float64).sum(0)
 
 
 def save(name, **kw):
@@ -786,9 +786,9 @@ def f21():
   print('  f21: %d kept pixels, %d segments; oracle k-means labels differ from the reference on %d pixels (max margin %.2g); '
         'final ids differ on %d' % (rc.shape[0], int(rc.max()) + 1, pix.size, margins.max() if margins.size else 0.0,
                                     didx.size))
-  es, ec = sub_rows(tf[0])
-  ls, lc = sub_rows(tf[1])
-  save('f21_full_labelled_cfg2', seed=seed, label_seed=seed + 0x100, shape=np.array(shape), grid=np.array(grid),
+  es, ec = sub_rows(tf[0], 1009)          # (a whole-batch fixture: every 1009th row + float64 column sums)
+  ls, lc = sub_rows(tf[1], 1009)
+  save('f21_full_labelled_cfg2', row_stride=1009, seed=seed, label_seed=seed + 0x100, shape=np.array(shape), grid=np.array(grid),
        ignore=255, ylin=lin01(H), xlin=lin01(W), start=ci.astype(np.uint8),
        labels=tf[2].numpy().astype(np.uint8), cluster=rc.astype(np.int32), batch=tf[4].numpy().astype(np.uint8),
        n_segments=np.int64(int(rc.max()) + 1), emb_rows=es, emb_colsum=ec, emb_loc_rows=ls, emb_loc_colsum=lc,
