@@ -868,8 +868,11 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
   }
   __syncthreads();
   HSGK_TS(2);
-  // phase 2a: the C1 chain of pixel jl (wave 0, lanes 0..31)
+  // phase 2a: the C1 chain of pixel jl (wave 0, lanes 0..31).  The chain is the workgroup's critical path -- its
+  // other three waves wait at the barrier below -- so the wave asks for issue priority over the other workgroups'
+  // waves on its SIMD for as long as it runs (m0.xcd_order bit 1).
   if (w == 0 && sub == 0) {
+    if (m0.xcd_order & 2) __builtin_amdgcn_s_setprio(3);
     const float *r = tile + jl * C;
     float ss = 0.0f;
     for (int q = 0; q < NQ; ++q) {
@@ -882,6 +885,7 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     float n1 = sqrtf(ss);
     if (!(n1 >= eps)) n1 = eps;
     nrm1[jl] = n1;
+    if (m0.xcd_order & 2) __builtin_amdgcn_s_setprio(0);
   } else if (m0on && w == 1) {
     // fused first M-step, off the critical path (wave 0 walks the chains meanwhile): the
     // first two distinct seed labels of this half tile get an LDS slot
@@ -918,8 +922,30 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
   }
   __syncthreads();
   HSGK_TS(4);
+  // FLAT: this wave's eight rows -> registers, and the `embeddings` rows (final since phase 2b) leave NOW, so that
+  // 28 % of the workgroup's store traffic flies during the second chain instead of after it (m0.xcd_order bit 2)
+  [[maybe_unused]] float4 rv[8];
+  [[maybe_unused]] const bool early = FLAT && (m0.xcd_order & 4);
+  if constexpr (FLAT) {
+    const bool act = lane < NQ;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = w + 4 * i;
+      rv[i] = *reinterpret_cast<const float4 *>(tile + j * C + (((act ? lane : 0) ^ (j & 15)) << 2));
+    }
+    if (early) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const long long rr = rowi[w + 4 * i];
+        const int64_t row = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rr >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)rr));
+        if (row >= 0 && act) HSGK_ROW_STORE(reinterpret_cast<float4 *>(emb + row * C + 4 * lane), rv[i]);
+      }
+    }
+  }
   // phase 2c
   if (w == 0 && sub == 0) {
+    if (m0.xcd_order & 2) __builtin_amdgcn_s_setprio(3);
     const float *r = tile + jl * C;
     float ss = 0.0f;
     for (int q = 0; q < NQ; ++q) {
@@ -935,6 +961,7 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
     float n2 = sqrtf(ss);
     if (!(n2 >= eps)) n2 = eps;
     nrm2[jl] = n2;
+    if (m0.xcd_order & 2) __builtin_amdgcn_s_setprio(0);
   }
   __syncthreads();
   HSGK_TS(5);
@@ -961,12 +988,6 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
   if constexpr (FLAT) {
     // ---- (NQ <= 64) this wave's eight rows -> registers; emb, the fp16 copy and the first M-step straight from them
     const bool act = lane < NQ;
-    float4 rv[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int j = w + 4 * i;
-      rv[i] = *reinterpret_cast<const float4 *>(tile + j * C + (((act ? lane : 0) ^ (j & 15)) << 2));
-    }
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     int nrun = 0;                              // rows in the current run: their to_fixed bias leaves with the flush
@@ -994,7 +1015,7 @@ __global__ __launch_bounds__(256) void prep_fast32_kernel(
       float e2 = 0.0f;                         // |row - fp16(row)|^2, this lane's columns
       if (act) {
         const float4 v = rv[i];
-        HSGK_ROW_STORE(reinterpret_cast<float4 *>(emb + row * C + 4 * lane), v);
+        if (!early) HSGK_ROW_STORE(reinterpret_cast<float4 *>(emb + row * C + 4 * lane), v);
         const float4 a = d2.quad(v);
         rv[i] = a;                             // (kept: the emb_loc row leaves through LDS below)
         if (m0on) {                            // (uniform; the bias of to_fixed_biased leaves at the flush)
@@ -1529,6 +1550,10 @@ int launch_prep(const hsgk_segkm_args &a, const int32_t *tile_off, const ChunkTa
   {
     const char *oe = getenv("HSGK_PREP_ORDER");      // "0": workgroup ids as they come (A/B; read per call)
     m0v.xcd_order = !(oe && oe[0] == '0');
+    // two scheduling experiments, measured neutral and off by default (profiles/r06_prep_ab.txt): bit 1 = issue
+    // priority for the wave that walks a norm chain, bit 2 = the `embeddings` rows stored before the second chain
+    const char *xe = getenv("HSGK_PREP_X");
+    m0v.xcd_order |= xe ? (atoi(xe) & 6) : 0;
   }
   if (fast && wrote_half) *wrote_half = xh != nullptr || m0v.tiles != nullptr;      // both fast kernels write the fp16 copy
   {
