@@ -63,7 +63,7 @@ class LossSet(ctypes.Structure):
 
 
 _lib = None
-ABI_VERSION = 400          # HSGK_VERSION the struct layouts / signatures below were written for
+ABI_VERSION = 401          # HSGK_VERSION the struct layouts / signatures below were written for
 
 _vp, _i64, _i32, _f32, _sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                               ctypes.c_float, ctypes.c_size_t)
@@ -103,6 +103,7 @@ SIGNATURES = {
     'hsgk_hier_assign': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'hsgk_hier_assign_bwd': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'hsgk_group_mean': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
+    'hsgk_group_mean_bwd': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     'hsgk_gather_labels': (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _vp]),
     'hsgk_pad_prototype_tables': (_i32, [_vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp,
                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

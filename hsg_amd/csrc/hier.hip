@@ -359,6 +359,77 @@ __global__ __launch_bounds__(128) void pad_fill_kernel(
   }
 }
 
+
+// Backward of group_mean (+ the optional normalisation), one workgroup per image: the group sums are formed again
+// in the forward's order (so that the mean and its norm are the forward's), the gradient of a group's mean vector
+//   gm = normalised ? (norm >= eps ? (g - out <out, g>) / norm : g / eps) : g          (out = mean / max(norm, eps))
+// is divided by the group's node count and handed to every unpadded node of the group.  Replaces the ATen
+// restatement the mirror differentiated through autograd (~25 small kernels per call); a tolerance quantity.
+__global__ __launch_bounds__(256) void group_mean_bwd_kernel(
+    const float *__restrict__ protos, const int64_t *__restrict__ labels, const uint8_t *__restrict__ masks,
+    int C, int N, int G, int normalized, float eps, const float *__restrict__ g_out, float *__restrict__ g_protos) {
+  extern __shared__ float sm[];              // [G][C] sums -> gradients of the means, [G] counts, [G] norms, [G] dots, int labels [N]
+  float *sums = sm;
+  float *cnt = sm + (size_t)G * C;
+  float *nrm = cnt + G;
+  float *dot = nrm + G;
+  int *lab = reinterpret_cast<int *>(dot + G);
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int n = tid; n < N; n += 256) {
+    const bool pad = masks ? masks[(int64_t)b * N + n] != 0 : false;
+    const int64_t l = labels[(int64_t)b * N + n];
+    lab[n] = (pad || l < 0 || l >= G) ? -1 : (int)l;
+  }
+  for (int i = tid; i < G * C; i += 256) sums[i] = 0.0f;
+  __syncthreads();
+  for (int g = tid; g < G; g += 256) {
+    float k = 0.0f;
+    for (int n = 0; n < N; ++n) k = k + (lab[n] == g ? 1.0f : 0.0f);
+    cnt[g] = fmaxf(k, 1e-12f);
+  }
+  for (int c = tid; c < C; c += 256) {         // (a thread owns column c of every group: no conflicts)
+    const float *p = protos + ((int64_t)b * C + c) * N;
+    for (int n = 0; n < N; ++n) {
+      const int g = lab[n];
+      if (g >= 0) sums[g * C + c] = sums[g * C + c] + p[n];
+    }
+  }
+  __syncthreads();
+  // per group (one wave each, round-robin): the mean, its norm, <out, g>
+  for (int g = w; g < G; g += 4) {
+    float ss = 0.0f, dd = 0.0f;
+    for (int c = lane; c < C; c += 64) {
+      const float m = sums[g * C + c] / cnt[g];
+      ss = fmaf(m, m, ss);
+      dd = fmaf(m, g_out[((int64_t)b * C + c) * G + g], dd);
+    }
+    for (int off = 32; off > 0; off >>= 1) { ss += __shfl_xor(ss, off); dd += __shfl_xor(dd, off); }
+    if (lane == 0) {
+      float nn = sqrtf(ss);
+      const bool clamped = !(nn >= eps);
+      nrm[g] = clamped ? -eps : nn;            // (sign = the clamped branch, where out = mean / eps is linear)
+      dot[g] = clamped ? 0.0f : dd / nn;       // <out, g> with out = mean / norm
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < G * C; i += 256) {
+    const int g = i / C, c = i - g * C;
+    const float go = g_out[((int64_t)b * C + c) * G + g];
+    float gm = go;
+    if (normalized) {
+      const float nn = nrm[g];
+      gm = nn < 0.0f ? go / (-nn) : (go - (sums[i] / cnt[g] / nn) * dot[g]) / nn;
+    }
+    sums[i] = gm / cnt[g];
+  }
+  __syncthreads();
+  for (int64_t i = tid; i < (int64_t)C * N; i += 256) {
+    const int c = (int)(i / N), n = (int)(i - (int64_t)c * N);
+    const int g = lab[n];
+    g_protos[(int64_t)b * C * N + i] = g >= 0 ? sums[g * C + c] : 0.0f;
+  }
+}
+
 }  // namespace hsgk
 
 using namespace hsgk;
@@ -417,6 +488,22 @@ int hsgk_group_mean(const float *protos, const int64_t *labels, const uint8_t *m
     hipLaunchKernelGGL(group_normalize_kernel, dim3((G + 63) / 64, B), dim3(64), 0, st, out, C, G, eps);
     HSGK_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+int hsgk_group_mean_bwd(const float *protos, const int64_t *labels, const uint8_t *masks, int B, int C, int N,
+                        int G, int normalized, float eps, const float *g_out, float *g_protos,
+                        hsgk_stream_t stream) {
+  HSGK_REQUIRE(B >= 0 && C >= 1 && N >= 1 && G >= 1, "bad shape");
+  if (B == 0) return 0;
+  (void)hipGetLastError();
+  const size_t lds = ((size_t)G * C + 3 * (size_t)G + (size_t)N) * 4;
+  HSGK_REQUIRE(lds <= 150 * 1024, "too many groups x channels for one workgroup");
+  HSGK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(group_mean_bwd_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(group_mean_bwd_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), protos, labels,
+                     masks, C, N, G, normalized, eps, g_out, g_protos);
+  HSGK_LAUNCH_CHECK();
   return 0;
 }
 

@@ -19,6 +19,10 @@
 //       the multi-rank exchange keeps its two collectives between the phases, hsg_amd/models/utils.py).  meta_host:
 //       int64[8] on the host = {rows of this rank, table rows, error bits, capacity needed, distinct images, most
 //       segments of one image, ...}; with a capacity error the tensors are empty and the caller regrows `cap`.
+//   hsgk::pad_prototype_tables / hier_assign / group_mean / gather_labels (round 6)
+//       hsg/models/embeddings/resnet_fcn_hsg.py:499-577, :638-672, :683-748, :751-780: the padded per-image tables,
+//       the two-level assignment (+ its one-launch backward), the masked group means (+ hsgk_group_mean_bwd) and
+//       the pixel -> group lookup -- one dispatch each, outputs allocated here.
 #include <ATen/ATen.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
@@ -445,6 +449,146 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> segment_by_km
   return {r[0], r[1], r[2], r[3], r[4], r[5], r[6]};
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The hierarchy entry points (round 6): hsg/models/embeddings/resnet_fcn_hsg.py:455-780.
+struct HierAssignFn : public torch::autograd::Function<HierAssignFn> {
+  static variable_list forward(AutogradContext *ctx, const Tensor &fine_logits, const c10::optional<Tensor> &coarse_logits) {
+    TORCH_CHECK(fine_logits.is_cuda(), "hsgk::hier_assign: tensors must be on a ROCm device (there is no CPU path)");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(fine_logits.device());
+    Tensor fl = fine_logits.detach().to(at::kFloat).contiguous();
+    const bool has_c = coarse_logits.has_value() && coarse_logits->defined();
+    Tensor cl = has_c ? coarse_logits->detach().to(at::kFloat).contiguous() : Tensor();
+    const int64_t B = fl.size(0), KF = fl.size(1), N = fl.size(2), KC = has_c ? cl.size(1) : 0;
+    auto i64 = fl.options().dtype(at::kLong);
+    Tensor fprob = at::empty_like(fl), flab = at::empty({B, N}, i64);
+    Tensor cprob = at::empty({B, std::max<int64_t>(KC, 1), N}, fl.options()), clab = at::empty({B, N}, i64);
+    check(hsgk_hier_assign(fl.data_ptr<float>(), has_c ? cl.data_ptr<float>() : nullptr, (int)B, (int)KF, (int)KC, (int)N,
+                           fprob.data_ptr<float>(), flab.data_ptr<int64_t>(), has_c ? cprob.data_ptr<float>() : nullptr,
+                           has_c ? clab.data_ptr<int64_t>() : nullptr, stream_of(fl)),
+          "hsgk_hier_assign");
+    ctx->save_for_backward({fl, has_c ? cl : at::empty({0}, fl.options())});
+    ctx->saved_data["has_c"] = has_c;
+    ctx->mark_non_differentiable({flab, clab});
+    return {fprob, flab, cprob, clab};
+  }
+  static variable_list backward(AutogradContext *ctx, variable_list g) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &fl = saved[0], &cl = saved[1];
+    const bool has_c = ctx->saved_data["has_c"].toBool();
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(fl.device());
+    const int64_t B = fl.size(0), KF = fl.size(1), N = fl.size(2), KC = has_c ? cl.size(1) : 0;
+    Tensor g1 = g[0].defined() ? g[0].to(at::kFloat).contiguous() : Tensor();
+    Tensor g2 = (has_c && g[2].defined()) ? g[2].to(at::kFloat).contiguous() : Tensor();
+    Tensor gfl = at::empty_like(fl), gcl = has_c ? at::empty_like(cl) : Tensor();
+    check(hsgk_hier_assign_bwd(fl.data_ptr<float>(), has_c ? cl.data_ptr<float>() : nullptr, (int)B, (int)KF, (int)KC,
+                               (int)N, g1.defined() ? g1.data_ptr<float>() : nullptr,
+                               g2.defined() ? g2.data_ptr<float>() : nullptr, gfl.data_ptr<float>(),
+                               has_c ? gcl.data_ptr<float>() : nullptr, stream_of(fl)),
+          "hsgk_hier_assign_bwd");
+    return {gfl, gcl};
+  }
+};
+
+std::tuple<Tensor, Tensor, Tensor, Tensor> hier_assign(const Tensor &fine_logits, const c10::optional<Tensor> &coarse_logits) {
+  auto r = HierAssignFn::apply(fine_logits, coarse_logits);
+  return {r[0], r[1], r[2], r[3]};
+}
+
+struct GroupMeanFn : public torch::autograd::Function<GroupMeanFn> {
+  static Tensor forward(AutogradContext *ctx, const Tensor &prototypes, const Tensor &labels,
+                        const c10::optional<Tensor> &masks, int64_t G, bool normalized) {
+    TORCH_CHECK(prototypes.is_cuda(), "hsgk::group_mean: tensors must be on a ROCm device (there is no CPU path)");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(prototypes.device());
+    Tensor p = prototypes.detach().to(at::kFloat).contiguous();
+    Tensor lab = labels.to(at::kLong).contiguous();
+    const bool has_m = masks.has_value() && masks->defined();
+    Tensor mk = has_m ? masks->to(at::kByte).contiguous() : Tensor();
+    const int64_t B = p.size(0), C = p.size(1), N = p.size(2);
+    Tensor out = at::empty({B, C, G}, p.options());
+    check(hsgk_group_mean(p.data_ptr<float>(), lab.data_ptr<int64_t>(), has_m ? mk.data_ptr<uint8_t>() : nullptr, (int)B,
+                          (int)C, (int)N, (int)G, normalized ? 1 : 0, kEps, out.data_ptr<float>(), stream_of(p)),
+          "hsgk_group_mean");
+    ctx->save_for_backward({p, lab, has_m ? mk : at::empty({0}, p.options().dtype(at::kByte))});
+    ctx->saved_data["G"] = G;
+    ctx->saved_data["normalized"] = normalized;
+    ctx->saved_data["has_m"] = has_m;
+    return out;
+  }
+  static variable_list backward(AutogradContext *ctx, variable_list g) {
+    auto saved = ctx->get_saved_variables();
+    const Tensor &p = saved[0], &lab = saved[1], &mk = saved[2];
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(p.device());
+    const int64_t B = p.size(0), C = p.size(1), N = p.size(2), G = ctx->saved_data["G"].toInt();
+    Tensor go = g[0].to(at::kFloat).contiguous(), gp = at::empty_like(p);
+    check(hsgk_group_mean_bwd(p.data_ptr<float>(), lab.data_ptr<int64_t>(),
+                              ctx->saved_data["has_m"].toBool() ? mk.data_ptr<uint8_t>() : nullptr, (int)B, (int)C, (int)N,
+                              (int)G, ctx->saved_data["normalized"].toBool() ? 1 : 0, kEps, go.data_ptr<float>(),
+                              gp.data_ptr<float>(), stream_of(p)),
+          "hsgk_group_mean_bwd");
+    return {gp, Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+Tensor group_mean(const Tensor &prototypes, const Tensor &labels, const c10::optional<Tensor> &masks, int64_t G,
+                  bool normalized) {
+  return GroupMeanFn::apply(prototypes, labels, masks, G, normalized);
+}
+
+Tensor gather_labels(const Tensor &table, const Tensor &img, const Tensor &seg) {
+  TORCH_CHECK(seg.is_cuda(), "hsgk::gather_labels: tensors must be on a ROCm device (there is no CPU path)");
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(seg.device());
+  Tensor t = table.to(at::kLong).contiguous(), s = vec_i64(seg, seg.device()), im = vec_i64(img, seg.device());
+  Tensor out = at::empty_like(s);
+  if (s.numel())
+    check(hsgk_gather_labels(t.data_ptr<int64_t>(), (int)t.size(1), im.data_ptr<int64_t>(), s.data_ptr<int64_t>(), s.numel(),
+                             out.data_ptr<int64_t>(), stream_of(s)),
+          "hsgk_gather_labels");
+  return out;
+}
+
+// rows[s] sit at table[slot[s]]: the gradient of a row is its table row's (the padded tables' autograd edge)
+struct PlacedRowsFn : public torch::autograd::Function<PlacedRowsFn> {
+  static Tensor forward(AutogradContext *ctx, const Tensor &rows, const Tensor &slot, const Tensor &table) {
+    ctx->save_for_backward({slot});
+    return table.view_as(table);
+  }
+  static variable_list backward(AutogradContext *ctx, variable_list g) {
+    return {g[0].index_select(0, ctx->get_saved_variables()[0]), Tensor(), Tensor()};
+  }
+};
+
+// (table [B*M, C], pos table [B*M, Cp] or empty, masks bool [B*M], labels / batch ids int64 [B*M], by_image int64 [n],
+//  pixel_image int64 [n]); protos / pos differentiable through their table rows
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> pad_prototype_tables(
+    const Tensor &seg_image, const Tensor &protos, const c10::optional<Tensor> &pos, const Tensor &seg_lab,
+    const Tensor &seg_batch, const Tensor &pixel_seg, int64_t B, int64_t M) {
+  TORCH_CHECK(protos.is_cuda(), "hsgk::pad_prototype_tables: tensors must be on a ROCm device (there is no CPU path)");
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(protos.device());
+  const auto dev = protos.device();
+  const bool has_p = pos.has_value() && pos->defined();
+  Tensor pr = protos.detach().to(at::kFloat).contiguous(), po = has_p ? pos->detach().to(at::kFloat).contiguous() : Tensor();
+  Tensor si = vec_i64(seg_image, dev), sl = vec_i64(seg_lab, dev), sb = vec_i64(seg_batch, dev), ps = vec_i64(pixel_seg, dev);
+  const int64_t P = pr.size(0), C = pr.size(1), Cp = has_p ? po.size(1) : 0, n = ps.size(0);
+  auto f32 = pr.options();
+  auto i64 = pr.options().dtype(at::kLong);
+  Tensor table = at::empty({B * M, C}, f32), ptab = has_p ? at::empty({B * M, Cp}, f32) : at::empty({0}, f32);
+  Tensor masks = at::empty({B * M}, pr.options().dtype(at::kBool)), plabs = at::empty({B * M}, i64), pbatch = at::empty({B * M}, i64);
+  Tensor by_image = at::empty({n}, i64), pixel_image = at::empty({n}, i64);
+  Tensor work = at::empty({2 * P + B + 1}, pr.options().dtype(at::kInt));
+  const bool need_grad = protos.requires_grad() || (has_p && pos->requires_grad());
+  Tensor slot = need_grad ? at::empty({P}, i64) : Tensor();
+  check(hsgk_pad_prototype_tables(si.data_ptr<int64_t>(), P, pr.data_ptr<float>(), (int)C, has_p ? po.data_ptr<float>() : nullptr,
+                                  (int)Cp, sl.data_ptr<int64_t>(), sb.data_ptr<int64_t>(), ps.data_ptr<int64_t>(), n, (int)B,
+                                  (int)M, table.data_ptr<float>(), has_p ? ptab.data_ptr<float>() : nullptr,
+                                  reinterpret_cast<uint8_t *>(masks.data_ptr<bool>()), plabs.data_ptr<int64_t>(),
+                                  pbatch.data_ptr<int64_t>(), by_image.data_ptr<int64_t>(), pixel_image.data_ptr<int64_t>(),
+                                  need_grad ? slot.data_ptr<int64_t>() : nullptr, work.data_ptr<int32_t>(), stream_of(pr)),
+        "hsgk_pad_prototype_tables");
+  if (protos.requires_grad()) table = PlacedRowsFn::apply(protos, slot, table);
+  if (has_p && pos->requires_grad()) ptab = PlacedRowsFn::apply(*pos, slot, ptab);
+  return {table, ptab, masks, plabs, pbatch, by_image, pixel_image};
+}
+
 int64_t abi_version() { return hsgk_version(); }
 
 }  // namespace
@@ -456,6 +600,11 @@ TORCH_LIBRARY(hsgk, m) {
         " -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)", &exchange_local);
   m.def("segsort_nll(Tensor emb, Tensor inst, Tensor proto, Tensor[] sems, Tensor[] psems, float[] kappas, int[] modes,"
         " Tensor? pixel_groups, Tensor? proto_groups) -> Tensor", &segsort_nll);
+  m.def("hier_assign(Tensor fine_logits, Tensor? coarse_logits) -> (Tensor, Tensor, Tensor, Tensor)", &hier_assign);
+  m.def("group_mean(Tensor prototypes, Tensor labels, Tensor? masks, int num_groups, bool normalized) -> Tensor", &group_mean);
+  m.def("gather_labels(Tensor table, Tensor img, Tensor seg) -> Tensor", &gather_labels);
+  m.def("pad_prototype_tables(Tensor seg_image, Tensor protos, Tensor? pos, Tensor seg_lab, Tensor seg_batch,"
+        " Tensor pixel_seg, int B, int M) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)", &pad_prototype_tables);
   m.def("segment_by_kmeans(Tensor x, Tensor? labels, Tensor loc, int loc_batch_stride, Tensor seed_map,"
         " int seed_batch_stride, int K, bool has_ignore, int ignore_index, int iterations, int batch_offset,"
         " int table_cap, int flags) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)", &segment_by_kmeans);

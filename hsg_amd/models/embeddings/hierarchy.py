@@ -21,7 +21,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-from hsg_amd import _lib, ops
+from hsg_amd import _lib, _torch_ops, ops
 
 
 # ---------------------------------------------------------------------------
@@ -57,6 +57,39 @@ class _PlacedRows(torch.autograd.Function):
   def backward(ctx, g):
     (slot,) = ctx.saved_tensors
     return g.index_select(0, slot), None, None
+
+
+def _pad_tables_ctypes(uimg, protos, pos, ulo, uhi, gid, B, M):
+  """hsgk_pad_prototype_tables through ctypes (HSGK_BINDING=ctypes; torch_ops.cpp: hsgk::pad_prototype_tables is the
+  same call in one dispatch)."""
+  dev = protos.device
+  P, C = protos.shape
+  n = gid.shape[0]
+  with torch.cuda.device(dev):
+    table = torch.empty((B * M, C), dtype=torch.float32, device=dev)
+    ptab = torch.empty((B * M, pos.shape[1]), dtype=torch.float32, device=dev) if pos is not None else None
+    masks = torch.empty((B * M,), dtype=torch.bool, device=dev)
+    plabs = torch.empty((B * M,), dtype=torch.long, device=dev)
+    pbatch = torch.empty((B * M,), dtype=torch.long, device=dev)
+    cluster_indices_by_image = torch.empty((n,), dtype=torch.long, device=dev)
+    pixel_image = torch.empty((n,), dtype=torch.long, device=dev)      # dense image number of every pixel
+    work = torch.empty((2 * P + B + 1,), dtype=torch.int32, device=dev)
+    need_grad = protos.requires_grad or (pos is not None and pos.requires_grad)
+    seg_slot = torch.empty((P,), dtype=torch.long, device=dev) if need_grad else None
+    protos_c, gid_c = protos.detach().contiguous(), gid.contiguous()
+    pos_c = pos.detach().contiguous() if pos is not None else None
+    _lib.check(_lib.lib().hsgk_pad_prototype_tables(
+        uimg.contiguous().data_ptr(), P, protos_c.data_ptr(), C, pos_c.data_ptr() if pos is not None else None,
+        pos.shape[1] if pos is not None else 0, ulo.contiguous().data_ptr(), uhi.contiguous().data_ptr(),
+        gid_c.data_ptr(), n, B, M, table.data_ptr(), ptab.data_ptr() if ptab is not None else None,
+        masks.data_ptr(), plabs.data_ptr(), pbatch.data_ptr(), cluster_indices_by_image.data_ptr(),
+        pixel_image.data_ptr(), seg_slot.data_ptr() if seg_slot is not None else None, work.data_ptr(),
+        _lib.stream_ptr()))
+  if protos.requires_grad:
+    table = _PlacedRows.apply(protos, seg_slot, table)
+  if pos is not None and pos.requires_grad:
+    ptab = _PlacedRows.apply(pos, seg_slot, ptab)
+  return table, ptab, masks, plabs, pbatch, cluster_indices_by_image, pixel_image
 
 
 def calculate_kmeans_prototypes(cluster_embeddings, cluster_indices, cluster_batch_indices,
@@ -133,30 +166,15 @@ def calculate_kmeans_prototypes(cluster_embeddings, cluster_indices, cluster_bat
   pos = None
   if cluster_pos_embeddings is not None:
     pos = ops.segment_reduce(cluster_pos_embeddings, gid, P, 1)        # segment means
-  with torch.cuda.device(dev):
-    table = torch.empty((B * M, C), dtype=torch.float32, device=dev)
-    ptab = torch.empty((B * M, pos.shape[1]), dtype=torch.float32, device=dev) if pos is not None else None
-    masks = torch.empty((B * M,), dtype=torch.bool, device=dev)
-    plabs = torch.empty((B * M,), dtype=torch.long, device=dev)
-    pbatch = torch.empty((B * M,), dtype=torch.long, device=dev)
-    cluster_indices_by_image = torch.empty((n,), dtype=torch.long, device=dev)
-    pixel_image = torch.empty((n,), dtype=torch.long, device=dev)      # dense image number of every pixel
-    work = torch.empty((2 * P + B + 1,), dtype=torch.int32, device=dev)
-    need_grad = protos.requires_grad or (pos is not None and pos.requires_grad)
-    seg_slot = torch.empty((P,), dtype=torch.long, device=dev) if need_grad else None
-    protos_c, gid_c = protos.detach().contiguous(), gid.contiguous()
-    pos_c = pos.detach().contiguous() if pos is not None else None
-    _lib.check(_lib.lib().hsgk_pad_prototype_tables(
-        uimg.contiguous().data_ptr(), P, protos_c.data_ptr(), C, pos_c.data_ptr() if pos is not None else None,
-        pos.shape[1] if pos is not None else 0, ulo.contiguous().data_ptr(), uhi.contiguous().data_ptr(),
-        gid_c.data_ptr(), n, B, M, table.data_ptr(), ptab.data_ptr() if ptab is not None else None,
-        masks.data_ptr(), plabs.data_ptr(), pbatch.data_ptr(), cluster_indices_by_image.data_ptr(),
-        pixel_image.data_ptr(), seg_slot.data_ptr() if seg_slot is not None else None, work.data_ptr(),
-        _lib.stream_ptr()))
-  if protos.requires_grad:
-    table = _PlacedRows.apply(protos, seg_slot, table)
-  if pos is not None and pos.requires_grad:
-    ptab = _PlacedRows.apply(pos, seg_slot, ptab)
+  tops = _torch_ops.ops()
+  if tops is not None:                   # the torch-extension binding: one dispatch, outputs allocated in C++
+    table, ptab, masks, plabs, pbatch, cluster_indices_by_image, pixel_image = tops.pad_prototype_tables(
+        uimg, protos, pos, ulo, uhi, gid, int(B), int(M))
+    if pos is None:
+      ptab = None
+  else:
+    table, ptab, masks, plabs, pbatch, cluster_indices_by_image, pixel_image = _pad_tables_ctypes(
+        uimg, protos, pos, ulo, uhi, gid, B, M)
   # rows come view by view (batch-major): they already are image by image when the views' image ids ascend --
   # known on the host when the id vector carries its host copy (gather_and_reorder_image_indices), else read
   views = ops.noted(image_indices, 'host') if image_indices is not None else None
@@ -248,7 +266,11 @@ def hierarchical_grouping_from_logits(fine_logits, coarse_logits=None):
   Returns (fine_labels, fine_probs, coarse_labels, coarse_probs).
   """
   ops.require_gpu(fine_logits, 'fine_logits')
-  fprob, flab, cprob, clab = _HierAssign.apply(fine_logits, coarse_logits)
+  tops = _torch_ops.ops()
+  if tops is not None and (coarse_logits is None or coarse_logits.shape[1] * coarse_logits.shape[2] <= 1024):
+    fprob, flab, cprob, clab = tops.hier_assign(fine_logits, coarse_logits)       # (one dispatch, C++ autograd node)
+  else:
+    fprob, flab, cprob, clab = _HierAssign.apply(fine_logits, coarse_logits)
   if coarse_logits is None:
     return flab, fprob, None, None
   return flab, fprob, clab, cprob
@@ -270,6 +292,11 @@ def _group_mean_torch(prototypes, labels, masks, num_groups, normalized):
     nrm = out.norm(dim=-1, keepdim=True)
     out = out / torch.where(nrm >= 1e-12, nrm, torch.full_like(nrm, 1e-12))
   return out.permute(0, 2, 1)
+
+
+def _group_bwd_fits(C, N, G):
+  """hsgk_group_mean_bwd keeps the [G, C] group sums of one image in LDS (csrc/hier.hip)."""
+  return (G * C + 3 * G + N) * 4 <= 150 * 1024
 
 
 class _GroupMean(torch.autograd.Function):
@@ -294,7 +321,17 @@ class _GroupMean(torch.autograd.Function):
   def backward(ctx, g):
     p, lab, masks = ctx.saved_tensors
     G, normalized, has_mask = ctx.cfg
-    with torch.enable_grad():
+    if _group_bwd_fits(p.shape[1], p.shape[2], G):       # one launch (hsgk_group_mean_bwd)
+      B, C, N = p.shape
+      go = g.contiguous().float()
+      mk = masks.contiguous().to(torch.uint8) if has_mask else None
+      with torch.cuda.device(p.device):
+        gp = torch.empty_like(p)
+        _lib.check(_lib.lib().hsgk_group_mean_bwd(
+            p.data_ptr(), lab.data_ptr(), mk.data_ptr() if mk is not None else None, B, C, N, G, int(normalized),
+            ctypes.c_float(1e-12), go.data_ptr(), gp.data_ptr(), _lib.stream_ptr()))
+      return gp, None, None, None, None
+    with torch.enable_grad():                            # (beyond the kernel's LDS working set: the ATen formulas)
       a = p.detach().requires_grad_(True)
       out = _group_mean_torch(a, lab, masks.bool() if has_mask else None, G, normalized)
       (ga,) = torch.autograd.grad(out, a, g)
@@ -307,6 +344,10 @@ def collect_nd_coarser_prototype(prototypes, prototype_grouping_labels,
   ops.require_gpu(prototypes, 'prototypes')
   if num_groups is None:
     num_groups = int(prototype_grouping_labels.max()) + 1
+  tops = _torch_ops.ops()
+  if tops is not None and _group_bwd_fits(prototypes.shape[1], prototypes.shape[2], int(num_groups)):
+    return tops.group_mean(prototypes, prototype_grouping_labels, prototype_padding_masks, int(num_groups),
+                           bool(normalized))
   return _GroupMean.apply(prototypes, prototype_grouping_labels, prototype_padding_masks,
                           int(num_groups), bool(normalized))
 
@@ -340,6 +381,10 @@ def collect_pixel_hierarchical_clustering_indices(cluster_indices_by_batch,
     img, order = known[0], known[1]
   else:
     img, order = _dense_image_index(cluster_batch_indices)
+  tops = _torch_ops.ops()
+  if tops is not None:
+    out = tops.gather_labels(finehrchy_prototype_grouping_labels, img, seg)
+    return out[order] if order is not None else out
   table = finehrchy_prototype_grouping_labels.long().contiguous()
   out = torch.empty_like(seg)
   if seg.numel() == 0:

@@ -573,7 +573,9 @@ def gather_clustering_and_update_prototypes(embeddings, embeddings_with_loc, clu
   sems, _ = _as_list(semantic_labels)
   insts, _ = _as_list(instance_labels)
   devices = [t.device for t in c_inds]
-  if not listed or (len(c_inds) == 1 and _world(group) > 1):
+  # (one GPU per process -- also when it arrives as one-element lists, the way pyscripts/train/train.py:190,219 call
+  #  it: the single-tensor exchange, i.e. ONE op of the torch-extension binding when this process is the world)
+  if not listed or len(c_inds) == 1:
     res = exchange_prototypes(embs[0], embs_loc[0], c_inds[0], b_inds[0], sems[0], insts[0], group=group)
     if _world(group) == 1:
       ops.note(res[5], 'index_count', int(res[0].shape[0]))
@@ -630,19 +632,6 @@ def get_params(model, prefixs, suffixes, exclude=None):
 
 
 # ---- hsg/models/utils.py:41-74 ---------------------------------------------------
-def reorder_image_indices(image_ids_all):
-  """Dense image index by first-occurrence order over the gathered id list."""
-  uniq, inv = torch.unique(image_ids_all, return_inverse=True)
-  n = image_ids_all.shape[0]
-  pos = torch.arange(n, dtype=torch.long, device=image_ids_all.device)
-  first = torch.full((uniq.shape[0],), n, dtype=torch.long, device=image_ids_all.device)
-  first = first.scatter_reduce(0, inv, pos, reduce='amin')
-  rank_of = torch.empty_like(first)
-  rank_of[torch.argsort(first)] = torch.arange(uniq.shape[0], dtype=torch.long,
-                                               device=image_ids_all.device)
-  return rank_of[inv]
-
-
 def gather_and_reorder_image_indices(image_indices, anchor_device=None, group=None):
   """Reference hsg/models/utils.py:41-74: every GPU receives the WHOLE
   re-indexed vector (it is later indexed with `batch_index + B * gpu_id`,
@@ -652,10 +641,12 @@ def gather_and_reorder_image_indices(image_indices, anchor_device=None, group=No
   anchor = torch.device(anchor_device) if anchor_device is not None else devices[0]
   local = _cat_to(ids, anchor).long() if len(ids) > 1 else ids[0].long()
   gathered, _ = _all_gather_rows(local, group, 'image_ids')
-  full = reorder_image_indices(gathered)
-  # (the `unique` above already waited for the device: the tiny vector's host copy costs nothing here and saves
-  #  the order checks of generate_clusters their reads)
-  host = full.tolist()
+  # The vector has two entries per image of the batch: its dense re-indexing (first-occurrence order, :60-72) is
+  # done on the host copy the order checks of generate_clusters want anyway -- one read and one small upload
+  # instead of `unique` (itself a host synchronisation), a scatter-min, a sort and an index_put on the device.
+  first = {}
+  host = [first.setdefault(v, len(first)) for v in gathered.tolist()]
+  full = torch.tensor(host, dtype=torch.long, device=gathered.device)
   if not listed:
     return ops.note(full, 'host', host)
   return [ops.note(full.to(d), 'host', host) for d in devices]

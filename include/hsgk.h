@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HSGK_VERSION 400
+#define HSGK_VERSION 401
 #define HSGK_CHUNK 2048          /* rows per segment-sum chunk (order C2)      */
 #define HSGK_EPS 1e-12f          /* normalize_embedding eps (general/common.py:101) */
 
@@ -383,6 +383,11 @@ HSGK_API int hsgk_hier_assign_bwd(const float *fine_logits, const float *coarse_
 HSGK_API int hsgk_group_mean(const float *protos, const int64_t *labels, const uint8_t *masks,
                              int B, int C, int N, int G, int normalized, float eps, float *out,
                              hsgk_stream_t stream);
+/* backward of hsgk_group_mean (what autograd derives from :706-746): g_out [B,C,G] -> g_protos [B,C,N]; padded
+ * nodes and nodes whose label lies outside [0, G) receive zero.                                              */
+HSGK_API int hsgk_group_mean_bwd(const float *protos, const int64_t *labels, const uint8_t *masks,
+                                 int B, int C, int N, int G, int normalized, float eps,
+                                 const float *g_out, float *g_protos, hsgk_stream_t stream);
 /* ---- resnet_fcn_hsg.py:751-780 pixel -> segment -> group label ---------------
  * out[i] = table[img[i] * M + seg[i]]                                           */
 HSGK_API int hsgk_gather_labels(const int64_t *table, int M, const int64_t *img,

@@ -1044,6 +1044,42 @@ def test_hierarchy_ops_vs_reference_golden(dev, fixture):
   assert np.array_equal(px_coarse.cpu().numpy(), g['px_coarse'])
 
 
+@pytest.mark.parametrize('B,C,N,G,normalized,masked', [(4, 128, 256, 8, True, True), (2, 256, 256, 64, True, True),
+                                                       (3, 70, 33, 5, False, True), (1, 32, 100, 4, True, False)])
+@pytest.mark.parametrize('binding', ['torch', 'ctypes'])
+def test_group_mean_backward_kernel_vs_autograd(dev, monkeypatch, binding, B, C, N, G, normalized, masked):
+  """hsgk_group_mean_bwd (round 6: one launch instead of autograd through the ATen restatement of
+  resnet_fcn_hsg.py:706-746) against float64 autograd of that restatement: empty groups, padded nodes, a group
+  whose mean is (numerically) zero takes the clamped branch; through both host bindings."""
+  import torch
+  from hsg_amd.models.embeddings import hierarchy as hz
+  if binding == 'ctypes':
+    monkeypatch.setenv('HSGK_BINDING', 'ctypes')
+  g = torch.Generator(device=dev).manual_seed(B * 1000 + C + N + G)
+  p = torch.randn((B, C, N), device=dev, generator=g)
+  lab = torch.randint(0, G, (B, N), device=dev, generator=g)
+  lab[lab == G - 1] = 0                                   # group G - 1 stays empty
+  masks = (torch.rand((B, N), device=dev, generator=g) < 0.2) if masked else None
+  if N >= 8:                                              # a group of two nodes that cancel: mean 0 -> clamped norm
+    lab[0, :2] = 1
+    lab[0, 2:][lab[0, 2:] == 1] = 0
+    p[0, :, 1] = -p[0, :, 0]
+    if masks is not None:
+      masks[0, :2] = False
+  w = torch.randn((B, C, G), device=dev, generator=g)
+  a = p.clone().requires_grad_(True)
+  out = hz.collect_nd_coarser_prototype(a, lab, masks, G, normalized)
+  (out * w).sum().backward()
+  b2 = p.double().requires_grad_(True)
+  ref = hz._group_mean_torch(b2, lab, masks, G, normalized)
+  (ref * w.double()).sum().backward()
+  assert (out.double() - ref).abs().max().item() <= 2e-6
+  want = b2.grad
+  # (the clamped group's gradient is g / eps = 1e12 x g in both; compare relative to each entry's own scale)
+  err = (a.grad.double() - want).abs() / want.abs().clamp(min=1.0)
+  assert err.max().item() <= 2e-5, err.max().item()
+
+
 @pytest.mark.parametrize('B,KF,KC,N', [(3, 8, 4, 256), (2, 44, 9, 700), (1, 5, 0, 33), (4, 16, 2, 64)])
 def test_hier_assign_backward_kernel_vs_autograd(dev, B, KF, KC, N):
   """hsgk_hier_assign_bwd (softmax backward of both levels and the chain through coarse_prob = softmax(coarse) x
