@@ -12,7 +12,7 @@ from torch.profiler import profile, ProfilerActivity
 util.TRAIN_STEP.update(B=4, C=128, H=56, W=56, grid=(4, 4), iters=15, M=256, KF=8, KC=4, label_divisor=255,
                        ignore=255, kappa=16.0, dmon_knn=4, image_ids=[0, 1, 0, 1])
 dev = torch.device('cuda:0')
-inp = util.train_step_inputs(1234)
+inp = util.device_inputs(util.train_step_inputs(1234), dev)      # the batch resident, as a training loop's loader leaves it
 emb_cls = [getattr(emb_mod, n) for n in dir(emb_mod) if n.startswith('Multiview')][0]
 mods = dict(embedding_cls=emb_cls, prediction_cls=pred_mod.Hsg, model_utils=mu,
             loc_fn=lambda hw, d: sc.generate_location_features(hw, d, 'float') - 0.5)
