@@ -759,6 +759,27 @@ def test_pipelined_prep_variant_is_bit_identical(dev, oracle, monkeypatch, shape
     assert a.shape == b.shape and np.array_equal(a, b), name
 
 
+@pytest.mark.parametrize('switch', ['HSGK_PREP_FLAT=0', 'HSGK_PREP_ORDER=0', 'HSGK_PREP_X=6'])
+@pytest.mark.parametrize('shape,grid,labelled', [((3, 256, 40, 56), (4, 4), True), ((2, 128, 65, 33), (2, 3), False),
+                                                 ((1, 256, 64, 64), (16, 16), False)])
+def test_prep_kernel_switches_are_bit_identical(dev, oracle, monkeypatch, switch, shape, grid, labelled):
+  """The A/B switches of the round-6 prep kernel -- phase 3 as in rounds 2-5, workgroup ids as
+  they come, the two scheduling experiments -- give the oracle's five outputs like the default does: with a label
+  map + ignore band (compacted half tiles that start on odd rows: the 8-byte head / tail of the flat stream), an odd
+  image size (ragged last tile) and a K = 256 shape (fp16 copy in tile order)."""
+  name, val = switch.split('=')
+  monkeypatch.setenv(name, val)
+  B, C, H, W = shape
+  x = synth.embeddings_nchw(synth.SEED_BASE + 654 + C, shape, 'mixture')
+  lab = synth.overseg_labels(synth.SEED_BASE + 18, B, H, W, regions=5, ignore_rows=3) if labelled else None
+  ign = 255 if labelled else None
+  loc = oracle.generate_location_features((H, W)) - np.float32(0.5)
+  got = _run_segkm(dev, x, lab, grid, ign, 3)
+  ref = oracle.segment_by_kmeans(x, lab, grid, loc, ign, 3)
+  for nm, a, b in zip(('emb', 'emb_loc', 'labels', 'cluster', 'batch'), got, ref):
+    assert a.shape == b.shape and np.array_equal(a, b), nm
+
+
 def _exchange_case(seed, sizes, C, nimg, ncl, nsem, ninst, shuffle_ids=False):
   """Per-source pixel sets with image-major rows (like segment_by_kmeans output) or arbitrary ids."""
   parts = []
