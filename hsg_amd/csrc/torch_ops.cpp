@@ -19,6 +19,8 @@
 //       the multi-rank exchange keeps its two collectives between the phases, hsg_amd/models/utils.py).  meta_host:
 //       int64[8] on the host = {rows of this rank, table rows, error bits, capacity needed, distinct images, most
 //       segments of one image, ...}; with a capacity error the tensors are empty and the caller regrows `cap`.
+//   hsgk::topk_prototypes (hsg/utils/segsort/eval.py:9-52) and hsgk::dmon_pool (hsg/utils/graph/loss.py:62-94, with its
+//       one-launch backward) (round 6)
 //   hsgk::pad_prototype_tables / hier_assign / group_mean / gather_labels (round 6)
 //       hsg/models/embeddings/resnet_fcn_hsg.py:499-577, :638-672, :683-748, :751-780: the padded per-image tables,
 //       the two-level assignment (+ its one-launch backward), the masked group means (+ hsgk_group_mean_bwd) and
@@ -589,6 +591,70 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> pad_prototype
   return {table, ptab, masks, plabs, pbatch, by_image, pixel_image};
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// hsg/utils/segsort/eval.py:9-52 (+ hsg/models/utils.py:243-309 with groups): the k best prototypes per query
+std::tuple<Tensor, Tensor> topk_prototypes(const Tensor &queries, const Tensor &prototypes, int64_t top_k,
+                                           const c10::optional<Tensor> &query_groups,
+                                           const c10::optional<Tensor> &prototype_groups) {
+  TORCH_CHECK(queries.is_cuda(), "hsgk::topk_prototypes: tensors must be on a ROCm device (there is no CPU path)");
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(queries.device());
+  Tensor q = rows_f32(queries.detach()), p = rows_f32(prototypes.detach());
+  const int64_t n = q.size(0), c = q.size(1), P = p.size(0);
+  const bool grouped = query_groups.has_value() && query_groups->defined();
+  Tensor qg = grouped ? vec_i64(*query_groups, q.device()) : Tensor();
+  Tensor pg = grouped ? vec_i64(*prototype_groups, q.device()) : Tensor();
+  Tensor idx = at::empty({n, top_k}, q.options().dtype(at::kLong)), val = at::empty({n, top_k}, q.options());
+  const size_t wsb = hsgk_topk_workspace_bytes(n, (int)c, P, (int)top_k);
+  Tensor ws = at::empty({(int64_t)wsb}, q.options().dtype(at::kByte));
+  check(hsgk_topk_prototypes_grouped(q.data_ptr<float>(), n, (int)c, p.data_ptr<float>(), P, (int)top_k,
+                                     grouped ? qg.data_ptr<int64_t>() : nullptr, grouped ? pg.data_ptr<int64_t>() : nullptr,
+                                     idx.data_ptr<int64_t>(), val.data_ptr<float>(), ws.data_ptr(), wsb, stream_of(q)),
+        "hsgk_topk_prototypes_grouped");
+  return {idx, val};
+}
+
+// hsg/utils/graph/loss.py:62-94 for an adjacency without gradient: per image t = (Tr(S^T A S) - |S^T d|^2 / 2m) / 2m
+// and c = |sum_i S_i|_2, one launch forward and one backward
+struct DmonPoolFn : public torch::autograd::Function<DmonPoolFn> {
+  static variable_list forward(AutogradContext *ctx, const Tensor &adj, const Tensor &s, const c10::optional<Tensor> &valid) {
+    TORCH_CHECK(s.is_cuda(), "hsgk::dmon_pool: tensors must be on a ROCm device (there is no CPU path)");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(s.device());
+    Tensor a = adj.detach().to(at::kFloat).contiguous(), sc = s.detach().to(at::kFloat).contiguous();
+    const bool has_v = valid.has_value() && valid->defined();
+    Tensor v = has_v ? valid->to(at::kByte).contiguous() : Tensor();
+    const int64_t B = sc.size(0), N = sc.size(1), K = sc.size(2);
+    Tensor t = at::empty({B}, sc.options()), c = at::empty({B}, sc.options());
+    const size_t nb = hsgk_dmon_pool_workspace_bytes((int)B, (int)N, (int)K);
+    Tensor saved = at::empty({(int64_t)nb}, sc.options().dtype(at::kByte));
+    check(hsgk_dmon_pool_fwd(a.data_ptr<float>(), sc.data_ptr<float>(), has_v ? v.data_ptr<uint8_t>() : nullptr, (int)B, (int)N,
+                             (int)K, t.data_ptr<float>(), c.data_ptr<float>(), saved.data_ptr(), nb, stream_of(sc)),
+          "hsgk_dmon_pool_fwd");
+    ctx->save_for_backward({a, sc, has_v ? v : at::empty({0}, sc.options().dtype(at::kByte)), saved});
+    ctx->saved_data["has_v"] = has_v;
+    return {t, c};
+  }
+  static variable_list backward(AutogradContext *ctx, variable_list g) {
+    auto sv = ctx->get_saved_variables();
+    const Tensor &a = sv[0], &sc = sv[1], &v = sv[2], &saved = sv[3];
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(sc.device());
+    const int64_t B = sc.size(0), N = sc.size(1), K = sc.size(2);
+    Tensor gt = g[0].defined() ? g[0].to(at::kFloat).contiguous() : at::zeros({B}, sc.options());
+    Tensor gc = g[1].defined() ? g[1].to(at::kFloat).contiguous() : at::zeros({B}, sc.options());
+    Tensor grad = at::empty_like(sc);
+    check(hsgk_dmon_pool_bwd(a.data_ptr<float>(), sc.data_ptr<float>(),
+                             ctx->saved_data["has_v"].toBool() ? v.data_ptr<uint8_t>() : nullptr, (int)B, (int)N, (int)K,
+                             saved.data_ptr(), gt.data_ptr<float>(), gc.data_ptr<float>(), grad.data_ptr<float>(),
+                             stream_of(sc)),
+          "hsgk_dmon_pool_bwd");
+    return {Tensor(), grad, Tensor()};
+  }
+};
+
+std::tuple<Tensor, Tensor> dmon_pool(const Tensor &adj, const Tensor &s, const c10::optional<Tensor> &valid) {
+  auto r = DmonPoolFn::apply(adj, s, valid);
+  return {r[0], r[1]};
+}
+
 int64_t abi_version() { return hsgk_version(); }
 
 }  // namespace
@@ -600,6 +666,9 @@ TORCH_LIBRARY(hsgk, m) {
         " -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)", &exchange_local);
   m.def("segsort_nll(Tensor emb, Tensor inst, Tensor proto, Tensor[] sems, Tensor[] psems, float[] kappas, int[] modes,"
         " Tensor? pixel_groups, Tensor? proto_groups) -> Tensor", &segsort_nll);
+  m.def("topk_prototypes(Tensor queries, Tensor prototypes, int top_k, Tensor? query_groups, Tensor? prototype_groups)"
+        " -> (Tensor, Tensor)", &topk_prototypes);
+  m.def("dmon_pool(Tensor adj, Tensor s, Tensor? valid) -> (Tensor, Tensor)", &dmon_pool);
   m.def("hier_assign(Tensor fine_logits, Tensor? coarse_logits) -> (Tensor, Tensor, Tensor, Tensor)", &hier_assign);
   m.def("group_mean(Tensor prototypes, Tensor labels, Tensor? masks, int num_groups, bool normalized) -> Tensor", &group_mean);
   m.def("gather_labels(Tensor table, Tensor img, Tensor seg) -> Tensor", &gather_labels);

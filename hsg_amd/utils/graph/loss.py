@@ -10,7 +10,7 @@ import math
 import torch
 from torch.nn.modules.loss import _Loss
 
-from hsg_amd import _lib
+from hsg_amd import _lib, _torch_ops
 from hsg_amd.utils.graph import common as graph_common
 
 MAX_FUSED_CLUSTERS = 32
@@ -68,7 +68,11 @@ def dmon_pool_loss(x, adj, s, mask=None, softmax=False):
   kt = 4 if K <= 4 else 8 if K <= 8 else 16 if K <= 16 else 32        # the kernels' padded cluster count (LDS: 64 KiB)
   if s.is_cuda and not adj.requires_grad and K <= MAX_FUSED_CLUSTERS and (N + 3) * kt <= 14000:
     valid = None if mask is None else mask.reshape(B, N).to(torch.uint8).contiguous()
-    t, c = _DmonPool.apply(adj.detach().to(torch.float32).contiguous(), s.to(torch.float32).contiguous(), valid)
+    tops = _torch_ops.ops()
+    if tops is not None:               # the torch-extension binding: one dispatch, C++ autograd node
+      t, c = tops.dmon_pool(adj, s, valid)
+    else:
+      t, c = _DmonPool.apply(adj.detach().to(torch.float32).contiguous(), s.to(torch.float32).contiguous(), valid)
     return torch.mean(1 - t), torch.mean(c) * (math.sqrt(K) / N)
   if mask is not None:
     s = s * mask.view(B, N, 1).to(s.dtype)

@@ -8,7 +8,7 @@
 """
 import torch
 
-from hsg_amd import _lib, ops
+from hsg_amd import _lib, _torch_ops, ops
 from hsg_amd.utils.general import common as common_utils
 
 
@@ -17,6 +17,9 @@ def top_k_indices(embeddings, prototypes, top_k, query_groups=None, prototype_gr
   two group vectors only prototypes of the query's own group compete; unfilled slots come
   back as index 0 with value -inf."""
   ops.require_gpu(embeddings, 'embeddings')
+  tops = _torch_ops.ops()
+  if tops is not None:                 # the torch-extension binding: one dispatch
+    return tops.topk_prototypes(embeddings, prototypes, int(top_k), query_groups, prototype_groups)
   q = embeddings.detach().reshape(-1, embeddings.shape[-1]).float().contiguous()
   p = prototypes.detach().reshape(-1, prototypes.shape[-1]).float().contiguous()
   n, c = q.shape
