@@ -191,6 +191,9 @@ int main(int argc, char **argv) {
     RUNX(32, 1, 1, 1, 1, 0, 1, 4096, "32 px, flat, consecutive rows, fp16 as 16-B pieces    4 wg/cu");
     RUNX(32, 1, 1, 1, 1, 1, 1, 4096, "32 px, flat, consec., fp16 16 B, XCD-contiguous tiles 4 wg/cu");
     RUNX(32, 0, 1, 1, 0, 1, 0, 4096, "32 px, kernel's stores, XCD-contiguous tiles          4 wg/cu");
+    RUNX(32, 1, 1, 1, 0, 1, 0, 4096, "32 px, flat emb_loc, XCD-contiguous (= round-6 kernel) 4 wg/cu");
+    RUNX(32, 1, 1, 1, 1, 1, 0, 4096, "32 px, flat, consecutive rows, XCD-contiguous          4 wg/cu");
+    RUNX(32, 1, 0, 1, 0, 1, 0, 4096, "32 px, flat, XCD-contiguous, no partials               4 wg/cu");
     RUNX(64, 1, 1, 1, 1, 0, 1, 0, "64 px, flat, consecutive rows, fp16 as 16-B pieces    2 wg/cu");
     RUNX(64, 1, 1, 1, 1, 1, 1, 0, "64 px, flat, consec., fp16 16 B, XCD-contiguous tiles 2 wg/cu");
     RUNX(128, 1, 1, 1, 1, 0, 1, 0, "128 px (1024 thr), flat, consec., fp16 16 B           1 wg/cu");
