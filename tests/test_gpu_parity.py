@@ -2248,6 +2248,7 @@ def test_torch_extension_binding_matches_the_ctypes_mirror_bit_for_bit(dev, monk
   import torch
   from hsg_amd import _lib, _torch_ops, ops
   from hsg_amd.models import utils as mu
+  monkeypatch.delenv('HSGK_BINDING', raising=False)      # (the suite may run with HSGK_BINDING=ctypes as a whole)
   assert _torch_ops.ops() is not None, 'libhsgk_torch.so is not built'
   x = torch.from_numpy(synth.gaussish(11, 5000 * 66).reshape(5000, 66).copy()).to(dev)
   lab = torch.from_numpy((synth.hash_u64(12, 5000) % np.uint64(37)).astype(np.int64)).to(dev)
