@@ -126,6 +126,13 @@ def pmc_traffic(group, workload):
   return None, None, None, None
 
 
+RESULT_FD = 1          # where the JSON line goes (main() sets the real stdout aside for it)
+
+
+def write_result(line):
+  os.write(RESULT_FD, (json.dumps(line) + '\n').encode())
+
+
 def free_port():
   s = socket.socket()
   s.bind(('127.0.0.1', 0))
@@ -249,6 +256,18 @@ def main():
   if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
     sys.exit(relaunch_as_ranks(args.gpus))
 
+  # The JSON line must be the ONLY thing on stdout: RCCL prints its version banner to the C-level stdout, buffered
+  # until the process exits -- i.e. AFTER the line.  The real stdout is set aside for the line; fd 1 becomes stderr
+  # for everything else (libraries, Python prints).  The descriptor survives the start-up retries (execve).
+  global RESULT_FD
+  if os.environ.get('HSGK_BENCH_RESULT_FD'):
+    RESULT_FD = int(os.environ['HSGK_BENCH_RESULT_FD'])
+  else:
+    RESULT_FD = os.dup(1)
+    os.set_inheritable(RESULT_FD, True)
+    os.environ['HSGK_BENCH_RESULT_FD'] = str(RESULT_FD)
+    sys.stdout.flush()
+    os.dup2(2, 1)
   import torch
   rank = int(os.environ.get('RANK', '0'))
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -295,10 +314,10 @@ def main():
         env['HSGK_BENCH_BACKEND'] = 'gloo'
         os.execve(sys.executable, [sys.executable] + sys.argv, env)
       if rank == 0:
-        print(json.dumps({'metric': 'pixel-embeddings clustered/sec', 'value': None, 'unit': 'pixels/s',
-                          'n_gpus': world, 'error': 'process-group start-up failed: %s' % what,
-                          'first_error': os.environ.get('HSGK_BENCH_FIRST_ERROR'),
-                          'second_error': os.environ.get('HSGK_BENCH_SECOND_ERROR')}), flush=True)
+        write_result({'metric': 'pixel-embeddings clustered/sec', 'value': None, 'unit': 'pixels/s',
+                      'n_gpus': world, 'error': 'process-group start-up failed: %s' % what,
+                      'first_error': os.environ.get('HSGK_BENCH_FIRST_ERROR'),
+                      'second_error': os.environ.get('HSGK_BENCH_SECOND_ERROR')})
       if from_thread:
         os._exit(1)
       sys.exit(1)
@@ -600,7 +619,7 @@ def main():
   def emit(instream):
     if rank != 0:
       return
-    print(json.dumps({
+    write_result({
         'metric': 'pixel-embeddings clustered/sec', 'value': round(value, 1),
         'unit': 'pixels/s', 'n_gpus': 1 if args.dry_ranks > 1 else world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
@@ -622,7 +641,7 @@ def main():
         'rccl_startup_second_error': os.environ.get('HSGK_BENCH_SECOND_ERROR'),
         'rccl_fell_back_to_gloo': os.environ.get('HSGK_BENCH_RETRIED') == '2',
         'roofline': roofline, 'roofline_mstep': roofline_mstep, 'roofline_prep': roofline_prep,
-        'roofline_iteration': roofline_iteration, 'cpu_baseline': cpu, 'extra_runs': extra}), flush=True)
+        'roofline_iteration': roofline_iteration, 'cpu_baseline': cpu, 'extra_runs': extra})
 
   # The same exchange with both collectives IN-STREAM on libhsgk's own RCCL communicator (the C entry points
   # hsgk_exchange_* / hsgk_comm_*): only with real RCCL ranks.  It runs last, under a watchdog that prints the
