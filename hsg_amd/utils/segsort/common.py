@@ -46,8 +46,26 @@ def initialize_cluster_labels(num_clusters, img_dimensions, device):
   return labels.to(device)
 
 
+_locfeat_cache = {}
+
+
 def generate_location_features(img_dimensions, device, feature_type='int'):
-  """[H,W,2] (y,x) location features (reference common.py:156-189)."""
+  """[H,W,2] (y,x) location features (reference common.py:156-189).  The table is a function of its arguments: a
+  device result is built once per (shape, device, type) -- `linspace` on the host, as the reference's bits are ATen's
+  CPU `linspace` bits, then one upload -- and every call returns a fresh COPY of it (callers shift it in place:
+  `local_features -= 0.5`, common.py:316): one device copy per call instead of host work and an upload."""
+  dev = torch.device(device)
+  if dev.type == 'cuda' and feature_type in ('int', 'float'):
+    if dev.index is None:
+      dev = torch.device('cuda', torch.cuda.current_device())
+    key = (int(img_dimensions[0]), int(img_dimensions[1]), str(dev), feature_type)
+    with _cache_lock:
+      hit = _locfeat_cache.get(key)
+    if hit is None:
+      hit = generate_location_features(img_dimensions, 'cpu', feature_type).to(dev)
+      with _cache_lock:
+        _locfeat_cache[key] = hit
+    return hit.clone()
   if feature_type == 'int':
     y = torch.arange(img_dimensions[0])
     x = torch.arange(img_dimensions[1])
